@@ -1,0 +1,114 @@
+#!/usr/bin/env python3
+"""ORACLE / TEST INFRASTRUCTURE ONLY.
+
+Generates the committed golden fixtures under tests/golden/ from the UNMODIFIED reference, compiled by
+oracle/Makefile into oracle/_ref/ (never committed) and driven by oracle/ref_driver.cpp.
+
+    python oracle/make_fixtures.py            # rebuilds every tests/golden/*.npz from tests/golden/*.ini
+
+A fixture is data only: hot-path inputs (background/thermodynamics spline tables, grids, parameters) and
+expected outputs (source functions, transfer functions, C_l, P(k)) for one .ini.  Large outputs of the two
+full-size configs are sub-sampled (16 k columns of sources_, 32 q columns + 8 l rows of transfer_); the
+`small` config keeps everything so that each stage can be tested in isolation on the GPU box.
+"""
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+GOLD = os.path.join(ROOT, "tests", "golden")
+DRIVER = os.path.join(HERE, "_ref", "ref_driver")
+
+
+def load_bin(path):
+    d = {}
+    with open(path, "rb") as f:
+        while True:
+            line = f.readline()
+            if not line:
+                break
+            parts = line.decode().split()
+            name, dt, nd = parts[0], parts[1], int(parts[2])
+            shape = [int(x) for x in parts[3:3 + nd]]
+            n = int(np.prod(shape))
+            dtype = np.float64 if dt == "f8" else np.int32
+            d[name] = np.frombuffer(f.read(n * dtype().itemsize), dtype=dtype).reshape(shape).copy()
+    return d
+
+
+def run_reference(cfg, tmpdir="/tmp"):
+    ini = os.path.join(GOLD, cfg + ".ini")
+    out = os.path.join(tmpdir, "cpt_ref_%s.bin" % cfg)
+    subprocess.check_call([DRIVER, "dump", ini, out], cwd=GOLD)
+    d = load_bin(out)
+    os.remove(out)
+    return d
+
+
+TABLE_KEYS = ("bg.", "th.")
+
+
+def pick_k_subset(nk, n=16):
+    idx = np.unique(np.round(np.linspace(0, nk - 1, n)).astype(int))
+    return idx
+
+
+def main():
+    cfgs = sys.argv[1:] or ["small", "lcdm", "explanatory"]
+    tables_written = False
+    for cfg in cfgs:
+        d = run_reference(cfg)
+        out = {}
+        tables = {}
+        for k, v in d.items():
+            if k.startswith(TABLE_KEYS):
+                tables[k] = v
+            elif k in ("pt.sources", "tr.transfer"):
+                pass
+            else:
+                out[k] = v
+        src = d["pt.sources"]  # [tp][tau][k]
+        if cfg == "small":
+            out["pt.sources"] = src
+            if "tr.transfer" in d:
+                out["tr.transfer"] = d["tr.transfer"]
+        else:
+            nk = src.shape[2]
+            ks = pick_k_subset(nk, 16)
+            out["pt.sources_k_index"] = ks.astype(np.int32)
+            out["pt.sources_subset"] = np.ascontiguousarray(src[:, :, ks])
+            # delta_m(k, tau0) column (P(k) input), all k
+            if int(d["pt.index_tp_delta_m"][0]) >= 0:
+                out["pt.delta_m_today"] = np.ascontiguousarray(src[int(d["pt.index_tp_delta_m"][0]), -1, :])
+            if "tr.transfer" in d:
+                t = d["tr.transfer"]  # [tt][l][q]
+                nq, nl = t.shape[2], t.shape[1]
+                qs = np.unique(np.round(np.linspace(0, nq - 1, 32)).astype(int))
+                ls = np.unique(np.round(np.linspace(0, nl - 1, 8)).astype(int))
+                out["tr.transfer_q_index"] = qs.astype(np.int32)
+                out["tr.transfer_l_index"] = ls.astype(np.int32)
+                out["tr.transfer_at_q"] = np.ascontiguousarray(t[:, :, qs])
+                out["tr.transfer_at_l"] = np.ascontiguousarray(t[:, ls, :])
+        np.savez_compressed(os.path.join(GOLD, cfg + ".npz"), **out)
+        # the three configs share one cosmology -> one table file; verified identical below
+        tpath = os.path.join(GOLD, "tables_lcdm.npz")
+        if not tables_written and cfg in ("small", "lcdm", "explanatory"):
+            if os.path.exists(tpath) and len(cfgs) < 3:
+                old = np.load(tpath)
+                for k in tables:
+                    assert np.array_equal(old[k], tables[k]), "tables differ between configs: " + k
+            else:
+                np.savez_compressed(tpath, **tables)
+            tables_written = True
+            ref_tables = tables
+        else:
+            for k in tables:
+                assert np.array_equal(ref_tables[k], tables[k]), "tables differ between configs: " + k
+        print(cfg, {k: v.shape for k, v in out.items() if v.size > 1000})
+
+
+if __name__ == "__main__":
+    main()
