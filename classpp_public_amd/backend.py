@@ -1,0 +1,136 @@
+"""Thin Python host layer over the C ABI (include/cpt.h): owns a cpt_handle, keeps bulk arrays in HBM as torch
+tensors (PyTorch is only the device-memory / stream / torch.distributed plumbing here, not the compute path).
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import capi
+from .capi import CptStepstat
+
+
+class CptError(RuntimeError):
+    """Computation failure inside the backend (the reference raises std::runtime_error -> CosmoComputationError)."""
+
+
+class CptInputError(ValueError):
+    """Invalid / unsupported input (the reference raises std::invalid_argument -> CosmoSevereError)."""
+
+
+def _dptr(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def _iptr(a):
+    return a.ctypes.data_as(C.POINTER(C.c_int))
+
+
+class Backend:
+    def __init__(self, inputs, device="cuda:0"):
+        if not torch.cuda.is_available():
+            raise CptError("no HIP device visible to torch: the cpt backend has no CPU fallback")
+        self.lib = capi.lib()
+        self.inp = inputs
+        self.device = torch.device(device)
+        torch.cuda.set_device(self.device)
+        h = C.c_void_p()
+        rc = self.lib.cpt_create(C.byref(inputs.config), C.byref(inputs.tables), C.byref(h))
+        if rc != capi.CPT_OK:
+            msg = self.lib.cpt_create_error().decode()
+            raise (CptInputError if rc in (capi.CPT_ERR_INVALID, capi.CPT_ERR_UNSUPPORTED) else CptError)(msg)
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.cpt_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc != capi.CPT_OK:
+            msg = self.lib.cpt_last_error(self.h).decode()
+            raise (CptInputError if rc in (capi.CPT_ERR_INVALID, capi.CPT_ERR_UNSUPPORTED) else CptError)(msg)
+
+    # ---- hot path A ----
+    def perturb_solve(self, k=None, tau=None, want_sources=True):
+        """-> (sources [tp][ntau][nk] torch f64 on device or None, stats ndarray of CptStepstat, status int32[nk])"""
+        k = np.ascontiguousarray(self.inp.k if k is None else k, dtype=np.float64)
+        tau = np.ascontiguousarray(self.inp.tau if tau is None else tau, dtype=np.float64)
+        nk, ntau = k.size, tau.size
+        out = None
+        ptr = None
+        if want_sources:
+            out = torch.empty((self.inp.config.tp_size, ntau, nk), dtype=torch.float64, device=self.device)
+            ptr = C.c_void_p(out.data_ptr())
+        stats = (CptStepstat * nk)()
+        status = np.zeros(nk, dtype=np.int32)
+        rc = self.lib.cpt_perturb_solve_batch(self.h, _dptr(k), nk, _dptr(tau), ntau, ptr, stats, _iptr(status))
+        self._check(rc)
+        return out, stats, status
+
+    # ---- hot path B ----
+    def transfer(self, sources=None, k=None, tau=None, q=None, l=None, k_size_cl=None):
+        """sources: torch f64 device tensor [tp][ntau][nk] (reference layout) or None (use resident sources).
+        -> transfer [tt][nl][nq] torch f64 on device"""
+        k = np.ascontiguousarray(self.inp.k if k is None else k, dtype=np.float64)
+        tau = np.ascontiguousarray(self.inp.tau if tau is None else tau, dtype=np.float64)
+        q = np.ascontiguousarray(self.inp.q if q is None else q, dtype=np.float64)
+        l = np.ascontiguousarray(self.inp.l if l is None else l, dtype=np.int32)
+        k_size_cl = self.inp.k_size_cl if k_size_cl is None else k_size_cl
+        sp = None
+        if sources is not None:
+            assert sources.is_cuda and sources.dtype == torch.float64 and sources.is_contiguous()
+            assert tuple(sources.shape) == (self.inp.config.tp_size, tau.size, k.size), sources.shape
+            sp = C.c_void_p(sources.data_ptr())
+        out = torch.empty((self.inp.config.tt_size, l.size, q.size), dtype=torch.float64, device=self.device)
+        rc = self.lib.cpt_transfer_batch(self.h, sp, _dptr(k), k.size, k_size_cl, _dptr(tau), tau.size, _dptr(q), q.size,
+                                         _iptr(l), l.size, C.c_void_p(out.data_ptr()))
+        self._check(rc)
+        return out
+
+    def get_sources(self, ntau, nk):
+        out = torch.empty((self.inp.config.tp_size, ntau, nk), dtype=torch.float64, device=self.device)
+        self._check(self.lib.cpt_get_sources(self.h, C.c_void_p(out.data_ptr())))
+        return out
+
+    def kernel_ms(self, stage):
+        ms, n = C.c_double(), C.c_int()
+        self._check(self.lib.cpt_last_kernel_ms(self.h, stage, C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
+    def transfer_work(self):
+        a, b, c = C.c_longlong(), C.c_longlong(), C.c_longlong()
+        self._check(self.lib.cpt_last_transfer_work(self.h, C.byref(a), C.byref(b), C.byref(c)))
+        return a.value, b.value, c.value
+
+    # ---- unit-test hooks ----
+    def dbg_bessel(self, l, xmax, cap_nx=20000):
+        l = np.ascontiguousarray(l, dtype=np.int32)
+        nx = C.c_int()
+        phi = np.zeros((l.size, cap_nx))
+        dphi = np.zeros((l.size, cap_nx))
+        chi = np.zeros(l.size)
+        self._check(self.lib.cpt_dbg_bessel(self.h, _iptr(l), l.size, float(xmax), C.byref(nx), _dptr(phi), _dptr(dphi),
+                                            _dptr(chi), cap_nx))
+        n = nx.value
+        return phi.reshape(-1)[: l.size * n].reshape(l.size, n), dphi.reshape(-1)[: l.size * n].reshape(l.size, n), chi
+
+    def dbg_lookup(self, tau):
+        tau = np.ascontiguousarray(tau, dtype=np.float64)
+        out = np.zeros((tau.size, 16))
+        self._check(self.lib.cpt_dbg_lookup(self.h, _dptr(tau), tau.size, _dptr(out)))
+        return out
+
+    def dbg_derivs(self, k, tau, tca_on, rsa_on, ufa_on, y):
+        y = np.ascontiguousarray(y, dtype=np.float64)
+        dy = np.zeros(64)
+        neq = C.c_int()
+        self._check(self.lib.cpt_dbg_derivs(self.h, float(k), float(tau), int(tca_on), int(rsa_on), int(ufa_on), _dptr(y),
+                                            _dptr(dy), C.byref(neq)))
+        return dy[: neq.value].copy()

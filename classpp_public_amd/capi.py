@@ -1,0 +1,118 @@
+"""ctypes mirror of include/cpt.h (the C ABI of the backend) and loader of the in-tree HIP library.
+
+The product path: Python -> ctypes -> classpp_public_amd/csrc/libcpt.so (hand-written HIP for gfx950).
+There is no CPU fallback: if the shared library is missing, importing `lib()` raises.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libcpt.so")
+
+CPT_OK, CPT_ERR_INVALID, CPT_ERR_RUNTIME, CPT_ERR_NO_DEVICE, CPT_ERR_UNSUPPORTED = 0, 1, 2, 3, 4
+
+_d, _i = C.c_double, C.c_int
+
+
+class CptConfig(C.Structure):
+    """struct cpt_config (include/cpt.h) -- field order must match exactly."""
+    _fields_ = [
+        ("H0", _d), ("K", _d), ("sgnK", _i),
+        ("has_cdm", _i), ("has_ur", _i), ("has_ncdm", _i), ("has_fld", _i), ("has_curvature", _i),
+        ("T_cmb", _d), ("a_today", _d),
+        ("YHe", _d), ("n_e", _d), ("tau0", _d), ("tau_rec", _d), ("tau_free_streaming", _d), ("tau_cut", _d),
+        ("angular_rescaling", _d),
+        ("gauge", _i),
+        ("switch_sw", _i), ("switch_eisw", _i), ("switch_lisw", _i), ("switch_dop", _i), ("switch_pol", _i),
+        ("eisw_lisw_split_z", _d), ("three_ceff2_ur", _d), ("three_cvis2_ur", _d),
+        ("tp_size", _i),
+        ("index_tp_t0", _i), ("index_tp_t1", _i), ("index_tp_t2", _i), ("index_tp_p", _i),
+        ("index_tp_delta_m", _i), ("index_tp_phi_plus_psi", _i),
+        ("start_small_k_at_tau_c_over_tau_h", _d), ("start_large_k_at_tau_h_over_tau_k", _d),
+        ("tight_coupling_trigger_tau_c_over_tau_h", _d), ("tight_coupling_trigger_tau_c_over_tau_k", _d),
+        ("tight_coupling_approximation", _i),
+        ("radiation_streaming_approximation", _i), ("radiation_streaming_trigger_tau_over_tau_k", _d),
+        ("ur_fluid_approximation", _i), ("ur_fluid_trigger_tau_over_tau_k", _d),
+        ("l_max_g", _i), ("l_max_pol_g", _i), ("l_max_ur", _i),
+        ("curvature_ini", _d),
+        ("tol_perturb_integration", _d), ("tol_tau_approx", _d), ("smallest_allowed_variation", _d),
+        ("tt_size", _i),
+        ("index_tt_t0", _i), ("index_tt_t1", _i), ("index_tt_t2", _i), ("index_tt_e", _i), ("index_tt_lcmb", _i),
+        ("lcmb_rescale", _d), ("lcmb_tilt", _d), ("lcmb_pivot", _d),
+        ("hyper_x_min", _d), ("hyper_sampling_flat", _d), ("hyper_phi_min_abs", _d),
+        ("transfer_neglect_delta_k_S_t0", _d), ("transfer_neglect_delta_k_S_t1", _d),
+        ("transfer_neglect_delta_k_S_t2", _d), ("transfer_neglect_delta_k_S_e", _d),
+        ("transfer_neglect_late_source", _d), ("l_switch_limber", _d),
+    ]
+
+
+_pd = C.POINTER(_d)
+
+
+class CptTables(C.Structure):
+    """struct cpt_tables (include/cpt.h)."""
+    _fields_ = [
+        ("bt_size", _i), ("bg_size", _i),
+        ("tau_table", _pd), ("background_table", _pd), ("d2background_dtau2_table", _pd),
+        ("index_bg_a", _i), ("index_bg_H", _i), ("index_bg_H_prime", _i), ("index_bg_rho_g", _i),
+        ("index_bg_rho_b", _i), ("index_bg_rho_cdm", _i), ("index_bg_rho_ur", _i),
+        ("tt_size", _i), ("th_size", _i),
+        ("z_table", _pd), ("thermodynamics_table", _pd), ("d2thermodynamics_dz2_table", _pd),
+        ("index_th_xe", _i), ("index_th_dkappa", _i), ("index_th_tau_d", _i), ("index_th_ddkappa", _i),
+        ("index_th_dddkappa", _i), ("index_th_exp_m_kappa", _i), ("index_th_g", _i), ("index_th_dg", _i),
+        ("index_th_cb2", _i),
+    ]
+
+
+class CptStepstat(C.Structure):
+    _fields_ = [("steps", _i), ("failed", _i), ("fevals", _i), ("jacobians", _i), ("factorisations", _i),
+                ("solves", _i), ("n_regimes", _i), ("tau_ini", _d)]
+
+
+# every symbol include/cpt.h declares (tests check that the built library exports all of them)
+EXPORTS = [
+    "cpt_create", "cpt_destroy", "cpt_last_error", "cpt_create_error", "cpt_perturb_solve_batch",
+    "cpt_transfer_batch", "cpt_get_sources", "cpt_last_kernel_ms", "cpt_last_transfer_work",
+    "cpt_dbg_lookup", "cpt_dbg_derivs", "cpt_dbg_bessel",
+]
+
+_lib = None
+
+
+def lib():
+    """Load libcpt.so (built in-tree by __graft_entry__.build()). Fails loudly when it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            "HIP extension %s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(there is no CPU fallback for the product path)" % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    vp, pi, ll = C.c_void_p, C.POINTER(_i), C.POINTER(C.c_longlong)
+    L.cpt_create.argtypes = [C.POINTER(CptConfig), C.POINTER(CptTables), C.POINTER(vp)]
+    L.cpt_create.restype = _i
+    L.cpt_destroy.argtypes = [vp]
+    L.cpt_destroy.restype = None
+    L.cpt_last_error.argtypes = [vp]
+    L.cpt_last_error.restype = C.c_char_p
+    L.cpt_create_error.argtypes = []
+    L.cpt_create_error.restype = C.c_char_p
+    L.cpt_perturb_solve_batch.argtypes = [vp, _pd, _i, _pd, _i, vp, C.POINTER(CptStepstat), pi]
+    L.cpt_perturb_solve_batch.restype = _i
+    L.cpt_transfer_batch.argtypes = [vp, vp, _pd, _i, _i, _pd, _i, _pd, _i, pi, _i, vp]
+    L.cpt_transfer_batch.restype = _i
+    L.cpt_get_sources.argtypes = [vp, vp]
+    L.cpt_get_sources.restype = _i
+    L.cpt_last_kernel_ms.argtypes = [vp, _i, _pd, pi]
+    L.cpt_last_kernel_ms.restype = _i
+    L.cpt_last_transfer_work.argtypes = [vp, ll, ll, ll]
+    L.cpt_last_transfer_work.restype = _i
+    L.cpt_dbg_lookup.argtypes = [vp, _pd, _i, _pd]
+    L.cpt_dbg_lookup.restype = _i
+    L.cpt_dbg_derivs.argtypes = [vp, _d, _d, _i, _i, _i, _pd, _pd, pi]
+    L.cpt_dbg_derivs.restype = _i
+    L.cpt_dbg_bessel.argtypes = [vp, pi, _i, _d, pi, _pd, _pd, _pd, _i]
+    L.cpt_dbg_bessel.restype = _i
+    _lib = L
+    return L

@@ -1,0 +1,245 @@
+// libcpt.so -- C ABI (include/cpt.h): handle life cycle, error reporting, table upload, layout transposes.
+// The two batched stages live in cpt_perturb.hip (hot path A) and cpt_transfer.hip (hot path B).
+#include "cpt_internal.h"
+
+static thread_local std::string g_create_err;
+
+int cpt_fail(cpt_handle* h, int code, const char* fmt, ...) {
+  char buf[2048];  // same size as the reference's ErrorMsg (include/common.h)
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  if (h)
+    h->err = buf;
+  else
+    g_create_err = buf;
+  return code;
+}
+
+// ---------------------------------------------------------------------------------------------
+// layout transposes between the reference's [tp][tau][k] and the resident k-major [tp][k][tau]
+// (tile through LDS so that both the read and the write are coalesced)
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_transpose(const double* __restrict__ in, double* __restrict__ out, int rows,
+                                                   int cols) {
+  // in: [batch][rows][cols] -> out: [batch][cols][rows]; 32x32 tiles, +1 padding against bank conflicts
+  __shared__ double tile[32][33];
+  const size_t base = (size_t)blockIdx.z * rows * cols;
+  int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+  int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  for (int j = ty; j < 32; j += 8) {
+    int r = r0 + j, c = c0 + tx;
+    if (r < rows && c < cols) tile[j][tx] = in[base + (size_t)r * cols + c];
+  }
+  __syncthreads();
+  for (int j = ty; j < 32; j += 8) {
+    int c = c0 + j, r = r0 + tx;
+    if (r < rows && c < cols) out[base + (size_t)c * rows + r] = tile[tx][j];
+  }
+}
+
+static int launch_transpose(cpt_handle* h, const double* in, double* out, int batch, int rows, int cols) {
+  dim3 grid((cols + 31) / 32, (rows + 31) / 32, batch);
+  hipLaunchKernelGGL(k_transpose, grid, dim3(256), 0, h->stream, in, out, rows, cols);
+  CPT_HIP(h, hipGetLastError());
+  return CPT_OK;
+}
+
+int cpt_transpose_to_kmajor(cpt_handle* h, const double* src, double* dst, int ntp, int ntau, int nk) {
+  return launch_transpose(h, src, dst, ntp, ntau, nk);
+}
+int cpt_transpose_from_kmajor(cpt_handle* h, const double* src, double* dst, int ntp, int ntau, int nk) {
+  return launch_transpose(h, src, dst, ntp, nk, ntau);
+}
+
+// ---------------------------------------------------------------------------------------------
+static int validate(const cpt_config* c) {
+  // physics branches of the reference that this backend does not implement (SURVEY.md S8f "not planned"/later)
+  if (c->sgnK != 0 || c->K != 0. || c->has_curvature)
+    return cpt_fail(nullptr, CPT_ERR_UNSUPPORTED, "non-flat space (K=%g) is not implemented by this backend", c->K);
+  if (c->has_ncdm) return cpt_fail(nullptr, CPT_ERR_UNSUPPORTED, "non-cold dark matter species are not implemented");
+  if (c->has_fld) return cpt_fail(nullptr, CPT_ERR_UNSUPPORTED, "dark-energy fluid perturbations are not implemented");
+  if (!c->has_cdm && c->gauge == CPT_GAUGE_SYNCHRONOUS)
+    return cpt_fail(nullptr, CPT_ERR_INVALID,
+                    "synchronous gauge needs cdm (the reference rejects this too, perturbations_module.cpp:560)");
+  if (c->gauge != CPT_GAUGE_SYNCHRONOUS)
+    return cpt_fail(nullptr, CPT_ERR_UNSUPPORTED, "only the synchronous gauge is implemented");
+  if (c->tight_coupling_approximation != CPT_TCA_COMPROMISE_CLASS &&
+      c->tight_coupling_approximation != CPT_TCA_FIRST_ORDER_CAMB)
+    return cpt_fail(nullptr, CPT_ERR_UNSUPPORTED, "tight_coupling_approximation=%d is not implemented",
+                    c->tight_coupling_approximation);
+  if (c->l_max_g < 4 || c->l_max_pol_g < 4 || (c->has_ur && c->l_max_ur < 4))
+    return cpt_fail(nullptr, CPT_ERR_INVALID, "l_max_g, l_max_pol_g, l_max_ur must be at least 4 (pm.cpp:3302-3330)");
+  if (3 + c->l_max_g - 2 + 3 + c->l_max_pol_g - 2 + 3 + (c->has_ur ? 3 + c->l_max_ur - 2 : 0) + 1 > CPT_WAVE)
+    return cpt_fail(nullptr, CPT_ERR_UNSUPPORTED,
+                    "hierarchy too large: one wavefront (64 lanes) owns one k-mode, need neq <= 64");
+  if (c->tp_size < 1 || c->tp_size > 8) return cpt_fail(nullptr, CPT_ERR_INVALID, "tp_size=%d out of range", c->tp_size);
+  const int tps[6] = {c->index_tp_t0, c->index_tp_t1, c->index_tp_t2, c->index_tp_p, c->index_tp_delta_m,
+                      c->index_tp_phi_plus_psi};
+  for (int i = 0; i < 6; i++)
+    if (tps[i] >= c->tp_size) return cpt_fail(nullptr, CPT_ERR_INVALID, "index_tp_* >= tp_size");
+  return CPT_OK;
+}
+
+extern "C" {
+
+const char* cpt_create_error(void) { return g_create_err.c_str(); }
+const char* cpt_last_error(const cpt_handle* h) { return h ? h->err.c_str() : ""; }
+
+int cpt_create(const cpt_config* cfg, const cpt_tables* t, cpt_handle** out) {
+  if (!cfg || !t || !out) return cpt_fail(nullptr, CPT_ERR_INVALID, "null argument");
+  *out = nullptr;
+  int rc = validate(cfg);
+  if (rc) return rc;
+  if (t->bt_size < 2 || t->tt_size < 2 || !t->tau_table || !t->background_table || !t->d2background_dtau2_table ||
+      !t->z_table || !t->thermodynamics_table || !t->d2thermodynamics_dz2_table)
+    return cpt_fail(nullptr, CPT_ERR_INVALID, "incomplete spline tables");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
+    return cpt_fail(nullptr, CPT_ERR_NO_DEVICE, "no HIP device available (this backend has no CPU fallback)");
+  cpt_handle* h = new cpt_handle();
+  h->cfg = *cfg;
+  auto bail = [&](int code) {
+    g_create_err = h->err;
+    cpt_destroy(h);
+    return code;
+  };
+  if (hipGetDevice(&h->device) != hipSuccess) return bail(cpt_fail(h, CPT_ERR_NO_DEVICE, "hipGetDevice failed"));
+  if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess)
+    return bail(cpt_fail(h, CPT_ERR_NO_DEVICE, "hipStreamCreate failed"));
+
+  // pack the columns the path reads, value / second derivative interleaved (see cpt_internal.h)
+  const int bgmap[BG_NCOL] = {t->index_bg_a,     t->index_bg_H,       t->index_bg_H_prime, t->index_bg_rho_g,
+                              t->index_bg_rho_b, t->index_bg_rho_cdm, t->index_bg_rho_ur};
+  const int thmap[TH_NCOL] = {t->index_th_xe,       t->index_th_dkappa,      t->index_th_tau_d,
+                              t->index_th_ddkappa,  t->index_th_dddkappa,    t->index_th_exp_m_kappa,
+                              t->index_th_g,        t->index_th_dg,          t->index_th_cb2};
+  std::vector<double> bg((size_t)t->bt_size * BG_NCOL * 2), th((size_t)t->tt_size * TH_NCOL * 2);
+  for (int r = 0; r < t->bt_size; r++)
+    for (int c = 0; c < BG_NCOL; c++) {
+      bool have = bgmap[c] >= 0 && bgmap[c] < t->bg_size;
+      bg[((size_t)r * BG_NCOL + c) * 2 + 0] = have ? t->background_table[(size_t)r * t->bg_size + bgmap[c]] : 0.;
+      bg[((size_t)r * BG_NCOL + c) * 2 + 1] = have ? t->d2background_dtau2_table[(size_t)r * t->bg_size + bgmap[c]] : 0.;
+    }
+  for (int r = 0; r < t->tt_size; r++)
+    for (int c = 0; c < TH_NCOL; c++) {
+      bool have = thmap[c] >= 0 && thmap[c] < t->th_size;
+      th[((size_t)r * TH_NCOL + c) * 2 + 0] = have ? t->thermodynamics_table[(size_t)r * t->th_size + thmap[c]] : 0.;
+      th[((size_t)r * TH_NCOL + c) * 2 + 1] = have ? t->d2thermodynamics_dz2_table[(size_t)r * t->th_size + thmap[c]] : 0.;
+    }
+  auto up = [&](double** d, const double* src, size_t n) -> bool {
+    if (hipMalloc((void**)d, n * sizeof(double)) != hipSuccess) return false;
+    return hipMemcpy(*d, src, n * sizeof(double), hipMemcpyHostToDevice) == hipSuccess;
+  };
+  if (!up(&h->d_tau_table, t->tau_table, t->bt_size) || !up(&h->d_bg, bg.data(), bg.size()) ||
+      !up(&h->d_z_table, t->z_table, t->tt_size) || !up(&h->d_th, th.data(), th.size()))
+    return bail(cpt_fail(h, CPT_ERR_NO_DEVICE, "table upload failed"));
+  h->tabs.bt_size = t->bt_size;
+  h->tabs.tt_size = t->tt_size;
+  h->tabs.tau_table = h->d_tau_table;
+  h->tabs.bg = h->d_bg;
+  h->tabs.z_table = h->d_z_table;
+  h->tabs.th = h->d_th;
+  if (hipMalloc((void**)&h->d_work, 4 * sizeof(unsigned long long)) != hipSuccess)
+    return bail(cpt_fail(h, CPT_ERR_NO_DEVICE, "hipMalloc failed"));
+  for (Timer* tm : {&h->t_perturb, &h->t_transfer}) {
+    if (hipEventCreate(&tm->a) != hipSuccess || hipEventCreate(&tm->b) != hipSuccess)
+      return bail(cpt_fail(h, CPT_ERR_NO_DEVICE, "hipEventCreate failed"));
+  }
+  *out = h;
+  return CPT_OK;
+}
+
+void cpt_destroy(cpt_handle* h) {
+  if (!h) return;
+  void* ptrs[] = {h->d_tau_table, h->d_bg, h->d_z_table, h->d_th, h->d_src, h->d_dd, h->d_u, h->d_k, h->d_tau, h->d_q,
+                  h->d_splc, h->d_l, h->d_ik, h->d_bes, h->d_chi_min, h->d_work, h->d_pt_scratch};
+  for (void* p : ptrs)
+    if (p) (void)hipFree(p);
+  for (Timer* tm : {&h->t_perturb, &h->t_transfer}) {
+    if (tm->a) (void)hipEventDestroy(tm->a);
+    if (tm->b) (void)hipEventDestroy(tm->b);
+  }
+  if (h->stream) (void)hipStreamDestroy(h->stream);
+  delete h;
+}
+
+int cpt_perturb_solve_batch(cpt_handle* h, const double* k, int nk, const double* tau_sampling, int ntau,
+                            double* sources_dev, cpt_stepstat* stats, int* status) {
+  if (!h) return CPT_ERR_INVALID;
+  h->err.clear();
+  if (!k || !tau_sampling || nk < 1 || ntau < 2) return cpt_fail(h, CPT_ERR_INVALID, "bad k / tau_sampling arguments");
+  return cpt_perturb_impl(h, k, nk, tau_sampling, ntau, sources_dev, stats, status);
+}
+
+int cpt_transfer_batch(cpt_handle* h, const double* sources_dev, const double* k, int nk, int k_size_cl,
+                       const double* tau_sampling, int ntau, const double* q, int nq, const int* l, int nl,
+                       double* transfer_dev) {
+  if (!h) return CPT_ERR_INVALID;
+  h->err.clear();
+  if (!k || !tau_sampling || !q || !l || !transfer_dev || nk < 3 || ntau < 3 || nq < 1 || nl < 1 || k_size_cl < 1 ||
+      k_size_cl > nk)
+    return cpt_fail(h, CPT_ERR_INVALID, "bad arguments to cpt_transfer_batch");
+  if (h->cfg.tt_size < 1 || h->cfg.tt_size > 5) return cpt_fail(h, CPT_ERR_INVALID, "tt_size=%d out of range", h->cfg.tt_size);
+  return cpt_transfer_impl(h, sources_dev, k, nk, k_size_cl, tau_sampling, ntau, q, nq, l, nl, transfer_dev);
+}
+
+int cpt_get_sources(cpt_handle* h, double* sources_dev) {
+  if (!h) return CPT_ERR_INVALID;
+  h->err.clear();
+  if (!h->d_src || !h->src_nk) return cpt_fail(h, CPT_ERR_INVALID, "no resident sources: run cpt_perturb_solve_batch first");
+  int rc = cpt_transpose_from_kmajor(h, h->d_src, sources_dev, h->cfg.tp_size, h->src_ntau, h->src_nk);
+  if (rc) return rc;
+  CPT_HIP(h, hipStreamSynchronize(h->stream));
+  return CPT_OK;
+}
+
+int cpt_last_kernel_ms(const cpt_handle* h, int stage, double* ms, int* launches) {
+  if (!h || !ms || !launches) return CPT_ERR_INVALID;
+  const Timer& t = stage == 0 ? h->t_perturb : h->t_transfer;
+  *ms = t.ms;
+  *launches = t.launches;
+  return CPT_OK;
+}
+
+int cpt_last_transfer_work(const cpt_handle* h, long long* integrals, long long* type_samples, long long* fused_samples) {
+  if (!h || !integrals || !type_samples || !fused_samples) return CPT_ERR_INVALID;
+  *integrals = h->work_integrals;
+  *type_samples = h->work_samples;
+  *fused_samples = h->work_fused;
+  return CPT_OK;
+}
+
+int cpt_dbg_lookup(cpt_handle* h, const double* tau, int n, double* out) {
+  if (!h) return CPT_ERR_INVALID;
+  h->err.clear();
+  return cpt_dbg_lookup_impl(h, tau, n, out);
+}
+
+int cpt_dbg_derivs(cpt_handle* h, double k, double tau, int tca_on, int rsa_on, int ufa_on, const double* y, double* dy,
+                   int* neq) {
+  if (!h) return CPT_ERR_INVALID;
+  h->err.clear();
+  return cpt_dbg_derivs_impl(h, k, tau, tca_on, rsa_on, ufa_on, y, dy, neq);
+}
+
+int cpt_dbg_bessel(cpt_handle* h, const int* l, int nl, double xmax, int* nx, double* phi, double* dphi,
+                   double* chi_at_phimin, int cap_nx) {
+  if (!h) return CPT_ERR_INVALID;
+  h->err.clear();
+  int rc = cpt_bessel_build(h, l, nl, xmax);
+  if (rc) return rc;
+  *nx = h->bes_nx;
+  if (h->bes_nx > cap_nx) return cpt_fail(h, CPT_ERR_INVALID, "cap_nx=%d too small for nx=%d", cap_nx, h->bes_nx);
+  std::vector<double2> tmp((size_t)nl * h->bes_nx);
+  CPT_HIP(h, hipMemcpy(tmp.data(), h->d_bes, tmp.size() * sizeof(double2), hipMemcpyDeviceToHost));
+  for (size_t i = 0; i < tmp.size(); i++) {
+    phi[i] = tmp[i].x;
+    dphi[i] = tmp[i].y;
+  }
+  CPT_HIP(h, hipMemcpy(chi_at_phimin, h->d_chi_min, nl * sizeof(double), hipMemcpyDeviceToHost));
+  return CPT_OK;
+}
+
+}  // extern "C"

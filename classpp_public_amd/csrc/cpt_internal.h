@@ -1,0 +1,102 @@
+// Internal definitions shared by the HIP translation units of libcpt.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/cpt.h"
+
+#define CPT_WAVE 64
+
+// Compact spline tables in HBM: only the columns the RHS / sampler read, one row contiguous,
+// value and second derivative interleaved: row r = { y[0], y''[0], y[1], y''[1], ... }.
+// background columns (reference: background_at_tau normal_info, source/background_module.cpp:125-199)
+enum { BG_A = 0, BG_H, BG_HP, BG_RHO_G, BG_RHO_B, BG_RHO_CDM, BG_RHO_UR, BG_NCOL };
+// thermodynamics columns (reference: thermodynamics_at_z, source/thermodynamics_module.cpp:114-285)
+enum { TH_XE = 0, TH_DKAPPA, TH_TAU_D, TH_DDKAPPA, TH_DDDKAPPA, TH_EXPMK, TH_G, TH_DG, TH_CB2, TH_NCOL };
+
+struct DevTables {
+  int bt_size, tt_size;
+  const double* tau_table;  // [bt_size]
+  const double* bg;         // [bt_size][BG_NCOL][2]
+  const double* z_table;    // [tt_size] ascending z
+  const double* th;         // [tt_size][TH_NCOL][2]
+};
+
+struct Timer {
+  hipEvent_t a = nullptr, b = nullptr;
+  double ms = 0;
+  int launches = 0;
+};
+
+struct cpt_handle {
+  cpt_config cfg;
+  int device = 0;
+  hipStream_t stream = nullptr;
+  std::string err;
+  // tables
+  DevTables tabs{};
+  double *d_tau_table = nullptr, *d_bg = nullptr, *d_z_table = nullptr, *d_th = nullptr;
+  // resident sources, k-major [tp][nk][ntau], left by the last perturb call or a transposed upload
+  double* d_src = nullptr;
+  size_t src_cap = 0;
+  int src_nk = 0, src_ntau = 0;
+  // transfer scratch
+  double *d_dd = nullptr, *d_u = nullptr;  // spline second derivative + scratch, same shape as d_src
+  size_t dd_cap = 0;
+  double *d_k = nullptr, *d_tau = nullptr, *d_q = nullptr, *d_splc = nullptr;
+  int *d_l = nullptr, *d_ik = nullptr;
+  size_t grid_cap_k = 0, grid_cap_tau = 0, grid_cap_q = 0, grid_cap_l = 0;
+  // Bessel table cache
+  double2* d_bes = nullptr;  // [nl][nx] {phi, dphi}
+  double* d_chi_min = nullptr;
+  size_t bes_cap = 0;
+  std::vector<int> bes_l;
+  double bes_xmax = -1;
+  int bes_nx = 0;
+  double bes_dx = 0;
+  unsigned long long* d_work = nullptr;  // [3] integrals, per-type samples, fused samples
+  long long work_integrals = 0, work_samples = 0, work_fused = 0;
+  // perturb scratch
+  void* d_pt_scratch = nullptr;
+  size_t pt_scratch_cap = 0;
+  Timer t_perturb, t_transfer;
+};
+
+int cpt_fail(cpt_handle* h, int code, const char* fmt, ...);
+
+#define CPT_HIP(h, call)                                                                         \
+  do {                                                                                           \
+    hipError_t e__ = (call);                                                                     \
+    if (e__ != hipSuccess)                                                                       \
+      return cpt_fail(h, CPT_ERR_NO_DEVICE, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e__), __FILE__, \
+                      __LINE__);                                                                 \
+  } while (0)
+
+template <class T>
+int cpt_reserve(cpt_handle* h, T** p, size_t* cap, size_t n) {
+  if (*cap >= n && *p) return CPT_OK;
+  if (*p) (void)hipFree(*p);
+  *p = nullptr;
+  *cap = 0;
+  CPT_HIP(h, hipMalloc((void**)p, n * sizeof(T)));
+  *cap = n;
+  return CPT_OK;
+}
+
+// stage entry points implemented in the other translation units
+int cpt_transfer_impl(cpt_handle* h, const double* sources_dev, const double* k, int nk, int k_size_cl,
+                      const double* tau_sampling, int ntau, const double* q, int nq, const int* l, int nl,
+                      double* transfer_dev);
+int cpt_bessel_build(cpt_handle* h, const int* l, int nl, double xmax);
+int cpt_perturb_impl(cpt_handle* h, const double* k, int nk, const double* tau_sampling, int ntau, double* sources_dev,
+                     cpt_stepstat* stats, int* status);
+int cpt_dbg_lookup_impl(cpt_handle* h, const double* tau, int n, double* out);
+int cpt_dbg_derivs_impl(cpt_handle* h, double k, double tau, int tca_on, int rsa_on, int ufa_on, const double* y,
+                        double* dy, int* neq);
+int cpt_transpose_to_kmajor(cpt_handle* h, const double* src_ref_layout, double* dst, int ntp, int ntau, int nk);
+int cpt_transpose_from_kmajor(cpt_handle* h, const double* src_kmajor, double* dst_ref_layout, int ntp, int ntau, int nk);

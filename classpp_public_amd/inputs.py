@@ -1,0 +1,105 @@
+"""Hot-path inputs for a named configuration.
+
+The backend's inputs (background / thermodynamics spline tables, k / tau / q / l grids, precision and physics
+parameters) are deterministic functions of an .ini, produced in the reference by modules that sit UPSTREAM of the
+hot path (InputModule, BackgroundModule, ThermodynamicsModule; SURVEY.md S2 marks them out of scope).  Until the
+backend has its own background + RECFAST they come from the committed fixtures tests/golden/*.npz,
+which were dumped from the unmodified reference by oracle/make_fixtures.py.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from .capi import CptConfig, CptTables
+
+GOLDEN = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+
+
+def _s(d, key):
+    v = d[key]
+    return v.reshape(-1)[0]
+
+
+class Inputs:
+    """config + tables + grids for one configuration (`small`, `lcdm`, `explanatory`)."""
+
+    def __init__(self, name, golden_dir=GOLDEN):
+        self.name = name
+        self.d = dict(np.load(os.path.join(golden_dir, name + ".npz")))
+        self.t = dict(np.load(os.path.join(golden_dir, "tables_lcdm.npz")))
+        d, t = self.d, self.t
+        c = CptConfig()
+        c.H0 = _s(d, "pba.H0"); c.K = _s(d, "pba.K"); c.sgnK = int(_s(d, "pba.sgnK"))
+        c.has_cdm = int(_s(d, "pba.has_cdm")); c.has_ur = int(_s(d, "pba.has_ur"))
+        c.has_ncdm = int(_s(d, "pba.has_ncdm")); c.has_fld = int(_s(d, "pba.has_fld"))
+        c.has_curvature = int(_s(d, "pba.has_curvature"))
+        c.T_cmb = _s(d, "pba.T_cmb"); c.a_today = _s(d, "pba.a_today")
+        c.YHe = _s(t, "th.YHe"); c.n_e = _s(t, "th.n_e"); c.tau0 = _s(t, "bg.conformal_age")
+        c.tau_rec = _s(t, "th.tau_rec"); c.tau_free_streaming = _s(t, "th.tau_free_streaming")
+        c.tau_cut = _s(t, "th.tau_cut"); c.angular_rescaling = _s(t, "th.angular_rescaling")
+        c.gauge = int(_s(d, "ppt.gauge"))
+        for f in ("switch_sw", "switch_eisw", "switch_lisw", "switch_dop", "switch_pol"):
+            setattr(c, f, int(_s(d, "ppt." + f)))
+        c.eisw_lisw_split_z = _s(d, "ppt.eisw_lisw_split_z")
+        c.three_ceff2_ur = _s(d, "ppt.three_ceff2_ur"); c.three_cvis2_ur = _s(d, "ppt.three_cvis2_ur")
+        c.tp_size = int(_s(d, "pt.tp_size"))
+        for f in ("t0", "t1", "t2", "p", "delta_m", "phi_plus_psi"):
+            setattr(c, "index_tp_" + f, int(_s(d, "pt.index_tp_" + f)))
+        for f in ("start_small_k_at_tau_c_over_tau_h", "start_large_k_at_tau_h_over_tau_k",
+                  "tight_coupling_trigger_tau_c_over_tau_h", "tight_coupling_trigger_tau_c_over_tau_k",
+                  "radiation_streaming_trigger_tau_over_tau_k", "ur_fluid_trigger_tau_over_tau_k", "curvature_ini",
+                  "tol_perturb_integration", "tol_tau_approx", "smallest_allowed_variation",
+                  "hyper_x_min", "hyper_sampling_flat", "hyper_phi_min_abs",
+                  "transfer_neglect_delta_k_S_t0", "transfer_neglect_delta_k_S_t1",
+                  "transfer_neglect_delta_k_S_t2", "transfer_neglect_delta_k_S_e",
+                  "transfer_neglect_late_source", "l_switch_limber"):
+            setattr(c, f, float(_s(d, "ppr." + f)))
+        for f in ("tight_coupling_approximation", "radiation_streaming_approximation", "ur_fluid_approximation",
+                  "l_max_g", "l_max_pol_g", "l_max_ur"):
+            setattr(c, f, int(_s(d, "ppr." + f)))
+        self.has_cls = "tr.q" in d
+        if self.has_cls:
+            c.tt_size = int(_s(d, "tr.tt_size"))
+            for f in ("t0", "t1", "t2", "e", "lcmb"):
+                setattr(c, "index_tt_" + f, int(_s(d, "tr.index_tt_" + f)))
+        c.lcmb_rescale = _s(d, "ptr.lcmb_rescale"); c.lcmb_tilt = _s(d, "ptr.lcmb_tilt")
+        c.lcmb_pivot = _s(d, "ptr.lcmb_pivot")
+        self.config = c
+
+        # tables (keep numpy arrays alive: the struct only holds raw pointers)
+        self._keep = []
+
+        def ptr(a):
+            a = np.ascontiguousarray(a, dtype=np.float64)
+            self._keep.append(a)
+            return a.ctypes.data_as(C.POINTER(C.c_double))
+
+        tb = CptTables()
+        tb.bt_size = int(_s(t, "bg.bt_size")); tb.bg_size = int(_s(t, "bg.bg_size"))
+        tb.tau_table = ptr(t["bg.tau_table"]); tb.background_table = ptr(t["bg.background_table"])
+        tb.d2background_dtau2_table = ptr(t["bg.d2background_dtau2_table"])
+        for f in ("a", "H", "H_prime", "rho_g", "rho_b", "rho_cdm", "rho_ur"):
+            setattr(tb, "index_bg_" + f, int(_s(t, "bg.index_bg_" + f)))
+        tb.tt_size = int(_s(t, "th.tt_size")); tb.th_size = int(_s(t, "th.th_size"))
+        tb.z_table = ptr(t["th.z_table"]); tb.thermodynamics_table = ptr(t["th.thermodynamics_table"])
+        tb.d2thermodynamics_dz2_table = ptr(t["th.d2thermodynamics_dz2_table"])
+        for f in ("xe", "dkappa", "tau_d", "ddkappa", "dddkappa", "exp_m_kappa", "g", "dg", "cb2"):
+            setattr(tb, "index_th_" + f, int(_s(t, "th.index_th_" + f)))
+        self.tables = tb
+
+        # grids
+        self.k = np.ascontiguousarray(d["pt.k"], dtype=np.float64)
+        self.k_size_cl = int(_s(d, "pt.k_size_cl"))
+        self.tau = np.ascontiguousarray(d["pt.tau_sampling"], dtype=np.float64)
+        if self.has_cls:
+            self.q = np.ascontiguousarray(d["tr.q"], dtype=np.float64)
+            self.l = np.ascontiguousarray(d["tr.l"], dtype=np.int32)
+
+    @property
+    def nk(self):
+        return self.k.size
+
+    @property
+    def ntau(self):
+        return self.tau.size

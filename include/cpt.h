@@ -1,0 +1,192 @@
+/* cpt.h -- C ABI of the MI355X-native perturbations -> transfer backend ("cpt").
+ *
+ * This is the drop-in boundary for ONE hot path of CLASS++ (AarhusCosmology/CLASSpp_public):
+ *   - the per-k stiff ODE integration of PerturbationsModule (loop body at
+ *     source/perturbations_module.cpp:668-718, i.e. perturb_solve :2463-2787 driving tools/evolver_ndf15.cpp:62-705)
+ *   - the line-of-sight Bessel quadrature of TransferModule (loop body at source/transfer_module.cpp:287-318,
+ *     i.e. transfer_compute_for_each_q :1488-1715).
+ * The reference has no FFI for this path; the seam is its C++ class API.  The two batched entry
+ * points below replace the BODIES of those two loops; thin C++ shim classes (classpp_public_amd/host/) reproduce
+ * the constructors / public data of PerturbationsModule / TransferModule on top of them.
+ *
+ * Conventions
+ *   - plain C, no exceptions cross the ABI: every call returns CPT_OK (0) or a nonzero error code and leaves a
+ *     message retrievable with cpt_last_error(); per-item status arrays report per-k-mode / per-q failures
+ *     (mirrors _SUCCESS_/_FAILURE_ + ErrorMsg, include/common.h:140-330).
+ *   - all arithmetic is IEEE double ("f64"); integers only for indices and flags.
+ *   - pointers named *_dev are DEVICE (HBM) pointers, all others are HOST pointers.  The library never takes
+ *     ownership of caller memory.
+ *   - a handle is bound to the HIP device current at cpt_create(); calls on one handle must be serialised by the
+ *     caller (the reference's module constructors are single-caller too, source/cosmology.cpp:16-86).
+ *   - there is NO CPU fallback: without a usable HIP device every compute entry point fails with CPT_ERR_NO_DEVICE.
+ */
+#ifndef CPT_H
+#define CPT_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CPT_OK 0
+#define CPT_ERR_INVALID 1     /* inconsistent / unsupported argument (reference: std::invalid_argument)      */
+#define CPT_ERR_RUNTIME 2     /* failure inside the computation (reference: std::runtime_error)              */
+#define CPT_ERR_NO_DEVICE 3   /* no HIP device / HIP runtime error                                           */
+#define CPT_ERR_UNSUPPORTED 4 /* physics branch of the reference that this backend does not implement (yet)  */
+
+/* gauges, as enum possible_gauges in source/perturbations.h */
+#define CPT_GAUGE_NEWTONIAN 0
+#define CPT_GAUGE_SYNCHRONOUS 1
+
+/* tight_coupling_approximation values, as enum tca_method in source/perturbations.h */
+#define CPT_TCA_FIRST_ORDER_MB 0
+#define CPT_TCA_FIRST_ORDER_CAMB 1
+#define CPT_TCA_FIRST_ORDER_CLASS 2
+#define CPT_TCA_SECOND_ORDER_CRS 3
+#define CPT_TCA_SECOND_ORDER_CLASS 4
+#define CPT_TCA_COMPROMISE_CLASS 5
+
+/* radiation_streaming_approximation (enum rsa_method): 0 rsa_null, 1 rsa_MD, 2 rsa_MD_with_reio, 3 rsa_none */
+#define CPT_RSA_NULL 0
+#define CPT_RSA_MD 1
+#define CPT_RSA_MD_WITH_REIO 2
+#define CPT_RSA_NONE 3
+/* ur_fluid_approximation (enum ufa_method): 0 ufa_mb, 1 ufa_hu, 2 ufa_CLASS, 3 ufa_none */
+#define CPT_UFA_MB 0
+#define CPT_UFA_HU 1
+#define CPT_UFA_CLASS 2
+#define CPT_UFA_NONE 3
+
+/* Flat POD with the physics flags / derived scalars / precision parameters the path reads
+ * (struct background / thermo / perturbs / precision / transfers of the reference).  */
+typedef struct cpt_config {
+  /* --- background (source/background.h) --- */
+  double H0;      /* [1/Mpc] */
+  double K;       /* curvature; only K == 0 is implemented                                     */
+  int sgnK;
+  int has_cdm, has_ur, has_ncdm, has_fld, has_curvature;
+  double T_cmb, a_today;
+  /* --- thermodynamics scalars (source/thermodynamics_module.h) --- */
+  double YHe, n_e;              /* used by the z > z_table_max analytic extrapolation, th.cpp:128-219 */
+  double tau0;                  /* conformal_age_                                                     */
+  double tau_rec;               /* tau_rec_                                                           */
+  double tau_free_streaming;    /* tau_free_streaming_                                                */
+  double tau_cut;               /* tau_cut_                                                           */
+  double angular_rescaling;     /* angular_rescaling_                                                 */
+  /* --- perturbation flags (source/perturbations.h:105-222) --- */
+  int gauge;
+  int switch_sw, switch_eisw, switch_lisw, switch_dop, switch_pol;
+  double eisw_lisw_split_z;
+  double three_ceff2_ur, three_cvis2_ur;
+  /* source types to produce and their slot in the sources table (reference order: t2,p,t0,t1,delta_m,phi+psi);
+     -1 = not requested (pm.cpp:1107-1150) */
+  int tp_size;
+  int index_tp_t0, index_tp_t1, index_tp_t2, index_tp_p, index_tp_delta_m, index_tp_phi_plus_psi;
+  /* --- precision (include/precisions.h) --- */
+  double start_small_k_at_tau_c_over_tau_h, start_large_k_at_tau_h_over_tau_k;
+  double tight_coupling_trigger_tau_c_over_tau_h, tight_coupling_trigger_tau_c_over_tau_k;
+  int tight_coupling_approximation;
+  int radiation_streaming_approximation;
+  double radiation_streaming_trigger_tau_over_tau_k;
+  int ur_fluid_approximation;
+  double ur_fluid_trigger_tau_over_tau_k;
+  int l_max_g, l_max_pol_g, l_max_ur;
+  double curvature_ini;
+  double tol_perturb_integration, tol_tau_approx, smallest_allowed_variation;
+  /* --- transfer (source/transfer.h, include/precisions.h:335-395) --- */
+  /* transfer types and their slot in the transfer table (reference order: t2,e,t0,t1,lcmb); -1 = absent */
+  int tt_size;
+  int index_tt_t0, index_tt_t1, index_tt_t2, index_tt_e, index_tt_lcmb;
+  double lcmb_rescale, lcmb_tilt, lcmb_pivot;
+  double hyper_x_min, hyper_sampling_flat, hyper_phi_min_abs;
+  double transfer_neglect_delta_k_S_t0, transfer_neglect_delta_k_S_t1, transfer_neglect_delta_k_S_t2,
+      transfer_neglect_delta_k_S_e;
+  double transfer_neglect_late_source;
+  double l_switch_limber;
+} cpt_config;
+
+/* Spline tables the RHS samples (all HOST pointers, row-major [n_lines][n_columns], copied to HBM by cpt_create):
+ *   background:     BackgroundModule::tau_table_, background_table_, d2background_dtau2_table_
+ *                   (source/background_module.h:166-178), columns located by the index_bg_* map;
+ *   thermodynamics: ThermodynamicsModule::z_table_, thermodynamics_table_, d2thermodynamics_dz2_table_
+ *                   (source/thermodynamics_module.h:120-125), columns located by the index_th_* map.          */
+typedef struct cpt_tables {
+  int bt_size, bg_size;
+  const double* tau_table;
+  const double* background_table;
+  const double* d2background_dtau2_table;
+  int index_bg_a, index_bg_H, index_bg_H_prime, index_bg_rho_g, index_bg_rho_b, index_bg_rho_cdm, index_bg_rho_ur;
+  int tt_size, th_size;
+  const double* z_table;
+  const double* thermodynamics_table;
+  const double* d2thermodynamics_dz2_table;
+  int index_th_xe, index_th_dkappa, index_th_tau_d, index_th_ddkappa, index_th_dddkappa, index_th_exp_m_kappa,
+      index_th_g, index_th_dg, index_th_cb2;
+} cpt_tables;
+
+/* per-k-mode work counters = the evolver's stepstat[6] (tools/evolver_ndf15.cpp:29-37) summed over regimes */
+typedef struct cpt_stepstat {
+  int steps, failed, fevals, jacobians, factorisations, solves;
+  int n_regimes;             /* number of constant-approximation intervals integrated     */
+  double tau_ini;            /* start time found by the bisection of pm.cpp:2545-2635      */
+} cpt_stepstat;
+
+typedef struct cpt_handle cpt_handle;
+
+/* Create a handle: validates cfg (unsupported physics -> CPT_ERR_UNSUPPORTED), uploads the tables. */
+int cpt_create(const cpt_config* cfg, const cpt_tables* tabs, cpt_handle** out);
+void cpt_destroy(cpt_handle* h);
+/* message of the last failing call on this handle ("" if none); valid until the next call on the handle */
+const char* cpt_last_error(const cpt_handle* h);
+/* message for a failure that happened before a handle existed (cpt_create) */
+const char* cpt_create_error(void);
+
+/* Hot path A: integrate nk scalar adiabatic k-modes (one wavefront per mode) and sample the source functions.
+ * Replaces the task body of PerturbationsModule::perturb_init (pm.cpp:686-707 -> perturb_solve).
+ *   k[nk], tau_sampling[ntau]         host arrays (reference: k_[md], tau_sampling_)
+ *   sources_dev                       device, reference layout sources_[ic*tp+tp][index_tau*k_size+index_k]
+ *                                     flattened as [tp_size][ntau][nk]; may be NULL (results stay resident in the
+ *                                     handle, k-major, for cpt_transfer_batch(..., NULL, ...))
+ *   stats[nk], status[nk]             host, may be NULL                                                       */
+int cpt_perturb_solve_batch(cpt_handle* h, const double* k, int nk, const double* tau_sampling, int ntau,
+                            double* sources_dev, cpt_stepstat* stats, int* status);
+
+/* Hot path B: all Delta_l^X(q) for nq wavenumbers and nl multipoles (flat space).
+ * Replaces the task body of TransferModule::transfer_init (tm.cpp:291-315 -> transfer_compute_for_each_q),
+ * including the k-spline of the sources (tm.cpp:604-639) and the flat Bessel table (tm.cpp:246-262).
+ *   sources_dev    device [tp_size][ntau][nk] (reference layout) or NULL = use the sources left resident by the
+ *                  last cpt_perturb_solve_batch on this handle
+ *   k[nk], tau_sampling[ntau], q[nq], l[nl]     host arrays (reference: ppt k_, tau_sampling_, ptr q_, l_)
+ *   k_size_cl      number of leading k values used for C_l's (reference k_size_cl_[md]); q beyond k[k_size_cl-1]
+ *                  give zero transfer (tm.cpp:1541)
+ *   transfer_dev   device, reference layout transfer_[((ic*tt+tt)*l_size+l)*q_size+q] = [tt_size][nl][nq]        */
+int cpt_transfer_batch(cpt_handle* h, const double* sources_dev, const double* k, int nk, int k_size_cl,
+                       const double* tau_sampling, int ntau, const double* q, int nq, const int* l, int nl,
+                       double* transfer_dev);
+
+/* Device-side copy of the resident sources into the reference layout [tp_size][ntau][nk] (device pointer). */
+int cpt_get_sources(cpt_handle* h, double* sources_dev);
+
+/* ---- measurement hooks (used by bench.py; they time with hipEvents on the library's own stream) ---- */
+/* milliseconds spent in the dominant kernel of the last call of each stage, and its launch count */
+int cpt_last_kernel_ms(const cpt_handle* h, int stage /*0 = perturb, 1 = transfer*/, double* ms, int* launches);
+/* work counters of the last transfer call: number of (q,l,type) integrals, of (q,l,type,tau) samples (the
+ * reference evaluates each separately) and of fused (q,l,tau) samples (types sharing one Phi_l row) */
+int cpt_last_transfer_work(const cpt_handle* h, long long* integrals, long long* type_samples,
+                           long long* fused_samples);
+
+/* ---- unit-test hooks: run single device functions so that parity tests can localise a discrepancy ---- */
+/* background_at_tau + thermodynamics_at_z at n times -> out[n][7 + 9] (a,H,H',rho_g,rho_b,rho_cdm,rho_ur,
+ * then xe,dkappa,tau_d,ddkappa,dddkappa,exp_m_kappa,g,dg,cb2) */
+int cpt_dbg_lookup(cpt_handle* h, const double* tau, int n, double* out);
+/* one RHS evaluation perturb_derivs(tau, y) for wavenumber k in the regime (tca_on, rsa_on, ufa_on):
+ * y[neq] in the reference's index order for that regime (pm.cpp:3302-3481); returns dy[neq] and neq       */
+int cpt_dbg_derivs(cpt_handle* h, double k, double tau, int tca_on, int rsa_on, int ufa_on, const double* y,
+                   double* dy, int* neq);
+/* flat spherical Bessel table phi[nl][nx], dphi[nl][nx] and chi_at_phimin[nl] as built for (l, xmax) */
+int cpt_dbg_bessel(cpt_handle* h, const int* l, int nl, double xmax, int* nx, double* phi, double* dphi,
+                   double* chi_at_phimin, int cap_nx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CPT_H */
