@@ -153,8 +153,9 @@ int cpt_create(const cpt_config* cfg, const cpt_tables* t, cpt_handle** out) {
 
 void cpt_destroy(cpt_handle* h) {
   if (!h) return;
+  // (d_splc and d_ik are interior pointers into d_k / d_q and must not be freed)
   void* ptrs[] = {h->d_tau_table, h->d_bg, h->d_z_table, h->d_th, h->d_src, h->d_dd, h->d_u, h->d_k, h->d_tau, h->d_q,
-                  h->d_splc, h->d_l, h->d_ik, h->d_bes, h->d_chi_min, h->d_work, h->d_pt_scratch};
+                  h->d_l, h->d_bes, h->d_chi_min, h->d_work, h->d_pt_scratch};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   for (Timer* tm : {&h->t_perturb, &h->t_transfer}) {

@@ -51,3 +51,36 @@ def transfer(inp, sources, threads=8):
                         dptr(inp.q), inp.q.size, iptr(inp.l), inp.l.size, dptr(out), threads, work)
     assert rc == 0, rc
     return out, (work[0], work[1])
+
+
+# ---- the real reference, when its build (oracle/_ref, not committed, travels with gpurun) is present ----
+REF_DRIVER = os.path.join(ORACLE_DIR, "_ref", "ref_driver")
+_ref_cache = {}
+
+
+def have_ref():
+    return os.path.exists(REF_DRIVER)
+
+
+def ref_run(cfg):
+    """Run the unmodified reference on tests/golden/<cfg>.ini and return all dumped arrays (full sources_, transfer_)."""
+    if cfg in _ref_cache:
+        return _ref_cache[cfg]
+    import sys
+    import tempfile
+    sys.path.insert(0, ORACLE_DIR)
+    from make_fixtures import load_bin
+    gold = os.path.join(ROOT, "tests", "golden")
+    with tempfile.TemporaryDirectory() as td:
+        out = os.path.join(td, cfg + ".bin")
+        subprocess.check_call([REF_DRIVER, "dump", os.path.join(gold, cfg + ".ini"), out], cwd=gold)
+        d = load_bin(out)
+    _ref_cache[cfg] = d
+    return d
+
+
+def ref_time(cfg, threads, reps=3):
+    import json
+    gold = os.path.join(ROOT, "tests", "golden")
+    out = subprocess.check_output([REF_DRIVER, "time", os.path.join(gold, cfg + ".ini"), str(threads), str(reps)], cwd=gold)
+    return json.loads(out.decode().strip().splitlines()[-1])

@@ -85,3 +85,28 @@ def test_transfer_edge_cases(small):
     bad = inp.q.copy(); bad[3] = bad[2]
     with pytest.raises(CptInputError):
         be.transfer(src, q=bad)
+
+
+@pytest.mark.parametrize("cfg", ["lcdm", "explanatory"])
+def test_transfer_full_size_vs_reference(cfg):
+    """BASELINE configs 1-2 at full size: sources_ from the real reference run live (oracle/_ref), transfer_ must
+    match the reference's own table everywhere; the committed sub-sampled golden vectors are checked as well."""
+    if not oracle_lib.have_ref():
+        pytest.skip("oracle/_ref (reference build) not present on this box")
+    from classpp_public_amd.backend import Backend
+    inp = Inputs(cfg)
+    be = Backend(inp)
+    ref = oracle_lib.ref_run(cfg)
+    src = torch.from_numpy(ref["pt.sources"]).cuda()
+    got = be.transfer(src).cpu().numpy()
+    want = ref["tr.transfer"]
+    assert np.array_equal(got == 0, want == 0)
+    assert rel_to_rowmax(got, want) < TOL
+    # committed golden subsets (same reference, frozen)
+    qs, ls = inp.d["tr.transfer_q_index"], inp.d["tr.transfer_l_index"]
+    assert rel_to_rowmax(np.swapaxes(got[:, :, qs], 1, 2), np.swapaxes(inp.d["tr.transfer_at_q"], 1, 2)) < 1e-7
+    assert rel_to_rowmax(got[:, ls, :], inp.d["tr.transfer_at_l"]) < TOL
+    ints, tsamp, fused = be.transfer_work()
+    ms, n = be.kernel_ms(1)
+    print("\n[%s] LOS kernel %.3f ms, %d integrals, %d type-samples, %d fused samples" % (cfg, ms, ints, tsamp, fused))
+    be.close()
