@@ -1,0 +1,956 @@
+// ORACLE / TEST INFRASTRUCTURE ONLY -- a plain scalar CPU restatement of hot path A of the reference:
+// the per-k integration of the scalar, adiabatic, synchronous-gauge Einstein-Boltzmann system for flat
+// LambdaCDM (+ massless neutrinos) through the tca / rsa / ufa regimes with the ndf15 stiff integrator.
+// Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library; the product
+// (classpp_public_amd/) never links it.  Pinned against sources_ dumped from the unmodified reference
+// (tests/golden/*.npz): see tests/test_oracle_perturb.py.
+//
+// pm.cpp = source/perturbations_module.cpp, ev.cpp = tools/evolver_ndf15.cpp, th.cpp = source/thermodynamics_module.cpp
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <thread>
+#include <vector>
+
+#include "../../include/cpt.h"
+
+namespace {
+
+constexpr double SIGMA_T = 6.6524616e-29, MPC_OVER_M = 3.085677581282e22, K_B = 1.3806504e-23, C_LIGHT = 2.99792458e8,
+                 M_H = 1.673575e-27, NOT4 = 3.9715;
+
+struct Bg { double a, H, Hp, rho_g, rho_b, rho_cdm, rho_ur; };
+struct Th { double xe, dkappa, tau_d, ddkappa, dddkappa, expmk, g, dg, cb2; };
+
+struct Model {
+  const cpt_config* c;
+  const cpt_tables* t;
+};
+
+// ---- spline row lookup: tools/arrays.c:1565-1628 / 2173-2225 (same bracket, same formula) ----
+inline int bracket_growing(const double* x, int n, double v) {  // x ascending; returns inf with x[inf] <= v <= x[inf+1]
+  int inf = 0, sup = n - 1;
+  while (sup - inf > 1) {
+    int mid = (int)(0.5 * (inf + sup));
+    if (v < x[mid]) sup = mid; else inf = mid;
+  }
+  return inf;
+}
+inline double spl(const double* tab, const double* dd, int ncol, int inf, int col, double a, double b, double h) {
+  return a * tab[(size_t)inf * ncol + col] + b * tab[(size_t)(inf + 1) * ncol + col] +
+         ((a * a * a - a) * dd[(size_t)inf * ncol + col] + (b * b * b - b) * dd[(size_t)(inf + 1) * ncol + col]) * h * h / 6.;
+}
+
+// background_at_tau, source/background_module.cpp:125-199
+bool bg_at_tau(const Model& m, double tau, Bg& o) {
+  const cpt_tables& t = *m.t;
+  if (tau < t.tau_table[0] || tau > t.tau_table[t.bt_size - 1]) return false;
+  int inf = bracket_growing(t.tau_table, t.bt_size, tau);
+  double h = t.tau_table[inf + 1] - t.tau_table[inf], b = (tau - t.tau_table[inf]) / h, a = 1 - b;
+  auto f = [&](int col) { return spl(t.background_table, t.d2background_dtau2_table, t.bg_size, inf, col, a, b, h); };
+  o.a = f(t.index_bg_a); o.H = f(t.index_bg_H); o.Hp = f(t.index_bg_H_prime); o.rho_g = f(t.index_bg_rho_g);
+  o.rho_b = f(t.index_bg_rho_b); o.rho_cdm = m.c->has_cdm ? f(t.index_bg_rho_cdm) : 0.;
+  o.rho_ur = m.c->has_ur ? f(t.index_bg_rho_ur) : 0.;
+  return true;
+}
+
+// thermodynamics_at_z, th.cpp:114-285 (spline branch + analytic extrapolation above the table)
+void th_at_z(const Model& m, double z, const Bg& bg, Th& o) {
+  const cpt_tables& t = *m.t;
+  const cpt_config& c = *m.c;
+  const int n = t.tt_size, nc = t.th_size;
+  if (z >= t.z_table[n - 1]) {
+    double x0 = t.thermodynamics_table[(size_t)(n - 1) * nc + t.index_th_xe];
+    o.xe = x0;
+    o.dkappa = (1. + z) * (1. + z) * c.n_e * x0 * SIGMA_T * MPC_OVER_M;
+    o.tau_d = t.thermodynamics_table[(size_t)(n - 1) * nc + t.index_th_tau_d] * std::pow((1 + z) / (1. + t.z_table[n - 1]), 2);
+    o.ddkappa = -bg.H * 2. / (1. + z) * o.dkappa;
+    o.dddkappa = (bg.H * bg.H / (1. + z) - bg.Hp) * 2. / (1. + z) * o.dkappa;
+    o.expmk = 0.; o.g = 0.; o.dg = 0.;
+    double wb = K_B / (C_LIGHT * C_LIGHT * M_H) * (1. + (1. / NOT4 - 1.) * c.YHe + x0 * (1. - c.YHe)) * c.T_cmb * (1. + z);
+    o.cb2 = wb * 4. / 3.;
+    return;
+  }
+  int inf = bracket_growing(t.z_table, n, z);
+  double h = t.z_table[inf + 1] - t.z_table[inf], b = (z - t.z_table[inf]) / h, a = 1 - b;
+  auto f = [&](int col) { return spl(t.thermodynamics_table, t.d2thermodynamics_dz2_table, nc, inf, col, a, b, h); };
+  o.xe = f(t.index_th_xe); o.dkappa = f(t.index_th_dkappa); o.tau_d = f(t.index_th_tau_d); o.ddkappa = f(t.index_th_ddkappa);
+  o.dddkappa = f(t.index_th_dddkappa); o.expmk = f(t.index_th_exp_m_kappa); o.g = f(t.index_th_g); o.dg = f(t.index_th_dg);
+  o.cb2 = f(t.index_th_cb2);
+}
+
+// ---- regime layout: pm.cpp:3302-3481 (scalars, synchronous gauge, LambdaCDM + ur) ----
+struct Layout {
+  int tca, rsa, ufa;  // 1 = approximation ON
+  int neq;
+  int delta_g, theta_g, shear_g, l3_g, pol0_g, pol1_g, pol2_g, pol3_g, delta_b, theta_b, delta_cdm, delta_ur, theta_ur,
+      shear_ur, l3_ur, eta;
+  int l_max_g, l_max_pol_g, l_max_ur;
+  std::vector<int> used_in_sources;
+};
+
+Layout make_layout(const cpt_config& c, int tca, int rsa, int ufa) {
+  Layout L;
+  L.tca = tca; L.rsa = rsa; L.ufa = ufa;
+  L.delta_g = L.theta_g = L.shear_g = L.l3_g = L.pol0_g = L.pol1_g = L.pol2_g = L.pol3_g = -1;
+  L.delta_ur = L.theta_ur = L.shear_ur = L.l3_ur = -1;
+  L.delta_cdm = -1;
+  L.l_max_g = c.l_max_g; L.l_max_pol_g = c.l_max_pol_g; L.l_max_ur = c.l_max_ur;
+  int i = 0;
+  if (!rsa) {
+    L.delta_g = i++; L.theta_g = i++;
+    if (!tca) {
+      L.shear_g = i++; L.l3_g = i; i += c.l_max_g - 2;
+      L.pol0_g = i++; L.pol1_g = i++; L.pol2_g = i++; L.pol3_g = i; i += c.l_max_pol_g - 2;
+    }
+  }
+  L.delta_b = i++; L.theta_b = i++;
+  if (c.has_cdm) L.delta_cdm = i++;
+  if (c.has_ur && !rsa) {
+    L.delta_ur = i++; L.theta_ur = i++; L.shear_ur = i++;
+    if (!ufa) { L.l3_ur = i; i += c.l_max_ur - 2; }
+  }
+  L.eta = i++;
+  L.neq = i;
+  // pm.cpp:3597-3640
+  L.used_in_sources.assign(L.neq, 1);
+  if (!rsa && !tca) {
+    for (int p = L.l3_g; p <= L.delta_g + L.l_max_g; p++) L.used_in_sources[p] = 0;
+    L.used_in_sources[L.pol1_g] = 0;
+    for (int p = L.pol3_g; p <= L.pol0_g + L.l_max_pol_g; p++) L.used_in_sources[p] = 0;
+  }
+  if (c.has_ur && !rsa && !ufa)
+    for (int p = L.l3_ur; p <= L.delta_ur + L.l_max_ur; p++) L.used_in_sources[p] = 0;
+  return L;
+}
+
+// ---- per-mode workspace (struct perturb_workspace, source/perturbations.h:300-420) ----
+struct Work {
+  Bg bg; Th th;
+  double h_prime, eta_prime, h_prime_prime, alpha, alpha_prime;
+  double delta_rho, rho_plus_p_theta, rho_plus_p_shear, delta_p, rho_plus_p_tot;
+  double delta_m, theta_m;
+  double rsa_delta_g, rsa_theta_g, rsa_delta_ur, rsa_theta_ur;
+  double tca_shear_g, tca_slip;
+  long fevals = 0;
+};
+
+// perturb_approximations, pm.cpp:5443-5670
+void approximations(const Model& m, double k, double tau, int* tca, int* rsa, int* ufa) {
+  const cpt_config& c = *m.c;
+  Bg bg; Th th;
+  bg_at_tau(m, tau, bg);
+  double tau_k = 1. / k, tau_h = 1. / (bg.H * bg.a);
+  th_at_z(m, 1. / bg.a - 1., bg, th);
+  if (th.dkappa == 0.) *tca = 0;
+  else {
+    double tau_c = 1. / th.dkappa;
+    *tca = ((tau_c / tau_h < c.tight_coupling_trigger_tau_c_over_tau_h) && (tau_c / tau_k < c.tight_coupling_trigger_tau_c_over_tau_k)) ? 1 : 0;
+  }
+  *rsa = ((tau / tau_k > c.radiation_streaming_trigger_tau_over_tau_k) && (tau > c.tau_free_streaming) &&
+          (c.radiation_streaming_approximation != CPT_RSA_NONE)) ? 1 : 0;
+  *ufa = 0;
+  if (c.has_ur) *ufa = ((tau / tau_k > c.ur_fluid_trigger_tau_over_tau_k) && (c.ur_fluid_approximation != CPT_UFA_NONE)) ? 1 : 0;
+}
+
+// perturb_rsa_delta_and_theta, pm.cpp:9530-9636 (synchronous gauge)
+void rsa_delta_and_theta(const Model& m, double k, const double* y, const Layout& L, double a_prime_over_a, Work& w) {
+  const cpt_config& c = *m.c;
+  double k2 = k * k;
+  if (c.radiation_streaming_approximation == CPT_RSA_NULL) { w.rsa_delta_g = 0.; w.rsa_theta_g = 0.; }
+  else {
+    w.rsa_delta_g = 4. / k2 * (a_prime_over_a * w.h_prime - k2 * y[L.eta]);
+    w.rsa_theta_g = -0.5 * w.h_prime;
+  }
+  if (c.radiation_streaming_approximation == CPT_RSA_MD_WITH_REIO) {
+    w.rsa_delta_g += -4. / k2 * w.th.dkappa * (y[L.theta_b] + 0.5 * w.h_prime);
+    w.rsa_theta_g += 3. / k2 * (w.th.ddkappa * (y[L.theta_b] + 0.5 * w.h_prime) +
+                                w.th.dkappa * (-a_prime_over_a * y[L.theta_b] + w.th.cb2 * k2 * y[L.delta_b] -
+                                               a_prime_over_a * w.h_prime + k2 * y[L.eta]));
+  }
+  if (c.has_ur) {
+    if (c.radiation_streaming_approximation == CPT_RSA_NULL) { w.rsa_delta_ur = 0.; w.rsa_theta_ur = 0.; }
+    else {
+      w.rsa_delta_ur = 4. / k2 * (a_prime_over_a * w.h_prime - k2 * y[L.eta]);
+      w.rsa_theta_ur = -0.5 * w.h_prime;
+    }
+  }
+  w.delta_rho += w.bg.rho_g * w.rsa_delta_g;
+  w.rho_plus_p_theta += 4. / 3. * w.bg.rho_g * w.rsa_theta_g;
+  if (c.has_ur) {
+    w.delta_rho += w.bg.rho_ur * w.rsa_delta_ur;
+    w.rho_plus_p_theta += 4. / 3. * w.bg.rho_ur * w.rsa_theta_ur;
+  }
+}
+
+// perturb_total_stress_energy + perturb_einstein, pm.cpp:6047-6703 + 5840-6045 (scalars, synchronous, flat)
+void einstein(const Model& m, double k, const double* y, const Layout& L, Work& w) {
+  const cpt_config& c = *m.c;
+  const Bg& bg = w.bg;
+  double a = bg.a, a2 = a * a, a_prime_over_a = bg.H * a, k2 = k * k;
+  double delta_g = 0, theta_g = 0, shear_g = 0, delta_ur = 0, theta_ur = 0, shear_ur = 0;
+  if (!L.tca) {
+    if (!L.rsa) { delta_g = y[L.delta_g]; theta_g = y[L.theta_g]; shear_g = y[L.shear_g]; }
+  } else { delta_g = y[L.delta_g]; theta_g = y[L.theta_g]; shear_g = 0.; }
+  if (c.has_ur && !L.rsa) { delta_ur = y[L.delta_ur]; theta_ur = y[L.theta_ur]; shear_ur = y[L.shear_ur]; }
+  double delta_p_b_over_rho_b = w.th.cb2 * y[L.delta_b];
+  w.delta_rho = bg.rho_g * delta_g + bg.rho_b * y[L.delta_b];
+  w.rho_plus_p_theta = 4. / 3. * bg.rho_g * theta_g + bg.rho_b * y[L.theta_b];
+  w.rho_plus_p_shear = 4. / 3. * bg.rho_g * shear_g;
+  w.delta_p = 1. / 3. * bg.rho_g * delta_g + bg.rho_b * delta_p_b_over_rho_b;
+  w.rho_plus_p_tot = 4. / 3. * bg.rho_g + bg.rho_b;
+  double delta_rho_m = bg.rho_b * y[L.delta_b], rho_m = bg.rho_b;
+  double rho_plus_p_theta_m = bg.rho_b * y[L.theta_b], rho_plus_p_m = bg.rho_b;
+  if (c.has_cdm) {
+    w.delta_rho += bg.rho_cdm * y[L.delta_cdm];
+    w.rho_plus_p_tot += bg.rho_cdm;
+    delta_rho_m += bg.rho_cdm * y[L.delta_cdm]; rho_m += bg.rho_cdm;
+    rho_plus_p_m += bg.rho_cdm;
+  }
+  if (c.has_ur) {
+    w.delta_rho += bg.rho_ur * delta_ur;
+    w.rho_plus_p_theta += 4. / 3. * bg.rho_ur * theta_ur;
+    w.rho_plus_p_shear += 4. / 3. * bg.rho_ur * shear_ur;
+    w.delta_p += 1. / 3. * bg.rho_ur * delta_ur;
+    w.rho_plus_p_tot += 4. / 3. * bg.rho_ur;
+  }
+  w.delta_m = delta_rho_m / rho_m;
+  w.theta_m = rho_plus_p_theta_m / rho_plus_p_m;
+  // Einstein equations, synchronous gauge, K = 0 (s2_squared = 1): pm.cpp:5906-5971
+  w.h_prime = (k2 * y[L.eta] + 1.5 * a2 * w.delta_rho) / (0.5 * a_prime_over_a);
+  if (L.rsa) rsa_delta_and_theta(m, k, y, L, a_prime_over_a, w);
+  w.eta_prime = (1.5 * a2 * w.rho_plus_p_theta) / k2;
+  w.h_prime_prime = -2. * a_prime_over_a * w.h_prime + 2. * k2 * y[L.eta] - 9. * a2 * w.delta_p;
+  w.alpha = (w.h_prime + 6. * w.eta_prime) / 2. / k2;
+  if (L.tca) {
+    double sg = 16. / 45. / w.th.dkappa * (y[L.theta_g] + k2 * w.alpha);
+    w.rho_plus_p_shear += 4. / 3. * bg.rho_g * sg;
+  }
+  w.alpha_prime = -2. * a_prime_over_a * w.alpha + y[L.eta] - 4.5 * (a2 / k2) * w.rho_plus_p_shear;
+  // gauge-invariant matter variables pm.cpp:5979-6005 (delta_m always tracked: cheap)
+  w.delta_m += 3. * bg.a * bg.H * w.theta_m / k2;
+  w.theta_m += w.alpha * k2;
+}
+
+// perturb_tca_slip_and_shear, pm.cpp:9229-9516 (first_order_CAMB and compromise_CLASS)
+void tca_slip_and_shear(const Model& m, double k, const double* y, const Layout& L, Work& w) {
+  const cpt_config& c = *m.c;
+  const Bg& bg = w.bg; const Th& th = w.th;
+  double k2 = k * k, a = bg.a, a_prime_over_a = bg.H * a;
+  double a_primeprime_over_a = bg.Hp * a + 2. * a_prime_over_a * a_prime_over_a;
+  double R = 4. / 3. * bg.rho_g / bg.rho_b;
+  double delta_g = y[L.delta_g], theta_g = y[L.theta_g], delta_b = y[L.delta_b], theta_b = y[L.theta_b];
+  double cb2 = th.cb2;
+  double tau_c = 1. / th.dkappa, dtau_c = -th.ddkappa * tau_c * tau_c;
+  double F = tau_c / (1 + R);
+  double F_prime = dtau_c / (1 + R) + tau_c * a_prime_over_a * R / (1 + R) / (1 + R);
+  double metric_continuity = w.h_prime / 2., metric_euler = 0., metric_shear = k2 * w.alpha, metric_shear_prime = k2 * w.alpha_prime;
+  double slip = (dtau_c / tau_c - 2. * a_prime_over_a / (1. + R)) * (theta_b - theta_g) +
+                F * (-a_primeprime_over_a * theta_b +
+                     k2 * (-a_prime_over_a * delta_g / 2. + cb2 * (-theta_b - metric_continuity) -
+                           4. / 3. * (-theta_g - metric_continuity) / 4.) -
+                     a_prime_over_a * metric_euler);
+  double shear_g = 16. / 45. * tau_c * (theta_g + metric_shear);
+  double theta_prime = (-a_prime_over_a * theta_b + k2 * (cb2 * delta_b + R / 4. * delta_g)) / (1. + R) + metric_euler;
+  double shear_g_prime = 16. / 45. * (tau_c * (theta_prime + metric_shear_prime) + dtau_c * (theta_g + metric_shear));
+  if (c.tight_coupling_approximation == CPT_TCA_COMPROMISE_CLASS) {
+    slip = (1. - 2. * a_prime_over_a * F) * slip +
+           F * k2 * (2. * a_prime_over_a * shear_g + shear_g_prime - (1. / 3. - cb2) * (F * theta_prime + 2. * F_prime * theta_b));
+    shear_g = (1. - 11. / 6. * dtau_c) * shear_g - 11. / 6. * tau_c * 16. / 45. * tau_c * (theta_prime + metric_shear_prime);
+  }
+  w.tca_shear_g = shear_g;
+  w.tca_slip = slip;
+}
+
+// perturb_derivs, pm.cpp:7861-9218 (scalars, synchronous, flat, no exotic species)
+void derivs(const Model& m, double k, double tau, const double* y, double* dy, const Layout& L, Work& w) {
+  const cpt_config& c = *m.c;
+  w.fevals++;
+  bg_at_tau(m, tau, w.bg);
+  th_at_z(m, 1. / w.bg.a - 1., w.bg, w.th);
+  einstein(m, k, y, L, w);
+  const Bg& bg = w.bg; const Th& th = w.th;
+  double k2 = k * k, a = bg.a, a_prime_over_a = bg.H * a;
+  double R = 4. / 3. * bg.rho_g / bg.rho_b;
+  double cotKgen = 1.0 / (k * tau);
+  double delta_g = 0, theta_g = 0;
+  if (!L.rsa) { delta_g = y[L.delta_g]; theta_g = y[L.theta_g]; }
+  double delta_b = y[L.delta_b], theta_b = y[L.theta_b];
+  double cb2 = th.cb2, delta_p_b_over_rho_b = cb2 * delta_b;
+  double metric_continuity = w.h_prime / 2., metric_euler = 0., metric_shear = k2 * w.alpha, metric_ufa_class = w.h_prime / 2.;
+  if (L.rsa) { delta_g = w.rsa_delta_g; theta_g = w.rsa_theta_g; }
+  if (!L.rsa) dy[L.delta_g] = -4. / 3. * (theta_g + metric_continuity);
+  dy[L.delta_b] = -(theta_b + metric_continuity);
+  if (!L.tca) {
+    dy[L.theta_b] = -a_prime_over_a * theta_b + metric_euler + k2 * delta_p_b_over_rho_b + R * th.dkappa * (theta_g - theta_b);
+  } else {
+    tca_slip_and_shear(m, k, y, L, w);
+    dy[L.theta_b] = (-a_prime_over_a * theta_b + k2 * (delta_p_b_over_rho_b + R * (delta_g / 4. - w.tca_shear_g)) + R * w.tca_slip) / (1. + R) + metric_euler;
+  }
+  if (!L.rsa) {
+    if (!L.tca) {
+      double P0 = (y[L.pol0_g] + y[L.pol2_g] + 2. * y[L.shear_g]) / 8.;
+      dy[L.theta_g] = k2 * (delta_g / 4. - y[L.shear_g]) + metric_euler + th.dkappa * (theta_b - theta_g);
+      dy[L.shear_g] = 0.5 * (8. / 15. * (theta_g + metric_shear) - 3. / 5. * k * y[L.l3_g] - th.dkappa * (2. * y[L.shear_g] - 4. / 5. * P0));
+      int l = 3;
+      dy[L.l3_g] = k / (2.0 * l + 1.0) * (l * 2. * y[L.shear_g] - (l + 1.) * y[L.l3_g + 1]) - th.dkappa * y[L.l3_g];
+      for (l = 4; l < L.l_max_g; l++)
+        dy[L.delta_g + l] = k / (2.0 * l + 1.0) * (l * y[L.delta_g + l - 1] - (l + 1) * y[L.delta_g + l + 1]) - th.dkappa * y[L.delta_g + l];
+      l = L.l_max_g;
+      dy[L.delta_g + l] = k * (y[L.delta_g + l - 1] - (1. + l) * cotKgen * y[L.delta_g + l]) - th.dkappa * y[L.delta_g + l];
+      dy[L.pol0_g] = -k * y[L.pol0_g + 1] - th.dkappa * (y[L.pol0_g] - 4. * P0);
+      dy[L.pol1_g] = k / 3. * (y[L.pol1_g - 1] - 2. * y[L.pol1_g + 1]) - th.dkappa * y[L.pol1_g];
+      dy[L.pol2_g] = k / 5. * (2. * y[L.pol2_g - 1] - 3. * y[L.pol2_g + 1]) - th.dkappa * (y[L.pol2_g] - 4. / 5. * P0);
+      for (l = 3; l < L.l_max_pol_g; l++)
+        dy[L.pol0_g + l] = k / (2. * l + 1) * (l * y[L.pol0_g + l - 1] - (l + 1.) * y[L.pol0_g + l + 1]) - th.dkappa * y[L.pol0_g + l];
+      l = L.l_max_pol_g;
+      dy[L.pol0_g + l] = k * (y[L.pol0_g + l - 1] - (l + 1) * cotKgen * y[L.pol0_g + l]) - th.dkappa * y[L.pol0_g + l];
+    } else {
+      dy[L.theta_g] = -(dy[L.theta_b] + a_prime_over_a * theta_b - k2 * delta_p_b_over_rho_b) / R + k2 * (0.25 * delta_g - w.tca_shear_g) + (1. + R) / R * metric_euler;
+    }
+  }
+  if (c.has_cdm) dy[L.delta_cdm] = -metric_continuity;
+  if (c.has_ur && !L.rsa) {
+    dy[L.delta_ur] = -4. / 3. * (y[L.theta_ur] + metric_continuity) +
+                     (1. - c.three_ceff2_ur) * a_prime_over_a * (y[L.delta_ur] + 4. * a_prime_over_a * y[L.theta_ur] / k / k);
+    dy[L.theta_ur] = k2 * (c.three_ceff2_ur * y[L.delta_ur] / 4. - y[L.shear_ur]) + metric_euler - (1. - c.three_ceff2_ur) * a_prime_over_a * y[L.theta_ur];
+    if (!L.ufa) {
+      dy[L.shear_ur] = 0.5 * (8. / 15. * (y[L.theta_ur] + metric_shear) - 3. / 5. * k * y[L.shear_ur + 1] -
+                              (1. - c.three_cvis2_ur) * (8. / 15. * (y[L.theta_ur] + metric_shear)));
+      int l = 3;
+      dy[L.l3_ur] = k / (2. * l + 1.) * (l * 2. * y[L.shear_ur] - (l + 1.) * y[L.l3_ur + 1]);
+      for (l = 4; l < L.l_max_ur; l++)
+        dy[L.delta_ur + l] = k / (2. * l + 1) * (l * y[L.delta_ur + l - 1] - (l + 1.) * y[L.delta_ur + l + 1]);
+      l = L.l_max_ur;
+      dy[L.delta_ur + l] = k * (y[L.delta_ur + l - 1] - (1. + l) * cotKgen * y[L.delta_ur + l]);
+    } else {
+      if (c.ur_fluid_approximation == CPT_UFA_MB) dy[L.shear_ur] = -3. / tau * y[L.shear_ur] + 2. / 3. * (y[L.theta_ur] + metric_shear);
+      if (c.ur_fluid_approximation == CPT_UFA_HU) dy[L.shear_ur] = -3. * a_prime_over_a * y[L.shear_ur] + 2. / 3. * (y[L.theta_ur] + metric_shear);
+      if (c.ur_fluid_approximation == CPT_UFA_CLASS) dy[L.shear_ur] = -3. / tau * y[L.shear_ur] + 2. / 3. * (y[L.theta_ur] + metric_ufa_class);
+    }
+  }
+  dy[L.eta] = w.eta_prime;
+}
+
+// perturb_sources, pm.cpp:6731-7285 (scalar types t0,t1,t2,p,delta_m,phi+psi in synchronous gauge)
+void sources(const Model& m, double k, double tau, const double* y, const double* dy, const Layout& L, Work& w, double* out) {
+  const cpt_config& c = *m.c;
+  bg_at_tau(m, tau, w.bg);
+  double z = c.a_today / w.bg.a - 1.;
+  th_at_z(m, z, w.bg, w.th);
+  const Bg& bg = w.bg; const Th& th = w.th;
+  double a_prime_over_a = bg.a * bg.H, a_prime_over_a_prime = bg.Hp * bg.a + std::pow(bg.H * bg.a, 2);
+  einstein(m, k, y, L, w);
+  double delta_g, P;
+  if (L.rsa) { delta_g = w.rsa_delta_g; P = 0.; }
+  else {
+    delta_g = y[L.delta_g];
+    if (L.tca) P = 5. * w.tca_shear_g / 8.;  // NB: left over from the last derivs call (pm.cpp:6810), see SURVEY "hidden state"
+    else P = (y[L.pol0_g] + y[L.pol2_g] + 2. * y[L.shear_g]) / 8.;
+  }
+  int switch_isw = 1;
+  if ((c.switch_eisw == 0) && (z >= c.eisw_lisw_split_z)) switch_isw = 0;
+  if ((c.switch_lisw == 0) && (z < c.eisw_lisw_split_z)) switch_isw = 0;
+  if (c.index_tp_t0 >= 0)
+    out[c.index_tp_t0] = c.switch_sw * th.g * (delta_g / 4. + w.alpha_prime) +
+                         switch_isw * (th.g * (y[L.eta] - w.alpha_prime - 2 * a_prime_over_a * w.alpha) +
+                                       th.expmk * 2. * (w.eta_prime - a_prime_over_a_prime * w.alpha - a_prime_over_a * w.alpha_prime)) +
+                         c.switch_dop * (th.g * (dy[L.theta_b] / k / k + w.alpha_prime) + th.dg * (y[L.theta_b] / k / k + w.alpha));
+  if (c.index_tp_t1 >= 0) out[c.index_tp_t1] = switch_isw * th.expmk * k * (w.alpha_prime + 2. * a_prime_over_a * w.alpha - y[L.eta]);
+  if (c.index_tp_t2 >= 0) out[c.index_tp_t2] = c.switch_pol * th.g * P;
+  if (c.index_tp_p >= 0) out[c.index_tp_p] = std::sqrt(6.) * th.g * P;
+  if (c.index_tp_phi_plus_psi >= 0) out[c.index_tp_phi_plus_psi] = y[L.eta] + w.alpha_prime;
+  if (c.index_tp_delta_m >= 0) out[c.index_tp_delta_m] = w.delta_m;
+}
+
+// ---- ndf15: ev.cpp:62-705 (+ numjac :1213-1539 in its dense mode, dense LU :1001-1064) ----
+struct Ndf {
+  int neq;
+  std::vector<double> J, LU, fac;  // dense Jacobian (row-major), LU of I - h*gamma*J, numjac increments
+  std::vector<int> piv;
+  long stat[6] = {0, 0, 0, 0, 0, 0};
+};
+
+bool ludcmp(std::vector<double>& A, int n, std::vector<int>& indx) {  // ev.cpp:1021-1064, 0-based
+  std::vector<double> vv(n);
+  for (int i = 0; i < n; i++) {
+    double big = 0.;
+    for (int j = 0; j < n; j++) big = std::max(big, std::fabs(A[i * n + j]));
+    if (big == 0.) return false;
+    vv[i] = 1.0 / big;
+  }
+  for (int j = 0; j < n; j++) {
+    for (int i = 0; i < j; i++) {
+      double sum = A[i * n + j];
+      for (int k = 0; k < i; k++) sum -= A[i * n + k] * A[k * n + j];
+      A[i * n + j] = sum;
+    }
+    double big = 0.; int imax = j;
+    for (int i = j; i < n; i++) {
+      double sum = A[i * n + j];
+      for (int k = 0; k < j; k++) sum -= A[i * n + k] * A[k * n + j];
+      A[i * n + j] = sum;
+      double dum = vv[i] * std::fabs(sum);
+      if (dum >= big) { big = dum; imax = i; }
+    }
+    if (j != imax) {
+      for (int k = 0; k < n; k++) std::swap(A[imax * n + k], A[j * n + k]);
+      vv[imax] = vv[j];
+    }
+    indx[j] = imax;
+    if (A[j * n + j] == 0.0) A[j * n + j] = 1e-50;
+    if (j != n - 1) {
+      double dum = 1.0 / A[j * n + j];
+      for (int i = j + 1; i < n; i++) A[i * n + j] *= dum;
+    }
+  }
+  return true;
+}
+void lubksb(const std::vector<double>& A, int n, const std::vector<int>& indx, double* b) {  // ev.cpp:1001-1019
+  int ii = -1;
+  for (int i = 0; i < n; i++) {
+    int ip = indx[i];
+    double sum = b[ip];
+    b[ip] = b[i];
+    if (ii >= 0) for (int j = ii; j <= i - 1; j++) sum -= A[i * n + j] * b[j];
+    else if (sum) ii = i;
+    b[i] = sum;
+  }
+  for (int i = n - 1; i >= 0; i--) {
+    double sum = b[i];
+    for (int j = i + 1; j < n; j++) sum -= A[i * n + j] * b[j];
+    b[i] = sum / A[i * n + i];
+  }
+}
+
+template <class F>
+void numjac(F&& f, double t, const double* y, const double* fval, Ndf& S, int* nfe) {  // ev.cpp:1213-1539, dense branch
+  const int n = S.neq;
+  const double eps = 1e-16, br = std::pow(eps, 0.875), bl = std::pow(eps, 0.75), bu = std::pow(eps, 0.25);
+  const double facmin = std::pow(eps, 0.78), facmax = 0.1, thresh = 1e-15, TINY = 1e-50;
+  std::vector<double> yscale(n), del(n), ydel(n), ffdel(n), Fdel((size_t)n * n), Difmax(n), absFdelRm(n), absFvalue(n), absFvalueRm(n), Fscale(n), tmp(n);
+  std::vector<int> Rowmax(n, 0), logj(n);
+  std::vector<double>& fac = S.fac;
+  for (int j = 0; j < n; j++) {
+    yscale[j] = std::max(std::fabs(y[j]), thresh);
+    del[j] = (y[j] + fac[j] * yscale[j]) - y[j];
+  }
+  for (int j = 0; j < n; j++) {
+    if (del[j] == 0.0) {
+      for (;;) {
+        if (fac[j] < facmax) {
+          fac[j] = std::min(100 * fac[j], facmax);
+          del[j] = (y[j] + fac[j] * yscale[j]) - y[j];
+          if (del[j] == 0.0) break;
+        } else { del[j] = thresh; break; }
+      }
+    }
+  }
+  for (int j = 0; j < n; j++) del[j] = (fval[j] >= 0.0) ? std::fabs(del[j]) : -std::fabs(del[j]);
+  for (int j = 0; j < n; j++) {
+    for (int i = 0; i < n; i++) ydel[i] = y[i];
+    ydel[j] += del[j];
+    f(t, ydel.data(), ffdel.data());
+    (*nfe)++;
+    for (int i = 0; i < n; i++) Fdel[(size_t)i * n + j] = ffdel[i];
+  }
+  for (int j = 0; j < n; j++) {
+    double Fdiff_new = 0.0, Fdiff_absrm = 0.0;
+    for (int i = 0; i < n; i++) {
+      Fdiff_absrm = std::max(std::fabs(Fdiff_new), Fdiff_absrm);
+      Fdiff_new = Fdel[(size_t)i * n + j] - fval[i];
+      S.J[(size_t)i * n + j] = Fdiff_new / del[j];
+      if (std::fabs(Fdiff_new) >= Fdiff_absrm) { Rowmax[j] = i; Difmax[j] = std::fabs(Fdiff_new); }
+    }
+    absFdelRm[j] = std::fabs(Fdel[(size_t)Rowmax[j] * n + j]);
+  }
+  for (int i = 0; i < n; i++) absFvalue[i] = std::fabs(fval[i]);
+  for (int j = 0; j < n; j++) absFvalueRm[j] = absFvalue[Rowmax[j]];
+  int logjpos = 0;
+  for (int j = 0; j < n; j++) {
+    if (((absFdelRm[j] < TINY) && (absFvalueRm[j] < TINY)) || (std::fabs(Difmax[j]) < TINY)) { logj[j] = 1; logjpos = 1; }
+    else logj[j] = 0;
+  }
+  if (logjpos == 1) {
+    for (int i = 0; i < n; i++) { ydel[i] = y[i]; Fscale[i] = std::max(absFdelRm[i], absFvalueRm[i]); }
+    for (int j = 0; j < n; j++) {
+      if ((logj[j] == 1) && (Difmax[j] <= (br * Fscale[j]))) {
+        double tmpfac = std::min(std::sqrt(fac[j]), facmax);
+        double del2 = (y[j] + tmpfac * yscale[j]) - y[j];
+        if ((tmpfac != fac[j]) && (del2 != 0.0)) {
+          del2 = (fval[j] >= 0.0) ? std::fabs(del2) : -std::fabs(del2);
+          ydel[j] = y[j] + del2;
+          f(t, ydel.data(), ffdel.data());
+          (*nfe)++;
+          ydel[j] = y[j];
+          int rowmax2 = 0; double difmax2 = 0., Fdiff_new = 0., Fdiff_absrm = 0.;
+          for (int i = 0; i < n; i++) {
+            Fdiff_absrm = std::max(Fdiff_absrm, std::fabs(Fdiff_new));
+            Fdiff_new = ffdel[i] - fval[i];
+            tmp[i] = Fdiff_new / del2;
+            if (std::fabs(Fdiff_new) >= Fdiff_absrm) { rowmax2 = i; difmax2 = std::fabs(Fdiff_new); }
+          }
+          double maxval1 = difmax2 * std::fabs(del2) * tmpfac, maxval2 = Difmax[j] * std::fabs(del[j]);
+          if (maxval1 >= maxval2) {
+            for (int i = 0; i < n; i++) S.J[(size_t)i * n + j] = tmp[i];
+            double ffscale = std::max(std::fabs(ffdel[rowmax2]), absFvalue[rowmax2]);
+            if (difmax2 <= bl * ffscale) fac[j] = std::min(10 * tmpfac, facmax);
+            else if (difmax2 > bu * ffscale) fac[j] = std::max(0.1 * tmpfac, facmin);
+            else fac[j] = tmpfac;
+          }
+        }
+      }
+    }
+  }
+}
+
+void adjust_stepsize(std::vector<double>& dif, int neq, double r, int k) {  // ev.cpp:907-943; dif[i*7 + j], j = 0..6
+  const double U[5][5] = {{-1, -2, -3, -4, -5}, {0, 1, 3, 6, 10}, {0, 0, -1, -4, -10}, {0, 0, 0, 1, 5}, {0, 0, 0, 0, -1}};
+  double RU[5][5], tv[5];
+  for (int ii = 1; ii <= 5; ii++) RU[0][ii - 1] = -ii * r;
+  for (int jj = 2; jj <= 5; jj++)
+    for (int ii = 1; ii <= 5; ii++) RU[jj - 1][ii - 1] = RU[jj - 2][ii - 1] * (1.0 - (1.0 + ii * r) / jj);
+  for (int ii = 0; ii < 5; ii++) {
+    for (int kk = 0; kk < 5; kk++) tv[kk] = RU[ii][kk];
+    for (int jj = 0; jj < 5; jj++) {
+      RU[ii][jj] = 0.0;
+      for (int kk = 0; kk < 5; kk++) RU[ii][jj] += tv[kk] * U[kk][jj];
+    }
+  }
+  for (int ii = 0; ii < neq; ii++) {
+    for (int kk = 0; kk < k; kk++) tv[kk] = dif[(size_t)ii * 7 + kk];
+    for (int jj = 0; jj < k; jj++) {
+      double s = 0.0;
+      for (int kk = 0; kk < k; kk++) s += tv[kk] * RU[kk][jj];
+      dif[(size_t)ii * 7 + jj] = s;
+    }
+  }
+}
+
+bool new_linearisation(Ndf& S, double hinvGak) {  // ev.cpp:945-998, dense branch
+  const int n = S.neq;
+  for (int i = 0; i < n; i++)
+    for (int j = 0; j < n; j++) S.LU[(size_t)i * n + j] = -hinvGak * S.J[(size_t)i * n + j] + (i == j ? 1.0 : 0.0);
+  return ludcmp(S.LU, n, S.piv);
+}
+
+// returns 0 ok, 1 "step size too small", 2 singular matrix
+template <class F, class O>
+int ndf15(F&& f, O&& output, double t0, double tfinal, double* y_inout, const int* used_in_output, int neq, double rtol,
+          double minimum_variation, const double* t_vec, int tres, Ndf& S) {
+  const double G[5] = {1.0, 3.0 / 2.0, 11.0 / 6.0, 25.0 / 12.0, 137.0 / 60.0};
+  const double alpha[5] = {-37.0 / 200, -1.0 / 9.0, -8.23e-2, -4.15e-2, 0};
+  double invGa[5], erconst[5];
+  const double abstol = 1e-15, eps = 1e-16, threshold = abstol;
+  const int maxit = 4, maxk = 5;
+  for (int i = 0; i < 5; i++) { invGa[i] = 1.0 / (G[i] * (1.0 - alpha[i])); erconst[i] = alpha[i] * G[i] + 1.0 / (2.0 + i); }
+  S.neq = neq;
+  S.J.assign((size_t)neq * neq, 0.); S.LU.assign((size_t)neq * neq, 0.); S.piv.assign(neq, 0);
+  S.fac.assign(neq, 1.490116119384765597872e-8);
+  std::vector<double> f0(neq), wt(neq), ddfddt(neq), pred(neq), y(neq), invwt(neq), rhs(neq), psi(neq), difkp1(neq), del(neq),
+      yinterp(neq), ypinterp(neq), tempvec1(neq), dif((size_t)neq * 7, 0.);
+  double* ynew = y_inout;
+  for (int i = 0; i < neq; i++) y[i] = y_inout[i];
+  int next = 0;
+  while (t_vec[next] < t0) next++;
+  double htspan = std::fabs(tfinal - t0);
+  f(t0, y.data(), f0.data()); S.stat[2]++;
+  int tdir = (tfinal - t0) < 0.0 ? -1 : 1;
+  double hmax = (tfinal - t0) / 10.0;
+  double t = t0;
+  int nfenj = 0;
+  numjac(f, t, y.data(), f0.data(), S, &nfenj);
+  S.stat[3]++; S.stat[2] += nfenj;
+  bool Jcurrent = true;
+  double hmin = 16.0 * eps * std::fabs(t);
+  double rh = 0.0;
+  for (int j = 0; j < neq; j++) { wt[j] = std::max(std::fabs(y[j]), threshold); rh = std::max(rh, 1.25 / std::sqrt(rtol) * std::fabs(f0[j] / wt[j])); }
+  double absh = std::min(hmax, htspan);
+  if (absh * rh > 1.0) absh = 1.0 / rh;
+  absh = std::max(absh, hmin);
+  double h = tdir * absh;
+  double tdel = (t + tdir * std::min(std::sqrt(eps) * std::max(std::fabs(t), std::fabs(t + h)), absh)) - t;
+  f(t + tdel, y.data(), tempvec1.data()); S.stat[2]++;
+  for (int i = 0; i < neq; i++) { ddfddt[i] = 0.0; for (int j = 0; j < neq; j++) ddfddt[i] += S.J[(size_t)i * neq + j] * f0[j]; }
+  rh = 0.0;
+  for (int i = 0; i < neq; i++) { ddfddt[i] += (tempvec1[i] - f0[i]) / tdel; rh = std::max(rh, 1.25 * std::sqrt(0.5 * std::fabs(ddfddt[i] / wt[i]) / rtol)); }
+  absh = std::min(hmax, htspan);
+  if (absh * rh > 1.0) absh = 1.0 / rh;
+  absh = std::max(absh, hmin);
+  h = tdir * absh;
+  int k = 1, klast = k;
+  double abshlast = absh;
+  for (int i = 0; i < neq; i++) dif[(size_t)i * 7 + 0] = h * f0[i];
+  double hinvGak = h * invGa[k - 1];
+  int nconhk = 0;
+  if (!new_linearisation(S, hinvGak)) return 2;
+  S.stat[4]++;
+  bool havrate = false, done = false, at_hmin = false;
+  double rate = 0., oldnrm = 0., tnew = t, err = 0.;
+  while (!done) {
+    hmin = minimum_variation;
+    absh = std::min(hmax, std::max(hmin, absh));
+    if (std::fabs(absh - hmin) < 100 * eps) { if (at_hmin) absh = abshlast; at_hmin = true; } else at_hmin = false;
+    h = tdir * absh;
+    if (1.1 * absh >= std::fabs(tfinal - t)) { h = tfinal - t; absh = std::fabs(h); done = true; }
+    if (((std::fabs(absh - abshlast) / absh) > 1e-6) || (k != klast)) {
+      adjust_stepsize(dif, neq, absh / abshlast, k);
+      hinvGak = h * invGa[k - 1];
+      nconhk = 0;
+      if (!new_linearisation(S, hinvGak)) return 2;
+      S.stat[4]++;
+      havrate = false;
+    }
+    bool nofailed = true;
+    for (;;) {
+      bool gotynew = false;
+      while (!gotynew) {
+        for (int i = 0; i < neq; i++) { psi[i] = 0.0; for (int j = 1; j <= k; j++) psi[i] += dif[(size_t)i * 7 + j - 1] * G[j - 1] * invGa[k - 1]; }
+        tnew = t + h;
+        if (done) tnew = tfinal;
+        h = tnew - t;
+        for (int i = 0; i < neq; i++) { pred[i] = y[i]; for (int j = 1; j <= k; j++) pred[i] += dif[(size_t)i * 7 + j - 1]; }
+        for (int i = 0; i < neq; i++) ynew[i] = pred[i];
+        double minnrm = 0.0;
+        for (int j = 0; j < neq; j++) {
+          difkp1[j] = 0.0;
+          invwt[j] = 1.0 / std::max(std::max(std::fabs(ynew[j]), std::fabs(y[j])), threshold);
+          minnrm = std::max(minnrm, 100 * eps * std::fabs(ynew[j] * invwt[j]));
+        }
+        bool tooslow = false;
+        for (int iter = 1; iter <= maxit; iter++) {
+          for (int i = 0; i < neq; i++) tempvec1[i] = psi[i] + difkp1[i];
+          f(tnew, ynew, f0.data()); S.stat[2]++;
+          for (int j = 0; j < neq; j++) rhs[j] = hinvGak * f0[j] - tempvec1[j];
+          for (int j = 0; j < neq; j++) del[j] = rhs[j];
+          lubksb(S.LU, neq, S.piv, del.data());
+          S.stat[5]++;
+          double newnrm = 0.0;
+          for (int j = 0; j < neq; j++) newnrm = std::max(newnrm, std::fabs(del[j] * invwt[j]));
+          for (int j = 0; j < neq; j++) { difkp1[j] += del[j]; ynew[j] = pred[j] + difkp1[j]; }
+          if (newnrm <= minnrm) { gotynew = true; break; }
+          else if (iter == 1) {
+            if (havrate) { double errit = newnrm * rate / (1.0 - rate); if (errit <= 0.05 * rtol) { gotynew = true; break; } }
+            else rate = 0.0;
+          } else if (newnrm > 0.9 * oldnrm) { tooslow = true; break; }
+          else {
+            rate = std::max(0.9 * rate, newnrm / oldnrm);
+            havrate = true;
+            double errit = newnrm * rate / (1.0 - rate);
+            if (errit <= 0.5 * rtol) { gotynew = true; break; }
+            else if (iter == maxit) { tooslow = true; break; }
+            else if (0.5 * rtol < errit * std::pow(rate, (maxit - iter))) { tooslow = true; break; }
+          }
+          oldnrm = newnrm;
+        }
+        if (tooslow) {
+          S.stat[1]++;
+          if (!Jcurrent) {
+            f(t, y.data(), f0.data());
+            nfenj = 0;
+            numjac(f, t, y.data(), f0.data(), S, &nfenj);
+            S.stat[3]++; S.stat[2] += nfenj + 1;
+            Jcurrent = true;
+          } else if (absh <= hmin) return 1;
+          else {
+            abshlast = absh;
+            absh = std::max(0.3 * absh, hmin);
+            h = tdir * absh;
+            done = false;
+            adjust_stepsize(dif, neq, absh / abshlast, k);
+            hinvGak = h * invGa[k - 1];
+            nconhk = 0;
+          }
+          if (!new_linearisation(S, hinvGak)) return 2;
+          S.stat[4]++;
+          havrate = false;
+        }
+      }
+      err = 0.0;
+      for (int j = 0; j < neq; j++) err = std::max(err, std::fabs(difkp1[j] * invwt[j]));
+      err = err * erconst[k - 1];
+      if (err > rtol) {
+        S.stat[1]++;
+        if (absh <= hmin) return 1;
+        abshlast = absh;
+        if (nofailed) {
+          nofailed = false;
+          double hopt = absh * std::max(0.1, 0.833 * std::pow((rtol / err), (1.0 / (k + 1))));
+          if (k > 1) {
+            double errkm1 = 0.0;
+            for (int j = 0; j < neq; j++) errkm1 = std::max(errkm1, std::fabs((dif[(size_t)j * 7 + k - 1] + difkp1[j]) * invwt[j]));
+            errkm1 = errkm1 * erconst[k - 2];
+            double hkm1 = absh * std::max(0.1, 0.769 * std::pow((rtol / errkm1), (1.0 / k)));
+            if (hkm1 > hopt) { hopt = std::min(absh, hkm1); k = k - 1; }
+          }
+          absh = std::max(hmin, hopt);
+        } else absh = std::max(hmin, 0.5 * absh);
+        h = tdir * absh;
+        if (absh < abshlast) done = false;
+        adjust_stepsize(dif, neq, absh / abshlast, k);
+        hinvGak = h * invGa[k - 1];
+        nconhk = 0;
+        if (!new_linearisation(S, hinvGak)) return 2;
+        S.stat[4]++;
+        havrate = false;
+      } else break;
+    }
+    S.stat[0]++;
+    for (int j = 0; j < neq; j++) { dif[(size_t)j * 7 + k + 1] = difkp1[j] - dif[(size_t)j * 7 + k]; dif[(size_t)j * 7 + k] = difkp1[j]; }
+    for (int j = k; j >= 1; j--) for (int i = 0; i < neq; i++) dif[(size_t)i * 7 + j - 1] += dif[(size_t)i * 7 + j];
+    while ((next < tres) && (tdir * (tnew - t_vec[next]) >= 0.0)) {
+      if (tnew == t_vec[next]) output(t_vec[next], ynew, f0.data(), next);
+      else {
+        // interp_from_dif ev.cpp:860-905
+        double s = (t_vec[next] - tnew) / h, prod = 1.0, sumfrac = 0., fact = 1.0, vecy[5], vecdy[5];
+        for (int j = 0; j < k; j++) { prod *= (s + j); fact *= (j + 1); sumfrac += 1.0 / (s + j); vecy[j] = prod / fact; vecdy[j] = prod * sumfrac / (h * fact); }
+        for (int i = 0; i < neq; i++) {
+          if (used_in_output[i]) {
+            double s1 = 0, s2 = 0;
+            for (int j = 0; j < k; j++) { s1 += vecy[j] * dif[(size_t)i * 7 + j]; s2 += vecdy[j] * dif[(size_t)i * 7 + j]; }
+            yinterp[i] = ynew[i] + s1; ypinterp[i] = s2;
+          }
+        }
+        output(t_vec[next], yinterp.data(), ypinterp.data(), next);
+      }
+      next++;
+    }
+    if (done) break;
+    klast = k;
+    abshlast = absh;
+    nconhk = std::min(nconhk + 1, maxk + 2);
+    if (nconhk >= k + 2) {
+      double temp = 1.2 * std::pow((err / rtol), (1.0 / (k + 1.0)));
+      double hopt = temp > 0.1 ? absh / temp : 10 * absh;
+      int kopt = k;
+      if (k > 1) {
+        double errkm1 = 0.0;
+        for (int j = 0; j < neq; j++) errkm1 = std::max(errkm1, std::fabs(dif[(size_t)j * 7 + k - 1] * invwt[j]));
+        errkm1 = errkm1 * erconst[k - 2];
+        temp = 1.3 * std::pow((errkm1 / rtol), (1.0 / k));
+        double hkm1 = temp > 0.1 ? absh / temp : 10 * absh;
+        if (hkm1 > hopt) { hopt = hkm1; kopt = k - 1; }
+      }
+      if (k < maxk) {
+        double errkp1 = 0.0;
+        for (int j = 0; j < neq; j++) errkp1 = std::max(errkp1, std::fabs(dif[(size_t)j * 7 + k + 1] * invwt[j]));
+        errkp1 = errkp1 * erconst[k];
+        temp = 1.4 * std::pow((errkp1 / rtol), (1.0 / (k + 2.0)));
+        double hkp1 = temp > 0.1 ? absh / temp : 10 * absh;
+        if (hkp1 > hopt) { hopt = hkp1; kopt = k + 1; }
+      }
+      if (hopt > absh) { absh = hopt; if (k != kopt) k = kopt; }
+    }
+    t = tnew;
+    for (int i = 0; i < neq; i++) y[i] = ynew[i];
+    Jcurrent = false;
+  }
+  f(tnew, ynew, f0.data());  // ev.cpp:653-662: leaves the workspace consistent for the next regime
+  return 0;
+}
+
+// perturb_initial_conditions, pm.cpp:4723-5408 (adiabatic, synchronous, flat)
+void initial_conditions(const Model& m, double k, double tau, const Layout& L, double* y) {
+  const cpt_config& c = *m.c;
+  Bg bg;
+  bg_at_tau(m, tau, bg);
+  double a = bg.a;
+  double rho_r = bg.rho_g, rho_m = bg.rho_b, rho_nu = 0.;
+  if (c.has_cdm) rho_m += bg.rho_cdm;
+  if (c.has_ur) { rho_r += bg.rho_ur; rho_nu += bg.rho_ur; }
+  double fracnu = rho_nu / rho_r, fracb = bg.rho_b / rho_m;
+  double om = a * rho_m / std::sqrt(rho_r);
+  double ktau_two = k * k * tau * tau, ktau_three = k * tau * ktau_two;
+  double s2_squared = 1.;
+  for (int i = 0; i < L.neq; i++) y[i] = 0.;
+  y[L.delta_g] = -ktau_two / 3. * (1. - om * tau / 5.) * c.curvature_ini * s2_squared;
+  y[L.theta_g] = -k * ktau_three / 36. * (1. - 3. * (1. + 5. * fracb - fracnu) / 20. / (1. - fracnu) * om * tau) * c.curvature_ini * s2_squared;
+  y[L.delta_b] = 3. / 4. * y[L.delta_g];
+  y[L.theta_b] = y[L.theta_g];
+  if (c.has_cdm) y[L.delta_cdm] = 3. / 4. * y[L.delta_g];
+  if (c.has_ur) {
+    double delta_ur = y[L.delta_g];
+    double theta_ur = -k * ktau_three / 36. / (4. * fracnu + 15.) *
+                      (4. * fracnu + 11. + 12. * s2_squared - 3. * (8. * fracnu * fracnu + 50. * fracnu + 275.) / 20. / (2. * fracnu + 15.) * tau * om) *
+                      c.curvature_ini * s2_squared;
+    double shear_ur = ktau_two / (45. + 12. * fracnu) * (3. * s2_squared - 1.) * (1. + (4. * fracnu - 5.) / 4. / (2. * fracnu + 15.) * tau * om) * c.curvature_ini;
+    double l3_ur = ktau_three * 2. / 7. / (12. * fracnu + 45.) * c.curvature_ini;
+    y[L.delta_ur] = delta_ur; y[L.theta_ur] = theta_ur; y[L.shear_ur] = shear_ur; y[L.l3_ur] = l3_ur;
+  }
+  y[L.eta] = c.curvature_ini * (1. - ktau_two / 12. / (15. + 4. * fracnu) *
+                                         (5. + 4. * s2_squared * fracnu - (16. * fracnu * fracnu + 280. * fracnu + 325) / 10. / (2. * fracnu + 15.) * tau * om));
+}
+
+// hand-over between regimes: pm.cpp:3777-4260
+void handover(const Model& m, double k, const Layout& Lo, const double* yo, const Layout& Ln, double* yn, const Work& w) {
+  const cpt_config& c = *m.c;
+  for (int i = 0; i < Ln.neq; i++) yn[i] = 0.;
+  yn[Ln.delta_b] = yo[Lo.delta_b]; yn[Ln.theta_b] = yo[Lo.theta_b];
+  if (c.has_cdm) yn[Ln.delta_cdm] = yo[Lo.delta_cdm];
+  yn[Ln.eta] = yo[Lo.eta];
+  if (Lo.tca && !Ln.tca) {  // pm.cpp:3880-3935
+    yn[Ln.delta_g] = yo[Lo.delta_g]; yn[Ln.theta_g] = yo[Lo.theta_g];
+    yn[Ln.shear_g] = w.tca_shear_g;
+    yn[Ln.l3_g] = 6. / 7. * k / w.th.dkappa * yn[Ln.shear_g];
+    yn[Ln.pol0_g] = 2.5 * yn[Ln.shear_g];
+    yn[Ln.pol1_g] = k / w.th.dkappa * (5. - 2.) / 6. * yn[Ln.shear_g];
+    yn[Ln.pol2_g] = 0.5 * yn[Ln.shear_g];
+    yn[Ln.pol3_g] = k / w.th.dkappa * 3. / 14. * yn[Ln.shear_g];
+    if (c.has_ur) {
+      yn[Ln.delta_ur] = yo[Lo.delta_ur]; yn[Ln.theta_ur] = yo[Lo.theta_ur]; yn[Ln.shear_ur] = yo[Lo.shear_ur];
+      if (!Ln.ufa) for (int l = 3; l <= Ln.l_max_ur; l++) yn[Ln.delta_ur + l] = yo[Lo.delta_ur + l];
+    }
+  }
+  if (!Lo.rsa && Ln.rsa) {  // pm.cpp:4003-4035: nothing to copy besides b, cdm, eta (photon/ur variables disappear)
+  }
+  if (c.has_ur && !Lo.ufa && Ln.ufa) {  // pm.cpp:4040-4110
+    if (!Ln.rsa) { yn[Ln.delta_g] = yo[Lo.delta_g]; yn[Ln.theta_g] = yo[Lo.theta_g]; }
+    if (!Ln.tca && !Ln.rsa) {
+      for (int l = 2; l <= Ln.l_max_g; l++) yn[Ln.delta_g + l] = yo[Lo.delta_g + l];
+      for (int l = 0; l <= Ln.l_max_pol_g; l++) yn[Ln.pol0_g + l] = yo[Lo.pol0_g + l];
+    }
+    if (!Ln.rsa) { yn[Ln.delta_ur] = yo[Lo.delta_ur]; yn[Ln.theta_ur] = yo[Lo.theta_ur]; yn[Ln.shear_ur] = yo[Lo.shear_ur]; }
+  }
+}
+
+struct ModeResult { cpt_stepstat st; int status; };
+
+// perturb_solve, pm.cpp:2463-2787. src: [tp][ntau][nk] (column ik written)
+int solve_mode(const Model& m, double k, int ik, int nk, const double* tau_sampling, int ntau, double* src, ModeResult* res) {
+  const cpt_config& c = *m.c;
+  const cpt_tables& t = *m.t;
+  memset(&res->st, 0, sizeof(res->st));
+  // ---- start time by bisection, pm.cpp:2545-2635 ----
+  double tau_lower = t.tau_table[0], tau_upper = tau_sampling[0], tau_mid = 0.5 * (tau_lower + tau_upper);
+  {
+    Bg bg; Th th;
+    bg_at_tau(m, tau_lower, bg);
+    th_at_z(m, 1. / bg.a - 1., bg, th);
+    if (bg.a * bg.H / th.dkappa > c.start_small_k_at_tau_c_over_tau_h) return 1;
+    if (k / bg.a / bg.H > c.start_large_k_at_tau_h_over_tau_k) return 1;
+  }
+  while ((tau_upper - tau_lower) / tau_lower > c.tol_tau_approx) {
+    Bg bg; Th th;
+    bg_at_tau(m, tau_mid, bg);
+    th_at_z(m, 1. / bg.a - 1., bg, th);
+    bool early = !((bg.a * bg.H / th.dkappa > c.start_small_k_at_tau_c_over_tau_h) || (k / bg.a / bg.H > c.start_large_k_at_tau_h_over_tau_k));
+    if (early) tau_lower = tau_mid; else tau_upper = tau_mid;
+    tau_mid = 0.5 * (tau_lower + tau_upper);
+  }
+  const double tau_ini = tau_mid, tau_end = tau_sampling[ntau - 1];
+  res->st.tau_ini = tau_ini;
+  // ---- regime schedule, pm.cpp:2940-3231 ----
+  int f_ini[3], f_end[3];
+  approximations(m, k, tau_ini, &f_ini[0], &f_ini[1], &f_ini[2]);
+  approximations(m, k, tau_end, &f_end[0], &f_end[1], &f_end[2]);
+  // tca goes 1 -> 0, rsa / ufa go 0 -> 1 (chronological order of the reference's enums)
+  std::vector<double> limits{tau_ini};
+  std::vector<double> sw;
+  for (int ap = 0; ap < 3; ap++) {
+    if (f_ini[ap] == f_end[ap]) continue;
+    if ((ap == 0 && !(f_ini[0] == 1 && f_end[0] == 0)) || (ap > 0 && !(f_ini[ap] == 0 && f_end[ap] == 1))) return 2;  // would go backward
+    double lo = tau_ini, hi = tau_end, mid = 0.5 * (lo + hi);
+    while (hi - lo > c.tol_tau_approx) {
+      int f[3];
+      approximations(m, k, mid, &f[0], &f[1], &f[2]);
+      if (f[ap] != f_ini[ap]) hi = mid; else lo = mid;
+      mid = 0.5 * (lo + hi);
+    }
+    sw.push_back(mid);
+  }
+  std::sort(sw.begin(), sw.end());
+  for (size_t i = 1; i < sw.size(); i++) if (sw[i] == sw[i - 1]) return 2;
+  for (double s : sw) limits.push_back(s);
+  limits.push_back(tau_end);
+  const int n_int = (int)limits.size() - 1;
+  res->st.n_regimes = n_int;
+
+  if (f_ini[0] != 1 || f_ini[1] != 0 || f_ini[2] != 0) return 3;  // pm.cpp:3720-3745: ICs assume tca on, rsa/ufa off
+  Work w;
+  Layout Lprev;
+  std::vector<double> y, yprev;
+  Ndf S;
+  for (int iv = 0; iv < n_int; iv++) {
+    int f[3];
+    approximations(m, k, iv == 0 ? limits[0] : 0.5 * (limits[iv] + limits[iv + 1]), &f[0], &f[1], &f[2]);
+    if (iv == 0) { f[0] = f_ini[0]; f[1] = f_ini[1]; f[2] = f_ini[2]; }
+    Layout L = make_layout(c, f[0], f[1], f[2]);
+    y.assign(L.neq, 0.);
+    if (iv == 0) initial_conditions(m, k, limits[0], L, y.data());
+    else {
+      int nsw = (f[0] != Lprev.tca) + (f[1] != Lprev.rsa) + (f[2] != Lprev.ufa);
+      if (nsw != 1) return 2;
+      handover(m, k, Lprev, yprev.data(), L, y.data(), w);
+    }
+    auto rhs = [&](double tau, const double* yy, double* dyy) { derivs(m, k, tau, yy, dyy, L, w); };
+    auto out = [&](double tau, const double* yy, const double* dyy, int it) {
+      double s[16];
+      sources(m, k, tau, yy, dyy, L, w, s);
+      for (int tp = 0; tp < c.tp_size; tp++) src[((size_t)tp * ntau + it) * nk + ik] = s[tp];
+    };
+    Ndf Sx;
+    int rc = ndf15(rhs, out, limits[iv], limits[iv + 1], y.data(), L.used_in_sources.data(), L.neq, c.tol_perturb_integration,
+                   c.smallest_allowed_variation, tau_sampling, ntau, Sx);
+    res->st.steps += Sx.stat[0]; res->st.failed += Sx.stat[1]; res->st.fevals += Sx.stat[2]; res->st.jacobians += Sx.stat[3];
+    res->st.factorisations += Sx.stat[4]; res->st.solves += Sx.stat[5];
+    if (rc) return 10 + rc;
+    Lprev = L;
+    yprev = y;
+  }
+  return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+// All k-modes on `threads` CPU threads (k descending like pm.cpp:685-707). sources: [tp][ntau][nk], host.
+int orc_perturb(const cpt_config* cfg, const cpt_tables* tabs, const double* k, int nk, const double* tau_sampling, int ntau,
+                double* sources, cpt_stepstat* stats, int* status, int threads) {
+  Model m{cfg, tabs};
+  threads = std::max(1, threads);
+  std::vector<int> rcs(nk, 0);
+  auto worker = [&](int tid) {
+    for (int ik = nk - 1 - tid; ik >= 0; ik -= threads) {
+      ModeResult r;
+      r.status = solve_mode(m, k[ik], ik, nk, tau_sampling, ntau, sources, &r);
+      rcs[ik] = r.status;
+      if (stats) stats[ik] = r.st;
+    }
+  };
+  std::vector<std::thread> pool;
+  for (int t = 1; t < threads; t++) pool.emplace_back(worker, t);
+  worker(0);
+  for (auto& t : pool) t.join();
+  int bad = 0;
+  for (int i = 0; i < nk; i++) { if (status) status[i] = rcs[i]; if (rcs[i]) bad++; }
+  return bad ? CPT_ERR_RUNTIME : CPT_OK;
+}
+
+// single-function hooks for unit tests
+int orc_lookup(const cpt_config* cfg, const cpt_tables* tabs, const double* tau, int n, double* out /*[n][16]*/) {
+  Model m{cfg, tabs};
+  for (int i = 0; i < n; i++) {
+    Bg bg; Th th;
+    if (!bg_at_tau(m, tau[i], bg)) return 1;
+    th_at_z(m, 1. / bg.a - 1., bg, th);
+    double* o = out + (size_t)i * 16;
+    o[0] = bg.a; o[1] = bg.H; o[2] = bg.Hp; o[3] = bg.rho_g; o[4] = bg.rho_b; o[5] = bg.rho_cdm; o[6] = bg.rho_ur;
+    o[7] = th.xe; o[8] = th.dkappa; o[9] = th.tau_d; o[10] = th.ddkappa; o[11] = th.dddkappa; o[12] = th.expmk; o[13] = th.g;
+    o[14] = th.dg; o[15] = th.cb2;
+  }
+  return 0;
+}
+
+int orc_derivs(const cpt_config* cfg, const cpt_tables* tabs, double k, double tau, int tca_on, int rsa_on, int ufa_on,
+               const double* y, double* dy, int* neq) {
+  Model m{cfg, tabs};
+  Layout L = make_layout(*cfg, tca_on, rsa_on, ufa_on);
+  Work w;
+  *neq = L.neq;
+  derivs(m, k, tau, y, dy, L, w);
+  return 0;
+}
+}

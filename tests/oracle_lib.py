@@ -84,3 +84,48 @@ def ref_time(cfg, threads, reps=3):
     gold = os.path.join(ROOT, "tests", "golden")
     out = subprocess.check_output([REF_DRIVER, "time", os.path.join(gold, cfg + ".ini"), str(threads), str(reps)], cwd=gold)
     return json.loads(out.decode().strip().splitlines()[-1])
+
+
+def _bind_perturb(L):
+    if getattr(L, "_perturb_bound", False):
+        return
+    L.orc_perturb.argtypes = [C.POINTER(CptConfig), C.POINTER(CptTables), _pd, _i, _pd, _i, _pd, C.POINTER(CptStepstat), _pi, _i]
+    L.orc_perturb.restype = _i
+    L.orc_lookup.argtypes = [C.POINTER(CptConfig), C.POINTER(CptTables), _pd, _i, _pd]
+    L.orc_lookup.restype = _i
+    L.orc_derivs.argtypes = [C.POINTER(CptConfig), C.POINTER(CptTables), _d, _d, _i, _i, _i, _pd, _pd, _pi]
+    L.orc_derivs.restype = _i
+    L._perturb_bound = True
+
+
+def perturb(inp, k=None, threads=8):
+    """CPU restatement of the perturbation stage. -> sources [tp][ntau][nk], stats, status"""
+    L = lib()
+    _bind_perturb(L)
+    k = np.ascontiguousarray(inp.k if k is None else k, dtype=np.float64)
+    out = np.zeros((inp.config.tp_size, inp.ntau, k.size))
+    stats = (CptStepstat * k.size)()
+    status = np.zeros(k.size, dtype=np.int32)
+    rc = L.orc_perturb(C.byref(inp.config), C.byref(inp.tables), dptr(k), k.size, dptr(inp.tau), inp.ntau, dptr(out), stats,
+                       iptr(status), threads)
+    return out, stats, status, rc
+
+
+def lookup(inp, tau):
+    L = lib()
+    _bind_perturb(L)
+    tau = np.ascontiguousarray(tau, dtype=np.float64)
+    out = np.zeros((tau.size, 16))
+    assert L.orc_lookup(C.byref(inp.config), C.byref(inp.tables), dptr(tau), tau.size, dptr(out)) == 0
+    return out
+
+
+def derivs(inp, k, tau, tca_on, rsa_on, ufa_on, y):
+    L = lib()
+    _bind_perturb(L)
+    y = np.ascontiguousarray(y, dtype=np.float64)
+    dy = np.zeros(64)
+    neq = C.c_int()
+    assert L.orc_derivs(C.byref(inp.config), C.byref(inp.tables), float(k), float(tau), int(tca_on), int(rsa_on), int(ufa_on),
+                        dptr(y), dptr(dy), C.byref(neq)) == 0
+    return dy[: neq.value].copy()
