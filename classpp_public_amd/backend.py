@@ -128,7 +128,9 @@ class Backend:
         return out
 
     def dbg_derivs(self, k, tau, tca_on, rsa_on, ufa_on, y):
-        y = np.ascontiguousarray(y, dtype=np.float64)
+        yy = np.zeros(64)
+        yy[: len(y)] = y
+        y = yy
         dy = np.zeros(64)
         neq = C.c_int()
         self._check(self.lib.cpt_dbg_derivs(self.h, float(k), float(tau), int(tca_on), int(rsa_on), int(ufa_on), _dptr(y),

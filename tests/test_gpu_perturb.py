@@ -1,0 +1,65 @@
+"""GPU parity tests of hot path A (classpp_public_amd/csrc/cpt_perturb.hip) through the C ABI.
+
+Checkers: the oracle (oracle/restate/perturb_oracle.cpp, pinned to the reference by tests/test_oracle_perturb.py)
+for single device functions, and the golden sources_ dumped from the unmodified reference for the whole stage.
+Tolerances for sources are those of tests/test_oracle_perturb.py (the reference's own rtol=1e-5 noise floor,
+documented there); single-function checks are at round-off level.
+"""
+import numpy as np
+import pytest
+import torch
+
+import oracle_lib
+from classpp_public_amd.inputs import Inputs
+from test_oracle_perturb import check_sources
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def small():
+    from classpp_public_amd.backend import Backend
+    inp = Inputs("small")
+    return inp, Backend(inp)
+
+
+def test_lookup_matches_oracle(small):
+    inp, be = small
+    t = inp.t["bg.tau_table"]
+    # random order on purpose: forward walks, backward jumps, table nodes, both ends, z above the thermo table
+    rng = np.random.default_rng(0)
+    tau = np.concatenate([np.exp(rng.uniform(np.log(t[0] * 1.0001), np.log(t[-1]), 400)), t[[0, 1, 17, 2000, -2, -1]],
+                          np.sort(np.exp(rng.uniform(np.log(1.0), np.log(t[-1]), 300)))])
+    got = be.dbg_lookup(tau)
+    want = oracle_lib.lookup(inp, tau)
+    scale = np.maximum(np.abs(want), 1e-300)
+    assert np.max(np.abs(got - want) / scale) < 1e-12
+
+
+@pytest.mark.parametrize("flags", [(1, 0, 0), (0, 0, 0), (0, 0, 1), (0, 1, 1), (1, 0, 1)])
+def test_derivs_match_oracle(small, flags):
+    inp, be = small
+    rng = np.random.default_rng(1)
+    for k, tau in [(1e-4, 50.0), (0.03, 150.0), (0.03, 290.0), (0.2, 3000.0), (0.5, 13000.0)]:
+        y = rng.normal(size=64)
+        want = oracle_lib.derivs(inp, k, tau, *flags, y)
+        got = be.dbg_derivs(k, tau, *flags, y[: want.size])
+        assert got.size == want.size
+        scale = np.max(np.abs(want))
+        assert np.max(np.abs(got - want)) < 1e-11 * scale, (k, tau, np.max(np.abs(got - want)) / scale)
+
+
+def test_perturb_small_all_modes(small):
+    inp, be = small
+    src, stats, status = be.perturb_solve()
+    assert not status.any()
+    got = src.cpu().numpy()
+    check_sources(inp.config, got, inp.d["pt.sources"])
+    osrc, ostats, _, _ = oracle_lib.perturb(inp)
+    # same algorithm => nearly the same amount of work as the CPU restatement
+    gs, os_ = sum(s.steps for s in stats), sum(s.steps for s in ostats)
+    assert abs(gs - os_) < 0.02 * os_, (gs, os_)
+    assert np.allclose([s.tau_ini for s in stats], [s.tau_ini for s in ostats], rtol=1e-9)
+    assert [s.n_regimes for s in stats] == [s.n_regimes for s in ostats]
+    ms, n = be.kernel_ms(0)
+    print("\n[small] perturb kernel %.3f ms for %d modes, %d steps" % (ms, inp.nk, gs))
