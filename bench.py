@@ -1,0 +1,178 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the perturbations -> transfer hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the hot path for one cosmology: integrate every k-mode (hot path A) and project the sources on
+the Bessel functions for every (q,l) (hot path B).  Workload at N=1: BASELINE.json configs[1] = flat LambdaCDM scalars,
+tCl+pCl+mPk, default precision (tests/golden/lcdm.ini: 567 k-modes, 738 sampling times, 2237 q x 101 l x 4 types).
+The spline tables and grids are resident in HBM / pinned on the handle before the timed region.  At N>1 the k grid is
+densified N-fold (the ~3000-mode grid of BASELINE configs[2] has no .pre file in the reference) and sharded
+round-robin, with the two exchanges of classpp_public_amd/sharded.py: per-GPU ODE work is fixed => "weak" scaling.
+
+Prints ONE JSON line (rank 0).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from classpp_public_amd.backend import Backend  # noqa: E402
+from classpp_public_amd.inputs import Inputs  # noqa: E402
+from classpp_public_amd.sharded import GpuCompute, densify_k, sharded_step  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+BYTES_PER_FEVAL = 800  # 384 B background row gather + 416 B thermodynamics row gather per RHS evaluation
+
+
+def cpu_baseline(cfg_name, nk):
+    """CPU path timed on this host's cores: the real reference (oracle/_ref) when its build travelled with the repo,
+    else the oracle's CPU restatement.  Test infrastructure used as a reported baseline only."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib
+    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    if oracle_lib.have_ref():
+        r = oracle_lib.ref_time(cfg_name, cores, reps=3)
+        return {"value": r["k_size"] / r["perturb_s"], "unit": "k-modes/s", "cores": cores, "kind": "reference",
+                "sample": "full %s.ini through the unmodified reference, best of 3: perturbations %.3f s (%d k-modes), "
+                          "transfer %.3f s" % (cfg_name, r["perturb_s"], r["k_size"], r["transfer_s"]),
+                "perturb_s": r["perturb_s"], "transfer_s": r["transfer_s"]}
+    inp = Inputs(cfg_name)
+    ks = np.arange(0, inp.nk, 4)
+    t0 = time.time()
+    _, _, _, rc = oracle_lib.perturb(inp, k=inp.k[ks], threads=cores)
+    dt = time.time() - t0
+    return {"value": ks.size / dt, "unit": "k-modes/s", "cores": cores, "kind": "port",
+            "sample": "every 4th k-mode of %s.ini (%d modes) through oracle/restate (dense-LU scalar port)" % (cfg_name, ks.size)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", default="lcdm")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit("--gpus %d needs torch.distributed.run with %d ranks (WORLD_SIZE=%d)" % (args.gpus, args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the cpt backend has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    inp = Inputs(args.config)
+    be = Backend(inp, device)
+    comp = GpuCompute(be)
+    k_all = densify_k(inp.k, world)
+    k_size_cl = (inp.k_size_cl - 1) * world + 1
+    nk_total = k_all.size
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def step():
+        if world == 1:
+            be.perturb_solve(want_sources=False)      # sources stay resident, k-major, in HBM
+            return be.transfer(None)
+        out, _ = sharded_step(comp, k_all, inp.l, rank, world, device, k_size_cl)
+        return out
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    kms, tms, fev, stp = [], [], [], []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+        kms.append(be.kernel_ms(0)[0])
+        tms.append(be.kernel_ms(1)[0])
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    # work counters of the last step (identical every step: the computation is deterministic)
+    if world == 1:
+        _, stats, _ = be.perturb_solve(want_sources=False)
+    else:
+        stats = comp.stats
+    fevals = sum(s.fevals for s in stats)
+    steps_tot = sum(s.steps for s in stats)
+    steps_max = max(s.steps for s in stats)
+    nk_local = len(stats)
+
+    if rank == 0:
+        ms_step = dt / args.steps * 1e3
+        k_ms = float(np.mean(kms))
+        t_ms = float(np.mean(tms))
+        alg_bytes = fevals * BYTES_PER_FEVAL + inp.config.tp_size * inp.ntau * nk_local * 8
+        achieved = alg_bytes / (k_ms * 1e-3) / 1e9
+        ints, tsamp, fused = be.transfer_work()
+        out = {
+            "metric": "k-modes/s (perturbations) + C_l wall-time, explanatory.ini, 1/2/4/8 GPUs",
+            "value": nk_total / (dt / args.steps),
+            "unit": "k-modes/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_step,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": "%s.ini: flat LCDM scalars tCl+pCl%s, default precision; %d k-modes x %d tau samples, "
+                                   "%d q x %d l x %d transfer types%s" % (
+                                       args.config, "+mPk" if inp.config.index_tp_delta_m >= 0 else "+lCl", nk_total, inp.ntau,
+                                       inp.q.size, inp.l.size, inp.config.tt_size,
+                                       "" if world == 1 else "; k grid densified %dx and sharded round-robin" % world),
+                       "inputs": "background/thermodynamics spline tables and grids from tests/golden (dumped from the reference)",
+                       "parallelism": "k-sharded x%d, l-sharded transfer, 2 RCCL exchanges" % world if world > 1 else "1 GPU"},
+            "stage_ms": {"perturb_kernel": k_ms, "los_kernel": t_ms, "step_wall": ms_step},
+            "perturb_kmodes_per_s_kernel": nk_local * world / (k_ms * 1e-3),
+            "ode_work": {"fevals": fevals, "steps": steps_tot, "max_steps_per_mode": steps_max,
+                         "us_per_step_critical_path": k_ms * 1e3 / steps_max},
+            "roofline": {"kernel": "k_perturb", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "note": "algorithmic bytes = fevals x 800 B + source output; the kernel is bound by the serial "
+                                 "dependency chain of the longest k-mode (SURVEY S8d), not by HBM",
+                         "los_kernel": {"achieved": fused * 72 / (t_ms * 1e-3) / 1e9, "unit": "GB/s", "peak": HBM_PEAK_GBS,
+                                        "frac": fused * 72 / (t_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                        "fused_samples": fused, "bytes_per_sample": 72}},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                out["cpu_baseline"] = cpu_baseline(args.config, inp.nk)
+            except Exception as e:  # the baseline is a report, never a reason to lose the measurement
+                out["cpu_baseline"] = {"value": None, "unit": "k-modes/s", "cores": 0, "kind": "port", "sample": "failed: %r" % (e,)}
+        print(json.dumps(out))
+    be.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

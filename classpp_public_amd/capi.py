@@ -88,6 +88,9 @@ def lib():
         raise RuntimeError(
             "HIP extension %s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
             "(there is no CPU fallback for the product path)" % LIB_PATH)
+    # PyTorch-ROCm ships its own HIP runtime: load it first so that libcpt.so binds to the SAME libamdhip64
+    # (two HIP runtimes in one process do not share the device context / streams / allocations).
+    import torch  # noqa: F401
     L = C.CDLL(LIB_PATH)
     vp, pi, ll = C.c_void_p, C.POINTER(_i), C.POINTER(C.c_longlong)
     L.cpt_create.argtypes = [C.POINTER(CptConfig), C.POINTER(CptTables), C.POINTER(vp)]

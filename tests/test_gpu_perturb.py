@@ -63,3 +63,36 @@ def test_perturb_small_all_modes(small):
     assert [s.n_regimes for s in stats] == [s.n_regimes for s in ostats]
     ms, n = be.kernel_ms(0)
     print("\n[small] perturb kernel %.3f ms for %d modes, %d steps" % (ms, inp.nk, gs))
+
+
+@pytest.mark.parametrize("cfg", ["lcdm", "explanatory"])
+def test_perturb_full_size(cfg):
+    """BASELINE configs 1-2: every k-mode integrated on the GPU; the 16 golden columns are compared with the reference."""
+    from classpp_public_amd.backend import Backend
+    inp = Inputs(cfg)
+    be = Backend(inp)
+    src, stats, status = be.perturb_solve()
+    assert not status.any()
+    got = src.cpu().numpy()
+    assert np.all(np.isfinite(got))
+    ks = inp.d["pt.sources_k_index"]
+    check_sources(inp.config, got[:, :, ks], inp.d["pt.sources_subset"])
+    if inp.config.index_tp_delta_m >= 0:  # delta_m(k, tau0) for every k: the P(k) input
+        dm = got[inp.config.index_tp_delta_m, -1, :]
+        assert np.max(np.abs(dm / inp.d["pt.delta_m_today"] - 1)) < 1e-5
+    ms, n = be.kernel_ms(0)
+    steps = np.array([s.steps for s in stats])
+    print("\n[%s] perturb kernel %.2f ms, %d modes -> %.0f k-modes/s; steps total %d max %d; fevals %d, LU %d, solves %d" % (
+        cfg, ms, inp.nk, inp.nk / ms * 1e3, steps.sum(), steps.max(), sum(s.fevals for s in stats),
+        sum(s.factorisations for s in stats), sum(s.solves for s in stats)))
+    # chained: transfer from the resident sources, compared with the reference's transfer_ golden subsets.
+    # Tolerance 1e-4 of the per-(type,l) max: the sources carry the rtol-level noise discussed in test_oracle_perturb.
+    tr = be.transfer(None).cpu().numpy()
+    ls = inp.d["tr.transfer_l_index"]
+    want = inp.d["tr.transfer_at_l"]
+    scale = np.max(np.abs(want), axis=-1, keepdims=True)
+    scale[scale == 0] = 1
+    err = np.max(np.abs(tr[:, ls, :] - want) / scale)
+    print("[%s] chained transfer: max err rel. to row max %.2e" % (cfg, err))
+    assert err < 2e-4
+    be.close()
