@@ -58,11 +58,48 @@ __device__ inline double first(double v) {
   return __hiloint2double(hi, lo);
 }
 __device__ inline int ufirst(int v) { return __builtin_amdgcn_readfirstlane(v); }
-__device__ inline double wave_max(double v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_xor(v, off, 64));
-  return first(v);
+// DPP row_shr:n on a double (lanes without a source keep their own value)
+template <int CTRL>
+__device__ inline double dpp_keep(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xf, 0xf, false);
+  hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
 }
+// max over the 64 lanes without touching LDS: 4 DPP steps inside each row of 16 + 4 readlanes (wave-uniform result)
+__device__ inline double wave_max(double v) {
+  v = fmax(v, dpp_keep<0x111>(v));  // row_shr:1
+  v = fmax(v, dpp_keep<0x112>(v));  // row_shr:2
+  v = fmax(v, dpp_keep<0x114>(v));  // row_shr:4
+  v = fmax(v, dpp_keep<0x118>(v));  // row_shr:8
+  return fmax(fmax(bcast(v, 15), bcast(v, 31)), fmax(bcast(v, 47), bcast(v, 63)));
+}
+// neighbours in the wave (hierarchy couplings): wave_shr:1 / wave_shl:1, lanes without a source get 0
+__device__ inline double lane_below(double v) {  // value of lane-1
+  int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x138, 0xf, 0xf, false);
+  int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x138, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+__device__ inline double lane_above(double v) {  // value of lane+1
+  int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x130, 0xf, 0xf, false);
+  int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x130, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+// x^p for the step-size heuristics (ev.cpp:497-505, 580-625): single precision is ample (the result only steers h)
+__device__ inline double fast_pow(double x, double p) { return (double)exp2f((float)p * log2f((float)x)); }
+// 1/x: hardware v_rcp_f64 seed + two Newton-Raphson refinements (full double accuracy to ~1 ulp, no IEEE division
+// expansion with its denormal/scale handling on the critical path)
+__device__ inline double fast_rcp(double x) {
+  double r = __builtin_amdgcn_rcp(x);
+  r = fma(r, fma(-x, r, 1.0), r);
+  r = fma(r, fma(-x, r, 1.0), r);
+  return r;
+}
+// NDF constants (ev.cpp:87-88, 171-174) as immediates: no private arrays, no scratch
+__device__ inline double ndf_G(int i) { return i == 0 ? 1.0 : i == 1 ? 1.5 : i == 2 ? 11.0 / 6.0 : i == 3 ? 25.0 / 12.0 : 137.0 / 60.0; }
+__device__ inline double ndf_alpha(int i) { return i == 0 ? -37.0 / 200 : i == 1 ? -1.0 / 9.0 : i == 2 ? -8.23e-2 : i == 3 ? -4.15e-2 : 0.; }
+__device__ inline double ndf_invGa(int i) { return 1.0 / (ndf_G(i) * (1.0 - ndf_alpha(i))); }
+__device__ inline double ndf_erconst(int i) { return ndf_alpha(i) * ndf_G(i) + 1.0 / (2.0 + i); }
 
 enum Role : int {
   R_NONE = 0, R_DELTA_G, R_THETA_G, R_SHEAR_G, R_LG /* l>=3 photon temperature */, R_POL /* l>=0 polarisation */,
@@ -140,7 +177,7 @@ struct BgV { double a, H, Hp, rg, rb, rc, ru; };
 struct ThV { double xe, dkappa, tau_d, ddkappa, dddkappa, expmk, g, dg, cb2; };
 
 // per-thread (scalar) lookup with binary search: used by the schedule search, where every lane probes its own tau
-__device__ inline int bsearch_up(const double* __restrict__ x, int n, double v) {  // arrays.c:1586-1594
+__device__ __forceinline__ int bsearch_up(const double* __restrict__ x, int n, double v) {  // arrays.c:1586-1594
   int inf = 0, sup = n - 1;
   while (sup - inf > 1) {
     int mid = (inf + sup) >> 1;
@@ -148,12 +185,12 @@ __device__ inline int bsearch_up(const double* __restrict__ x, int n, double v) 
   }
   return inf;
 }
-__device__ inline double spl2(const double2 lo, const double2 hi, double a, double b, double h2) {
+__device__ __forceinline__ double spl2(const double2 lo, const double2 hi, double a, double b, double h2) {
   return a * lo.x + b * hi.x + ((a * a * a - a) * lo.y + (b * b * b - b) * hi.y) * h2;
 }
 // a, H and dkappa at tau (what perturb_approximations and the start-time search need)
-__device__ inline void lookup_aHk(const PtParams& P, double tau, double* a_, double* H_, double* dk_) {
-  const DevTables& T = P.tabs;
+struct AHK { double a, H, dk; };
+__device__ __noinline__ AHK lookup_aHk(DevTables T, double n_e, double tau) {
   int inf = bsearch_up(T.tau_table, T.bt_size, tau);
   double h = T.tau_table[inf + 1] - T.tau_table[inf], b = (tau - T.tau_table[inf]) / h, a = 1. - b, h2 = h * h / 6.;
   const double2* r0 = (const double2*)T.bg + (size_t)inf * BG_NCOL;
@@ -163,122 +200,149 @@ __device__ inline void lookup_aHk(const PtParams& P, double tau, double* a_, dou
   double dk;
   if (z >= T.z_table[T.tt_size - 1]) {
     double x0 = ((const double2*)T.th)[(size_t)(T.tt_size - 1) * TH_NCOL + TH_XE].x;
-    dk = (1. + z) * (1. + z) * P.n_e * x0 * SIGMA_T * MPC_OVER_M;
+    dk = (1. + z) * (1. + z) * n_e * x0 * SIGMA_T * MPC_OVER_M;
   } else {
     int iz = bsearch_up(T.z_table, T.tt_size, z);
     double hz = T.z_table[iz + 1] - T.z_table[iz], bz = (z - T.z_table[iz]) / hz, az = 1. - bz;
     const double2* t0 = (const double2*)T.th + (size_t)iz * TH_NCOL;
     dk = spl2(t0[TH_DKAPPA], t0[TH_NCOL + TH_DKAPPA], az, bz, hz * hz / 6.);
   }
-  *a_ = av; *H_ = Hv; *dk_ = dk;
+  AHK r;
+  r.a = av; r.H = Hv; r.dk = dk;
+  return r;
 }
 
-// wave-cooperative cached lookup used by the RHS / sampler (all arguments and results wave-uniform)
+// Wave-cooperative cached lookup used by the RHS / sampler (all arguments and results wave-uniform).
+// A window of 64 consecutive table rows is staged in LDS (one coalesced copy when the wave walks out of it), its 64
+// abscissae sit in lane registers: the bracket is one ballot+popcount, the two rows come from LDS, and a step that
+// stays in the same table cell re-uses the rows already in registers.  Everything that depends on tau only
+// (reciprocals, tight-coupling coefficients) is derived here once and shared by the Newton iterations and by the
+// columns of the Jacobian, which all evaluate the RHS at the same tau.
 struct Lookup {
-  // abscissa windows (lane l holds x[base + l], +huge past the end) and cached rows (lane c < ncol holds column c)
-  double bgx, thx;
+  double bgx, thx;                 // lane l: abscissa of window row l (+huge past the table end)
   int bg_base, th_base, bg_inf, th_inf;
-  double2 bg_lo, bg_hi, th_lo, th_hi;
+  double2 bg_lo, bg_hi, th_lo, th_hi;  // lane c: column c of rows inf / inf+1
+  double2* bgw;                    // LDS [64][BG_NCOL]
+  double2* thw;                    // LDS [64][TH_NCOL]
   double tau_cached;
   BgV bg;
   ThV th;
+  // derived, tau-only
+  double a2, aH, two_over_aH, R, inv_1pR, inv_R, tau_c, dtau_c, F, Fp, app, inv_tau, aHp;
 };
 
-__device__ inline void window_load(const double* __restrict__ x, int n, int base, int lane, double* xw) {
-  int i = base + lane;
+__device__ __forceinline__ void window_stage(const double* __restrict__ x, const double2* __restrict__ rows, int n, int ncol,
+                                             int base, int lane, double* xw, double2* w) {
+  const int i = base + lane;
   *xw = (i < n) ? x[i] : 1e300;
+  const size_t g0 = (size_t)base * ncol, gend = (size_t)n * ncol;
+  for (int e = lane; e < 64 * ncol; e += 64) w[e] = (g0 + e < gend) ? rows[g0 + e] : make_double2(0., 0.);
 }
 
-// returns inf with x[inf] <= v <= x[inf+1] (x ascending), repositioning the 64-entry window when needed
-__device__ inline int window_find(const double* __restrict__ x, int n, double v, int lane, double* xw, int* base, int bias) {
-  double lo = bcast(*xw, 0), hi = bcast(*xw, 63);
+// returns inf with x[inf] <= v <= x[inf+1] (x ascending), re-staging the 64-row window when v leaves it
+__device__ __forceinline__ int window_find(const double* __restrict__ x, const double2* __restrict__ rows, int n, int ncol, double v,
+                                           int lane, double* xw, double2* w, int* base, int bias) {
+  const double lo = bcast(*xw, 0), hi = bcast(*xw, 63);
   if (!(v >= lo && v < hi)) {
     int inf = bsearch_up(x, n, v);  // uniform
     int nb = inf - bias;
     if (nb > n - 64) nb = n - 64;
     if (nb < 0) nb = 0;
     *base = nb;
-    window_load(x, n, nb, lane, xw);
+    window_stage(x, rows, n, ncol, nb, lane, xw, w);
   }
-  unsigned long long m = __ballot(*xw <= v);
-  int cnt = __popcll(m);
-  int inf = *base + cnt - 1;
+  const unsigned long long m = __ballot(*xw <= v);
+  int inf = *base + __popcll(m) - 1;
   if (inf > n - 2) inf = n - 2;
   if (inf < 0) inf = 0;
   return inf;
 }
 
-__device__ inline void lookup_init(const PtParams& P, Lookup& Q, int lane) {
+__device__ __forceinline__ void lookup_init(const PtParams& P, Lookup& Q, double2* bgw, double2* thw, int lane) {
+  Q.bgw = bgw; Q.thw = thw;
   Q.bg_base = 0; Q.th_base = 0; Q.bg_inf = -1; Q.th_inf = -1; Q.tau_cached = -1.;
-  window_load(P.tabs.tau_table, P.tabs.bt_size, 0, lane, &Q.bgx);
-  window_load(P.tabs.z_table, P.tabs.tt_size, 0, lane, &Q.thx);
+  window_stage(P.tabs.tau_table, (const double2*)P.tabs.bg, P.tabs.bt_size, BG_NCOL, 0, lane, &Q.bgx, bgw);
+  window_stage(P.tabs.z_table, (const double2*)P.tabs.th, P.tabs.tt_size, TH_NCOL, 0, lane, &Q.thx, thw);
   Q.bg_lo = Q.bg_hi = Q.th_lo = Q.th_hi = make_double2(0., 0.);
 }
 
 // background_at_tau (normal_info, source/background_module.cpp:125-199) + thermodynamics_at_z (th.cpp:114-285)
-__device__ inline void lookup(const PtParams& P, Lookup& Q, double tau, int lane) {
+__device__ __forceinline__ void lookup(const PtParams& P, Lookup& Q, double tau, int lane) {
   if (tau == Q.tau_cached) return;
   Q.tau_cached = tau;
   const DevTables& T = P.tabs;
-  int inf = window_find(T.tau_table, T.bt_size, tau, lane, &Q.bgx, &Q.bg_base, 8);  // tau grows along a mode
+  const int inf = window_find(T.tau_table, (const double2*)T.bg, T.bt_size, BG_NCOL, tau, lane, &Q.bgx, Q.bgw, &Q.bg_base, 8);
   if (inf != Q.bg_inf) {
     Q.bg_inf = inf;
     if (lane < BG_NCOL) {
-      const double2* r = (const double2*)T.bg + (size_t)inf * BG_NCOL + lane;
+      const double2* r = Q.bgw + (inf - Q.bg_base) * BG_NCOL + lane;
       Q.bg_lo = r[0];
       Q.bg_hi = r[BG_NCOL];
     }
   }
   {
-    double x0 = bcast(Q.bgx, inf - Q.bg_base), x1 = bcast(Q.bgx, inf - Q.bg_base + 1);
-    double h = x1 - x0, b = (tau - x0) / h, a = 1. - b;
-    double v = spl2(Q.bg_lo, Q.bg_hi, a, b, h * h / 6.);
+    const double x0 = bcast(Q.bgx, inf - Q.bg_base), x1 = bcast(Q.bgx, inf - Q.bg_base + 1);
+    const double h = x1 - x0, b = (tau - x0) / h, a = 1. - b;
+    const double v = spl2(Q.bg_lo, Q.bg_hi, a, b, h * h / 6.);
     Q.bg.a = bcast(v, BG_A); Q.bg.H = bcast(v, BG_H); Q.bg.Hp = bcast(v, BG_HP); Q.bg.rg = bcast(v, BG_RHO_G);
     Q.bg.rb = bcast(v, BG_RHO_B); Q.bg.rc = bcast(v, BG_RHO_CDM); Q.bg.ru = bcast(v, BG_RHO_UR);
   }
-  const double z = 1. / Q.bg.a - 1.;
+  const double inv_a = 1. / Q.bg.a;
+  const double z = inv_a - 1.;
   const double zmax = T.z_table[T.tt_size - 1];
+  ThV& t = Q.th;
   if (z >= zmax) {  // analytic extrapolation, th.cpp:128-219
     const double2* last = (const double2*)T.th + (size_t)(T.tt_size - 1) * TH_NCOL;
-    double x0 = last[TH_XE].x;
-    ThV& t = Q.th;
+    const double x0 = last[TH_XE].x;
     t.xe = x0;
     t.dkappa = (1. + z) * (1. + z) * P.n_e * x0 * SIGMA_T * MPC_OVER_M;
-    double r = (1. + z) / (1. + zmax);
+    const double r = (1. + z) / (1. + zmax);
     t.tau_d = last[TH_TAU_D].x * r * r;
     t.ddkappa = -Q.bg.H * 2. / (1. + z) * t.dkappa;
     t.dddkappa = (Q.bg.H * Q.bg.H / (1. + z) - Q.bg.Hp) * 2. / (1. + z) * t.dkappa;
     t.expmk = 0.; t.g = 0.; t.dg = 0.;
-    double wb = K_B / (C_LIGHT * C_LIGHT * M_H) * (1. + (1. / NOT4 - 1.) * P.YHe + x0 * (1. - P.YHe)) * P.T_cmb * (1. + z);
+    const double wb = K_B / (C_LIGHT * C_LIGHT * M_H) * (1. + (1. / NOT4 - 1.) * P.YHe + x0 * (1. - P.YHe)) * P.T_cmb * (1. + z);
     t.cb2 = wb * 4. / 3.;
     Q.th_inf = -1;
-    return;
-  }
-  int iz = window_find(T.z_table, T.tt_size, z, lane, &Q.thx, &Q.th_base, 54);  // z decreases along a mode
-  if (iz != Q.th_inf) {
-    Q.th_inf = iz;
-    if (lane < TH_NCOL) {
-      const double2* r = (const double2*)T.th + (size_t)iz * TH_NCOL + lane;
-      Q.th_lo = r[0];
-      Q.th_hi = r[TH_NCOL];
+  } else {
+    const int iz = window_find(T.z_table, (const double2*)T.th, T.tt_size, TH_NCOL, z, lane, &Q.thx, Q.thw, &Q.th_base, 54);
+    if (iz != Q.th_inf) {
+      Q.th_inf = iz;
+      if (lane < TH_NCOL) {
+        const double2* r = Q.thw + (iz - Q.th_base) * TH_NCOL + lane;
+        Q.th_lo = r[0];
+        Q.th_hi = r[TH_NCOL];
+      }
     }
-  }
-  {
-    double x0 = bcast(Q.thx, iz - Q.th_base), x1 = bcast(Q.thx, iz - Q.th_base + 1);
-    double h = x1 - x0, b = (z - x0) / h, a = 1. - b;
-    double v = spl2(Q.th_lo, Q.th_hi, a, b, h * h / 6.);
-    ThV& t = Q.th;
+    const double x0 = bcast(Q.thx, iz - Q.th_base), x1 = bcast(Q.thx, iz - Q.th_base + 1);
+    const double h = x1 - x0, b = (z - x0) / h, a = 1. - b;
+    const double v = spl2(Q.th_lo, Q.th_hi, a, b, h * h / 6.);
     t.xe = bcast(v, TH_XE); t.dkappa = bcast(v, TH_DKAPPA); t.tau_d = bcast(v, TH_TAU_D); t.ddkappa = bcast(v, TH_DDKAPPA);
     t.dddkappa = bcast(v, TH_DDDKAPPA); t.expmk = bcast(v, TH_EXPMK); t.g = bcast(v, TH_G); t.dg = bcast(v, TH_DG);
     t.cb2 = bcast(v, TH_CB2);
   }
+  // tau-only derived quantities (one division each, shared by every RHS evaluation at this tau)
+  const BgV& bg = Q.bg;
+  Q.a2 = bg.a * bg.a;
+  Q.aH = bg.a * bg.H;
+  Q.two_over_aH = 2.0 / Q.aH;
+  Q.R = 4. / 3. * bg.rg / bg.rb;
+  Q.inv_1pR = 1.0 / (1.0 + Q.R);
+  Q.inv_R = 1.0 / Q.R;
+  Q.tau_c = 1.0 / t.dkappa;                      // pm.cpp:9290-9297
+  Q.dtau_c = -t.ddkappa * Q.tau_c * Q.tau_c;
+  Q.F = Q.tau_c * Q.inv_1pR;
+  Q.Fp = Q.dtau_c * Q.inv_1pR + Q.tau_c * Q.aH * Q.R * Q.inv_1pR * Q.inv_1pR;
+  Q.app = bg.Hp * bg.a + 2. * Q.aH * Q.aH;       // a''/a
+  Q.aHp = bg.Hp * bg.a + Q.aH * Q.aH;            // (a'/a)'
+  Q.inv_tau = 1.0 / tau;
 }
 
 // ---- physics ------------------------------------------------------------------------------------
 // per-lane constants of the current regime: dy_i = A y[i-1] - B y[i+1] - (D kappa' + G/tau) y[i] + E_role
 struct LaneEq { int role, ell; double A, B, D, G; };
 
-__device__ inline LaneEq make_lane_eq(const PtParams& P, const Layout& L, int lane, double k) {
+__device__ __forceinline__ LaneEq make_lane_eq(const PtParams& P, const Layout& L, int lane, double k) {
   LaneEq e;
   role_of(L, lane, &e.role, &e.ell);
   e.A = e.B = e.D = e.G = 0.;
@@ -319,103 +383,91 @@ __device__ inline LaneEq make_lane_eq(const PtParams& P, const Layout& L, int la
   return e;
 }
 
-// metric + fluid summary left behind by the last einstein/derivs call (struct perturb_workspace of the reference)
+// metric + fluid summary left behind by the last RHS evaluation (struct perturb_workspace of the reference)
 struct Metric {
-  double hp, etap, hpp, alpha, alphap, delta_m;
-  double rsa_dg, rsa_tg, rsa_dur, rsa_tur;
-  double tca_shear_g, tca_slip;
+  double hp, etap, alpha, alphap, delta_m;
+  double rsa_dg, rsa_tg;
+  double tca_shear_g;
 };
 
-// perturb_total_stress_energy + perturb_einstein (pm.cpp:6047-6703, 5840-6045), synchronous gauge, K=0.
-// y: this lane's component; the few named components are broadcast with v_readlane.
-__device__ inline void einstein(const PtParams& P, const Layout& L, const Lookup& Q, double k, double y, Metric& M) {
+// perturb_derivs (pm.cpp:7861-9218) with perturb_total_stress_energy + perturb_einstein (pm.cpp:6047-6703, 5840-6045),
+// perturb_rsa_delta_and_theta (pm.cpp:9530-9636) and perturb_tca_slip_and_shear (pm.cpp:9229-9516) folded in;
+// synchronous gauge, K = 0.  y: this lane's component (named components are broadcast with v_readlane).
+// Returns dy of this lane and leaves M describing the state (tau, y).
+__device__ __forceinline__ double rhs(const PtParams& P, const Layout& L, const LaneEq& e, Lookup& Q, Metric& M, double k,
+                                      double inv_k2, double tau, double y, int lane) {
+  lookup(P, Q, tau, lane);
   const BgV& bg = Q.bg; const ThV& th = Q.th;
-  const double a2 = bg.a * bg.a, aH = bg.a * bg.H, k2 = k * k;
+  const double a2 = Q.a2, aH = Q.aH, k2 = k * k, R = Q.R;
+  // ---- stress-energy sums ----
   double dg = 0., tg = 0., sg = 0., dur = 0., tur = 0., sur = 0.;
   if (!L.rsa) { dg = bcast(y, L.dg); tg = bcast(y, L.tg); if (!L.tca) sg = bcast(y, L.sg); }
   if (P.has_ur && !L.rsa) { dur = bcast(y, L.dur); tur = bcast(y, L.tur); sur = bcast(y, L.sur); }
   const double db = bcast(y, L.db), tb = bcast(y, L.tb), eta = bcast(y, L.eta);
   const double dc = P.has_cdm ? bcast(y, L.dc) : 0.;
+  const double cb2 = th.cb2;
   double delta_rho = bg.rg * dg + bg.rb * db;
   double rpt = 4. / 3. * bg.rg * tg + bg.rb * tb;
   double rps = 4. / 3. * bg.rg * sg;
-  double delta_p = 1. / 3. * bg.rg * dg + bg.rb * (th.cb2 * db);
+  double delta_p = 1. / 3. * bg.rg * dg + bg.rb * (cb2 * db);
   double delta_rho_m = bg.rb * db, rho_m = bg.rb;
-  const double rpt_m = bg.rb * tb;
   if (P.has_cdm) { delta_rho += bg.rc * dc; delta_rho_m += bg.rc * dc; rho_m += bg.rc; }
-  if (P.has_ur) {
-    delta_rho += bg.ru * dur; rpt += 4. / 3. * bg.ru * tur; rps += 4. / 3. * bg.ru * sur; delta_p += 1. / 3. * bg.ru * dur;
-  }
-  M.hp = (k2 * eta + 1.5 * a2 * delta_rho) / (0.5 * aH);
-  if (L.rsa) {  // perturb_rsa_delta_and_theta pm.cpp:9530-9636
-    if (P.rsa_method == CPT_RSA_NULL) { M.rsa_dg = 0.; M.rsa_tg = 0.; }
-    else { M.rsa_dg = 4. / k2 * (aH * M.hp - k2 * eta); M.rsa_tg = -0.5 * M.hp; }
+  if (P.has_ur) { delta_rho += bg.ru * dur; rpt += 4. / 3. * bg.ru * tur; rps += 4. / 3. * bg.ru * sur; delta_p += 1. / 3. * bg.ru * dur; }
+  // ---- Einstein equations ----
+  const double hp = (k2 * eta + 1.5 * a2 * delta_rho) * Q.two_over_aH;
+  if (L.rsa) {
+    double rdg = 0., rtg = 0., rdur = 0., rtur = 0.;
+    if (P.rsa_method != CPT_RSA_NULL) { rdg = 4. * inv_k2 * (aH * hp - k2 * eta); rtg = -0.5 * hp; }
     if (P.rsa_method == CPT_RSA_MD_WITH_REIO) {
-      M.rsa_dg += -4. / k2 * th.dkappa * (tb + 0.5 * M.hp);
-      M.rsa_tg += 3. / k2 * (th.ddkappa * (tb + 0.5 * M.hp) + th.dkappa * (-aH * tb + th.cb2 * k2 * db - aH * M.hp + k2 * eta));
+      rdg += -4. * inv_k2 * th.dkappa * (tb + 0.5 * hp);
+      rtg += 3. * inv_k2 * (th.ddkappa * (tb + 0.5 * hp) + th.dkappa * (-aH * tb + cb2 * k2 * db - aH * hp + k2 * eta));
     }
-    M.rsa_dur = 0.; M.rsa_tur = 0.;
-    if (P.has_ur && P.rsa_method != CPT_RSA_NULL) { M.rsa_dur = 4. / k2 * (aH * M.hp - k2 * eta); M.rsa_tur = -0.5 * M.hp; }
-    delta_rho += bg.rg * M.rsa_dg;
-    rpt += 4. / 3. * bg.rg * M.rsa_tg;
-    if (P.has_ur) { delta_rho += bg.ru * M.rsa_dur; rpt += 4. / 3. * bg.ru * M.rsa_tur; }
+    if (P.has_ur && P.rsa_method != CPT_RSA_NULL) { rdur = 4. * inv_k2 * (aH * hp - k2 * eta); rtur = -0.5 * hp; }
+    delta_rho += bg.rg * rdg;
+    rpt += 4. / 3. * bg.rg * rtg;
+    if (P.has_ur) { delta_rho += bg.ru * rdur; rpt += 4. / 3. * bg.ru * rtur; }
+    M.rsa_dg = rdg; M.rsa_tg = rtg;
+    dg = rdg; tg = rtg;  // pm.cpp:8085-8088: the equations below use the streaming values
   }
-  M.etap = (1.5 * a2 * rpt) / k2;
-  M.hpp = -2. * aH * M.hp + 2. * k2 * eta - 9. * a2 * delta_p;
-  M.alpha = (M.hp + 6. * M.etap) / 2. / k2;
-  if (L.tca) rps += 4. / 3. * bg.rg * (16. / 45. / th.dkappa * (tg + k2 * M.alpha));
-  M.alphap = -2. * aH * M.alpha + eta - 4.5 * (a2 / k2) * rps;
-  M.delta_m = delta_rho_m / rho_m + 3. * aH * (rpt_m / rho_m) / k2;  // pm.cpp:6573, 5979-5981
-}
-
-// perturb_derivs (pm.cpp:7861-9218). Returns dy of this lane; leaves M (and tca_shear_g / slip) updated.
-__device__ inline double rhs(const PtParams& P, const Layout& L, const LaneEq& e, Lookup& Q, Metric& M, double k, double tau,
-                             double y, int lane) {
-  lookup(P, Q, tau, lane);
-  einstein(P, L, Q, k, y, M);
-  const BgV& bg = Q.bg; const ThV& th = Q.th;
-  const double aH = bg.a * bg.H, k2 = k * k;
-  const double R = 4. / 3. * bg.rg / bg.rb;
-  const double mc = 0.5 * M.hp;          // metric_continuity
-  const double ms = k2 * M.alpha;        // metric_shear
-  double dg = 0., tg = 0.;
-  if (!L.rsa) { dg = bcast(y, L.dg); tg = bcast(y, L.tg); } else { dg = M.rsa_dg; tg = M.rsa_tg; }
-  const double db = bcast(y, L.db), tb = bcast(y, L.tb);
-  const double cb2 = th.cb2;
-  // neighbours in the hierarchy
-  const double ym = __shfl_up(y, 1, 64), yp = __shfl_down(y, 1, 64);
-  double dy = e.A * ym - e.B * yp - (e.D * th.dkappa + e.G / tau) * y;
-  // role-specific source terms (uniform values, selected per lane)
-  double dtb, E = 0.;
+  const double etap = 1.5 * a2 * rpt * inv_k2;
+  const double alpha = (hp + 6. * etap) * 0.5 * inv_k2;
+  if (L.tca) rps += 4. / 3. * bg.rg * (16. / 45. * Q.tau_c * (tg + k2 * alpha));
+  const double alphap = -2. * aH * alpha + eta - 4.5 * (a2 * inv_k2) * rps;
+  M.hp = hp; M.etap = etap; M.alpha = alpha; M.alphap = alphap;
+  M.delta_m = (delta_rho_m + 3. * aH * (bg.rb * tb) * inv_k2) / rho_m;  // pm.cpp:6573, 5979-5981
+  (void)delta_p;  // h'' is only needed by tight-coupling schemes this backend does not implement
+  // ---- equations of motion ----
+  const double mc = 0.5 * hp;   // metric_continuity
+  const double ms = k2 * alpha; // metric_shear
+  const double ym = lane_below(y), yp = lane_above(y);
+  double dy = e.A * ym - e.B * yp - (e.D * th.dkappa + e.G * Q.inv_tau) * y;
+  double dtb, tca_shear = 0.;
   if (!L.tca) {
     dtb = -aH * tb + k2 * cb2 * db + R * th.dkappa * (tg - tb);  // pm.cpp:8108-8113
   } else {
-    // perturb_tca_slip_and_shear pm.cpp:9229-9516 (first_order_CAMB / compromise_CLASS)
-    const double app = bg.Hp * bg.a + 2. * aH * aH;
-    const double tau_c = 1. / th.dkappa, dtau_c = -th.ddkappa * tau_c * tau_c;
-    const double F = tau_c / (1. + R);
-    const double Fp = dtau_c / (1. + R) + tau_c * aH * R / (1. + R) / (1. + R);
-    double slip = (dtau_c / tau_c - 2. * aH / (1. + R)) * (tb - tg) +
-                  F * (-app * tb + k2 * (-aH * dg / 2. + cb2 * (-tb - mc) - 4. / 3. * (-tg - mc) / 4.));
+    const double tau_c = Q.tau_c, dtau_c = Q.dtau_c, F = Q.F;
+    double slip = (dtau_c * th.dkappa - 2. * aH * Q.inv_1pR) * (tb - tg) +
+                  F * (-Q.app * tb + k2 * (-aH * dg * 0.5 + cb2 * (-tb - mc) - (-tg - mc) / 3.));
     double shear = 16. / 45. * tau_c * (tg + ms);
-    const double theta_prime = (-aH * tb + k2 * (cb2 * db + R / 4. * dg)) / (1. + R);
-    const double msp = k2 * M.alphap;
+    const double theta_prime = (-aH * tb + k2 * (cb2 * db + R * 0.25 * dg)) * Q.inv_1pR;
+    const double msp = k2 * alphap;
     const double shear_prime = 16. / 45. * (tau_c * (theta_prime + msp) + dtau_c * (tg + ms));
     if (P.tca_method == CPT_TCA_COMPROMISE_CLASS) {
-      slip = (1. - 2. * aH * F) * slip + F * k2 * (2. * aH * shear + shear_prime - (1. / 3. - cb2) * (F * theta_prime + 2. * Fp * tb));
+      slip = (1. - 2. * aH * F) * slip + F * k2 * (2. * aH * shear + shear_prime - (1. / 3. - cb2) * (F * theta_prime + 2. * Q.Fp * tb));
       shear = (1. - 11. / 6. * dtau_c) * shear - 11. / 6. * tau_c * 16. / 45. * tau_c * (theta_prime + msp);
     }
+    tca_shear = shear;
     M.tca_shear_g = shear;
-    M.tca_slip = slip;
-    dtb = (-aH * tb + k2 * (cb2 * db + R * (dg / 4. - shear)) + R * slip) / (1. + R);  // pm.cpp:8123-8129
+    dtb = (-aH * tb + k2 * (cb2 * db + R * (dg * 0.25 - shear)) + R * slip) * Q.inv_1pR;  // pm.cpp:8123-8129
   }
   double P0 = 0.;  // Pi = G_gamma0 + G_gamma2 + F_gamma2 (pm.cpp:8142)
-  if (!L.tca && !L.rsa) P0 = (bcast(y, L.pol0) + bcast(y, L.pol0 + 2) + 2. * bcast(y, L.sg)) / 8.;
+  if (!L.tca && !L.rsa) P0 = (bcast(y, L.pol0) + bcast(y, L.pol0 + 2) + 2. * sg) * 0.125;
+  double E = 0.;
   switch (e.role) {
     case R_DELTA_G: E = -4. / 3. * mc; break;
     case R_THETA_G:
       if (!L.tca) E = th.dkappa * tb;
-      else { dy = 0.; E = -(dtb + aH * tb - k2 * cb2 * db) / R + k2 * (0.25 * dg - M.tca_shear_g); }  // pm.cpp:8214-8217
+      else { dy = 0.; E = -(dtb + aH * tb - k2 * cb2 * db) * Q.inv_R + k2 * (0.25 * dg - tca_shear); }  // pm.cpp:8214-8217
       break;
     case R_SHEAR_G: E = 4. / 15. * ms + 0.4 * th.dkappa * P0; break;
     case R_POL:
@@ -425,7 +477,7 @@ __device__ inline double rhs(const PtParams& P, const Layout& L, const LaneEq& e
     case R_DELTA_B: E = -mc; break;
     case R_THETA_B: dy = 0.; E = dtb; break;
     case R_DELTA_CDM: E = -mc; break;
-    case R_DELTA_UR: E = -4. / 3. * mc + (1. - P.three_ceff2_ur) * aH * (y + 4. * aH * yp / k2); break;
+    case R_DELTA_UR: E = -4. / 3. * mc + (1. - P.three_ceff2_ur) * aH * (y + 4. * aH * yp * inv_k2); break;
     case R_THETA_UR: E = -(1. - P.three_ceff2_ur) * aH * y; break;
     case R_SHEAR_UR:
       if (!L.ufa) E = 4. / 15. * P.three_cvis2_ur * ms;
@@ -433,27 +485,24 @@ __device__ inline double rhs(const PtParams& P, const Layout& L, const LaneEq& e
       else if (P.ufa_method == CPT_UFA_MB) E = 2. / 3. * ms;
       else E = 2. / 3. * ms - 3. * aH * y;                                    // ufa_hu
       break;
-    case R_ETA: E = M.etap; break;
+    case R_ETA: E = etap; break;
     default: break;
   }
   return (e.role == R_NONE) ? 0. : dy + E;
 }
 
-// perturb_sources (pm.cpp:6731-7285): writes the tp_size source values of sample `it` for this mode (lane 0 stores)
-__device__ inline void sample_sources(const PtParams& P, const Layout& L, Lookup& Q, Metric& M, double k, double tau, double y,
-                                      double dy, int it, int ik, int lane) {
-  lookup(P, Q, tau, lane);
-  const double tca_shear_keep = M.tca_shear_g;  // left over from the last derivs call (pm.cpp:6810)
-  einstein(P, L, Q, k, y, M);
-  M.tca_shear_g = tca_shear_keep;
+// perturb_sources (pm.cpp:6731-7285): the RHS has just been evaluated at (tau, y) => Q and M describe the sample.
+// dy is the dense-output derivative (only theta_b' is used, pm.cpp:6883). Lane 0 stores the tp_size values.
+__device__ __forceinline__ void store_sources(const PtParams& P, const Layout& L, const Lookup& Q, const Metric& M, double k,
+                                              double inv_k2, double y, double dy, double tca_shear_prev, int it, int ik, int lane) {
   const BgV& bg = Q.bg; const ThV& th = Q.th;
   const double z = P.a_today / bg.a - 1.;
-  const double aH = bg.a * bg.H, aHp = bg.Hp * bg.a + aH * aH;
+  const double aH = Q.aH, aHp = Q.aHp;
   double delta_g, Pi;
   if (L.rsa) { delta_g = M.rsa_dg; Pi = 0.; }
   else {
     delta_g = bcast(y, L.dg);
-    if (L.tca) Pi = 5. * M.tca_shear_g / 8.;
+    if (L.tca) Pi = 5. * tca_shear_prev / 8.;  // left over from the last derivs call of the evolver (pm.cpp:6810)
     else Pi = (bcast(y, L.pol0) + bcast(y, L.pol0 + 2) + 2. * bcast(y, L.sg)) / 8.;
   }
   const double eta = bcast(y, L.eta), tb = bcast(y, L.tb), dtb = bcast(dy, L.tb);
@@ -466,7 +515,7 @@ __device__ inline void sample_sources(const PtParams& P, const Layout& L, Lookup
       P.src[P.tp_t0 * tstride + base] =
           P.switch_sw * th.g * (delta_g / 4. + M.alphap) +
           switch_isw * (th.g * (eta - M.alphap - 2 * aH * M.alpha) + th.expmk * 2. * (M.etap - aHp * M.alpha - aH * M.alphap)) +
-          P.switch_dop * (th.g * (dtb / k / k + M.alphap) + th.dg * (tb / k / k + M.alpha));
+          P.switch_dop * (th.g * (dtb * inv_k2 + M.alphap) + th.dg * (tb * inv_k2 + M.alpha));
     if (P.tp_t1 >= 0) P.src[P.tp_t1 * tstride + base] = switch_isw * th.expmk * k * (M.alphap + 2. * aH * M.alpha - eta);
     if (P.tp_t2 >= 0) P.src[P.tp_t2 * tstride + base] = P.switch_pol * th.g * Pi;
     if (P.tp_p >= 0) P.src[P.tp_p * tstride + base] = sqrt(6.) * th.g * Pi;
@@ -476,9 +525,9 @@ __device__ inline void sample_sources(const PtParams& P, const Layout& L, Lookup
 }
 
 // perturb_approximations (pm.cpp:5443-5670) evaluated independently by every lane at its own tau
-__device__ inline void approx_flags(const PtParams& P, double k, double tau, int* tca, int* rsa, int* ufa) {
-  double a, H, dk;
-  lookup_aHk(P, tau, &a, &H, &dk);
+__device__ __forceinline__ void approx_flags(const PtParams& P, double k, double tau, int* tca, int* rsa, int* ufa) {
+  const AHK q = lookup_aHk(P.tabs, P.n_e, tau);
+  const double a = q.a, H = q.H, dk = q.dk;
   const double tau_h = 1. / (H * a);
   if (dk == 0.) *tca = 0;
   else {
@@ -491,17 +540,16 @@ __device__ inline void approx_flags(const PtParams& P, double k, double tau, int
 
 // 64-ary search for the time at which a monotone predicate flips between lo (false) and hi (true):
 // kind 0: "no longer early enough to start" (pm.cpp:2590-2635), kind 1..3: approximation ap-1 differs from `ref`
-__device__ inline double search_flip(const PtParams& P, double k, double lo, double hi, double tol_abs, double tol_rel, int kind,
-                                     int ref, int lane) {
+__device__ __forceinline__ double search_flip(const PtParams& P, double k, double lo, double hi, double tol_abs, double tol_rel,
+                                           int kind, int ref, int lane) {
   for (int round = 0; round < 64; round++) {
     const double width = hi - lo;
     if (kind == 0 ? (width / lo <= tol_rel) : (width <= tol_abs)) break;
     const double t = lo + width * (double)(lane + 1) / 65.;
     bool pred;
     if (kind == 0) {
-      double a, H, dk;
-      lookup_aHk(P, t, &a, &H, &dk);
-      pred = (a * H / dk > P.start_small_k) || (k / a / H > P.start_large_k);
+      const AHK q = lookup_aHk(P.tabs, P.n_e, t);
+      pred = (q.a * q.H / q.dk > P.start_small_k) || (k / q.a / q.H > P.start_large_k);
     } else {
       int f[3];
       approx_flags(P, k, t, &f[0], &f[1], &f[2]);
@@ -517,351 +565,474 @@ __device__ inline double search_flip(const PtParams& P, double k, double lo, dou
 }
 
 // ---- linear algebra in LDS (row i owned by lane i) -----------------------------------------------
-// new_linearisation (ev.cpp:945-998): LU <- I - hg*J, then factorise in place.
-// Elimination without row exchanges: `ord` (lane register) is the step at which this lane's row was the pivot row
-// (-1: not yet); perm[j] (LDS ints) is the pivot row of step j.  Pivot choice: the diagonal row j if it is still
-// free and |a_jj| >= 1e-3 max|a_ij| (sparse.c:171 threshold pivoting), else the row of largest magnitude.
-__device__ inline bool factorise(const double* __restrict__ J, double* __restrict__ A, int* __restrict__ perm, int n, int S,
-                                 double hg, int lane, int* ord_out) {
+// new_linearisation (ev.cpp:945-998): A <- I - hg*J, factorised in place with row exchanges, so that after the
+// factorisation the pivot row of step j IS row j (lane j): the substitution loops then broadcast from a lane whose
+// index is the loop counter - no permutation look-ups on the dependent chain.  `rowperm` (lane i: original index of
+// the row now at position i) permutes the right-hand side once per solve.  Pivot choice: the diagonal if
+// |a_jj| >= 1e-3 max|a_ij| (threshold pivoting as tools/sparse.c:171; tested with one ballot), else the largest
+// magnitude.  Structural zeros of the pivot row are skipped (ballot), so the work follows the sparsity of J
+// (4-6 entries per row) although the storage is dense.
+struct LuReg { double rpiv; int rowperm; };
+
+__device__ __forceinline__ bool factorise(const double* __restrict__ J, double* __restrict__ A, int n, int S, double hg, int lane,
+                                          LuReg& F) {
+  // The system is padded with identity rows/columns up to a multiple of 8 (np), so that the substitution loops run
+  // over whole 8-column chunks without per-element guards.
+  const int np = (n + 7) & ~7;
   if (lane < n) {
     for (int c = 0; c < n; c++) A[lane * S + c] = -hg * J[lane * S + c] + (c == lane ? 1.0 : 0.0);
+    for (int c = n; c < np; c++) A[lane * S + c] = 0.;
+  } else if (lane < np) {
+    for (int c = 0; c < np; c++) A[lane * S + c] = (c == lane) ? 1.0 : 0.;
   }
-  int ord = (lane < n) ? -1 : 1 << 20;
+  int rowperm = lane;
+  double rpiv = 1.;
+  double anext = (lane < n) ? A[lane * S] : 0.;  // column j of my row, fetched one step ahead
   for (int j = 0; j < n; j++) {
-    const double aij = (ord < 0) ? A[lane * S + j] : 0.;
+    double aij = (lane >= j && lane < n) ? anext : 0.;
     const double mag = fabs(aij);
-    const double big = wave_max(mag);
-    if (big == 0.) return false;
-    const double diag = bcast(mag, j);  // 0 when row j is already used
-    int p;
-    if (diag >= 1e-3 * big) p = j;
-    else p = __ffsll((long long)__ballot(mag == big)) - 1;
-    const double piv = bcast(aij, p);
-    if (lane == p) ord = j;
-    if (lane == 0) perm[j] = p;
+    const double diag = bcast(mag, j);
+    if (__ballot(mag > 1e3 * diag) != 0ull || diag == 0.) {  // rare: the diagonal is not an acceptable pivot
+      const double big = wave_max(mag);
+      if (big == 0.) return false;
+      const int p = __ffsll((long long)__ballot(mag == big)) - 1;
+      // exchange rows p and j (all columns; lane c moves column c) and the bookkeeping that travels with the rows
+      if (lane < n) { const double tp = A[p * S + lane], tj = A[j * S + lane]; A[p * S + lane] = tj; A[j * S + lane] = tp; }
+      const int rp_p = __builtin_amdgcn_readlane(rowperm, p), rp_j = __builtin_amdgcn_readlane(rowperm, j);
+      if (lane == p) rowperm = rp_j;
+      if (lane == j) rowperm = rp_p;
+      const double a_p = bcast(aij, p), a_j = bcast(aij, j);
+      if (lane == p) aij = a_j;
+      if (lane == j) aij = a_p;
+      const double n_p = bcast(anext, p), n_j = bcast(anext, j);
+      if (lane == p) anext = n_j;
+      if (lane == j) anext = n_p;
+    }
+    const double rp = fast_rcp(bcast(aij, j));
+    if (lane == j) rpiv = rp;
     double m = 0.;
-    if (ord < 0 && aij != 0.) { m = aij / piv; A[lane * S + j] = m; }
-    // pivot row (columns > j) into registers: lane c holds A[p][c]
-    const double prow = (lane > j && lane < n) ? A[p * S + lane] : 0.;
+    if (lane > j && lane < n && aij != 0.) { m = aij * rp; A[lane * S + j] = m; }
+    // pivot row (columns > j) into registers: lane c holds A[j][c]
+    const double prow = (lane > j && lane < n) ? A[j * S + lane] : 0.;
     unsigned long long nz = __ballot(prow != 0.);
-    while (nz) {
-      const int c = __ffsll((long long)nz) - 1;
+    // column j+1 of my row is needed next: if the pivot row touches it, take the updated value from the update below
+    const bool next_touched = (j + 1 < n) && ((nz >> (j + 1)) & 1ull);
+    if (!next_touched && j + 1 < n && lane < n) anext = A[lane * S + j + 1];
+    while (nz) {  // up to three pivot-row entries per trip: their LDS round trips overlap
+      const int c0 = __ffsll((long long)nz) - 1;
       nz &= nz - 1;
-      const double rc = bcast(prow, c);
-      if (m != 0.) A[lane * S + c] -= m * rc;
+      int c1 = -1, c2 = -1;
+      if (nz) { c1 = __ffsll((long long)nz) - 1; nz &= nz - 1; }
+      if (nz) { c2 = __ffsll((long long)nz) - 1; nz &= nz - 1; }
+      const double r0 = bcast(prow, c0);
+      const double r1 = (c1 >= 0) ? bcast(prow, c1) : 0.;
+      const double r2 = (c2 >= 0) ? bcast(prow, c2) : 0.;
+      if (lane > j && lane < n) {
+        double a0 = A[lane * S + c0];
+        double a1 = (c1 >= 0) ? A[lane * S + c1] : 0.;
+        double a2 = (c2 >= 0) ? A[lane * S + c2] : 0.;
+        if (m != 0.) {
+          a0 -= m * r0;
+          A[lane * S + c0] = a0;
+          if (c1 >= 0) { a1 -= m * r1; A[lane * S + c1] = a1; }
+          if (c2 >= 0) { a2 -= m * r2; A[lane * S + c2] = a2; }
+        }
+        if (c0 == j + 1) anext = a0;
+        if (c1 == j + 1) anext = a1;
+        if (c2 == j + 1) anext = a2;
+      }
     }
   }
-  *ord_out = ord;
+  F.rowperm = rowperm; F.rpiv = rpiv;
   return true;
 }
 
-// solve A x = b with the factors above; b: lane i holds b_i; returns x with lane j holding x_j
-__device__ inline double lu_solve(const double* __restrict__ A, const int* __restrict__ perm, int n, int S, int ord, double b,
-                                  int lane) {
-  for (int j = 0; j < n; j++) {  // forward: rows pivoted later than step j eliminate column j
-    const int p = ufirst(perm[j]);
-    const double bp = bcast(b, p);
-    if (bp != 0.) {
-      if (ord > j && lane < n) b -= A[lane * S + j] * bp;
+// solve (I - hg J) x = b with the factors above; b: lane i holds b_i; returns x with lane j holding x_j.
+// The multipliers of 8 consecutive columns are fetched from LDS together (independent reads in flight); the loops are
+// fully unrolled so that every broadcast reads a lane known at compile time: the dependent chain per column is
+// v_readlane + v_fma only.
+__device__ __forceinline__ double lu_solve(const double* __restrict__ A, const LuReg& F, int n, int S, double b, int lane) {
+  const int np = (n + 7) & ~7;  // identity-padded size (see factorise)
+  const double* myrow = A + (lane < np ? lane : 0) * S;
+  b = __shfl(b, F.rowperm, 64);  // row exchanges of the factorisation
+#pragma unroll
+  for (int j0 = 0; j0 < 64; j0 += 8) {  // forward: L has unit diagonal, rows below j eliminate column j
+    if (j0 < np) {
+      double r[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) r[u] = myrow[j0 + u];
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+        const double bj = bcast(b, j0 + u);
+        b = (lane > j0 + u) ? b - r[u] * bj : b;
+      }
     }
   }
-  double x = 0.;
-  for (int j = n - 1; j >= 0; j--) {  // backward
-    const int p = ufirst(perm[j]);
-    const double xj = bcast(b, p) / A[p * S + j];
-    if (lane == j) x = xj;
-    if (xj != 0.) {
-      if (ord < j && lane < n) b -= A[lane * S + j] * xj;
+#pragma unroll
+  for (int j0 = 56; j0 >= 0; j0 -= 8) {  // backward
+    if (j0 < np) {
+      double r[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) r[u] = myrow[j0 + u];
+#pragma unroll
+      for (int u = 7; u >= 0; u--) {
+        const double xj = bcast(b * F.rpiv, j0 + u);  // lane j holds b_j: x_j = b_j / u_jj
+        b = (lane < j0 + u) ? b - r[u] * xj : ((lane == j0 + u) ? xj : b);
+      }
     }
   }
-  return x;
+  return (lane < n) ? b : 0.;
 }
 
-// adjust_stepsize (ev.cpp:907-943): dif[0..k-1] <- dif[0..k-1] * RU(r)
-__device__ inline void adjust_stepsize(double* dif, double r, int k) {
+// adjust_stepsize (ev.cpp:907-943): dif[0..k-1] <- dif[0..k-1] * RU(r); every index static => registers only
+__device__ __forceinline__ void adjust_stepsize(double* dif, double r, int k) {
   const double U[5][5] = {{-1, -2, -3, -4, -5}, {0, 1, 3, 6, 10}, {0, 0, -1, -4, -10}, {0, 0, 0, 1, 5}, {0, 0, 0, 0, -1}};
-  double RU[5][5], tv[5];
-  for (int ii = 1; ii <= 5; ii++) RU[0][ii - 1] = -ii * r;
-  for (int jj = 2; jj <= 5; jj++)
-    for (int ii = 1; ii <= 5; ii++) RU[jj - 1][ii - 1] = RU[jj - 2][ii - 1] * (1.0 - (1.0 + ii * r) / jj);
-  for (int ii = 0; ii < 5; ii++) {
-    for (int kk = 0; kk < 5; kk++) tv[kk] = RU[ii][kk];
+  double R0[5][5], RU[5][5], tv[5];
+#pragma unroll
+  for (int ii = 0; ii < 5; ii++) R0[0][ii] = -(ii + 1) * r;
+#pragma unroll
+  for (int jj = 1; jj < 5; jj++)
+#pragma unroll
+    for (int ii = 0; ii < 5; ii++) R0[jj][ii] = R0[jj - 1][ii] * (1.0 - (1.0 + (ii + 1) * r) / (jj + 1));
+#pragma unroll
+  for (int ii = 0; ii < 5; ii++)
+#pragma unroll
     for (int jj = 0; jj < 5; jj++) {
-      double s = 0.0;
-      for (int kk = 0; kk < 5; kk++) s += tv[kk] * U[kk][jj];
-      RU[ii][jj] = s;
+      double sacc = 0.0;
+#pragma unroll
+      for (int m = 0; m < 5; m++) sacc += R0[ii][m] * U[m][jj];
+      RU[ii][jj] = sacc;
     }
-  }
-  for (int kk = 0; kk < 5; kk++) tv[kk] = dif[kk];
+#pragma unroll
+  for (int m = 0; m < 5; m++) tv[m] = (m < k) ? dif[m] : 0.;
+#pragma unroll
   for (int jj = 0; jj < 5; jj++) {
-    if (jj < k) {
-      double s = 0.0;
-      for (int kk = 0; kk < 5; kk++)
-        if (kk < k) s += tv[kk] * RU[kk][jj];
-      dif[jj] = s;
-    }
+    double sacc = 0.0;
+#pragma unroll
+    for (int m = 0; m < 5; m++) sacc += tv[m] * RU[m][jj];  // tv[m] = 0 for m >= k
+    if (jj < k) dif[jj] = sacc;
   }
 }
 
 struct Stat { int steps, failed, fevals, jacs, lus, solves; };
 
-// evolver_ndf15 (ev.cpp:62-705) for one interval of constant approximation scheme. Returns 0 / error code.
-__device__ int ndf15(const PtParams& P, const Layout& L, const LaneEq& e, Lookup& Q, Metric& M, double k, int ik, double t0,
-                     double tfinal, double& y_io, double* Jm, double* Am, int* perm, Stat& st, int lane, int& budget) {
-  const double G[5] = {1.0, 3.0 / 2.0, 11.0 / 6.0, 25.0 / 12.0, 137.0 / 60.0};
-  const double alpha[5] = {-37.0 / 200, -1.0 / 9.0, -8.23e-2, -4.15e-2, 0};
-  double invGa[5], erconst[5];
-  for (int i = 0; i < 5; i++) { invGa[i] = 1.0 / (G[i] * (1.0 - alpha[i])); erconst[i] = alpha[i] * G[i] + 1.0 / (2.0 + i); }
+#ifdef CPT_PROFILE
+__device__ unsigned long long g_prof[8];
+#define PROF_DECL unsigned long long pf_t0 = 0
+#define PROF_START() pf_t0 = clock64()
+#define PROF_STOP(slot) prof[slot] += clock64() - pf_t0
+#else
+#define PROF_DECL
+#define PROF_START()
+#define PROF_STOP(slot)
+#endif
+
+// register selects on the backward-difference array (static indices only => no scratch)
+__device__ __forceinline__ double dif_get(const double* dif, int i) {
+  double v = 0.;
+#pragma unroll
+  for (int j = 0; j < 7; j++) if (j == i) v = dif[j];
+  return v;
+}
+
+// evolver_ndf15 (ev.cpp:62-705) for one interval of constant approximation scheme, as ONE flat loop so that the RHS
+// is instantiated exactly twice: a "service" slot (Jacobian columns, the initial f(t0+tdel), sampled outputs, the
+// final evaluation) and the Newton slot.  Returns 0 / error code (1 step too small, 2 singular, 4 budget).
+__device__ __forceinline__ int ndf15(const PtParams& P, const Layout& L, const LaneEq& e, Lookup& Q, Metric& M, double k,
+                                     double inv_k2, int ik, double t0, double tfinal, double& y_io, double* Jm, double* Am,
+                                     Stat& st, int lane, int& budget, unsigned long long* prof) {
+  PROF_DECL;
   const double eps = 1e-16, threshold = 1e-15, rtol = P.rtol;
   const int maxit = 4, maxk = 5, n = L.neq, S = P.stride;
   const bool act = lane < n;
   const double* ts = P.tau_s;
   const int tres = P.ntau;
+  const double htspan = fabs(tfinal - t0), hmax = (tfinal - t0) / 10.0;
+  enum { B_NONE = 0, B_JAC_INIT, B_F1, B_JAC, B_SAMPLE, B_FINAL };
 
-  auto jacobian = [&](double t) {  // J e_j = f(t, e_j): exact for a linear homogeneous system
-    for (int j = 0; j < n; j++) {
-      const double col = rhs(P, L, e, Q, M, k, t, (lane == j) ? 1.0 : 0.0, lane);
-      if (act) Jm[lane * S + j] = col;
-    }
-    st.fevals += n;
-    st.jacs++;
-  };
-
-  double y = y_io, ynew = y_io;
+  LuReg F;
+  F.rpiv = 0.; F.rowperm = lane;
+  double y = y_io, ynew = y_io, f0 = 0., fnewton = 0., wt = 0., tdel = 0.;
   double dif[7] = {0., 0., 0., 0., 0., 0., 0.};
   int next = 0;
   while (next < tres && ts[next] < t0) next++;
-  const double htspan = fabs(tfinal - t0);
-  double f0 = rhs(P, L, e, Q, M, k, t0, y, lane);
-  st.fevals++;
-  const double hmax = (tfinal - t0) / 10.0;
-  double t = t0;
-  jacobian(t);
-  bool Jcurrent = true;
-  double hmin = 16.0 * eps * fabs(t);
-  const double wt = fmax(fabs(y), threshold);
-  double rh = wave_max(act ? 1.25 / sqrt(rtol) * fabs(f0 / wt) : 0.);
-  double absh = fmin(hmax, htspan);
-  if (absh * rh > 1.0) absh = 1.0 / rh;
-  absh = fmax(absh, hmin);
-  double h = absh;
-  const double tdel = (t + fmin(sqrt(eps) * fmax(fabs(t), fabs(t + h)), absh)) - t;
-  const double f1 = rhs(P, L, e, Q, M, k, t + tdel, y, lane);
-  st.fevals++;
-  {
-    // ddfddt = J f0 + (f(t+tdel) - f0)/tdel  (ev.cpp:261-270)
-    double acc = 0.;
-    for (int j = 0; j < n; j++) {
-      const double fj = bcast(f0, j);
-      if (act) acc += Jm[lane * S + j] * fj;
-    }
-    acc += (f1 - f0) / tdel;
-    rh = wave_max(act ? 1.25 * sqrt(0.5 * fabs(acc / wt) / rtol) : 0.);
-  }
-  absh = fmin(hmax, htspan);
-  if (absh * rh > 1.0) absh = 1.0 / rh;
-  absh = fmax(absh, hmin);
-  h = absh;
-  int kk = 1, klast = 1;
-  double abshlast = absh;
-  dif[0] = h * f0;
-  double hinvGak = h * invGa[kk - 1];
-  int nconhk = 0, ord = 0;
-  if (!factorise(Jm, Am, perm, n, S, hinvGak, lane, &ord)) return 2;
-  st.lus++;
-  bool havrate = false, done = false, at_hmin = false;
-  double rate = 0., oldnrm = 0., tnew = t, err = 0., invwt = 0., difkp1 = 0.;
+  double t = t0, tnew = t0, h = 0., absh = 0., abshlast = 0., hmin = 16.0 * eps * fabs(t0), hinvGak = 0.;
+  int kk = 1, klast = 1, nconhk = 0;
+  bool Jcurrent = false, havrate = false, done = false, at_hmin = false, nofailed = true;
+  bool new_step = false, need_fact = false, post_step = false;
+  double rate = 0., oldnrm = 0., err = 0., invwt = 0., difkp1 = 0.;
+  double yi = 0., ypi = 0., tn = 0.;
+  int batch = B_JAC_INIT;
 
-  while (!done) {
+  // dense output at the next sample time (ev.cpp:547-571, interp_from_dif :860-905)
+  auto prepare_sample = [&]() {
+    tn = ts[next];
+    if (tnew == tn) { yi = ynew; ypi = fnewton; }
+    else {
+      const double s = (tn - tnew) / h;
+      double prod = 1.0, sumfrac = 0., fact = 1.0;
+      yi = ynew; ypi = 0.;
+#pragma unroll
+      for (int j = 0; j < 5; j++) {
+        if (j < kk) {
+          prod *= (s + j); fact *= (j + 1); sumfrac += 1.0 / (s + j);
+          yi += (prod / fact) * dif[j];
+          ypi += (prod * sumfrac / (h * fact)) * dif[j];
+        }
+      }
+    }
+  };
+
+  for (;;) {
     if (--budget < 0) return 4;
-    hmin = P.min_var;
-    absh = fmin(hmax, fmax(hmin, absh));
-    if (fabs(absh - hmin) < 100 * eps) { if (at_hmin) absh = abshlast; at_hmin = true; } else at_hmin = false;
-    h = absh;
-    if (1.1 * absh >= fabs(tfinal - t)) { h = tfinal - t; absh = fabs(h); done = true; }
-    if (((fabs(absh - abshlast) / absh) > 1e-6) || (kk != klast)) {
-      adjust_stepsize(dif, absh / abshlast, kk);
-      hinvGak = h * invGa[kk - 1];
-      nconhk = 0;
-      if (!factorise(Jm, Am, perm, n, S, hinvGak, lane, &ord)) return 2;
+    // ------------------------------------------------------------------ service slot
+    if (batch != B_NONE) {
+      PROF_START();
+      const int nreq = (batch == B_JAC_INIT || batch == B_JAC) ? n : 1;
+      const double tca_keep = M.tca_shear_g;
+      for (int r = 0; r < nreq; r++) {
+        double tq, yq;
+        if (batch == B_JAC_INIT || batch == B_JAC) { tq = t; yq = (lane == r) ? 1.0 : 0.0; }  // J e_r = f(t, e_r)
+        else if (batch == B_F1) { tq = t + tdel; yq = y; }
+        else if (batch == B_SAMPLE) { tq = tn; yq = yi; }
+        else { tq = tnew; yq = ynew; }
+        const double dyq = rhs(P, L, e, Q, M, k, inv_k2, tq, yq, lane);
+        st.fevals++;
+        if (batch == B_JAC_INIT || batch == B_JAC) { if (act) Jm[lane * S + r] = dyq; }
+        else if (batch == B_F1) f0 = dyq;  // temporarily f(t0 + tdel)
+        else if (batch == B_SAMPLE) store_sources(P, L, Q, M, k, inv_k2, yi, ypi, tca_keep, next, ik, lane);
+      }
+      if (batch == B_FINAL) { PROF_STOP(3); break; }  // ev.cpp:653-662: M, Q left at (tfinal, y) for the hand-over
+      if (batch == B_JAC_INIT) {
+        st.jacs++;
+        Jcurrent = true;
+        // f0 = f(t0, y) = J y ; first guess of h (ev.cpp:225-250)
+        double acc = 0.;
+        for (int j = 0; j < n; j++) { const double yj = bcast(y, j); if (act) acc += Jm[lane * S + j] * yj; }
+        fnewton = acc;
+        wt = fmax(fabs(y), threshold);
+        const double rh = wave_max(act ? 1.25 / sqrt(rtol) * fabs(fnewton / wt) : 0.);
+        absh = fmin(hmax, htspan);
+        if (absh * rh > 1.0) absh = 1.0 / rh;
+        absh = fmax(absh, hmin);
+        h = absh;
+        tdel = (t + fmin(sqrt(eps) * fmax(fabs(t), fabs(t + h)), absh)) - t;
+        batch = B_F1;
+        PROF_STOP(3);
+        continue;
+      }
+      if (batch == B_F1) {
+        // ddfddt = J f0 + (f(t+tdel) - f0)/tdel  (ev.cpp:261-283)
+        double acc = 0.;
+        for (int j = 0; j < n; j++) { const double fj = bcast(fnewton, j); if (act) acc += Jm[lane * S + j] * fj; }
+        acc += (f0 - fnewton) / tdel;
+        const double rh = wave_max(act ? 1.25 * sqrt(0.5 * fabs(acc / wt) / rtol) : 0.);
+        absh = fmin(hmax, htspan);
+        if (absh * rh > 1.0) absh = 1.0 / rh;
+        absh = fmax(absh, hmin);
+        h = absh;
+        kk = 1; klast = 1; abshlast = absh;
+        dif[0] = h * fnewton;
+        hinvGak = h * ndf_invGa(kk - 1);
+        nconhk = 0;
+        need_fact = true;
+        new_step = true;
+        batch = B_NONE;
+        PROF_STOP(3);
+      } else if (batch == B_JAC) {
+        st.jacs++;
+        st.fevals++;  // the reference also re-evaluates f(t,y) here (ev.cpp:451)
+        M.tca_shear_g = tca_keep;
+        Jcurrent = true;
+        need_fact = true;
+        batch = B_NONE;
+        PROF_STOP(3);
+      } else {  // B_SAMPLE
+        M.tca_shear_g = tca_keep;
+        next++;
+        if ((next < tres) && (tnew - ts[next] >= 0.0)) {
+          prepare_sample();  // stay in B_SAMPLE
+          PROF_STOP(4);
+          continue;
+        } else {
+          batch = B_NONE;
+          post_step = true;
+        }
+        PROF_STOP(4);
+      }
+    }
+    // ------------------------------------------------------------------ after an accepted step (ev.cpp:573-635)
+    if (post_step) {
+      post_step = false;
+      if (done) { batch = B_FINAL; continue; }
+      klast = kk;
+      abshlast = absh;
+      nconhk = min(nconhk + 1, maxk + 2);
+      if (nconhk >= kk + 2) {
+        double temp = 1.2 * fast_pow((err / rtol), (1.0 / (kk + 1.0)));
+        double hopt = temp > 0.1 ? absh / temp : 10 * absh;
+        int kopt = kk;
+        if (kk > 1) {
+          const double errkm1 = wave_max(act ? fabs(dif_get(dif, kk - 1) * invwt) : 0.) * ndf_erconst(kk - 2);
+          temp = 1.3 * fast_pow((errkm1 / rtol), (1.0 / kk));
+          const double hkm1 = temp > 0.1 ? absh / temp : 10 * absh;
+          if (hkm1 > hopt) { hopt = hkm1; kopt = kk - 1; }
+        }
+        if (kk < maxk) {
+          const double errkp1 = wave_max(act ? fabs(dif_get(dif, kk + 1) * invwt) : 0.) * ndf_erconst(kk);
+          temp = 1.4 * fast_pow((errkp1 / rtol), (1.0 / (kk + 2.0)));
+          const double hkp1 = temp > 0.1 ? absh / temp : 10 * absh;
+          if (hkp1 > hopt) { hopt = hkp1; kopt = kk + 1; }
+        }
+        if (hopt > absh) { absh = hopt; kk = kopt; }
+      }
+      t = tnew;
+      y = ynew;
+      Jcurrent = false;
+      new_step = true;
+    }
+    // ------------------------------------------------------------------ start of a step (ev.cpp:299-334)
+    if (new_step) {
+      new_step = false;
+      hmin = P.min_var;
+      absh = fmin(hmax, fmax(hmin, absh));
+      if (fabs(absh - hmin) < 100 * eps) { if (at_hmin) absh = abshlast; at_hmin = true; } else at_hmin = false;
+      h = absh;
+      if (1.1 * absh >= fabs(tfinal - t)) { h = tfinal - t; absh = fabs(h); done = true; }
+      if (((fabs(absh - abshlast) / absh) > 1e-6) || (kk != klast)) {
+        adjust_stepsize(dif, absh / abshlast, kk);
+        hinvGak = h * ndf_invGa(kk - 1);
+        nconhk = 0;
+        need_fact = true;
+      }
+      nofailed = true;
+    }
+    if (need_fact) {
+      need_fact = false;
+      PROF_START();
+      if (!factorise(Jm, Am, n, S, hinvGak, lane, F)) return 2;
+      PROF_STOP(2);
       st.lus++;
       havrate = false;
     }
-    bool nofailed = true;
-    for (;;) {
-      bool gotynew = false;
-      while (!gotynew) {
-        if (--budget < 0) return 4;
-        double psi = 0., pred = y;
-#pragma unroll
-        for (int j = 0; j < 5; j++)
-          if (j < kk) { psi += dif[j] * (G[j] * invGa[kk - 1]); pred += dif[j]; }
-        tnew = t + h;
-        if (done) tnew = tfinal;
-        h = tnew - t;
-        ynew = pred;
-        difkp1 = 0.;
-        invwt = 1.0 / fmax(fmax(fabs(ynew), fabs(y)), threshold);
-        const double minnrm = wave_max(act ? 100 * eps * fabs(ynew * invwt) : 0.);
-        bool tooslow = false;
-        for (int iter = 1; iter <= maxit; iter++) {
-          f0 = rhs(P, L, e, Q, M, k, tnew, ynew, lane);
-          st.fevals++;
-          const double rhsv = act ? hinvGak * f0 - (psi + difkp1) : 0.;
-          const double del = lu_solve(Am, perm, n, S, ord, rhsv, lane);
-          st.solves++;
-          const double newnrm = wave_max(act ? fabs(del * invwt) : 0.);
-          difkp1 += del;
-          ynew = pred + difkp1;
-          if (newnrm <= minnrm) { gotynew = true; break; }
-          else if (iter == 1) {
-            if (havrate) { const double errit = newnrm * rate / (1.0 - rate); if (errit <= 0.05 * rtol) { gotynew = true; break; } }
-            else rate = 0.0;
-          } else if (newnrm > 0.9 * oldnrm) { tooslow = true; break; }
-          else {
-            rate = fmax(0.9 * rate, newnrm / oldnrm);
-            havrate = true;
-            const double errit = newnrm * rate / (1.0 - rate);
-            if (errit <= 0.5 * rtol) { gotynew = true; break; }
-            else if (iter == maxit) { tooslow = true; break; }
-            else if (0.5 * rtol < errit * pow(rate, (double)(maxit - iter))) { tooslow = true; break; }
-          }
-          oldnrm = newnrm;
-        }
-        if (tooslow) {
-          st.failed++;
-          if (!Jcurrent) {
-            jacobian(t);
-            st.fevals++;  // the reference also re-evaluates f(t,y) here (ev.cpp:451)
-            Jcurrent = true;
-          } else if (absh <= hmin) return 1;
-          else {
-            abshlast = absh;
-            absh = fmax(0.3 * absh, hmin);
-            h = absh;
-            done = false;
-            adjust_stepsize(dif, absh / abshlast, kk);
-            hinvGak = h * invGa[kk - 1];
-            nconhk = 0;
-          }
-          if (!factorise(Jm, Am, perm, n, S, hinvGak, lane, &ord)) return 2;
-          st.lus++;
-          havrate = false;
-        }
-      }
-      err = wave_max(act ? fabs(difkp1 * invwt) : 0.) * erconst[kk - 1];
-      if (err > rtol) {
-        st.failed++;
-        if (absh <= hmin) return 1;
-        abshlast = absh;
-        if (nofailed) {
-          nofailed = false;
-          double hopt = absh * fmax(0.1, 0.833 * pow((rtol / err), (1.0 / (kk + 1))));
-          if (kk > 1) {
-            double dk1 = 0.;
-#pragma unroll
-            for (int j = 0; j < 5; j++) if (j == kk - 1) dk1 = dif[j];
-            const double errkm1 = wave_max(act ? fabs((dk1 + difkp1) * invwt) : 0.) * erconst[kk - 2];
-            const double hkm1 = absh * fmax(0.1, 0.769 * pow((rtol / errkm1), (1.0 / kk)));
-            if (hkm1 > hopt) { hopt = fmin(absh, hkm1); kk = kk - 1; }
-          }
-          absh = fmax(hmin, hopt);
-        } else absh = fmax(hmin, 0.5 * absh);
-        h = absh;
-        if (absh < abshlast) done = false;
-        adjust_stepsize(dif, absh / abshlast, kk);
-        hinvGak = h * invGa[kk - 1];
-        nconhk = 0;
-        if (!factorise(Jm, Am, perm, n, S, hinvGak, lane, &ord)) return 2;
-        st.lus++;
-        havrate = false;
-      } else break;
-    }
-    st.steps++;
-    // update the backward differences (ev.cpp:537-545)
+    // ------------------------------------------------------------------ predictor + simplified Newton (ev.cpp:342-445)
+    double psi = 0., pred = y;
     {
-      double old_k = 0.;
+      const double iga = ndf_invGa(kk - 1);
 #pragma unroll
-      for (int j = 0; j < 7; j++) if (j == kk) old_k = dif[j];
+      for (int j = 0; j < 5; j++)
+        if (j < kk) { psi += dif[j] * (ndf_G(j) * iga); pred += dif[j]; }
+    }
+    tnew = t + h;
+    if (done) tnew = tfinal;
+    h = tnew - t;
+    ynew = pred;
+    difkp1 = 0.;
+    invwt = fast_rcp(fmax(fmax(fabs(ynew), fabs(y)), threshold));
+    const double minnrm = wave_max(act ? 100 * eps * fabs(ynew * invwt) : 0.);
+    bool tooslow = false;
+    for (int iter = 1; iter <= maxit; iter++) {
+      PROF_START();
+      fnewton = rhs(P, L, e, Q, M, k, inv_k2, tnew, ynew, lane);
+      PROF_STOP(0);
+      st.fevals++;
+      const double rhsv = act ? hinvGak * fnewton - (psi + difkp1) : 0.;
+      PROF_START();
+      const double del = lu_solve(Am, F, n, S, rhsv, lane);
+      PROF_STOP(1);
+      st.solves++;
+      const double newnrm = wave_max(act ? fabs(del * invwt) : 0.);
+      difkp1 += del;
+      ynew = pred + difkp1;
+      if (newnrm <= minnrm) break;
+      else if (iter == 1) {
+        if (havrate) { const double errit = newnrm * rate / (1.0 - rate); if (errit <= 0.05 * rtol) break; }
+        else rate = 0.0;
+      } else if (newnrm > 0.9 * oldnrm) { tooslow = true; break; }
+      else {
+        rate = fmax(0.9 * rate, newnrm / oldnrm);
+        havrate = true;
+        const double errit = newnrm * rate / (1.0 - rate);
+        if (errit <= 0.5 * rtol) break;
+        else if (iter == maxit) { tooslow = true; break; }
+        else if (0.5 * rtol < errit * fast_pow(rate, (double)(maxit - iter))) { tooslow = true; break; }
+      }
+      oldnrm = newnrm;
+    }
+    if (tooslow) {  // ev.cpp:446-479
+      st.failed++;
+      if (!Jcurrent) { batch = B_JAC; continue; }
+      if (absh <= hmin) return 1;
+      abshlast = absh;
+      absh = fmax(0.3 * absh, hmin);
+      h = absh;
+      done = false;
+      adjust_stepsize(dif, absh / abshlast, kk);
+      hinvGak = h * ndf_invGa(kk - 1);
+      nconhk = 0;
+      need_fact = true;
+      continue;
+    }
+    // ------------------------------------------------------------------ error test (ev.cpp:483-532)
+    err = wave_max(act ? fabs(difkp1 * invwt) : 0.) * ndf_erconst(kk - 1);
+    if (err > rtol) {
+      st.failed++;
+      if (absh <= hmin) return 1;
+      abshlast = absh;
+      if (nofailed) {
+        nofailed = false;
+        double hopt = absh * fmax(0.1, 0.833 * fast_pow((rtol / err), (1.0 / (kk + 1))));
+        if (kk > 1) {
+          const double errkm1 = wave_max(act ? fabs((dif_get(dif, kk - 1) + difkp1) * invwt) : 0.) * ndf_erconst(kk - 2);
+          const double hkm1 = absh * fmax(0.1, 0.769 * fast_pow((rtol / errkm1), (1.0 / kk)));
+          if (hkm1 > hopt) { hopt = fmin(absh, hkm1); kk = kk - 1; }
+        }
+        absh = fmax(hmin, hopt);
+      } else absh = fmax(hmin, 0.5 * absh);
+      h = absh;
+      if (absh < abshlast) done = false;
+      adjust_stepsize(dif, absh / abshlast, kk);
+      hinvGak = h * ndf_invGa(kk - 1);
+      nconhk = 0;
+      need_fact = true;
+      continue;
+    }
+    // ------------------------------------------------------------------ accepted: update differences (ev.cpp:537-545)
+    st.steps++;
+    {
+      const double old_k = dif_get(dif, kk);
 #pragma unroll
       for (int j = 0; j < 7; j++) {
         if (j == kk + 1) dif[j] = difkp1 - old_k;
         if (j == kk) dif[j] = difkp1;
       }
+#pragma unroll
+      for (int j = 5; j >= 1; j--) if (j <= kk) dif[j - 1] += dif[j];
     }
-#pragma unroll
-    for (int j = 5; j >= 1; j--) if (j <= kk) dif[j - 1] += dif[j];
-    // sampled output (ev.cpp:547-571)
-    while ((next < tres) && (tnew - ts[next] >= 0.0)) {
-      const double tn = ts[next];
-      if (tnew == tn) sample_sources(P, L, Q, M, k, tn, ynew, f0, next, ik, lane);
-      else {
-        // interp_from_dif ev.cpp:860-905
-        const double s = (tn - tnew) / h;
-        double prod = 1.0, sumfrac = 0., fact = 1.0, yi = ynew, ypi = 0.;
-#pragma unroll
-        for (int j = 0; j < 5; j++) {
-          if (j < kk) {
-            prod *= (s + j); fact *= (j + 1); sumfrac += 1.0 / (s + j);
-            yi += (prod / fact) * dif[j];
-            ypi += (prod * sumfrac / (h * fact)) * dif[j];
-          }
-        }
-        sample_sources(P, L, Q, M, k, tn, yi, ypi, next, ik, lane);
-      }
-      next++;
-    }
-    if (done) break;
-    klast = kk;
-    abshlast = absh;
-    nconhk = min(nconhk + 1, maxk + 2);
-    if (nconhk >= kk + 2) {
-      double temp = 1.2 * pow((err / rtol), (1.0 / (kk + 1.0)));
-      double hopt = temp > 0.1 ? absh / temp : 10 * absh;
-      int kopt = kk;
-      if (kk > 1) {
-        double dk1 = 0.;
-#pragma unroll
-        for (int j = 0; j < 5; j++) if (j == kk - 1) dk1 = dif[j];
-        const double errkm1 = wave_max(act ? fabs(dk1 * invwt) : 0.) * erconst[kk - 2];
-        temp = 1.3 * pow((errkm1 / rtol), (1.0 / kk));
-        const double hkm1 = temp > 0.1 ? absh / temp : 10 * absh;
-        if (hkm1 > hopt) { hopt = hkm1; kopt = kk - 1; }
-      }
-      if (kk < maxk) {
-        double dk2 = 0.;
-#pragma unroll
-        for (int j = 0; j < 7; j++) if (j == kk + 1) dk2 = dif[j];
-        const double errkp1 = wave_max(act ? fabs(dk2 * invwt) : 0.) * erconst[kk];
-        temp = 1.4 * pow((errkp1 / rtol), (1.0 / (kk + 2.0)));
-        const double hkp1 = temp > 0.1 ? absh / temp : 10 * absh;
-        if (hkp1 > hopt) { hopt = hkp1; kopt = kk + 1; }
-      }
-      if (hopt > absh) { absh = hopt; kk = kopt; }
-    }
-    t = tnew;
-    y = ynew;
-    Jcurrent = false;
+    if ((next < tres) && (tnew - ts[next] >= 0.0)) { batch = B_SAMPLE; prepare_sample(); }
+    else post_step = true;
   }
-  // final call leaves M (tca_shear_g, ...) and the thermo row at tfinal for the regime hand-over (ev.cpp:653-662)
-  (void)rhs(P, L, e, Q, M, k, tnew, ynew, lane);
-  st.fevals++;
   y_io = ynew;
   return 0;
 }
 
 // perturb_initial_conditions (pm.cpp:4723-5408): adiabatic, synchronous gauge, flat. Returns this lane's y.
-__device__ inline double initial_conditions(const PtParams& P, const Layout& L, const LaneEq& e, Lookup& Q, double k, double tau,
-                                            int lane) {
-  lookup(P, Q, tau, lane);
-  const BgV& bg = Q.bg;
-  const double a = bg.a;
-  double rho_r = bg.rg, rho_m = bg.rb, rho_nu = 0.;
-  if (P.has_cdm) rho_m += bg.rc;
-  if (P.has_ur) { rho_r += bg.ru; rho_nu += bg.ru; }
-  const double fracnu = rho_nu / rho_r, fracb = bg.rb / rho_m;
+__device__ __noinline__ double initial_conditions(DevTables T, int has_cdm, int has_ur, double ci, int role, int ell,
+                                                  double k, double tau) {
+  // background row at tau (scalar lookup: executed once per mode)
+  const int inf = bsearch_up(T.tau_table, T.bt_size, tau);
+  const double hh = T.tau_table[inf + 1] - T.tau_table[inf], b = (tau - T.tau_table[inf]) / hh, aa = 1. - b, h2 = hh * hh / 6.;
+  const double2* r0 = (const double2*)T.bg + (size_t)inf * BG_NCOL;
+  const double2* r1 = r0 + BG_NCOL;
+  const double a = spl2(r0[BG_A], r1[BG_A], aa, b, h2), rg = spl2(r0[BG_RHO_G], r1[BG_RHO_G], aa, b, h2),
+               rb = spl2(r0[BG_RHO_B], r1[BG_RHO_B], aa, b, h2), rc = spl2(r0[BG_RHO_CDM], r1[BG_RHO_CDM], aa, b, h2),
+               ru = spl2(r0[BG_RHO_UR], r1[BG_RHO_UR], aa, b, h2);
+  double rho_r = rg, rho_m = rb, rho_nu = 0.;
+  if (has_cdm) rho_m += rc;
+  if (has_ur) { rho_r += ru; rho_nu += ru; }
+  const double fracnu = rho_nu / rho_r, fracb = rb / rho_m;
   const double om = a * rho_m / sqrt(rho_r);
-  const double kt2 = k * k * tau * tau, kt3 = k * tau * kt2, ci = P.curvature_ini;
+  const double kt2 = k * k * tau * tau, kt3 = k * tau * kt2;
   const double delta_g = -kt2 / 3. * (1. - om * tau / 5.) * ci;
   const double theta_g = -k * kt3 / 36. * (1. - 3. * (1. + 5. * fracb - fracnu) / 20. / (1. - fracnu) * om * tau) * ci;
   const double theta_ur = -k * kt3 / 36. / (4. * fracnu + 15.) *
@@ -870,7 +1041,7 @@ __device__ inline double initial_conditions(const PtParams& P, const Layout& L, 
   const double l3_ur = kt3 * 2. / 7. / (12. * fracnu + 45.) * ci;
   const double eta = ci * (1. - kt2 / 12. / (15. + 4. * fracnu) *
                                     (5. + 4. * fracnu - (16. * fracnu * fracnu + 280. * fracnu + 325) / 10. / (2. * fracnu + 15.) * tau * om));
-  switch (e.role) {
+  switch (role) {
     case R_DELTA_G: return delta_g;
     case R_THETA_G: return theta_g;
     case R_DELTA_B: return 0.75 * delta_g;
@@ -879,7 +1050,7 @@ __device__ inline double initial_conditions(const PtParams& P, const Layout& L, 
     case R_DELTA_UR: return delta_g;
     case R_THETA_UR: return theta_ur;
     case R_SHEAR_UR: return shear_ur;
-    case R_LUR: return e.ell == 3 ? l3_ur : 0.;
+    case R_LUR: return ell == 3 ? l3_ur : 0.;
     case R_ETA: return eta;
     default: return 0.;
   }
@@ -891,12 +1062,18 @@ __global__ void __launch_bounds__(64) k_perturb(PtParams P) {
   const int lane = threadIdx.x;
   const int ik = P.order[blockIdx.x];
   const double k = P.k[ik];
+  const double inv_k2 = 1.0 / (k * k);
   const int S = P.stride;
   double* Jm = lds;
   double* Am = lds + P.rows * S;
-  int* perm = (int*)(lds + 2 * P.rows * S);
+  double2* bgw = (double2*)(lds + 2 * P.rows * S);  // even number of doubles => 16-byte aligned
+  double2* thw = bgw + 64 * BG_NCOL;
 
   Stat st = {0, 0, 0, 0, 0, 0};
+  unsigned long long prof[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#ifdef CPT_PROFILE
+  const unsigned long long t_begin = clock64();
+#endif
   int status = 0, n_regimes = 0;
   int budget = P.max_steps;
   const double tau_end = P.tau_s[P.ntau - 1];
@@ -905,57 +1082,64 @@ __global__ void __launch_bounds__(64) k_perturb(PtParams P) {
   double tau_ini;
   {
     const double tl = P.tabs.tau_table[0];
-    double a, H, dk;
-    lookup_aHk(P, tl, &a, &H, &dk);
-    if ((a * H / dk > P.start_small_k) || (k / a / H > P.start_large_k)) status = 20;
-    tau_ini = search_flip(P, k, tl, P.tau_s[0], 0., P.tol_tau_approx, 0, 0, lane);
-    tau_ini = first(tau_ini);
+    const AHK q = lookup_aHk(P.tabs, P.n_e, tl);
+    if ((q.a * q.H / q.dk > P.start_small_k) || (k / q.a / q.H > P.start_large_k)) status = 20;
+    tau_ini = first(search_flip(P, k, tl, P.tau_s[0], 0., P.tol_tau_approx, 0, 0, lane));
   }
   // ---- regime schedule: pm.cpp:2940-3231 ----
-  int f_ini[3], f_end[3];
-  approx_flags(P, k, tau_ini, &f_ini[0], &f_ini[1], &f_ini[2]);
-  approx_flags(P, k, tau_end, &f_end[0], &f_end[1], &f_end[2]);
-  double sw[3];
-  int sw_ap[3], nsw = 0;
+  int fi0, fi1, fi2, fe0, fe1, fe2;
+  approx_flags(P, k, tau_ini, &fi0, &fi1, &fi2);
+  approx_flags(P, k, tau_end, &fe0, &fe1, &fe2);
+  fi0 = ufirst(fi0); fi1 = ufirst(fi1); fi2 = ufirst(fi2); fe0 = ufirst(fe0); fe1 = ufirst(fe1); fe2 = ufirst(fe2);
+  double sw0 = 0., sw1 = 0., sw2 = 0.;
+  int ap0 = 0, ap1 = 0, ap2 = 0, nsw = 0;
+#pragma unroll 1
   for (int ap = 0; ap < 3; ap++) {
-    f_ini[ap] = ufirst(f_ini[ap]); f_end[ap] = ufirst(f_end[ap]);
-    if (f_ini[ap] == f_end[ap]) continue;
-    const bool fwd = (ap == 0) ? (f_ini[0] == 1 && f_end[0] == 0) : (f_ini[ap] == 0 && f_end[ap] == 1);
+    const int fi = (ap == 0) ? fi0 : (ap == 1 ? fi1 : fi2), fe = (ap == 0) ? fe0 : (ap == 1 ? fe1 : fe2);
+    if (fi == fe) continue;
+    const bool fwd = (ap == 0) ? (fi == 1 && fe == 0) : (fi == 0 && fe == 1);  // tca: on->off, rsa/ufa: off->on
     if (!fwd) { status = 21; continue; }
-    sw[nsw] = first(search_flip(P, k, tau_ini, tau_end, P.tol_tau_approx, 0., ap + 1, f_ini[ap], lane));
-    sw_ap[nsw] = ap;
+    const double tsw = first(search_flip(P, k, tau_ini, tau_end, P.tol_tau_approx, 0., ap + 1, fi, lane));
+    if (nsw == 0) { sw0 = tsw; ap0 = ap; } else if (nsw == 1) { sw1 = tsw; ap1 = ap; } else { sw2 = tsw; ap2 = ap; }
     nsw++;
   }
-  // sort the (at most 3) switches chronologically
-  for (int i = 0; i < nsw; i++)
-    for (int j = i + 1; j < nsw; j++)
-      if (sw[j] < sw[i]) { double t = sw[i]; sw[i] = sw[j]; sw[j] = t; int a = sw_ap[i]; sw_ap[i] = sw_ap[j]; sw_ap[j] = a; }
-  for (int i = 1; i < nsw; i++) if (sw[i] == sw[i - 1]) status = 22;
-  if (!(f_ini[0] == 1 && f_ini[1] == 0 && f_ini[2] == 0)) status = 23;  // pm.cpp:3720-3745
+  // sort the (at most 3) switches chronologically (scalars only: no private arrays)
+  if (nsw >= 2 && sw1 < sw0) { double t = sw0; sw0 = sw1; sw1 = t; int a = ap0; ap0 = ap1; ap1 = a; }
+  if (nsw == 3) {
+    if (sw2 < sw1) { double t = sw1; sw1 = sw2; sw2 = t; int a = ap1; ap1 = ap2; ap2 = a; }
+    if (sw1 < sw0) { double t = sw0; sw0 = sw1; sw1 = t; int a = ap0; ap0 = ap1; ap1 = a; }
+  }
+  if ((nsw >= 2 && sw1 == sw0) || (nsw == 3 && sw2 == sw1)) status = 22;
+  if (!(fi0 == 1 && fi1 == 0 && fi2 == 0)) status = 23;  // pm.cpp:3720-3745
 
   if (status == 0) {
     Lookup Q;
-    lookup_init(P, Q, lane);
+    lookup_init(P, Q, bgw, thw, lane);
     Metric M;
-    M.tca_shear_g = 0.; M.tca_slip = 0.; M.rsa_dg = M.rsa_tg = M.rsa_dur = M.rsa_tur = 0.;
-    int flags[3] = {f_ini[0], f_ini[1], f_ini[2]};
-    Layout L = make_layout(P, flags[0], flags[1], flags[2]);
+    M.hp = M.etap = M.alpha = M.alphap = M.delta_m = 0.;
+    M.tca_shear_g = 0.; M.rsa_dg = M.rsa_tg = 0.;
+    int f_tca = fi0, f_rsa = fi1, f_ufa = fi2;
+    Layout L = make_layout(P, f_tca, f_rsa, f_ufa);
     LaneEq e = make_lane_eq(P, L, lane, k);
-    double y = initial_conditions(P, L, e, Q, k, tau_ini, lane);
+    double y = initial_conditions(P.tabs, P.has_cdm, P.has_ur, P.curvature_ini, e.role, e.ell, k, tau_ini);
+#ifdef CPT_PROFILE
+    prof[6] = clock64() - t_begin;  // schedule search + initial conditions
+#endif
     for (int iv = 0; iv <= nsw && status == 0; iv++) {
-      const double ta = (iv == 0) ? tau_ini : sw[iv - 1];
-      const double tb = (iv == nsw) ? tau_end : sw[iv];
+      const double ta = (iv == 0) ? tau_ini : (iv == 1 ? sw0 : (iv == 2 ? sw1 : sw2));
+      const double tb = (iv == nsw) ? tau_end : (iv == 0 ? sw0 : (iv == 1 ? sw1 : sw2));
       if (iv > 0) {
         // hand-over to the new scheme: pm.cpp:3777-4260
         const Layout Lo = L;
-        flags[sw_ap[iv - 1]] ^= 1;
-        L = make_layout(P, flags[0], flags[1], flags[2]);
+        const int ap = (iv == 1) ? ap0 : (iv == 2 ? ap1 : ap2);
+        if (ap == 0) f_tca ^= 1; else if (ap == 1) f_rsa ^= 1; else f_ufa ^= 1;
+        L = make_layout(P, f_tca, f_rsa, f_ufa);
         e = make_lane_eq(P, L, lane, k);
         const int src_i = index_of(Lo, e.role, e.ell);
         double yn = __shfl(y, src_i < 0 ? 0 : src_i, 64);
         if (src_i < 0 || e.role == R_NONE) yn = 0.;
         if (Lo.tca && !L.tca) {  // tight coupling switched off: seed shear, l=3 and polarisation (pm.cpp:3893-3916)
-          const double sh = M.tca_shear_g, kod = k / Q.th.dkappa;
+          const double sh = M.tca_shear_g, kod = k * Q.tau_c;
           if (e.role == R_SHEAR_G) yn = sh;
           if (e.role == R_LG && e.ell == 3) yn = 6. / 7. * kod * sh;
           if (e.role == R_POL) {
@@ -969,10 +1153,15 @@ __global__ void __launch_bounds__(64) k_perturb(PtParams P) {
         y = yn;
       }
       n_regimes++;
-      const int rc = ndf15(P, L, e, Q, M, k, ik, ta, tb, y, Jm, Am, perm, st, lane, budget);
+      const int rc = ndf15(P, L, e, Q, M, k, inv_k2, ik, ta, tb, y, Jm, Am, st, lane, budget, prof);
       if (rc) status = 10 + rc;
     }
   }
+#ifdef CPT_PROFILE
+  prof[7] = clock64() - t_begin;
+  if (lane == 0 && blockIdx.x == 0)  // the heaviest mode = the critical path
+    for (int i = 0; i < 8; i++) g_prof[i] = prof[i];
+#endif
   if (lane == 0) {
     if (P.status) P.status[ik] = status;
     if (P.stats) {
@@ -986,9 +1175,10 @@ __global__ void __launch_bounds__(64) k_perturb(PtParams P) {
 
 // ---- unit-test kernels -----------------------------------------------------------------------------
 __global__ void __launch_bounds__(64) k_dbg_lookup(PtParams P, const double* tau, int n, double* out) {
+  __shared__ __attribute__((aligned(16))) double2 w[64 * (BG_NCOL + TH_NCOL)];
   const int lane = threadIdx.x;
   Lookup Q;
-  lookup_init(P, Q, lane);
+  lookup_init(P, Q, w, w + 64 * BG_NCOL, lane);
   for (int i = 0; i < n; i++) {
     lookup(P, Q, tau[i], lane);
     if (lane == 0) {
@@ -1002,15 +1192,17 @@ __global__ void __launch_bounds__(64) k_dbg_lookup(PtParams P, const double* tau
 
 __global__ void __launch_bounds__(64) k_dbg_derivs(PtParams P, double k, double tau, int tca, int rsa, int ufa, const double* y,
                                                    double* dy, int* neq) {
+  __shared__ __attribute__((aligned(16))) double2 w[64 * (BG_NCOL + TH_NCOL)];
   const int lane = threadIdx.x;
   Lookup Q;
-  lookup_init(P, Q, lane);
+  lookup_init(P, Q, w, w + 64 * BG_NCOL, lane);
   Metric M;
-  M.tca_shear_g = 0.; M.tca_slip = 0.; M.rsa_dg = M.rsa_tg = M.rsa_dur = M.rsa_tur = 0.;
+  M.hp = M.etap = M.alpha = M.alphap = M.delta_m = 0.;
+  M.tca_shear_g = 0.; M.rsa_dg = M.rsa_tg = 0.;
   Layout L = make_layout(P, tca, rsa, ufa);
   LaneEq e = make_lane_eq(P, L, lane, k);
   const double yl = (lane < L.neq) ? y[lane] : 0.;
-  const double d = rhs(P, L, e, Q, M, k, tau, yl, lane);
+  const double d = rhs(P, L, e, Q, M, k, 1.0 / (k * k), tau, yl, lane);
   if (lane < L.neq) dy[lane] = d;
   if (lane == 0) *neq = L.neq;
 }
@@ -1033,13 +1225,15 @@ void fill_params(const cpt_handle* h, PtParams& P) {
   P.curvature_ini = c.curvature_ini; P.rtol = c.tol_perturb_integration; P.tol_tau_approx = c.tol_tau_approx;
   P.min_var = c.smallest_allowed_variation;
   int neq_max = 3 + c.l_max_g - 2 + c.l_max_pol_g + 1 + 2 + (c.has_cdm ? 1 : 0) + (c.has_ur ? 3 + c.l_max_ur - 2 : 0) + 1;
-  P.rows = neq_max;
-  P.stride = neq_max | 1;  // odd => lane i accessing row i hits 64 distinct bank pairs
+  P.rows = (neq_max + 7) & ~7;   // identity padding to a multiple of 8 (see factorise)
+  P.stride = P.rows | 1;  // odd => lane i accessing row i hits 64 distinct bank pairs
   P.max_steps = 400000;
   P.k = nullptr; P.tau_s = nullptr; P.order = nullptr; P.nk = 0; P.ntau = 0; P.src = nullptr; P.stats = nullptr; P.status = nullptr;
 }
 
-size_t perturb_lds_bytes(const PtParams& P) { return (size_t)2 * P.rows * P.stride * sizeof(double) + 64 * sizeof(int) + 16; }
+size_t perturb_lds_bytes(const PtParams& P) {
+  return (size_t)2 * P.rows * P.stride * sizeof(double) + (size_t)64 * (BG_NCOL + TH_NCOL) * sizeof(double2);
+}
 
 }  // namespace
 
@@ -1111,6 +1305,17 @@ int cpt_perturb_impl(cpt_handle* h, const double* k, int nk, const double* tau, 
     }
   }
   return CPT_OK;
+}
+
+// cycles spent by the heaviest mode of the last perturb launch: rhs(Newton), lu_solve, factorise, jacobian, sampling,
+// adjust_stepsize, schedule, total.  Zeros unless built with -DCPT_PROFILE (diagnostic builds only, tools/prof_run.py).
+extern "C" int cpt_dbg_profile(unsigned long long* out) {
+#ifdef CPT_PROFILE
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_prof), 8 * sizeof(unsigned long long)) == hipSuccess ? 0 : 3;
+#else
+  for (int i = 0; i < 8; i++) out[i] = 0;
+  return 0;
+#endif
 }
 
 int cpt_dbg_lookup_impl(cpt_handle* h, const double* tau, int n, double* out) {

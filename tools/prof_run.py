@@ -1,0 +1,30 @@
+"""Diagnostic: in-kernel cycle breakdown of the heaviest k-mode (needs a libcpt built with -DCPT_PROFILE).
+    hipcc ... -DCPT_PROFILE -o classpp_public_amd/csrc/libcpt_prof.so ...;  python tools/prof_run.py <lib> [config]"""
+import ctypes as C
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from classpp_public_amd import capi
+
+capi.LIB_PATH = os.path.abspath(sys.argv[1])
+from classpp_public_amd.backend import Backend
+from classpp_public_amd.inputs import Inputs
+
+inp = Inputs(sys.argv[2] if len(sys.argv) > 2 else "lcdm")
+be = Backend(inp)
+for i in range(2):
+    src, stats, status = be.perturb_solve(want_sources=False)
+print("kernel ms", be.kernel_ms(0))
+out = (C.c_ulonglong * 8)()
+L = capi.lib()
+L.cpt_dbg_profile.argtypes = [C.POINTER(C.c_ulonglong)]
+L.cpt_dbg_profile(out)
+names = ["rhs(newton)", "lu_solve", "factorise", "jacobian", "sampling", "adjust", "schedule", "total"]
+tot = max(out[7], 1)
+s = stats[len(stats) - 1]
+print("heaviest mode: steps", s.steps, "fevals", s.fevals, "lus", s.factorisations, "solves", s.solves, "jacs", s.jacobians)
+for n, v in zip(names, out):
+    print("%-12s %12d cycles %5.1f%%" % (n, v, 100.0 * v / tot))
+print("cycles/step %.0f  rhs cycles/call %.0f  solve cycles/call %.0f  factorise cycles/call %.0f  jac cycles/call %.0f" % (
+    tot / s.steps, out[0] / s.solves, out[1] / s.solves, out[2] / max(s.factorisations, 1), out[3] / max(s.jacobians, 1)))
