@@ -89,6 +89,13 @@ __device__ inline double lane_above(double v) {  // value of lane+1
 __device__ inline double fast_pow(double x, double p) { return (double)exp2f((float)p * log2f((float)x)); }
 // 1/x: hardware v_rcp_f64 seed + two Newton-Raphson refinements (full double accuracy to ~1 ulp, no IEEE division
 // expansion with its denormal/scale handling on the critical path)
+// Hide a lane-dependent integer from loop-invariant code motion: without this, hipcc hoists the dozens of
+// `lane > j` / `role == X` masks of the hot inline functions out of the step loop, keeps them in SGPR pairs, runs
+// out of SGPRs and spills them into VGPR lanes (two v_readlane + exec juggling per use).
+__device__ inline int opaque(int v) {
+  asm volatile("" : "+v"(v));
+  return v;
+}
 __device__ inline double fast_rcp(double x) {
   double r = __builtin_amdgcn_rcp(x);
   r = fma(r, fma(-x, r, 1.0), r);
@@ -463,7 +470,8 @@ __device__ __forceinline__ double rhs(const PtParams& P, const Layout& L, const 
   double P0 = 0.;  // Pi = G_gamma0 + G_gamma2 + F_gamma2 (pm.cpp:8142)
   if (!L.tca && !L.rsa) P0 = (bcast(y, L.pol0) + bcast(y, L.pol0 + 2) + 2. * sg) * 0.125;
   double E = 0.;
-  switch (e.role) {
+  const int role = opaque(e.role);
+  switch (role) {
     case R_DELTA_G: E = -4. / 3. * mc; break;
     case R_THETA_G:
       if (!L.tca) E = th.dkappa * tb;
@@ -488,7 +496,7 @@ __device__ __forceinline__ double rhs(const PtParams& P, const Layout& L, const 
     case R_ETA: E = etap; break;
     default: break;
   }
-  return (e.role == R_NONE) ? 0. : dy + E;
+  return (role == R_NONE) ? 0. : dy + E;
 }
 
 // perturb_sources (pm.cpp:6731-7285): the RHS has just been evaluated at (tau, y) => Q and M describe the sample.
@@ -579,6 +587,7 @@ __device__ __forceinline__ bool factorise(const double* __restrict__ J, double* 
   // The system is padded with identity rows/columns up to a multiple of 8 (np), so that the substitution loops run
   // over whole 8-column chunks without per-element guards.
   const int np = (n + 7) & ~7;
+  lane = opaque(lane);
   if (lane < n) {
     for (int c = 0; c < n; c++) A[lane * S + c] = -hg * J[lane * S + c] + (c == lane ? 1.0 : 0.0);
     for (int c = n; c < np; c++) A[lane * S + c] = 0.;
@@ -643,6 +652,11 @@ __device__ __forceinline__ bool factorise(const double* __restrict__ J, double* 
       }
     }
   }
+  // scale the U part of every row by its reciprocal pivot: U becomes unit upper triangular and the backward
+  // substitution needs no multiply on its dependent chain (the right-hand side is scaled once, in parallel)
+  if (lane < n) {
+    for (int c = lane + 1; c < n; c++) A[lane * S + c] *= rpiv;
+  }
   F.rowperm = rowperm; F.rpiv = rpiv;
   return true;
 }
@@ -653,6 +667,7 @@ __device__ __forceinline__ bool factorise(const double* __restrict__ J, double* 
 // v_readlane + v_fma only.
 __device__ __forceinline__ double lu_solve(const double* __restrict__ A, const LuReg& F, int n, int S, double b, int lane) {
   const int np = (n + 7) & ~7;  // identity-padded size (see factorise)
+  lane = opaque(lane);
   const double* myrow = A + (lane < np ? lane : 0) * S;
   b = __shfl(b, F.rowperm, 64);  // row exchanges of the factorisation
 #pragma unroll
@@ -662,23 +677,22 @@ __device__ __forceinline__ double lu_solve(const double* __restrict__ A, const L
 #pragma unroll
       for (int u = 0; u < 8; u++) r[u] = myrow[j0 + u];
 #pragma unroll
-      for (int u = 0; u < 8; u++) {
-        const double bj = bcast(b, j0 + u);
-        b = (lane > j0 + u) ? b - r[u] * bj : b;
-      }
+      for (int u = 0; u < 8; u++) r[u] = (lane > j0 + u) ? r[u] : 0.;  // masking is off the dependent chain
+#pragma unroll
+      for (int u = 0; u < 8; u++) b = fma(-r[u], bcast(b, j0 + u), b);
     }
   }
+  b *= F.rpiv;  // U is stored with unit diagonal
 #pragma unroll
-  for (int j0 = 56; j0 >= 0; j0 -= 8) {  // backward
+  for (int j0 = 56; j0 >= 0; j0 -= 8) {  // backward: lane j already holds x_j when column j is eliminated
     if (j0 < np) {
       double r[8];
 #pragma unroll
       for (int u = 0; u < 8; u++) r[u] = myrow[j0 + u];
 #pragma unroll
-      for (int u = 7; u >= 0; u--) {
-        const double xj = bcast(b * F.rpiv, j0 + u);  // lane j holds b_j: x_j = b_j / u_jj
-        b = (lane < j0 + u) ? b - r[u] * xj : ((lane == j0 + u) ? xj : b);
-      }
+      for (int u = 0; u < 8; u++) r[u] = (lane < j0 + u) ? r[u] : 0.;
+#pragma unroll
+      for (int u = 7; u >= 0; u--) b = fma(-r[u], bcast(b, j0 + u), b);
     }
   }
   return (lane < n) ? b : 0.;
