@@ -94,6 +94,22 @@ class Backend:
         self._check(rc)
         return out
 
+    # ---- "next" rows: observables ----
+    def cl(self, transfer, q=None):
+        """transfer: device [tt][nl][nq] -> C_l table [nl][ct_size] on device (cpt_cl_batch)"""
+        q = np.ascontiguousarray(self.inp.q if q is None else q, dtype=np.float64)
+        nl = transfer.shape[1]
+        out = torch.empty((nl, self.inp.spectra.ct_size), dtype=torch.float64, device=self.device)
+        self._check(self.lib.cpt_cl_batch(self.h, C.byref(self.inp.spectra), C.c_void_p(transfer.data_ptr()), _dptr(q), q.size, nl,
+                                          C.c_void_p(out.data_ptr())))
+        return out
+
+    def pk_linear(self, k=None):
+        k = np.ascontiguousarray(self.inp.k if k is None else k, dtype=np.float64)
+        out = torch.empty(k.size, dtype=torch.float64, device=self.device)
+        self._check(self.lib.cpt_pk_linear(self.h, C.byref(self.inp.spectra), _dptr(k), k.size, C.c_void_p(out.data_ptr())))
+        return out
+
     def get_sources(self, ntau, nk):
         out = torch.empty((self.inp.config.tp_size, ntau, nk), dtype=torch.float64, device=self.device)
         self._check(self.lib.cpt_get_sources(self.h, C.c_void_p(out.data_ptr())))

@@ -60,7 +60,7 @@ class CptTables(C.Structure):
         ("z_table", _pd), ("thermodynamics_table", _pd), ("d2thermodynamics_dz2_table", _pd),
         ("index_th_xe", _i), ("index_th_dkappa", _i), ("index_th_tau_d", _i), ("index_th_ddkappa", _i),
         ("index_th_dddkappa", _i), ("index_th_exp_m_kappa", _i), ("index_th_g", _i), ("index_th_dg", _i),
-        ("index_th_cb2", _i),
+        ("index_th_cb2", _i), ("index_th_rate", _i),
     ]
 
 
@@ -69,11 +69,17 @@ class CptStepstat(C.Structure):
                 ("solves", _i), ("n_regimes", _i), ("tau_ini", _d)]
 
 
+class CptSpectraParams(C.Structure):
+    _fields_ = [("A_s", _d), ("n_s", _d), ("alpha_s", _d), ("k_pivot", _d), ("ct_size", _i),
+                ("index_ct_tt", _i), ("index_ct_ee", _i), ("index_ct_te", _i), ("index_ct_bb", _i), ("index_ct_pp", _i),
+                ("index_ct_tp", _i), ("index_ct_ep", _i)]
+
+
 # every symbol include/cpt.h declares (tests check that the built library exports all of them)
 EXPORTS = [
     "cpt_create", "cpt_destroy", "cpt_last_error", "cpt_create_error", "cpt_perturb_solve_batch",
     "cpt_transfer_batch", "cpt_get_sources", "cpt_last_kernel_ms", "cpt_last_transfer_work",
-    "cpt_dbg_lookup", "cpt_dbg_derivs", "cpt_dbg_bessel",
+    "cpt_dbg_lookup", "cpt_dbg_derivs", "cpt_dbg_bessel", "cpt_cl_batch", "cpt_pk_linear",
 ]
 
 _lib = None
@@ -111,6 +117,10 @@ def lib():
     L.cpt_last_kernel_ms.restype = _i
     L.cpt_last_transfer_work.argtypes = [vp, ll, ll, ll]
     L.cpt_last_transfer_work.restype = _i
+    L.cpt_cl_batch.argtypes = [vp, C.POINTER(CptSpectraParams), vp, _pd, _i, _i, vp]
+    L.cpt_cl_batch.restype = _i
+    L.cpt_pk_linear.argtypes = [vp, C.POINTER(CptSpectraParams), _pd, _i, vp]
+    L.cpt_pk_linear.restype = _i
     L.cpt_dbg_lookup.argtypes = [vp, _pd, _i, _pd]
     L.cpt_dbg_lookup.restype = _i
     L.cpt_dbg_derivs.argtypes = [vp, _d, _d, _i, _i, _i, _pd, _pd, pi]

@@ -186,6 +186,21 @@ int cpt_transfer_batch(cpt_handle* h, const double* sources_dev, const double* k
   return cpt_transfer_impl(h, sources_dev, k, nk, k_size_cl, tau_sampling, ntau, q, nq, l, nl, transfer_dev);
 }
 
+int cpt_cl_batch(cpt_handle* h, const cpt_spectra_params* sp, const double* transfer_dev, const double* q, int nq, int nl,
+                 double* cl_dev) {
+  if (!h) return CPT_ERR_INVALID;
+  h->err.clear();
+  if (!sp || !transfer_dev || !q || !cl_dev || nq < 3 || nl < 1) return cpt_fail(h, CPT_ERR_INVALID, "bad arguments to cpt_cl_batch");
+  return cpt_cl_impl(h, sp, transfer_dev, q, nq, nl, cl_dev);
+}
+
+int cpt_pk_linear(cpt_handle* h, const cpt_spectra_params* sp, const double* k, int nk, double* pk_dev) {
+  if (!h) return CPT_ERR_INVALID;
+  h->err.clear();
+  if (!sp || !k || !pk_dev || nk < 1) return cpt_fail(h, CPT_ERR_INVALID, "bad arguments to cpt_pk_linear");
+  return cpt_pk_impl(h, sp, k, nk, pk_dev);
+}
+
 int cpt_get_sources(cpt_handle* h, double* sources_dev) {
   if (!h) return CPT_ERR_INVALID;
   h->err.clear();

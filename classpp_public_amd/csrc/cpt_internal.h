@@ -47,7 +47,7 @@ struct cpt_handle {
   int src_nk = 0, src_ntau = 0;
   // transfer scratch
   double *d_dd = nullptr, *d_u = nullptr;  // spline second derivative + scratch, same shape as d_src
-  size_t dd_cap = 0;
+  size_t dd_cap = 0, u_cap = 0;
   double *d_k = nullptr, *d_tau = nullptr, *d_q = nullptr, *d_splc = nullptr;
   int *d_l = nullptr, *d_ik = nullptr;
   size_t grid_cap_k = 0, grid_cap_tau = 0, grid_cap_q = 0, grid_cap_l = 0;
@@ -95,6 +95,9 @@ int cpt_transfer_impl(cpt_handle* h, const double* sources_dev, const double* k,
 int cpt_bessel_build(cpt_handle* h, const int* l, int nl, double xmax);
 int cpt_perturb_impl(cpt_handle* h, const double* k, int nk, const double* tau_sampling, int ntau, double* sources_dev,
                      cpt_stepstat* stats, int* status);
+int cpt_cl_impl(cpt_handle* h, const cpt_spectra_params* sp, const double* transfer_dev, const double* q, int nq, int nl,
+                double* cl_dev);
+int cpt_pk_impl(cpt_handle* h, const cpt_spectra_params* sp, const double* k, int nk, double* pk_dev);
 int cpt_dbg_lookup_impl(cpt_handle* h, const double* tau, int n, double* out);
 int cpt_dbg_derivs_impl(cpt_handle* h, double k, double tau, int tca_on, int rsa_on, int ufa_on, const double* y,
                         double* dy, int* neq);

@@ -1,0 +1,159 @@
+// C++ shim classes of include/cpt_modules.hpp: host logic only (grids, memory, error mapping); the compute is in
+// libcpt.so behind the C ABI.  Link: g++ ... cpt_modules.cpp cpt_grids.cpp -L../csrc -lcpt -lamdhip64
+#include "../../include/cpt_modules.hpp"
+
+#include <hip/hip_runtime_api.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+namespace cpt {
+
+namespace {
+template <class T>
+T* xalloc(size_t n) {
+  T* p = (T*)malloc(n * sizeof(T));
+  if (!p) throw std::runtime_error("could not allocate memory");  // class_alloc, include/common.h:140-330
+  return p;
+}
+[[noreturn]] void raise(int code, const char* msg) {
+  if (code == CPT_ERR_INVALID || code == CPT_ERR_UNSUPPORTED) throw std::invalid_argument(msg);
+  throw std::runtime_error(msg);
+}
+}  // namespace
+
+PerturbationsModule::PerturbationsModule(const Inputs& in) {
+  error_message_[0] = '\n';
+  const cpt_config& c = in.config;
+  // ---- perturb_indices_of_perturbs (pm.cpp:843-1235): the index contract comes in through cpt_config ----
+  ic_size_ = xalloc<int>(1); ic_size_[0] = 1;
+  tp_size_ = xalloc<int>(1); tp_size_[0] = c.tp_size;
+  index_tp_t0_ = c.index_tp_t0; index_tp_t1_ = c.index_tp_t1; index_tp_t2_ = c.index_tp_t2; index_tp_p_ = c.index_tp_p;
+  index_tp_delta_m_ = c.index_tp_delta_m; index_tp_phi_plus_psi_ = c.index_tp_phi_plus_psi;
+  has_source_t_ = c.index_tp_t0 >= 0; has_source_p_ = c.index_tp_p >= 0; has_source_delta_m_ = c.index_tp_delta_m >= 0;
+  has_source_phi_plus_psi_ = c.index_tp_phi_plus_psi >= 0;
+  // ---- perturb_get_k_list (pm.cpp:1628-2238) ----
+  k_size_ = xalloc<int>(1); k_size_cl_ = xalloc<int>(1); k_size_cmb_ = xalloc<int>(1);
+  k_ = xalloc<double*>(1);
+  k_[0] = nullptr;
+  std::vector<double> tmp(1 << 20);
+  int rc = cpt_host_k_list(&c, &in.grid, tmp.data(), (int)tmp.size(), &k_size_[0], &k_size_cl_[0], &k_size_cmb_[0]);
+  if (rc) { snprintf(error_message_, sizeof(error_message_), "%s", cpt_host_error()); raise(rc, error_message_); }
+  k_[0] = xalloc<double>(k_size_[0]);
+  memcpy(k_[0], tmp.data(), sizeof(double) * k_size_[0]);
+  k_min_ = k_[0][0];
+  k_max_ = k_[0][k_size_[0] - 1];
+  // ---- perturb_timesampling_for_sources (pm.cpp:1247-1619) ----
+  rc = cpt_host_tau_sampling(&c, &in.tables, &in.grid, tmp.data(), (int)tmp.size(), &tau_size_);
+  if (rc) { snprintf(error_message_, sizeof(error_message_), "%s", cpt_host_error()); raise(rc, error_message_); }
+  tau_sampling_ = xalloc<double>(tau_size_);
+  memcpy(tau_sampling_, tmp.data(), sizeof(double) * tau_size_);
+  ln_tau_size_ = 1;  // z_max_pk = 0 (pm.cpp:1554-1556)
+  // ---- the k loop (pm.cpp:668-718) on the GPU ----
+  rc = cpt_create(&c, &in.tables, &h_);
+  if (rc) { snprintf(error_message_, sizeof(error_message_), "%s", cpt_create_error()); raise(rc, error_message_); }
+  const int nk = k_size_[0], ntp = c.tp_size;
+  stats_ = xalloc<cpt_stepstat>(nk);
+  double* d_src = nullptr;
+  const size_t nsrc = (size_t)ntp * tau_size_ * nk;
+  if (hipMalloc((void**)&d_src, nsrc * sizeof(double)) != hipSuccess) raise(CPT_ERR_RUNTIME, "hipMalloc failed");
+  rc = cpt_perturb_solve_batch(h_, k_[0], nk, tau_sampling_, tau_size_, d_src, stats_, nullptr);
+  if (rc) {
+    snprintf(error_message_, sizeof(error_message_), "%s", cpt_last_error(h_));
+    (void)hipFree(d_src);
+    raise(rc, error_message_);
+  }
+  // sources_[md][ic*tp+tp][tau*k_size+k]: one malloc per type like the reference (pm.cpp:1597-1616)
+  sources_ = xalloc<double**>(1);
+  sources_[0] = xalloc<double*>(ntp);
+  for (int tp = 0; tp < ntp; tp++) {
+    sources_[0][tp] = xalloc<double>((size_t)tau_size_ * nk);
+    if (hipMemcpy(sources_[0][tp], d_src + (size_t)tp * tau_size_ * nk, sizeof(double) * (size_t)tau_size_ * nk,
+                  hipMemcpyDeviceToHost) != hipSuccess) {
+      (void)hipFree(d_src);
+      raise(CPT_ERR_RUNTIME, "hipMemcpy of the sources failed");
+    }
+  }
+  (void)hipFree(d_src);
+}
+
+PerturbationsModule::~PerturbationsModule() {
+  if (sources_) {
+    for (int tp = 0; tp < tp_size_[0]; tp++) free(sources_[0][tp]);
+    free(sources_[0]);
+    free(sources_);
+  }
+  if (k_) { free(k_[0]); free(k_); }
+  free(k_size_); free(k_size_cl_); free(k_size_cmb_); free(tau_sampling_); free(ic_size_); free(tp_size_); free(stats_);
+  cpt_destroy(h_);
+}
+
+double PerturbationsModule::kernel_ms() const {
+  double ms = 0; int n = 0;
+  cpt_last_kernel_ms(h_, 0, &ms, &n);
+  return ms;
+}
+
+TransferModule::TransferModule(const Inputs& in, std::shared_ptr<const PerturbationsModule> pt)
+    : perturbations_module_(std::move(pt)) {
+  error_message_[0] = '\n';
+  const cpt_config& c = in.config;
+  const PerturbationsModule& P = *perturbations_module_;
+  // ---- transfer_indices_of_transfers (tm.cpp:402-540) ----
+  tt_size_ = xalloc<int>(1); tt_size_[0] = c.tt_size;
+  index_tt_t0_ = c.index_tt_t0; index_tt_t1_ = c.index_tt_t1; index_tt_t2_ = c.index_tt_t2; index_tt_e_ = c.index_tt_e;
+  index_tt_lcmb_ = c.index_tt_lcmb;
+  std::vector<double> tmp(1 << 22);
+  std::vector<int> itmp(1 << 16);
+  int nl = 0;
+  int rc = cpt_host_l_list(&c, &in.grid, itmp.data(), (int)itmp.size(), &nl);
+  if (rc) { snprintf(error_message_, sizeof(error_message_), "%s", cpt_host_error()); raise(rc, error_message_); }
+  l_size_max_ = nl;
+  l_ = xalloc<int>(nl);
+  memcpy(l_, itmp.data(), sizeof(int) * nl);
+  l_size_ = xalloc<int>(1); l_size_[0] = nl;
+  l_size_tt_ = xalloc<int*>(1);
+  l_size_tt_[0] = xalloc<int>(c.tt_size);
+  for (int t = 0; t < c.tt_size; t++) l_size_tt_[0][t] = nl;  // every CMB type runs to l_scalar_max (tm.cpp:790-870)
+  rc = cpt_host_q_list(&c, &in.grid, P.k_min_, P.k_[0][P.k_size_cl_[0] - 1], tmp.data(), (int)tmp.size(), &q_size_);
+  if (rc) { snprintf(error_message_, sizeof(error_message_), "%s", cpt_host_error()); raise(rc, error_message_); }
+  q_ = xalloc<double>(q_size_);
+  memcpy(q_, tmp.data(), sizeof(double) * q_size_);
+  k_ = xalloc<double*>(1);
+  k_[0] = xalloc<double>(q_size_);
+  memcpy(k_[0], q_, sizeof(double) * q_size_);  // flat space: k = q (tm.cpp:1106-1167)
+  index_q_flat_approximation_ = 0;
+  // ---- the q loop (tm.cpp:287-318) on the GPU, from the sources left resident in HBM by the perturbation stage ----
+  const size_t ntr = (size_t)c.tt_size * nl * q_size_;
+  double* d_tr = nullptr;
+  if (hipMalloc((void**)&d_tr, ntr * sizeof(double)) != hipSuccess) raise(CPT_ERR_RUNTIME, "hipMalloc failed");
+  rc = cpt_transfer_batch(P.handle(), nullptr, P.k_[0], P.k_size_[0], P.k_size_cl_[0], P.tau_sampling_, P.tau_size_, q_, q_size_,
+                          l_, nl, d_tr);
+  if (rc) {
+    snprintf(error_message_, sizeof(error_message_), "%s", cpt_last_error(P.handle()));
+    (void)hipFree(d_tr);
+    raise(rc, error_message_);
+  }
+  transfer_ = xalloc<double*>(1);
+  transfer_[0] = xalloc<double>(ntr);
+  hipError_t e = hipMemcpy(transfer_[0], d_tr, ntr * sizeof(double), hipMemcpyDeviceToHost);
+  (void)hipFree(d_tr);
+  if (e != hipSuccess) raise(CPT_ERR_RUNTIME, "hipMemcpy of the transfer functions failed");
+}
+
+TransferModule::~TransferModule() {
+  if (transfer_) { free(transfer_[0]); free(transfer_); }
+  if (k_) { free(k_[0]); free(k_); }
+  if (l_size_tt_) { free(l_size_tt_[0]); free(l_size_tt_); }
+  free(q_); free(l_); free(l_size_); free(tt_size_);
+}
+
+double TransferModule::kernel_ms() const {
+  double ms = 0; int n = 0;
+  cpt_last_kernel_ms(perturbations_module_->handle(), 1, &ms, &n);
+  return ms;
+}
+
+}  // namespace cpt

@@ -11,7 +11,7 @@ import os
 
 import numpy as np
 
-from .capi import CptConfig, CptTables
+from .capi import CptConfig, CptSpectraParams, CptTables
 
 GOLDEN = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
 
@@ -84,9 +84,22 @@ class Inputs:
         tb.tt_size = int(_s(t, "th.tt_size")); tb.th_size = int(_s(t, "th.th_size"))
         tb.z_table = ptr(t["th.z_table"]); tb.thermodynamics_table = ptr(t["th.thermodynamics_table"])
         tb.d2thermodynamics_dz2_table = ptr(t["th.d2thermodynamics_dz2_table"])
-        for f in ("xe", "dkappa", "tau_d", "ddkappa", "dddkappa", "exp_m_kappa", "g", "dg", "cb2"):
+        for f in ("xe", "dkappa", "tau_d", "ddkappa", "dddkappa", "exp_m_kappa", "g", "dg", "cb2", "rate"):
             setattr(tb, "index_th_" + f, int(_s(t, "th.index_th_" + f)))
         self.tables = tb
+
+        # primordial spectrum + C_l slots (struct primordial / SpectraModule index_ct_*)
+        sp = CptSpectraParams()
+        sp.A_s = _s(d, "ppm.A_s"); sp.n_s = _s(d, "ppm.n_s"); sp.alpha_s = _s(d, "ppm.alpha_s"); sp.k_pivot = _s(d, "ppm.k_pivot")
+        sp.ct_size = int(_s(d, "sp.ct_size")) if "sp.ct_size" in d else 0
+        for f in ("tt", "ee", "te", "pp", "tp", "ep"):
+            setattr(sp, "index_ct_" + f, int(_s(d, "sp.index_ct_" + f)) if ("sp.index_ct_" + f) in d else -1)
+        used = {getattr(sp, "index_ct_" + f) for f in ("tt", "ee", "te", "pp", "tp", "ep")}
+        sp.index_ct_bb = -1
+        for i in range(sp.ct_size):  # the remaining slot of a scalar run is BB (identically zero)
+            if i not in used:
+                sp.index_ct_bb = i
+        self.spectra = sp
 
         # grids
         self.k = np.ascontiguousarray(d["pt.k"], dtype=np.float64)

@@ -121,6 +121,7 @@ typedef struct cpt_tables {
   const double* d2thermodynamics_dz2_table;
   int index_th_xe, index_th_dkappa, index_th_tau_d, index_th_ddkappa, index_th_dddkappa, index_th_exp_m_kappa,
       index_th_g, index_th_dg, index_th_cb2;
+  int index_th_rate; /* only read by the host-side time sampling (include/cpt_host.h), never by the kernels */
 } cpt_tables;
 
 /* per-k-mode work counters = the evolver's stepstat[6] (tools/evolver_ndf15.cpp:29-37) summed over regimes */
@@ -162,6 +163,26 @@ int cpt_perturb_solve_batch(cpt_handle* h, const double* k, int nk, const double
 int cpt_transfer_batch(cpt_handle* h, const double* sources_dev, const double* k, int nk, int k_size_cl,
                        const double* tau_sampling, int ntau, const double* q, int nq, const int* l, int nl,
                        double* transfer_dev);
+
+/* ---- "next" rows of the scope table (SURVEY S8f-2,3): what turns the path's outputs into observables ---- */
+/* analytic primordial spectrum P_R(k) = A_s exp((n_s-1) ln(k/k_pivot) + alpha_s/2 ln^2(k/k_pivot))
+ * (source/primordial_module.cpp:911-925) and the slots of the C_l types in the output table (reference order
+ * tt,ee,te,bb,pp,tp,ep; -1 = absent; source/spectra_module.h:47-53) */
+typedef struct cpt_spectra_params {
+  double A_s, n_s, alpha_s, k_pivot;
+  int ct_size;
+  int index_ct_tt, index_ct_ee, index_ct_te, index_ct_bb, index_ct_pp, index_ct_tp, index_ct_ep;
+} cpt_spectra_params;
+
+/* C_l = 4 pi int dk/k P_R(k) Delta_l^X(q) Delta_l^Y(q): integrand splined in q and integrated
+ * (SpectraModule::spectra_compute_cl, source/spectra_module.cpp:958-1353; flat space, one initial condition).
+ *   transfer_dev  device [tt_size][nl][nq] as produced by cpt_transfer_batch;  q[nq] host
+ *   cl_dev        device [nl][ct_size] = cl_[md][(l*ic_ic+0)*ct_size+ct]                                        */
+int cpt_cl_batch(cpt_handle* h, const cpt_spectra_params* sp, const double* transfer_dev, const double* q, int nq, int nl,
+                 double* cl_dev);
+/* linear matter power spectrum today P(k) = 2 pi^2/k^3 delta_m(k,tau0)^2 P_R(k) from the sources resident in the handle
+ * (NonlinearModule::nonlinear_pk_linear, source/nonlinear_module.cpp:1886-2040); pk_dev device [nk]               */
+int cpt_pk_linear(cpt_handle* h, const cpt_spectra_params* sp, const double* k, int nk, double* pk_dev);
 
 /* Device-side copy of the resident sources into the reference layout [tp_size][ntau][nk] (device pointer). */
 int cpt_get_sources(cpt_handle* h, double* sources_dev);

@@ -1,0 +1,48 @@
+/* cpt_host.h -- host-side (CPU, C++ inside, C ABI outside) companions of the hot path: the sampling grids that
+ * the reference's module constructors build before entering the parallel loops.  They are cheap (< 1 ms), run once
+ * per cosmology and must be reproduced EXACTLY, because every downstream spline is defined on them (SURVEY S8a rows
+ * A2, A3, B1):
+ *   cpt_host_k_list        PerturbationsModule::perturb_get_k_list               pm.cpp:1628-1868 (scalars)
+ *   cpt_host_tau_sampling  PerturbationsModule::perturb_timesampling_for_sources pm.cpp:1247-1533
+ *   cpt_host_l_list        TransferModule::transfer_get_l_list                   tm.cpp:694-790
+ *   cpt_host_q_list        TransferModule::transfer_get_q_list (+ _k_list)       tm.cpp:884-1096 (flat: k = q)
+ * Built into classpp_public_amd/host/libcpt_host.so (g++, no HIP).  The C++ shim classes that mirror the reference's
+ * PerturbationsModule / TransferModule data contract on top of libcpt.so are declared in include/cpt_modules.hpp.
+ */
+#ifndef CPT_HOST_H
+#define CPT_HOST_H
+#include "cpt.h"
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* precision / physics parameters read by the grid builders (include/precisions.h:162-178, 202, 231, 335-376) */
+typedef struct cpt_grid_params {
+  /* k grid */
+  double k_min_tau0, k_max_tau0_over_l_max, k_step_sub, k_step_super, k_step_transition, k_step_super_reduction,
+      k_per_decade_for_pk, k_per_decade_for_bao, k_bao_center, k_bao_width;
+  int has_cls, has_pk_matter, l_scalar_max;
+  double k_max_for_pk;
+  double rs_rec;          /* ThermodynamicsModule::rs_rec_   */
+  double tau_ini_thermo;  /* ThermodynamicsModule::tau_ini_  */
+  /* tau sampling */
+  double start_sources_at_tau_c_over_tau_h, perturb_sampling_stepsize;
+  /* l, q grids */
+  double l_linstep, l_logstep, q_linstep, q_logstep_spline, q_logstep_open;
+} cpt_grid_params;
+
+/* Every function returns CPT_OK or CPT_ERR_INVALID (message via cpt_host_error()); *_size are outputs; `cap` is the
+ * capacity of the caller's array (CPT_ERR_INVALID if too small, with the needed size stored in *_size). */
+int cpt_host_k_list(const cpt_config* cfg, const cpt_grid_params* g, double* k, int cap, int* k_size, int* k_size_cl,
+                    int* k_size_cmb);
+int cpt_host_tau_sampling(const cpt_config* cfg, const cpt_tables* tabs, const cpt_grid_params* g, double* tau, int cap,
+                          int* tau_size);
+int cpt_host_l_list(const cpt_config* cfg, const cpt_grid_params* g, int* l, int cap, int* l_size);
+int cpt_host_q_list(const cpt_config* cfg, const cpt_grid_params* g, double k_min, double k_max_cl, double* q, int cap,
+                    int* q_size);
+const char* cpt_host_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

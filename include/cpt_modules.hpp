@@ -1,0 +1,87 @@
+// cpt_modules.hpp -- C++ shim classes with the constructor semantics and the PUBLIC DATA CONTRACT of the reference's
+// PerturbationsModule (source/perturbations_module.h:9-178) and TransferModule (source/transfer_module.h:9-57), built
+// on the C ABI of include/cpt.h (GPU kernels) and include/cpt_host.h (grids).  Same member names, same array layouts,
+// same ownership (malloc'd by the module, freed in its destructor, consumers never write), same error behaviour: all
+// work happens in the constructor; unsupported / inconsistent input throws std::invalid_argument, a failure inside the
+// computation throws std::runtime_error (pm.cpp:37-39, tm.cpp:43-45; classy maps them to CosmoSevereError /
+// CosmoComputationError).  What differs by necessity: the constructors take a cpt::Inputs (flat POD config + spline
+// tables + grid parameters) instead of InputModulePtr / BackgroundModulePtr / ThermodynamicsModulePtr; INTEGRATION.md
+// shows the adapter that fills it from those reference modules.
+#pragma once
+#include <memory>
+#include <stdexcept>
+#include <string>
+
+#include "cpt_host.h"
+
+namespace cpt {
+
+struct Inputs {
+  cpt_config config;
+  cpt_tables tables;      // host pointers into the caller's (reference modules') tables; only read during construction
+  cpt_grid_params grid;
+};
+
+class PerturbationsModule {
+ public:
+  explicit PerturbationsModule(const Inputs& in);
+  ~PerturbationsModule();
+  PerturbationsModule(const PerturbationsModule&) = delete;
+
+  // ---- data contract of source/perturbations_module.h (scalar mode, adiabatic ic) ----
+  int index_md_scalars_ = 0, md_size_ = 1;
+  int index_ic_ad_ = 0;
+  int* ic_size_ = nullptr;
+  int index_tp_t0_ = -1, index_tp_t1_ = -1, index_tp_t2_ = -1, index_tp_p_ = -1, index_tp_delta_m_ = -1,
+      index_tp_phi_plus_psi_ = -1;
+  int* tp_size_ = nullptr;
+  short has_source_t_ = 0, has_source_p_ = 0, has_source_delta_m_ = 0, has_source_phi_plus_psi_ = 0;
+  double*** sources_ = nullptr;  // sources_[md][ic*tp_size+tp][index_tau*k_size+index_k]
+  double* ln_tau_ = nullptr;
+  int ln_tau_size_ = 1;
+  double* tau_sampling_ = nullptr;
+  int tau_size_ = 0;
+  int* k_size_cl_ = nullptr;
+  int* k_size_ = nullptr;
+  double** k_ = nullptr;
+  double k_min_ = 0., k_max_ = 0.;
+  mutable char error_message_[2048];
+
+  // ---- extras of this backend ----
+  cpt_handle* handle() const { return h_; }       // device handle holding the sources resident in HBM (k-major)
+  const cpt_stepstat* stepstat() const { return stats_; }  // per-k work counters (the evolver's stepstat[6])
+  double kernel_ms() const;
+
+ private:
+  cpt_handle* h_ = nullptr;
+  cpt_stepstat* stats_ = nullptr;
+  int* k_size_cmb_ = nullptr;
+};
+
+class TransferModule {
+ public:
+  TransferModule(const Inputs& in, std::shared_ptr<const PerturbationsModule> perturbations_module);
+  ~TransferModule();
+  TransferModule(const TransferModule&) = delete;
+
+  // ---- data contract of source/transfer_module.h ----
+  int index_tt_t0_ = -1, index_tt_t1_ = -1, index_tt_t2_ = -1, index_tt_e_ = -1, index_tt_lcmb_ = -1;
+  int* tt_size_ = nullptr;
+  int l_size_max_ = 0;
+  int** l_size_tt_ = nullptr;
+  int* l_size_ = nullptr;
+  int* l_ = nullptr;
+  int q_size_ = 0;
+  double* q_ = nullptr;
+  double** k_ = nullptr;
+  int index_q_flat_approximation_ = 0;
+  double** transfer_ = nullptr;  // transfer_[md][((ic*tt_size+tt)*l_size+l)*q_size+q]
+  mutable char error_message_[2048];
+
+  double kernel_ms() const;
+
+ private:
+  std::shared_ptr<const PerturbationsModule> perturbations_module_;
+};
+
+}  // namespace cpt

@@ -1,0 +1,57 @@
+// Test driver for the C++ shim classes (include/cpt_modules.hpp): reads a flat dump of cpt::Inputs written by
+// tests/test_gpu_host_shim.py, builds PerturbationsModule and TransferModule exactly like the reference's Cosmology
+// getters would (source/cosmology.cpp:30-35, 68-73), and writes the public tables back for comparison.
+#include <cstdio>
+#include <cstdlib>
+#include <memory>
+#include <vector>
+
+#include "../include/cpt_modules.hpp"
+
+static void rd(FILE* f, void* p, size_t n) {
+  if (fread(p, 1, n, f) != n) { fprintf(stderr, "short read\n"); exit(2); }
+}
+
+int main(int argc, char** argv) {
+  if (argc < 3) { fprintf(stderr, "usage: host_shim_demo <inputs.bin> <outputs.bin>\n"); return 2; }
+  FILE* f = fopen(argv[1], "rb");
+  if (!f) { perror("open"); return 2; }
+  cpt::Inputs in;
+  rd(f, &in.config, sizeof(in.config));
+  rd(f, &in.tables, sizeof(in.tables));
+  rd(f, &in.grid, sizeof(in.grid));
+  const cpt_tables& t = in.tables;
+  std::vector<double> tau(t.bt_size), bg((size_t)t.bt_size * t.bg_size), d2bg(bg.size()), z(t.tt_size),
+      th((size_t)t.tt_size * t.th_size), d2th(th.size());
+  rd(f, tau.data(), tau.size() * 8); rd(f, bg.data(), bg.size() * 8); rd(f, d2bg.data(), d2bg.size() * 8);
+  rd(f, z.data(), z.size() * 8); rd(f, th.data(), th.size() * 8); rd(f, d2th.data(), d2th.size() * 8);
+  fclose(f);
+  in.tables.tau_table = tau.data(); in.tables.background_table = bg.data(); in.tables.d2background_dtau2_table = d2bg.data();
+  in.tables.z_table = z.data(); in.tables.thermodynamics_table = th.data(); in.tables.d2thermodynamics_dz2_table = d2th.data();
+  int bad_flag = argc > 3 ? atoi(argv[3]) : 0;
+  if (bad_flag == 1) in.config.has_ncdm = 1;            // must raise std::invalid_argument
+  if (bad_flag == 2) in.grid.k_step_transition = 0.;    // must raise std::invalid_argument (reference: class_test)
+  try {
+    auto pt = std::make_shared<const cpt::PerturbationsModule>(in);
+    cpt::TransferModule tr(in, pt);
+    FILE* o = fopen(argv[2], "wb");
+    int md = pt->index_md_scalars_;
+    int hdr[8] = {pt->k_size_[md], pt->k_size_cl_[md], pt->tau_size_, pt->tp_size_[md], tr.q_size_, tr.l_size_[md], tr.tt_size_[md], 0};
+    fwrite(hdr, sizeof(int), 8, o);
+    fwrite(pt->k_[md], 8, hdr[0], o);
+    fwrite(pt->tau_sampling_, 8, hdr[2], o);
+    for (int tp = 0; tp < hdr[3]; tp++) fwrite(pt->sources_[md][tp], 8, (size_t)hdr[2] * hdr[0], o);
+    fwrite(tr.q_, 8, hdr[4], o);
+    fwrite(tr.l_, 4, hdr[5], o);
+    fwrite(tr.transfer_[md], 8, (size_t)hdr[6] * hdr[5] * hdr[4], o);
+    fclose(o);
+    printf("ok perturb %.2f ms transfer(LOS) %.3f ms\n", pt->kernel_ms(), tr.kernel_ms());
+  } catch (std::invalid_argument& e) {
+    printf("invalid_argument: %s\n", e.what());
+    return 10;
+  } catch (std::runtime_error& e) {
+    printf("runtime_error: %s\n", e.what());
+    return 11;
+  }
+  return 0;
+}

@@ -129,3 +129,40 @@ def derivs(inp, k, tau, tca_on, rsa_on, ufa_on, y):
     assert L.orc_derivs(C.byref(inp.config), C.byref(inp.tables), float(k), float(tau), int(tca_on), int(rsa_on), int(ufa_on),
                         dptr(y), dptr(dy), C.byref(neq)) == 0
     return dy[: neq.value].copy()
+
+
+def _bind_spectra(L):
+    if getattr(L, "_spectra_bound", False):
+        return
+    from classpp_public_amd.capi import CptSpectraParams
+    L.orc_cl.argtypes = [C.POINTER(CptConfig), C.POINTER(CptSpectraParams), _pd, _pd, _i, _i, _pd]
+    L.orc_cl_at_integer_l.argtypes = [_pi, _i, _i, _pd, _i, _pd]
+    L.orc_pk.argtypes = [C.POINTER(CptSpectraParams), _pd, _i, _pd, _pd]
+    L._spectra_bound = True
+
+
+def cl_table(inp, transfer):
+    L = lib()
+    _bind_spectra(L)
+    tr = np.ascontiguousarray(transfer, dtype=np.float64)
+    out = np.zeros((tr.shape[1], inp.spectra.ct_size))
+    assert L.orc_cl(C.byref(inp.config), C.byref(inp.spectra), dptr(tr), dptr(inp.q), inp.q.size, tr.shape[1], dptr(out)) == 0
+    return out
+
+
+def cl_at_integer_l(inp, cl, lmax):
+    L = lib()
+    _bind_spectra(L)
+    cl = np.ascontiguousarray(cl, dtype=np.float64)
+    out = np.zeros((cl.shape[1], lmax + 1))
+    assert L.orc_cl_at_integer_l(iptr(inp.l), inp.l.size, cl.shape[1], dptr(cl), lmax, dptr(out)) == 0
+    return out
+
+
+def pk_linear(inp, delta_m_today):
+    L = lib()
+    _bind_spectra(L)
+    dm = np.ascontiguousarray(delta_m_today, dtype=np.float64)
+    out = np.zeros(inp.k.size)
+    assert L.orc_pk(C.byref(inp.spectra), dptr(inp.k), inp.k.size, dptr(dm), dptr(out)) == 0
+    return out

@@ -1,0 +1,82 @@
+"""CPU-side checks of the drop-in boundary: the in-tree HIP library loads, exports every symbol that include/cpt.h
+declares, validates its inputs before touching a device, and fails LOUDLY (no CPU fallback) when there is no GPU."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from classpp_public_amd import capi
+from classpp_public_amd.inputs import Inputs
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    src = open(os.path.join(ROOT, "include", "cpt.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(cpt_[a-z_0-9]+)\s*\(", src)))
+
+
+def test_header_symbols_all_exported():
+    lib = capi.lib()
+    names = declared_symbols()
+    assert set(names) == set(capi.EXPORTS), (set(names) ^ set(capi.EXPORTS))
+    for n in names:
+        assert hasattr(lib, n), n
+
+
+def test_struct_layout_matches_header():
+    """field order of the ctypes mirror == field order of the C struct (parsed from the header)"""
+    src = open(os.path.join(ROOT, "include", "cpt.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    for cname, cls in (("cpt_config", capi.CptConfig), ("cpt_tables", capi.CptTables), ("cpt_stepstat", capi.CptStepstat)):
+        body = re.search(r"typedef struct %s \{(.*?)\} %s;" % (cname, cname), src, flags=re.S).group(1)
+        fields = []
+        for decl in body.split(";"):
+            decl = decl.strip()
+            if not decl:
+                continue
+            m = re.match(r"(const\s+)?(double|int)\s*\*?\s*(.*)", decl, flags=re.S)
+            assert m, decl
+            for name in m.group(3).split(","):
+                fields.append(name.strip().lstrip("*").strip())
+        assert fields == [f[0] for f in cls._fields_], cname
+
+
+def test_unsupported_physics_is_rejected_before_any_device_work():
+    inp = Inputs("small")
+    lib = capi.lib()
+    for field, value, code in (("sgnK", 1, capi.CPT_ERR_UNSUPPORTED), ("has_ncdm", 1, capi.CPT_ERR_UNSUPPORTED),
+                               ("gauge", 0, capi.CPT_ERR_UNSUPPORTED), ("l_max_g", 3, capi.CPT_ERR_INVALID),
+                               ("tp_size", 0, capi.CPT_ERR_INVALID)):
+        cfg = capi.CptConfig.from_buffer_copy(inp.config)
+        setattr(cfg, field, value)
+        h = C.c_void_p()
+        rc = lib.cpt_create(C.byref(cfg), C.byref(inp.tables), C.byref(h))
+        assert rc == code, (field, rc)
+        assert not h.value
+        assert len(lib.cpt_create_error()) > 0
+
+
+def test_no_cpu_fallback():
+    """Without a GPU the product path must refuse to run (never route through the oracle or any CPU code)."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    inp = Inputs("small")
+    lib = capi.lib()
+    h = C.c_void_p()
+    rc = lib.cpt_create(C.byref(inp.config), C.byref(inp.tables), C.byref(h))
+    assert rc == capi.CPT_ERR_NO_DEVICE
+    assert b"no CPU fallback" in lib.cpt_create_error()
+    from classpp_public_amd.backend import Backend, CptError
+    with pytest.raises(CptError):
+        Backend(inp)
+    # the product sources never reference the oracle
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "classpp_public_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                txt = open(os.path.join(dirpath, f)).read()
+                assert "oracle_lib" not in txt and "libcpt_oracle" not in txt and "oracle/" not in txt.replace("oracle/make_fixtures.py", ""), f

@@ -1,0 +1,77 @@
+"""The C++ shim classes (include/cpt_modules.hpp) exercised the way the reference's Cosmology getters exercise the
+real modules: construct PerturbationsModule, then TransferModule from it, read the public tables.  Checked against
+the golden vectors of the unmodified reference; error behaviour: std::invalid_argument for unsupported / inconsistent
+input (classy: CosmoSevereError), as the reference's constructors do."""
+import ctypes as C
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from classpp_public_amd import hostlib
+from classpp_public_amd.inputs import Inputs
+from test_oracle_perturb import check_sources
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def build_demo(tmp):
+    exe = os.path.join(tmp, "host_shim_demo")
+    host = os.path.join(ROOT, "classpp_public_amd", "host")
+    csrc = os.path.join(ROOT, "classpp_public_amd", "csrc")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-o", exe, os.path.join(ROOT, "tests", "host_shim_demo.cpp"),
+                           "-L" + host, "-lcpt_host", "-L" + csrc, "-lcpt",
+                           "-Wl,-rpath," + host, "-Wl,-rpath," + csrc])
+    return exe
+
+
+def write_inputs(inp, path):
+    g = hostlib.grid_params(inp)
+    t = inp.t
+    with open(path, "wb") as f:
+        f.write(bytes(inp.config)); f.write(bytes(inp.tables)); f.write(bytes(g))
+        for key in ("bg.tau_table", "bg.background_table", "bg.d2background_dtau2_table", "th.z_table",
+                    "th.thermodynamics_table", "th.d2thermodynamics_dz2_table"):
+            f.write(np.ascontiguousarray(t[key], dtype=np.float64).tobytes())
+
+
+def run_demo(exe, inp_path, out_path, flag=0):
+    import torch
+    env = dict(os.environ)
+    # one HIP runtime per process: use the one PyTorch ships, like the Python host layer does
+    env["LD_LIBRARY_PATH"] = os.path.join(os.path.dirname(torch.__file__), "lib") + ":" + env.get("LD_LIBRARY_PATH", "")
+    p = subprocess.run([exe, inp_path, out_path, str(flag)], capture_output=True, text=True, env=env)
+    return p.returncode, p.stdout + p.stderr
+
+
+def test_shim_modules_small(tmp_path):
+    inp = Inputs("small")
+    exe = build_demo(str(tmp_path))
+    ipath, opath = str(tmp_path / "in.bin"), str(tmp_path / "out.bin")
+    write_inputs(inp, ipath)
+    rc, out = run_demo(exe, ipath, opath)
+    assert rc == 0, out
+    print(out)
+    with open(opath, "rb") as f:
+        hdr = np.frombuffer(f.read(32), dtype=np.int32)
+        nk, nkcl, ntau, ntp, nq, nl, ntt = [int(x) for x in hdr[:7]]
+        k = np.frombuffer(f.read(8 * nk)); tau = np.frombuffer(f.read(8 * ntau))
+        src = np.frombuffer(f.read(8 * ntp * ntau * nk)).reshape(ntp, ntau, nk)
+        q = np.frombuffer(f.read(8 * nq)); l = np.frombuffer(f.read(4 * nl), dtype=np.int32)
+        tr = np.frombuffer(f.read(8 * ntt * nl * nq)).reshape(ntt, nl, nq)
+    d = inp.d
+    assert np.array_equal(k, d["pt.k"]) and nkcl == int(d["pt.k_size_cl"][0]) and np.array_equal(tau, d["pt.tau_sampling"])
+    assert np.array_equal(q, d["tr.q"]) and np.array_equal(l, d["tr.l"])
+    check_sources(inp.config, src, d["pt.sources"])
+    ref = d["tr.transfer"]
+    scale = np.max(np.abs(ref), axis=-1, keepdims=True)
+    scale[scale == 0] = 1
+    assert np.max(np.abs(tr - ref) / scale) < 1e-3  # coarse tau sampling of `small` amplifies the source noise
+    # error mapping
+    rc, out = run_demo(exe, ipath, opath, flag=1)
+    assert rc == 10 and "invalid_argument" in out and "non-cold dark matter" in out
+    rc, out = run_demo(exe, ipath, opath, flag=2)
+    assert rc == 10 and "division by zero" in out

@@ -1,0 +1,36 @@
+"""Pins the oracle's C_l assembly / l-interpolation / P(k) (oracle/restate/spectra_oracle.cpp) against the reference's
+own spectra: fed with the reference's transfer_ table it must give the reference's cl_ table and cl_output()."""
+import numpy as np
+
+import oracle_lib
+from classpp_public_amd.inputs import Inputs
+
+
+def test_cl_from_reference_transfer_small():
+    inp = Inputs("small")
+    d = inp.d
+    cl = oracle_lib.cl_table(inp, d["tr.transfer"])
+    ref = d["sp.cl_table"]
+    assert cl.shape == ref.shape
+    scale = np.max(np.abs(ref), axis=0, keepdims=True)
+    scale[scale == 0] = 1
+    assert np.max(np.abs(cl - ref) / scale) < 1e-12
+    lmax = int(d["sp.l_max_tot"][0])
+    full = oracle_lib.cl_at_integer_l(inp, cl, lmax)
+    sp = inp.spectra
+    for name, idx in (("tt", sp.index_ct_tt), ("ee", sp.index_ct_ee), ("te", sp.index_ct_te), ("pp", sp.index_ct_pp),
+                      ("tp", sp.index_ct_tp), ("ep", sp.index_ct_ep)):
+        if idx < 0:
+            continue
+        want = d["sp.cl_" + name]
+        assert np.max(np.abs(full[idx] - want)) < 1e-12 * np.max(np.abs(want)), name
+
+
+def test_pk_from_reference_delta_m():
+    inp = Inputs("small")
+    d = inp.d
+    dm = d["pt.sources"][inp.config.index_tp_delta_m, -1, :]
+    pk = oracle_lib.pk_linear(inp, dm)
+    # the reference tabulates ln P on the same k grid (nonlinear_module.cpp:1886-2040): exp(log()) round trip only
+    assert np.allclose(d["nl.k"], inp.k, rtol=1e-14)
+    assert np.max(np.abs(pk / d["nl.pk_lin_z0"] - 1)) < 1e-12

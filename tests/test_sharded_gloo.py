@@ -1,0 +1,93 @@
+"""world_size-2 test of the multi-process path (classpp_public_amd/sharded.py) on CPU with the gloo backend.
+The compute object is the ORACLE here (tests may use it); on the GPU box the same plumbing runs over RCCL with the
+HIP backend (bench.py --gpus N).  Checks: the sharded sources equal the single-process sources bit for bit and the
+transfer functions to round-off (k-modes and multipoles are independent units; the exchanges only move data)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+class OracleCompute:
+    def __init__(self, inp):
+        self.inp = inp
+
+    def perturb(self, k_subset):
+        import oracle_lib
+        src, self.stats, status, rc = oracle_lib.perturb(self.inp, k=k_subset, threads=2)
+        assert rc == 0
+        return torch.from_numpy(src)
+
+    def transfer(self, sources_full, k_all, l_subset, k_size_cl):
+        import ctypes as C
+        import oracle_lib
+        L = oracle_lib.lib()
+        inp = self.inp
+        src = np.ascontiguousarray(sources_full.numpy())
+        l_subset = np.ascontiguousarray(l_subset, dtype=np.int32)
+        out = np.zeros((inp.config.tt_size, l_subset.size, inp.q.size))
+        k_all = np.ascontiguousarray(k_all)
+        rc = L.orc_transfer(C.byref(inp.config), oracle_lib.dptr(src), oracle_lib.dptr(k_all), k_all.size, k_size_cl,
+                            oracle_lib.dptr(inp.tau), inp.ntau, oracle_lib.dptr(inp.q), inp.q.size, oracle_lib.iptr(l_subset),
+                            l_subset.size, oracle_lib.dptr(out), 2, None)
+        assert rc == 0
+        return torch.from_numpy(out)
+
+
+def _worker(rank, world, port, ret):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from classpp_public_amd.inputs import Inputs
+    from classpp_public_amd.sharded import densify_k, sharded_step
+    inp = Inputs("small")
+    # keep the test light: every 4th k (35 modes), densified x2 -> 69 modes over 2 ranks
+    k_all = densify_k(inp.k[::4], 2)
+    comp = OracleCompute(inp)
+    out, full = sharded_step(comp, k_all, inp.l, rank, world, torch.device("cpu"), k_all.size)
+    if rank == 0:
+        ret["sharded"] = out.numpy()
+        ret["full_sources"] = full.numpy()
+        ret["k_all"] = k_all
+    dist.destroy_process_group()
+
+
+def test_two_ranks_equal_one_rank():
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from classpp_public_amd.inputs import Inputs
+    from classpp_public_amd.sharded import sharded_step
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    port = 29500 + (os.getpid() % 1000)
+    mp.spawn(_worker, args=(2, port, ret), nprocs=2, join=True)
+    inp = Inputs("small")
+    comp = OracleCompute(inp)
+    k_all = ret["k_all"]
+    single, full1 = sharded_step(comp, k_all, inp.l, 0, 1, torch.device("cpu"), k_all.size)
+    assert np.array_equal(ret["full_sources"], full1.numpy())
+    # sources: bit for bit.  Transfer functions: each rank builds the Bessel table for ITS multipoles, so the
+    # recurrences start from a different l_max (hyperspherical.c:517-603) => round-off level differences only.
+    a, b = ret["sharded"], single.numpy()
+    scale = np.max(np.abs(b), axis=-1, keepdims=True)
+    scale[scale == 0] = 1
+    assert np.array_equal(a == 0, b == 0)
+    assert np.max(np.abs(a - b) / scale) < 1e-10
+    assert ret["sharded"].shape == (inp.config.tt_size, inp.l.size, inp.q.size)
+
+
+def test_densify_and_shards_partition_the_grid():
+    from classpp_public_amd.sharded import densify_k, shard_indices
+    k = np.geomspace(1e-4, 1.0, 17)
+    d = densify_k(k, 4)
+    assert d.size == 16 * 4 + 1 and np.all(np.diff(d) > 0) and np.allclose(d[::4], k)
+    for world in (1, 2, 3, 8):
+        idx = np.concatenate([shard_indices(d.size, r, world) for r in range(world)])
+        assert sorted(idx.tolist()) == list(range(d.size))
