@@ -58,6 +58,20 @@ def cpu_baseline(cfg_name, nk):
             "sample": "every 4th k-mode of %s.ini (%d modes) through oracle/restate (dense-LU scalar port)" % (cfg_name, ks.size)}
 
 
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the rocprofv3 --pmc passes committed under profiles/ (FETCH_SIZE and
+    WRITE_SIZE are collected in separate runs of this same command; FETCH_SIZE doubled per MI355X_MICROARCH.md)."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
+    if not files:
+        return None
+    try:
+        d = json.load(open(files[-1]))
+        return d["kernels"][kernel]["hbm_bytes_fetch_x2"]
+    except Exception:
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -93,12 +107,20 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    has_pk = inp.config.index_tp_delta_m >= 0
+
     def step():
+        # tables-in -> C_l (and P(k)) out, nothing leaves HBM in between
         if world == 1:
             be.perturb_solve(want_sources=False)      # sources stay resident, k-major, in HBM
-            return be.transfer(None)
+            tr = be.transfer(None)
+            cl = be.cl(tr)
+            pk = be.pk_linear() if has_pk else None
+            return cl, pk
         out, _ = sharded_step(comp, k_all, inp.l, rank, world, device, k_size_cl)
-        return out
+        if rank == 0:
+            return be.cl(out), None
+        return None, None
 
     for _ in range(args.warmup):
         step()
@@ -152,11 +174,13 @@ def main():
                        "inputs": "background/thermodynamics spline tables and grids from tests/golden (dumped from the reference)",
                        "parallelism": "k-sharded x%d, l-sharded transfer, 2 RCCL exchanges" % world if world > 1 else "1 GPU"},
             "stage_ms": {"perturb_kernel": k_ms, "los_kernel": t_ms, "step_wall": ms_step},
+            "cl_wall_ms": ms_step,
             "perturb_kmodes_per_s_kernel": nk_local * world / (k_ms * 1e-3),
             "ode_work": {"fevals": fevals, "steps": steps_tot, "max_steps_per_mode": steps_max,
                          "us_per_step_critical_path": k_ms * 1e3 / steps_max},
             "roofline": {"kernel": "k_perturb", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": pmc_traffic("k_perturb") if (world == 1 and args.config == "lcdm") else None,
                          "note": "algorithmic bytes = fevals x 800 B + source output; the kernel is bound by the serial "
                                  "dependency chain of the longest k-mode (SURVEY S8d), not by HBM",
                          "los_kernel": {"achieved": fused * 72 / (t_ms * 1e-3) / 1e9, "unit": "GB/s", "peak": HBM_PEAK_GBS,
