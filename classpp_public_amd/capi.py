@@ -79,7 +79,7 @@ class CptSpectraParams(C.Structure):
 EXPORTS = [
     "cpt_create", "cpt_destroy", "cpt_last_error", "cpt_create_error", "cpt_perturb_solve_batch",
     "cpt_transfer_batch", "cpt_get_sources", "cpt_last_kernel_ms", "cpt_last_transfer_work",
-    "cpt_dbg_lookup", "cpt_dbg_derivs", "cpt_dbg_bessel", "cpt_cl_batch", "cpt_pk_linear",
+    "cpt_dbg_lookup", "cpt_dbg_derivs", "cpt_dbg_solve", "cpt_dbg_bessel", "cpt_cl_batch", "cpt_pk_linear",
 ]
 
 _lib = None
@@ -125,6 +125,8 @@ def lib():
     L.cpt_dbg_lookup.restype = _i
     L.cpt_dbg_derivs.argtypes = [vp, _d, _d, _i, _i, _i, _pd, _pd, pi]
     L.cpt_dbg_derivs.restype = _i
+    L.cpt_dbg_solve.argtypes = [vp, _d, _d, _i, _i, _i, _d, _pd, _pd]
+    L.cpt_dbg_solve.restype = _i
     L.cpt_dbg_bessel.argtypes = [vp, pi, _i, _d, pi, _pd, _pd, _pd, _i]
     L.cpt_dbg_bessel.restype = _i
     _lib = L

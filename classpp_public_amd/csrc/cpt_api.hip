@@ -240,6 +240,13 @@ int cpt_dbg_derivs(cpt_handle* h, double k, double tau, int tca_on, int rsa_on, 
   return cpt_dbg_derivs_impl(h, k, tau, tca_on, rsa_on, ufa_on, y, dy, neq);
 }
 
+int cpt_dbg_solve(cpt_handle* h, double k, double tau, int tca_on, int rsa_on, int ufa_on, double hg, const double* b,
+                  double* x) {
+  if (!h) return CPT_ERR_INVALID;
+  h->err.clear();
+  return cpt_dbg_solve_impl(h, k, tau, tca_on, rsa_on, ufa_on, hg, b, x);
+}
+
 int cpt_dbg_bessel(cpt_handle* h, const int* l, int nl, double xmax, int* nx, double* phi, double* dphi,
                    double* chi_at_phimin, int cap_nx) {
   if (!h) return CPT_ERR_INVALID;

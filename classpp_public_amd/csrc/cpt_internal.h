@@ -101,5 +101,7 @@ int cpt_pk_impl(cpt_handle* h, const cpt_spectra_params* sp, const double* k, in
 int cpt_dbg_lookup_impl(cpt_handle* h, const double* tau, int n, double* out);
 int cpt_dbg_derivs_impl(cpt_handle* h, double k, double tau, int tca_on, int rsa_on, int ufa_on, const double* y,
                         double* dy, int* neq);
+int cpt_dbg_solve_impl(cpt_handle* h, double k, double tau, int tca_on, int rsa_on, int ufa_on, double hg, const double* b,
+                       double* x);
 int cpt_transpose_to_kmajor(cpt_handle* h, const double* src_ref_layout, double* dst, int ntp, int ntau, int nk);
 int cpt_transpose_from_kmajor(cpt_handle* h, const double* src_kmajor, double* dst_ref_layout, int ntp, int ntau, int nk);

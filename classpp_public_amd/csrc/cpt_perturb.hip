@@ -1,12 +1,12 @@
 // Hot path A on MI355X: per-k stiff integration of the scalar Einstein-Boltzmann system.
 //
 // ONE WAVEFRONT OWNS ONE k-MODE (block = 64 threads = 1 wave).  Lane i owns equation i of the current regime:
-// the state y, the backward differences dif[0..6], the Newton iterates, all live in lane registers; the dense
-// Jacobian J and the LU factors of (I - h*gamma*J) live in LDS (row i is read/written by lane i, odd row stride =>
-// bank-conflict free); the adaptive order/step control is scalar control flow that is uniform in the wave, so
-// divergence between modes never crosses a wavefront.  The background / thermodynamics spline tables are read
-// through a 64-entry abscissa window held in lane registers (wave-parallel bracket search by ballot+popcount) and
-// a row cache, so a step that stays inside the current table cell issues no global load at all.
+// the state y, the backward differences dif[0..6], the Newton iterates, the Jacobian and the factors of
+// (I - h*gamma*J) all live in lane registers (the matrix is never stored densely: see "structured linear algebra");
+// the adaptive order/step control is scalar control flow that is uniform in the wave, so divergence between modes
+// never crosses a wavefront.  The background / thermodynamics spline tables are read through a 64-row window staged
+// in LDS whose abscissae sit in lane registers (wave-parallel bracket search by ballot+popcount) plus a row cache, so
+// a step that stays inside the current table cell touches no memory at all.
 //
 // Restates (not translates): perturb_solve pm.cpp:2463-2787, perturb_approximations :5443-5670,
 // perturb_vector_init :3271-4688, perturb_initial_conditions :4723-5408, perturb_einstein/total_stress_energy
@@ -14,9 +14,10 @@
 // :9530-9636, perturb_sources :6731-7285, background_at_tau / thermodynamics_at_z, and evolver_ndf15
 // ev.cpp:62-705 (+ interp_from_dif :860-905, adjust_stepsize :907-943, new_linearisation :945-998).
 // Differences by design: the Jacobian is obtained exactly as J e_j = f(tau, e_j) (the system is linear and
-// homogeneous in y) instead of by adaptive finite differences (ev.cpp:1213-1539); the LU is a wave-cooperative
-// dense elimination with threshold-diagonal pivoting that skips structural zeros of the pivot row (the reference:
-// sparse left-looking LU, tools/sparse.c:130-278); switch times are located by a 64-ary search instead of bisection.
+// homogeneous in y) instead of by adaptive finite differences (ev.cpp:1213-1539); the factorisation uses the
+// structure of the equations (three tridiagonal hierarchy tails + a <=16x16 dense core) instead of a numerically
+// discovered sparsity pattern with AMD ordering (tools/sparse.c:130-599); switch times are located by a 64-ary
+// search instead of bisection.
 #include "cpt_internal.h"
 
 namespace {
@@ -41,8 +42,6 @@ struct PtParams {
   double* src;  // [tp][nk][ntau]
   cpt_stepstat* stats;
   int* status;
-  int stride;  // LDS row stride of J / LU (odd)
-  int rows;    // number of rows reserved (largest neq over the regimes)
   int max_steps;
 };
 
@@ -74,17 +73,28 @@ __device__ inline double wave_max(double v) {
   v = fmax(v, dpp_keep<0x118>(v));  // row_shr:8
   return fmax(fmax(bcast(v, 15), bcast(v, 31)), fmax(bcast(v, 47), bcast(v, 63)));
 }
+// Cross-lane reads must execute with EVERY lane active: a DPP / bpermute source lane that is masked off by EXEC
+// yields 0.  Never call these inside a lane-dependent branch or the lazy arm of a ?: - hoist the call into its own
+// statement.  The volatile asm additionally stops the compiler from sinking the (side-effect free) instruction into
+// a divergent arm of a later select.
+__device__ inline double pin(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  asm volatile("" : "+v"(lo), "+v"(hi));
+  return __hiloint2double(hi, lo);
+}
 // neighbours in the wave (hierarchy couplings): wave_shr:1 / wave_shl:1, lanes without a source get 0
 __device__ inline double lane_below(double v) {  // value of lane-1
   int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x138, 0xf, 0xf, false);
   int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x138, 0xf, 0xf, false);
-  return __hiloint2double(hi, lo);
+  return pin(__hiloint2double(hi, lo));
 }
 __device__ inline double lane_above(double v) {  // value of lane+1
   int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x130, 0xf, 0xf, false);
   int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x130, 0xf, 0xf, false);
-  return __hiloint2double(hi, lo);
+  return pin(__hiloint2double(hi, lo));
 }
+// ds_bpermute with a per-lane source index, pinned for the same reason
+__device__ inline double shfl_all(double v, int src) { return pin(__shfl(v, src, 64)); }
 // x^p for the step-size heuristics (ev.cpp:497-505, 580-625): single precision is ample (the result only steers h)
 __device__ inline double fast_pow(double x, double p) { return (double)exp2f((float)p * log2f((float)x)); }
 // 1/x: hardware v_rcp_f64 seed + two Newton-Raphson refinements (full double accuracy to ~1 ulp, no IEEE division
@@ -113,68 +123,113 @@ enum Role : int {
   R_DELTA_B, R_THETA_B, R_DELTA_CDM, R_DELTA_UR, R_THETA_UR, R_SHEAR_UR, R_LUR /* l>=3 ur */, R_ETA
 };
 
-// regime layout, pm.cpp:3302-3481 (scalars, synchronous gauge); all members wave-uniform
+// Regime layout (all members wave-uniform).  The equations of pm.cpp:3302-3481 are placed CORE FIRST: the (at most 13)
+// densely coupled variables - densities, velocities, shears, polarisation l<=2, metric - occupy lanes 0..nc-1, then
+// the three free-streaming hierarchy tails (photon temperature l>=3, polarisation l>=3, ur l>=3) in ascending l.
+// A tail is a tridiagonal chain that touches the core only through its l=3 element (l3 <-> shear / pol2): that
+// structure, fixed per regime and shared by all modes, is what the linear algebra below exploits.
 struct Layout {
-  int tca, rsa, ufa, neq;
-  int dg, tg, sg, l3g, pol0, db, tb, dc, dur, tur, sur, l3ur, eta;
+  int tca, rsa, ufa, neq, nc;
+  int dg, tg, sg, p0, p1, p2, db, tb, dc, dur, tur, sur, eta;  // core slots, -1 = absent
+  int g3, gN, q3, qN, u3, uN;                                  // tails: lane of l=3 and length (0 = absent)
   int lmg, lmp, lmu;
 };
 
-__device__ inline Layout make_layout(const PtParams& P, int tca, int rsa, int ufa) {
+__device__ __forceinline__ Layout make_layout(const PtParams& P, int tca, int rsa, int ufa) {
   Layout L;
   L.tca = tca; L.rsa = rsa; L.ufa = ufa;
-  L.dg = L.tg = L.sg = L.l3g = L.pol0 = L.dc = L.dur = L.tur = L.sur = L.l3ur = -1;
+  L.dg = L.tg = L.sg = L.p0 = L.p1 = L.p2 = L.dc = L.dur = L.tur = L.sur = -1;
+  L.g3 = L.q3 = L.u3 = -1; L.gN = L.qN = L.uN = 0;
   L.lmg = P.l_max_g; L.lmp = P.l_max_pol_g; L.lmu = P.l_max_ur;
   int i = 0;
   if (!rsa) {
     L.dg = i++; L.tg = i++;
-    if (!tca) { L.sg = i++; L.l3g = i; i += P.l_max_g - 2; L.pol0 = i; i += P.l_max_pol_g + 1; }
+    if (!tca) { L.sg = i++; L.p0 = i++; L.p1 = i++; L.p2 = i++; }
   }
   L.db = i++; L.tb = i++;
   if (P.has_cdm) L.dc = i++;
-  if (P.has_ur && !rsa) {
-    L.dur = i++; L.tur = i++; L.sur = i++;
-    if (!ufa) { L.l3ur = i; i += P.l_max_ur - 2; }
-  }
+  if (P.has_ur && !rsa) { L.dur = i++; L.tur = i++; L.sur = i++; }
   L.eta = i++;
+  L.nc = i;
+  if (!rsa && !tca) {
+    L.g3 = i; L.gN = P.l_max_g - 2; i += L.gN;
+    L.q3 = i; L.qN = P.l_max_pol_g - 2; i += L.qN;
+  }
+  if (P.has_ur && !rsa && !ufa) { L.u3 = i; L.uN = P.l_max_ur - 2; i += L.uN; }
   L.neq = i;
   return L;
 }
 
 // (role, multipole) of equation i in layout L
-__device__ inline void role_of(const Layout& L, int i, int* role, int* ell) {
+__device__ __forceinline__ void role_of(const Layout& L, int i, int* role, int* ell) {
   *role = R_NONE; *ell = 0;
   if (i < 0 || i >= L.neq) return;
   if (i == L.dg) { *role = R_DELTA_G; return; }
   if (i == L.tg) { *role = R_THETA_G; *ell = 1; return; }
   if (i == L.sg) { *role = R_SHEAR_G; *ell = 2; return; }
-  if (L.l3g >= 0 && i >= L.l3g && i < L.l3g + L.lmg - 2) { *role = R_LG; *ell = 3 + (i - L.l3g); return; }
-  if (L.pol0 >= 0 && i >= L.pol0 && i <= L.pol0 + L.lmp) { *role = R_POL; *ell = i - L.pol0; return; }
+  if (i == L.p0) { *role = R_POL; *ell = 0; return; }
+  if (i == L.p1) { *role = R_POL; *ell = 1; return; }
+  if (i == L.p2) { *role = R_POL; *ell = 2; return; }
   if (i == L.db) { *role = R_DELTA_B; return; }
   if (i == L.tb) { *role = R_THETA_B; return; }
   if (i == L.dc) { *role = R_DELTA_CDM; return; }
   if (i == L.dur) { *role = R_DELTA_UR; return; }
   if (i == L.tur) { *role = R_THETA_UR; *ell = 1; return; }
   if (i == L.sur) { *role = R_SHEAR_UR; *ell = 2; return; }
-  if (L.l3ur >= 0 && i >= L.l3ur && i < L.l3ur + L.lmu - 2) { *role = R_LUR; *ell = 3 + (i - L.l3ur); return; }
   if (i == L.eta) { *role = R_ETA; return; }
+  if (L.gN > 0 && i >= L.g3 && i < L.g3 + L.gN) { *role = R_LG; *ell = 3 + (i - L.g3); return; }
+  if (L.qN > 0 && i >= L.q3 && i < L.q3 + L.qN) { *role = R_POL; *ell = 3 + (i - L.q3); return; }
+  if (L.uN > 0 && i >= L.u3 && i < L.u3 + L.uN) { *role = R_LUR; *ell = 3 + (i - L.u3); return; }
 }
-// inverse: index of (role, ell) in layout L, -1 if absent
-__device__ inline int index_of(const Layout& L, int role, int ell) {
+// inverse: lane of (role, ell) in layout L, -1 if absent
+__device__ __forceinline__ int index_of(const Layout& L, int role, int ell) {
   switch (role) {
     case R_DELTA_G: return L.dg;
     case R_THETA_G: return L.tg;
     case R_SHEAR_G: return L.sg;
-    case R_LG: return (L.l3g >= 0 && ell <= L.lmg) ? L.l3g + ell - 3 : -1;
-    case R_POL: return (L.pol0 >= 0 && ell <= L.lmp) ? L.pol0 + ell : -1;
+    case R_LG: return (L.gN > 0 && ell >= 3 && ell <= L.lmg) ? L.g3 + ell - 3 : -1;
+    case R_POL:
+      if (ell == 0) return L.p0;
+      if (ell == 1) return L.p1;
+      if (ell == 2) return L.p2;
+      return (L.qN > 0 && ell <= L.lmp) ? L.q3 + ell - 3 : -1;
     case R_DELTA_B: return L.db;
     case R_THETA_B: return L.tb;
     case R_DELTA_CDM: return L.dc;
     case R_DELTA_UR: return L.dur;
     case R_THETA_UR: return L.tur;
     case R_SHEAR_UR: return L.sur;
-    case R_LUR: return (L.l3ur >= 0 && ell <= L.lmu) ? L.l3ur + ell - 3 : -1;
+    case R_LUR: return (L.uN > 0 && ell >= 3 && ell <= L.lmu) ? L.u3 + ell - 3 : -1;
     case R_ETA: return L.eta;
+    default: return -1;
+  }
+}
+// index of (role, ell) in the REFERENCE's ordering of the same regime (pm.cpp:3302-3481): only the unit-test hook
+// cpt_dbg_derivs needs it, to exchange y / dy with the oracle in the reference's order
+__device__ __forceinline__ int ref_index_of(const PtParams& P, int tca, int rsa, int ufa, int role, int ell) {
+  int i = 0, dg = -1, tg = -1, sg = -1, l3g = -1, pol0 = -1, db, tb, dc = -1, dur = -1, tur = -1, sur = -1, l3ur = -1, eta;
+  if (!rsa) {
+    dg = i++; tg = i++;
+    if (!tca) { sg = i++; l3g = i; i += P.l_max_g - 2; pol0 = i; i += P.l_max_pol_g + 1; }
+  }
+  db = i++; tb = i++;
+  if (P.has_cdm) dc = i++;
+  if (P.has_ur && !rsa) { dur = i++; tur = i++; sur = i++; if (!ufa) { l3ur = i; i += P.l_max_ur - 2; } }
+  eta = i++;
+  switch (role) {
+    case R_DELTA_G: return dg;
+    case R_THETA_G: return tg;
+    case R_SHEAR_G: return sg;
+    case R_LG: return l3g >= 0 ? l3g + ell - 3 : -1;
+    case R_POL: return pol0 >= 0 ? pol0 + ell : -1;
+    case R_DELTA_B: return db;
+    case R_THETA_B: return tb;
+    case R_DELTA_CDM: return dc;
+    case R_DELTA_UR: return dur;
+    case R_THETA_UR: return tur;
+    case R_SHEAR_UR: return sur;
+    case R_LUR: return l3ur >= 0 ? l3ur + ell - 3 : -1;
+    case R_ETA: return eta;
     default: return -1;
   }
 }
@@ -346,46 +401,36 @@ __device__ __forceinline__ void lookup(const PtParams& P, Lookup& Q, double tau,
 }
 
 // ---- physics ------------------------------------------------------------------------------------
-// per-lane constants of the current regime: dy_i = A y[i-1] - B y[i+1] - (D kappa' + G/tau) y[i] + E_role
-struct LaneEq { int role, ell; double A, B, D, G; };
+// Per-lane description of the current regime.
+//   tails:  dy_l = A y_{l-1} - B y_{l+1} - (D kappa' + G/tau) y_l     (y_{l-1} of the l=3 element is a core variable)
+//   core:   explicit equations, computed wave-uniformly and selected by role
+// chain: 0 = core, 1 = photon temperature tail, 2 = polarisation tail, 3 = ur tail.
+struct LaneEq {
+  int role, ell, chain;
+  bool first, last;  // l == 3 / l == l_max of a tail
+  double A, B, D, G;
+};
 
 __device__ __forceinline__ LaneEq make_lane_eq(const PtParams& P, const Layout& L, int lane, double k) {
   LaneEq e;
   role_of(L, lane, &e.role, &e.ell);
   e.A = e.B = e.D = e.G = 0.;
-  const double k2 = k * k;
+  e.chain = 0; e.first = false; e.last = false;
   const int l = e.ell;
-  switch (e.role) {
-    case R_DELTA_G: e.B = 4. / 3.; break;                                    // pm.cpp:8095
-    case R_THETA_G: if (!L.tca) { e.A = k2 / 4.; e.B = k2; e.D = 1.; } break;  // pm.cpp:8145-8148 (tca: fully special)
-    case R_SHEAR_G: e.A = 4. / 15.; e.B = 0.3 * k; e.D = 1.; break;           // pm.cpp:8151-8155
-    case R_LG:
-      if (l == 3) { e.A = 6. * k / 7.; e.B = 4. * k / 7.; }                   // pm.cpp:8158-8161 (F2 = 2 shear)
-      else if (l < L.lmg) { e.A = k * l / (2. * l + 1.); e.B = k * (l + 1.) / (2. * l + 1.); }
-      else { e.A = k; e.G = 1. + l; }                                         // pm.cpp:8171-8176, cotKgen = 1/(k tau)
-      e.D = 1.;
-      break;
-    case R_POL:
-      if (l == 0) { e.B = k; }                                                // pm.cpp:8179-8181
-      else if (l == 1) { e.A = k / 3.; e.B = 2. * k / 3.; }
-      else if (l == 2) { e.A = 2. * k / 5.; e.B = 3. * k / 5.; }
-      else if (l < L.lmp) { e.A = k * l / (2. * l + 1.); e.B = k * (l + 1.) / (2. * l + 1.); }
-      else { e.A = k; e.G = 1. + l; }
-      e.D = 1.;
-      break;
-    case R_DELTA_B: e.B = 1.; break;                                          // pm.cpp:8101
-    case R_DELTA_UR: e.B = 4. / 3.; break;                                    // pm.cpp:8630-8634
-    case R_THETA_UR: e.A = k2 * P.three_ceff2_ur / 4.; e.B = k2; break;       // pm.cpp:8637-8641
-    case R_SHEAR_UR:
-      if (!L.ufa) { e.A = 4. / 15. * P.three_cvis2_ur; e.B = 0.3 * k; }       // pm.cpp:8645-8651
-      else { e.A = 2. / 3.; if (P.ufa_method != CPT_UFA_HU) e.G = 3.; }        // pm.cpp:8687-8708 (hu: -3 aH, in E)
-      break;
-    case R_LUR:
-      if (l == 3) { e.A = 6. * k / 7.; e.B = 4. * k / 7.; }
-      else if (l < L.lmu) { e.A = k * l / (2. * l + 1.); e.B = k * (l + 1.) / (2. * l + 1.); }
-      else { e.A = k; e.G = 1. + l; }
-      break;
-    default: break;
+  int lm = 0;
+  if (e.role == R_LG) { e.chain = 1; lm = L.lmg; e.D = 1.; }
+  else if (e.role == R_POL && l >= 3) { e.chain = 2; lm = L.lmp; e.D = 1.; }
+  else if (e.role == R_LUR) { e.chain = 3; lm = L.lmu; }
+  if (e.chain) {
+    e.first = (l == 3); e.last = (l == lm);
+    if (l == 3 && e.chain != 2) { e.A = 6. * k / 7.; e.B = 4. * k / 7.; }     // pm.cpp:8158-8161: F_2 = 2 shear
+    else if (l < lm) { e.A = k * l / (2. * l + 1.); e.B = k * (l + 1.) / (2. * l + 1.); }
+    else { e.A = k; e.G = 1. + l; }                                             // pm.cpp:8171-8176, cotKgen = 1/(k tau)
+  } else {
+    // coupling of the core "parent" of a tail to the tail's first element: -B y_{l=3}
+    if (e.role == R_SHEAR_G) e.B = 0.3 * k;                                     // pm.cpp:8151-8155
+    else if (e.role == R_POL && l == 2) e.B = 3. * k / 5.;                      // pm.cpp:8191-8193
+    else if (e.role == R_SHEAR_UR && !L.ufa) e.B = 0.3 * k;                     // pm.cpp:8645-8651
   }
   return e;
 }
@@ -405,29 +450,33 @@ __device__ __forceinline__ double rhs(const PtParams& P, const Layout& L, const 
                                       double inv_k2, double tau, double y, int lane) {
   lookup(P, Q, tau, lane);
   const BgV& bg = Q.bg; const ThV& th = Q.th;
-  const double a2 = Q.a2, aH = Q.aH, k2 = k * k, R = Q.R;
-  // ---- stress-energy sums ----
-  double dg = 0., tg = 0., sg = 0., dur = 0., tur = 0., sur = 0.;
-  if (!L.rsa) { dg = bcast(y, L.dg); tg = bcast(y, L.tg); if (!L.tca) sg = bcast(y, L.sg); }
-  if (P.has_ur && !L.rsa) { dur = bcast(y, L.dur); tur = bcast(y, L.tur); sur = bcast(y, L.sur); }
+  const double a2 = Q.a2, aH = Q.aH, k2 = k * k, R = Q.R, kap = th.dkappa;
+  // ---- named components ----
+  double dg = 0., tg = 0., sg = 0., p0 = 0., p1 = 0., p2 = 0., dur = 0., tur = 0., sur = 0.;
+  double g3 = 0., q3 = 0., u3 = 0.;  // first elements of the tails
+  if (!L.rsa) {
+    dg = bcast(y, L.dg); tg = bcast(y, L.tg);
+    if (!L.tca) { sg = bcast(y, L.sg); p0 = bcast(y, L.p0); p1 = bcast(y, L.p1); p2 = bcast(y, L.p2); g3 = bcast(y, L.g3); q3 = bcast(y, L.q3); }
+  }
+  if (P.has_ur && !L.rsa) { dur = bcast(y, L.dur); tur = bcast(y, L.tur); sur = bcast(y, L.sur); if (!L.ufa) u3 = bcast(y, L.u3); }
   const double db = bcast(y, L.db), tb = bcast(y, L.tb), eta = bcast(y, L.eta);
   const double dc = P.has_cdm ? bcast(y, L.dc) : 0.;
   const double cb2 = th.cb2;
+  // ---- stress-energy sums ----
   double delta_rho = bg.rg * dg + bg.rb * db;
   double rpt = 4. / 3. * bg.rg * tg + bg.rb * tb;
   double rps = 4. / 3. * bg.rg * sg;
-  double delta_p = 1. / 3. * bg.rg * dg + bg.rb * (cb2 * db);
   double delta_rho_m = bg.rb * db, rho_m = bg.rb;
   if (P.has_cdm) { delta_rho += bg.rc * dc; delta_rho_m += bg.rc * dc; rho_m += bg.rc; }
-  if (P.has_ur) { delta_rho += bg.ru * dur; rpt += 4. / 3. * bg.ru * tur; rps += 4. / 3. * bg.ru * sur; delta_p += 1. / 3. * bg.ru * dur; }
+  if (P.has_ur) { delta_rho += bg.ru * dur; rpt += 4. / 3. * bg.ru * tur; rps += 4. / 3. * bg.ru * sur; }
   // ---- Einstein equations ----
   const double hp = (k2 * eta + 1.5 * a2 * delta_rho) * Q.two_over_aH;
   if (L.rsa) {
     double rdg = 0., rtg = 0., rdur = 0., rtur = 0.;
     if (P.rsa_method != CPT_RSA_NULL) { rdg = 4. * inv_k2 * (aH * hp - k2 * eta); rtg = -0.5 * hp; }
     if (P.rsa_method == CPT_RSA_MD_WITH_REIO) {
-      rdg += -4. * inv_k2 * th.dkappa * (tb + 0.5 * hp);
-      rtg += 3. * inv_k2 * (th.ddkappa * (tb + 0.5 * hp) + th.dkappa * (-aH * tb + cb2 * k2 * db - aH * hp + k2 * eta));
+      rdg += -4. * inv_k2 * kap * (tb + 0.5 * hp);
+      rtg += 3. * inv_k2 * (th.ddkappa * (tb + 0.5 * hp) + kap * (-aH * tb + cb2 * k2 * db - aH * hp + k2 * eta));
     }
     if (P.has_ur && P.rsa_method != CPT_RSA_NULL) { rdur = 4. * inv_k2 * (aH * hp - k2 * eta); rtur = -0.5 * hp; }
     delta_rho += bg.rg * rdg;
@@ -442,18 +491,15 @@ __device__ __forceinline__ double rhs(const PtParams& P, const Layout& L, const 
   const double alphap = -2. * aH * alpha + eta - 4.5 * (a2 * inv_k2) * rps;
   M.hp = hp; M.etap = etap; M.alpha = alpha; M.alphap = alphap;
   M.delta_m = (delta_rho_m + 3. * aH * (bg.rb * tb) * inv_k2) / rho_m;  // pm.cpp:6573, 5979-5981
-  (void)delta_p;  // h'' is only needed by tight-coupling schemes this backend does not implement
-  // ---- equations of motion ----
   const double mc = 0.5 * hp;   // metric_continuity
   const double ms = k2 * alpha; // metric_shear
-  const double ym = lane_below(y), yp = lane_above(y);
-  double dy = e.A * ym - e.B * yp - (e.D * th.dkappa + e.G * Q.inv_tau) * y;
+  // ---- baryon velocity / tight coupling ----
   double dtb, tca_shear = 0.;
   if (!L.tca) {
-    dtb = -aH * tb + k2 * cb2 * db + R * th.dkappa * (tg - tb);  // pm.cpp:8108-8113
+    dtb = -aH * tb + k2 * cb2 * db + R * kap * (tg - tb);  // pm.cpp:8108-8113
   } else {
     const double tau_c = Q.tau_c, dtau_c = Q.dtau_c, F = Q.F;
-    double slip = (dtau_c * th.dkappa - 2. * aH * Q.inv_1pR) * (tb - tg) +
+    double slip = (dtau_c * kap - 2. * aH * Q.inv_1pR) * (tb - tg) +
                   F * (-Q.app * tb + k2 * (-aH * dg * 0.5 + cb2 * (-tb - mc) - (-tg - mc) / 3.));
     double shear = 16. / 45. * tau_c * (tg + ms);
     const double theta_prime = (-aH * tb + k2 * (cb2 * db + R * 0.25 * dg)) * Q.inv_1pR;
@@ -467,36 +513,47 @@ __device__ __forceinline__ double rhs(const PtParams& P, const Layout& L, const 
     M.tca_shear_g = shear;
     dtb = (-aH * tb + k2 * (cb2 * db + R * (dg * 0.25 - shear)) + R * slip) * Q.inv_1pR;  // pm.cpp:8123-8129
   }
-  double P0 = 0.;  // Pi = G_gamma0 + G_gamma2 + F_gamma2 (pm.cpp:8142)
-  if (!L.tca && !L.rsa) P0 = (bcast(y, L.pol0) + bcast(y, L.pol0 + 2) + 2. * sg) * 0.125;
-  double E = 0.;
-  const int role = opaque(e.role);
-  switch (role) {
-    case R_DELTA_G: E = -4. / 3. * mc; break;
-    case R_THETA_G:
-      if (!L.tca) E = th.dkappa * tb;
-      else { dy = 0.; E = -(dtb + aH * tb - k2 * cb2 * db) * Q.inv_R + k2 * (0.25 * dg - tca_shear); }  // pm.cpp:8214-8217
-      break;
-    case R_SHEAR_G: E = 4. / 15. * ms + 0.4 * th.dkappa * P0; break;
-    case R_POL:
-      if (e.ell == 0) E = 4. * th.dkappa * P0;
-      else if (e.ell == 2) E = 0.8 * th.dkappa * P0;
-      break;
-    case R_DELTA_B: E = -mc; break;
-    case R_THETA_B: dy = 0.; E = dtb; break;
-    case R_DELTA_CDM: E = -mc; break;
-    case R_DELTA_UR: E = -4. / 3. * mc + (1. - P.three_ceff2_ur) * aH * (y + 4. * aH * yp * inv_k2); break;
-    case R_THETA_UR: E = -(1. - P.three_ceff2_ur) * aH * y; break;
-    case R_SHEAR_UR:
-      if (!L.ufa) E = 4. / 15. * P.three_cvis2_ur * ms;
-      else if (P.ufa_method == CPT_UFA_CLASS) E = 2. / 3. * mc;               // metric_ufa_class = h'/2
-      else if (P.ufa_method == CPT_UFA_MB) E = 2. / 3. * ms;
-      else E = 2. / 3. * ms - 3. * aH * y;                                    // ufa_hu
-      break;
-    case R_ETA: E = etap; break;
-    default: break;
+  // ---- tails: one formula for every lane; the l=3 element takes its lower neighbour from the core ----
+  const int chain = opaque(e.chain);
+  const double core_below = (chain == 1) ? sg : (chain == 2) ? p2 : sur;
+  const double ylow = lane_below(y);  // NOT inside the ?: below - the operator is lazy, the l=3 lane would be masked off
+  const double ym = e.first ? core_below : ylow;
+  const double yp = lane_above(y);
+  double dy = e.A * ym - e.B * yp - (e.D * kap + e.G * Q.inv_tau) * y;
+  if (chain == 0) {
+    // ---- core equations (wave-uniform values, selected per lane) ----
+    const double P0 = (p0 + p2 + 2. * sg) * 0.125;  // Pi = G_gamma0 + G_gamma2 + F_gamma2 (pm.cpp:8142)
+    const double c3 = P.three_ceff2_ur, v3 = P.three_cvis2_ur;
+    double v = 0.;
+    switch (opaque(e.role)) {
+      case R_DELTA_G: v = -4. / 3. * (tg + mc); break;                                             // pm.cpp:8095
+      case R_THETA_G:
+        if (!L.tca) v = k2 * (0.25 * dg - sg) + kap * (tb - tg);                                   // pm.cpp:8145-8148
+        else v = -(dtb + aH * tb - k2 * cb2 * db) * Q.inv_R + k2 * (0.25 * dg - tca_shear);        // pm.cpp:8214-8217
+        break;
+      case R_SHEAR_G: v = 4. / 15. * (tg + ms) - 0.3 * k * g3 - kap * (sg - 0.4 * P0); break;      // pm.cpp:8151-8155
+      case R_POL:
+        if (e.ell == 0) v = -k * p1 - kap * (p0 - 4. * P0);                                        // pm.cpp:8179-8181
+        else if (e.ell == 1) v = k / 3. * (p0 - 2. * p2) - kap * p1;                               // pm.cpp:8184-8186
+        else v = k / 5. * (2. * p1 - 3. * q3) - kap * (p2 - 0.8 * P0);                             // pm.cpp:8189-8191
+        break;
+      case R_DELTA_B: v = -(tb + mc); break;                                                       // pm.cpp:8101
+      case R_THETA_B: v = dtb; break;
+      case R_DELTA_CDM: v = -mc; break;                                                            // pm.cpp:8240
+      case R_DELTA_UR: v = -4. / 3. * (tur + mc) + (1. - c3) * aH * (dur + 4. * aH * tur * inv_k2); break;  // pm.cpp:8630-8634
+      case R_THETA_UR: v = k2 * (c3 * 0.25 * dur - sur) - (1. - c3) * aH * tur; break;             // pm.cpp:8637-8641
+      case R_SHEAR_UR:
+        if (!L.ufa) v = 4. / 15. * v3 * (tur + ms) - 0.3 * k * u3;                                 // pm.cpp:8645-8651
+        else if (P.ufa_method == CPT_UFA_CLASS) v = -3. * Q.inv_tau * sur + 2. / 3. * (tur + mc);  // pm.cpp:8704-8708
+        else if (P.ufa_method == CPT_UFA_MB) v = -3. * Q.inv_tau * sur + 2. / 3. * (tur + ms);
+        else v = -3. * aH * sur + 2. / 3. * (tur + ms);                                            // ufa_hu
+        break;
+      case R_ETA: v = etap; break;                                                                 // pm.cpp:8896
+      default: v = 0.; break;
+    }
+    dy = v;
   }
-  return (role == R_NONE) ? 0. : dy + E;
+  return dy;
 }
 
 // perturb_sources (pm.cpp:6731-7285): the RHS has just been evaluated at (tau, y) => Q and M describe the sample.
@@ -511,7 +568,7 @@ __device__ __forceinline__ void store_sources(const PtParams& P, const Layout& L
   else {
     delta_g = bcast(y, L.dg);
     if (L.tca) Pi = 5. * tca_shear_prev / 8.;  // left over from the last derivs call of the evolver (pm.cpp:6810)
-    else Pi = (bcast(y, L.pol0) + bcast(y, L.pol0 + 2) + 2. * bcast(y, L.sg)) / 8.;
+    else Pi = (bcast(y, L.p0) + bcast(y, L.p2) + 2. * bcast(y, L.sg)) / 8.;
   }
   const double eta = bcast(y, L.eta), tb = bcast(y, L.tb), dtb = bcast(dy, L.tb);
   int switch_isw = 1;
@@ -572,130 +629,171 @@ __device__ __forceinline__ double search_flip(const PtParams& P, double k, doubl
   return 0.5 * (lo + hi);
 }
 
-// ---- linear algebra in LDS (row i owned by lane i) -----------------------------------------------
-// new_linearisation (ev.cpp:945-998): A <- I - hg*J, factorised in place with row exchanges, so that after the
-// factorisation the pivot row of step j IS row j (lane j): the substitution loops then broadcast from a lane whose
-// index is the loop counter - no permutation look-ups on the dependent chain.  `rowperm` (lane i: original index of
-// the row now at position i) permutes the right-hand side once per solve.  Pivot choice: the diagonal if
-// |a_jj| >= 1e-3 max|a_ij| (threshold pivoting as tools/sparse.c:171; tested with one ballot), else the largest
-// magnitude.  Structural zeros of the pivot row are skipped (ballot), so the work follows the sparsity of J
-// (4-6 entries per row) although the storage is dense.
-struct LuReg { double rpiv; int rowperm; };
+// ---- structured linear algebra: (I - hg J) x = b -------------------------------------------------------------------
+// J = [ J_cc  J_ct ]   core (nc <= 16 lanes, dense)        J_ct: only (parent of a tail, its l=3 element)
+//     [ J_tc  J_tt ]   tails (three tridiagonal chains)     J_tc: only (l=3 element, parent)
+// The reference discovers this sparsity numerically, orders it with AMD and runs a sparse LU (tools/sparse.c:130-599);
+// here it is a property of the equations, known per regime:
+//   * tails: eliminated from l_max downwards with the continued fraction d'_l = d_l - c_l a_{l+1}/d'_{l+1}.  Each lane
+//     holds (a_l, d_l, c_l) of its row; the recurrence is run SYSTOLICALLY: every lane recomputes its d' from the
+//     value its upper neighbour holds (one DPP wave_shl per sweep), after n sweeps the n lanes furthest from l_max
+//     are final.  Three chains advance at once; no LDS, no global memory.
+//   * the Schur complement on the core changes 3 diagonal entries only; the core matrix (<= 16 x 16) lives in
+//     registers, one row per lane, and is factorised with threshold-diagonal pivoting (tools/sparse.c:171) by
+//     fully unrolled readlane/fma code.
+struct Jac {
+  double Jc[16];   // lane i < nc: row i of J_cc
+  double jdiag;    // tail lanes: J_ll = -(D kappa' + G/tau) frozen at the time of the Jacobian (ev.cpp keeps J fixed)
+};
+struct LuReg {
+  double Ac[16];   // lane i < nc: row i of the core factors (L below / unit-diagonal U above the diagonal)
+  double rpivc;    // lane j < nc: reciprocal of the j-th core pivot
+  int rowperm;     // lane i < nc: original row now at position i (identity on tail lanes)
+  double a, c;     // tail lanes: sub-/super-diagonal of (I - hg J);   core parents: c = coupling to the tail's l=3
+  double rinv;     // tail lanes: 1 / d'_l
+  double r;        // tail lanes: a_l / d'_l
+  int first_lane;  // core parents: lane of the l=3 element of their tail (-1: none)
+};
 
-__device__ __forceinline__ bool factorise(const double* __restrict__ J, double* __restrict__ A, int n, int S, double hg, int lane,
-                                          LuReg& F) {
-  // The system is padded with identity rows/columns up to a multiple of 8 (np), so that the substitution loops run
-  // over whole 8-column chunks without per-element guards.
-  const int np = (n + 7) & ~7;
+template <int N>
+__device__ __forceinline__ double reg_get(const double (&a)[N], int i) {
+  double v = 0.;
+#pragma unroll
+  for (int j = 0; j < N; j++) if (j == i) v = a[j];
+  return v;
+}
+
+__device__ __forceinline__ bool factorise(const Layout& L, const LaneEq& e, const Jac& J, double hg, int maxlen, int lane, LuReg& F) {
   lane = opaque(lane);
-  if (lane < n) {
-    for (int c = 0; c < n; c++) A[lane * S + c] = -hg * J[lane * S + c] + (c == lane ? 1.0 : 0.0);
-    for (int c = n; c < np; c++) A[lane * S + c] = 0.;
-  } else if (lane < np) {
-    for (int c = 0; c < np; c++) A[lane * S + c] = (c == lane) ? 1.0 : 0.;
+  const int nc = L.nc;
+  const int chain = opaque(e.chain);
+  // ---- tails ----
+  const double a = chain ? -hg * e.A : 0.;            // coefficient of x_{l-1} in row l
+  const double c = chain ? hg * e.B : 0.;             // coefficient of x_{l+1}
+  const double d = 1.0 - hg * J.jdiag;
+  double dp = d, r = 0.;
+  for (int s = 0; s < maxlen; s++) {
+    r = a * fast_rcp(dp);
+    const double r_up = lane_above(r);
+    dp = e.last ? d : d - c * r_up;
   }
+  const double rinv = fast_rcp(dp);
+  r = a * rinv;
+  F.a = a; F.rinv = chain ? rinv : 0.; F.r = chain ? r : 0.;
+  // ---- core: A_cc = I - hg J_cc, Schur-corrected on the diagonal of the parents of the tails ----
+  int first_lane = -1;
+  double cpar = 0.;
+  if (!chain) {
+    const int role = opaque(e.role);
+    if (role == R_SHEAR_G && L.gN > 0) first_lane = L.g3;
+    else if (role == R_POL && e.ell == 2 && L.qN > 0) first_lane = L.q3;
+    else if (role == R_SHEAR_UR && L.uN > 0) first_lane = L.u3;
+    if (first_lane >= 0) cpar = hg * e.B;  // row parent, column l3:  -hg * (-B)
+  }
+  F.first_lane = first_lane;
+  F.c = chain ? c : cpar;
+  const double r3 = shfl_all(r, first_lane < 0 ? 0 : first_lane);
+  const double schur = (first_lane >= 0) ? cpar * r3 : 0.;
+  double A[16];
+#pragma unroll
+  for (int j = 0; j < 16; j++) A[j] = (lane < nc && j < nc) ? ((j == lane ? 1.0 : 0.0) - hg * J.Jc[j]) : ((j == lane) ? 1.0 : 0.0);
+#pragma unroll
+  for (int j = 0; j < 16; j++) if (j == lane) A[j] -= schur;
   int rowperm = lane;
-  double rpiv = 1.;
-  double anext = (lane < n) ? A[lane * S] : 0.;  // column j of my row, fetched one step ahead
-  for (int j = 0; j < n; j++) {
-    double aij = (lane >= j && lane < n) ? anext : 0.;
-    const double mag = fabs(aij);
-    const double diag = bcast(mag, j);
-    if (__ballot(mag > 1e3 * diag) != 0ull || diag == 0.) {  // rare: the diagonal is not an acceptable pivot
-      const double big = wave_max(mag);
-      if (big == 0.) return false;
-      const int p = __ffsll((long long)__ballot(mag == big)) - 1;
-      // exchange rows p and j (all columns; lane c moves column c) and the bookkeeping that travels with the rows
-      if (lane < n) { const double tp = A[p * S + lane], tj = A[j * S + lane]; A[p * S + lane] = tj; A[j * S + lane] = tp; }
-      const int rp_p = __builtin_amdgcn_readlane(rowperm, p), rp_j = __builtin_amdgcn_readlane(rowperm, j);
-      if (lane == p) rowperm = rp_j;
-      if (lane == j) rowperm = rp_p;
-      const double a_p = bcast(aij, p), a_j = bcast(aij, j);
-      if (lane == p) aij = a_j;
-      if (lane == j) aij = a_p;
-      const double n_p = bcast(anext, p), n_j = bcast(anext, j);
-      if (lane == p) anext = n_j;
-      if (lane == j) anext = n_p;
-    }
-    const double rp = fast_rcp(bcast(aij, j));
-    if (lane == j) rpiv = rp;
-    double m = 0.;
-    if (lane > j && lane < n && aij != 0.) { m = aij * rp; A[lane * S + j] = m; }
-    // pivot row (columns > j) into registers: lane c holds A[j][c]
-    const double prow = (lane > j && lane < n) ? A[j * S + lane] : 0.;
-    unsigned long long nz = __ballot(prow != 0.);
-    // column j+1 of my row is needed next: if the pivot row touches it, take the updated value from the update below
-    const bool next_touched = (j + 1 < n) && ((nz >> (j + 1)) & 1ull);
-    if (!next_touched && j + 1 < n && lane < n) anext = A[lane * S + j + 1];
-    while (nz) {  // up to three pivot-row entries per trip: their LDS round trips overlap
-      const int c0 = __ffsll((long long)nz) - 1;
-      nz &= nz - 1;
-      int c1 = -1, c2 = -1;
-      if (nz) { c1 = __ffsll((long long)nz) - 1; nz &= nz - 1; }
-      if (nz) { c2 = __ffsll((long long)nz) - 1; nz &= nz - 1; }
-      const double r0 = bcast(prow, c0);
-      const double r1 = (c1 >= 0) ? bcast(prow, c1) : 0.;
-      const double r2 = (c2 >= 0) ? bcast(prow, c2) : 0.;
-      if (lane > j && lane < n) {
-        double a0 = A[lane * S + c0];
-        double a1 = (c1 >= 0) ? A[lane * S + c1] : 0.;
-        double a2 = (c2 >= 0) ? A[lane * S + c2] : 0.;
-        if (m != 0.) {
-          a0 -= m * r0;
-          A[lane * S + c0] = a0;
-          if (c1 >= 0) { a1 -= m * r1; A[lane * S + c1] = a1; }
-          if (c2 >= 0) { a2 -= m * r2; A[lane * S + c2] = a2; }
+  double rpivc = 1.;
+  bool ok = true;
+#pragma unroll
+  for (int j = 0; j < 16; j++) {
+    if (j < nc) {
+      const double mag = (lane >= j && lane < nc) ? fabs(A[j]) : 0.;
+      const double diag = bcast(mag, j);
+      if (__ballot(mag > 1e3 * diag) != 0ull || diag == 0.) {  // rare: the diagonal is not an acceptable pivot
+        const double big = wave_max(mag);
+        if (big == 0.) ok = false;
+        const int p = __ffsll((long long)__ballot(mag == big && big > 0.)) - 1;
+        if (p > j) {
+          // exchange rows p and j (register rows of two lanes) and the row bookkeeping
+#pragma unroll
+          for (int cidx = 0; cidx < 16; cidx++) {
+            const double vp = bcast(A[cidx], p), vj = bcast(A[cidx], j);
+            if (lane == p) A[cidx] = vj;
+            if (lane == j) A[cidx] = vp;
+          }
+          const int rp_p = __builtin_amdgcn_readlane(rowperm, p), rp_j = __builtin_amdgcn_readlane(rowperm, j);
+          if (lane == p) rowperm = rp_j;
+          if (lane == j) rowperm = rp_p;
         }
-        if (c0 == j + 1) anext = a0;
-        if (c1 == j + 1) anext = a1;
-        if (c2 == j + 1) anext = a2;
+      }
+      const double rp = fast_rcp(bcast(A[j], j));
+      if (lane == j) rpivc = rp;
+      const double m = (lane > j && lane < nc) ? A[j] * rp : 0.;
+      if (lane > j && lane < nc) A[j] = m;
+#pragma unroll
+      for (int cidx = j + 1; cidx < 16; cidx++) {
+        const double pj = bcast(A[cidx], j);
+        A[cidx] = fma(-m, pj, A[cidx]);   // m = 0 on rows <= j
       }
     }
   }
-  // scale the U part of every row by its reciprocal pivot: U becomes unit upper triangular and the backward
-  // substitution needs no multiply on its dependent chain (the right-hand side is scaled once, in parallel)
-  if (lane < n) {
-    for (int c = lane + 1; c < n; c++) A[lane * S + c] *= rpiv;
+  // unit-diagonal U: scale the upper part of every row by its reciprocal pivot
+#pragma unroll
+  for (int j = 0; j < 16; j++) {
+    F.Ac[j] = (j > lane) ? A[j] * rpivc : A[j];
   }
-  F.rowperm = rowperm; F.rpiv = rpiv;
-  return true;
+  F.rpivc = rpivc;
+  F.rowperm = rowperm;
+  return ok;
 }
 
-// solve (I - hg J) x = b with the factors above; b: lane i holds b_i; returns x with lane j holding x_j.
-// The multipliers of 8 consecutive columns are fetched from LDS together (independent reads in flight); the loops are
-// fully unrolled so that every broadcast reads a lane known at compile time: the dependent chain per column is
-// v_readlane + v_fma only.
-__device__ __forceinline__ double lu_solve(const double* __restrict__ A, const LuReg& F, int n, int S, double b, int lane) {
-  const int np = (n + 7) & ~7;  // identity-padded size (see factorise)
+// solve (I - hg J) x = b; lane i holds b_i on entry and x_i on return
+__device__ __forceinline__ double lu_solve(const Layout& L, const LaneEq& e, const LuReg& F, int maxlen, double b, int lane) {
   lane = opaque(lane);
-  const double* myrow = A + (lane < np ? lane : 0) * S;
-  b = __shfl(b, F.rowperm, 64);  // row exchanges of the factorisation
-#pragma unroll
-  for (int j0 = 0; j0 < 64; j0 += 8) {  // forward: L has unit diagonal, rows below j eliminate column j
-    if (j0 < np) {
-      double r[8];
-#pragma unroll
-      for (int u = 0; u < 8; u++) r[u] = myrow[j0 + u];
-#pragma unroll
-      for (int u = 0; u < 8; u++) r[u] = (lane > j0 + u) ? r[u] : 0.;  // masking is off the dependent chain
-#pragma unroll
-      for (int u = 0; u < 8; u++) b = fma(-r[u], bcast(b, j0 + u), b);
+  const int nc = L.nc;
+  const int chain = opaque(e.chain);
+  // 1. tails, downward sweep: b'_l = b_l - c_l b'_{l+1} / d'_{l+1}
+  double bp = b;
+  if (maxlen > 0) {
+    for (int s = 0; s < maxlen; s++) {
+      const double t_up = lane_above(bp * F.rinv);
+      bp = (chain && !e.last) ? b - F.c * t_up : b;
     }
   }
-  b *= F.rpiv;  // U is stored with unit diagonal
+  // 2. core right-hand side: parents of the tails see b'_3 / d'_3
+  const double t3 = shfl_all(bp * F.rinv, F.first_lane < 0 ? 0 : F.first_lane);  // executed by every lane
+  const double bc = (F.first_lane >= 0) ? b - F.c * t3 : b;
+  // 3. core solve with the register-resident factors
+  double x = shfl_all(chain ? 0. : bc, F.rowperm);
+  if (chain) x = 0.;
 #pragma unroll
-  for (int j0 = 56; j0 >= 0; j0 -= 8) {  // backward: lane j already holds x_j when column j is eliminated
-    if (j0 < np) {
-      double r[8];
-#pragma unroll
-      for (int u = 0; u < 8; u++) r[u] = myrow[j0 + u];
-#pragma unroll
-      for (int u = 0; u < 8; u++) r[u] = (lane < j0 + u) ? r[u] : 0.;
-#pragma unroll
-      for (int u = 7; u >= 0; u--) b = fma(-r[u], bcast(b, j0 + u), b);
+  for (int j = 0; j < 16; j++) {   // forward, unit lower
+    if (j < nc) {
+      const double xj = bcast(x, j);
+      const double m = (lane > j && lane < nc) ? F.Ac[j] : 0.;
+      x = fma(-m, xj, x);
     }
   }
-  return (lane < n) ? b : 0.;
+  x *= (lane < nc) ? F.rpivc : 1.0;
+#pragma unroll
+  for (int j = 15; j >= 0; j--) {  // backward, unit upper
+    if (j < nc) {
+      const double xj = bcast(x, j);
+      const double u = (lane < j) ? F.Ac[j] : 0.;
+      x = fma(-u, xj, x);
+    }
+  }
+  // 4. tails, upward sweep: x_l = (b'_l - a_l x_{l-1}) / d'_l, the l=3 element takes x_{l-1} from its core parent
+  if (maxlen > 0) {
+    const int parent = (chain == 1) ? L.sg : (chain == 2) ? L.p2 : L.sur;
+    const double xpar = shfl_all(x, (chain && parent >= 0) ? parent : 0);
+    double xt = 0.;
+    for (int s = 0; s < maxlen; s++) {
+      const double xlow = lane_below(xt);
+      const double below = e.first ? xpar : xlow;
+      xt = (bp - F.a * below) * F.rinv;
+    }
+    if (chain) x = xt;
+  }
+  return (lane < L.neq) ? x : 0.;
 }
 
 // adjust_stepsize (ev.cpp:907-943): dif[0..k-1] <- dif[0..k-1] * RU(r); every index static => registers only
@@ -750,33 +848,40 @@ __device__ __forceinline__ double dif_get(const double* dif, int i) {
 }
 
 // evolver_ndf15 (ev.cpp:62-705) for one interval of constant approximation scheme, as ONE flat loop so that the RHS
-// is instantiated exactly twice: a "service" slot (Jacobian columns, the initial f(t0+tdel), sampled outputs, the
+// is instantiated exactly twice: a "service" slot (Jacobian columns, f(t0), f(t0+tdel), J f0, sampled outputs, the
 // final evaluation) and the Newton slot.  Returns 0 / error code (1 step too small, 2 singular, 4 budget).
 __device__ __forceinline__ int ndf15(const PtParams& P, const Layout& L, const LaneEq& e, Lookup& Q, Metric& M, double k,
-                                     double inv_k2, int ik, double t0, double tfinal, double& y_io, double* Jm, double* Am,
-                                     Stat& st, int lane, int& budget, unsigned long long* prof) {
+                                     double inv_k2, int ik, double t0, double tfinal, double& y_io, Stat& st, int lane,
+                                     int& budget, unsigned long long* prof) {
   PROF_DECL;
   const double eps = 1e-16, threshold = 1e-15, rtol = P.rtol;
-  const int maxit = 4, maxk = 5, n = L.neq, S = P.stride;
+  const int maxit = 4, maxk = 5, n = L.neq;
   const bool act = lane < n;
   const double* ts = P.tau_s;
   const int tres = P.ntau;
   const double htspan = fabs(tfinal - t0), hmax = (tfinal - t0) / 10.0;
-  enum { B_NONE = 0, B_JAC_INIT, B_F1, B_JAC, B_SAMPLE, B_FINAL };
+  const int maxlen = max(L.gN, max(L.qN, L.uN));
+  enum { B_NONE = 0, B_JAC, B_F0, B_F1, B_JF0, B_SAMPLE, B_FINAL };
 
+  Jac J;
+#pragma unroll
+  for (int j = 0; j < 16; j++) J.Jc[j] = 0.;
+  J.jdiag = 0.;
   LuReg F;
-  F.rpiv = 0.; F.rowperm = lane;
-  double y = y_io, ynew = y_io, f0 = 0., fnewton = 0., wt = 0., tdel = 0.;
+#pragma unroll
+  for (int j = 0; j < 16; j++) F.Ac[j] = 0.;
+  F.rpivc = 1.; F.rowperm = lane; F.a = F.c = F.rinv = F.r = 0.; F.first_lane = -1;
+  double y = y_io, ynew = y_io, f0 = 0., f1 = 0., fnewton = 0., wt = 0., tdel = 0.;
   double dif[7] = {0., 0., 0., 0., 0., 0., 0.};
   int next = 0;
   while (next < tres && ts[next] < t0) next++;
   double t = t0, tnew = t0, h = 0., absh = 0., abshlast = 0., hmin = 16.0 * eps * fabs(t0), hinvGak = 0.;
   int kk = 1, klast = 1, nconhk = 0;
   bool Jcurrent = false, havrate = false, done = false, at_hmin = false, nofailed = true;
-  bool new_step = false, need_fact = false, post_step = false;
+  bool new_step = false, need_fact = false, post_step = false, init = true;
   double rate = 0., oldnrm = 0., err = 0., invwt = 0., difkp1 = 0.;
   double yi = 0., ypi = 0., tn = 0.;
-  int batch = B_JAC_INIT;
+  int batch = B_JAC;
 
   // dense output at the next sample time (ev.cpp:547-571, interp_from_dif :860-905)
   auto prepare_sample = [&]() {
@@ -802,30 +907,42 @@ __device__ __forceinline__ int ndf15(const PtParams& P, const Layout& L, const L
     // ------------------------------------------------------------------ service slot
     if (batch != B_NONE) {
       PROF_START();
-      const int nreq = (batch == B_JAC_INIT || batch == B_JAC) ? n : 1;
+      const int nreq = (batch == B_JAC) ? L.nc : 1;
       const double tca_keep = M.tca_shear_g;
       for (int r = 0; r < nreq; r++) {
         double tq, yq;
-        if (batch == B_JAC_INIT || batch == B_JAC) { tq = t; yq = (lane == r) ? 1.0 : 0.0; }  // J e_r = f(t, e_r)
+        if (batch == B_JAC) { tq = t; yq = (lane == r) ? 1.0 : 0.0; }  // J e_r = f(t, e_r): exact, the system is linear
+        else if (batch == B_F0) { tq = t; yq = y; }
         else if (batch == B_F1) { tq = t + tdel; yq = y; }
+        else if (batch == B_JF0) { tq = t; yq = f0; }                  // J f0 = f(t, f0)
         else if (batch == B_SAMPLE) { tq = tn; yq = yi; }
         else { tq = tnew; yq = ynew; }
         const double dyq = rhs(P, L, e, Q, M, k, inv_k2, tq, yq, lane);
         st.fevals++;
-        if (batch == B_JAC_INIT || batch == B_JAC) { if (act) Jm[lane * S + r] = dyq; }
-        else if (batch == B_F1) f0 = dyq;  // temporarily f(t0 + tdel)
+        if (batch == B_JAC) {
+#pragma unroll
+          for (int j = 0; j < 16; j++) if (j == r) J.Jc[j] = (lane < L.nc) ? dyq : 0.;
+        } else if (batch == B_F0) f0 = dyq;
+        else if (batch == B_F1) f1 = dyq;
+        else if (batch == B_JF0) fnewton = dyq;  // temporarily J f0
         else if (batch == B_SAMPLE) store_sources(P, L, Q, M, k, inv_k2, yi, ypi, tca_keep, next, ik, lane);
       }
       if (batch == B_FINAL) { PROF_STOP(3); break; }  // ev.cpp:653-662: M, Q left at (tfinal, y) for the hand-over
-      if (batch == B_JAC_INIT) {
+      if (batch == B_JAC) {
+        // the tails' diagonal is analytic: freeze kappa' and 1/tau at the time of this Jacobian
+        J.jdiag = -(e.D * Q.th.dkappa + e.G * Q.inv_tau);
         st.jacs++;
+        M.tca_shear_g = tca_keep;
         Jcurrent = true;
-        // f0 = f(t0, y) = J y ; first guess of h (ev.cpp:225-250)
-        double acc = 0.;
-        for (int j = 0; j < n; j++) { const double yj = bcast(y, j); if (act) acc += Jm[lane * S + j] * yj; }
-        fnewton = acc;
+        if (init) { batch = B_F0; PROF_STOP(3); continue; }
+        st.fevals++;  // the reference also re-evaluates f(t,y) here (ev.cpp:451)
+        need_fact = true;
+        batch = B_NONE;
+        PROF_STOP(3);
+      } else if (batch == B_F0) {
+        // first guess of h (ev.cpp:225-250)
         wt = fmax(fabs(y), threshold);
-        const double rh = wave_max(act ? 1.25 / sqrt(rtol) * fabs(fnewton / wt) : 0.);
+        const double rh = wave_max(act ? 1.25 / sqrt(rtol) * fabs(f0 / wt) : 0.);
         absh = fmin(hmax, htspan);
         if (absh * rh > 1.0) absh = 1.0 / rh;
         absh = fmax(absh, hmin);
@@ -834,31 +951,25 @@ __device__ __forceinline__ int ndf15(const PtParams& P, const Layout& L, const L
         batch = B_F1;
         PROF_STOP(3);
         continue;
-      }
-      if (batch == B_F1) {
+      } else if (batch == B_F1) {
+        batch = B_JF0;
+        PROF_STOP(3);
+        continue;
+      } else if (batch == B_JF0) {
         // ddfddt = J f0 + (f(t+tdel) - f0)/tdel  (ev.cpp:261-283)
-        double acc = 0.;
-        for (int j = 0; j < n; j++) { const double fj = bcast(fnewton, j); if (act) acc += Jm[lane * S + j] * fj; }
-        acc += (f0 - fnewton) / tdel;
+        const double acc = fnewton + (f1 - f0) / tdel;
         const double rh = wave_max(act ? 1.25 * sqrt(0.5 * fabs(acc / wt) / rtol) : 0.);
         absh = fmin(hmax, htspan);
         if (absh * rh > 1.0) absh = 1.0 / rh;
         absh = fmax(absh, hmin);
         h = absh;
         kk = 1; klast = 1; abshlast = absh;
-        dif[0] = h * fnewton;
+        dif[0] = h * f0;
         hinvGak = h * ndf_invGa(kk - 1);
         nconhk = 0;
         need_fact = true;
         new_step = true;
-        batch = B_NONE;
-        PROF_STOP(3);
-      } else if (batch == B_JAC) {
-        st.jacs++;
-        st.fevals++;  // the reference also re-evaluates f(t,y) here (ev.cpp:451)
-        M.tca_shear_g = tca_keep;
-        Jcurrent = true;
-        need_fact = true;
+        init = false;
         batch = B_NONE;
         PROF_STOP(3);
       } else {  // B_SAMPLE
@@ -924,12 +1035,16 @@ __device__ __forceinline__ int ndf15(const PtParams& P, const Layout& L, const L
     if (need_fact) {
       need_fact = false;
       PROF_START();
-      if (!factorise(Jm, Am, n, S, hinvGak, lane, F)) return 2;
+      if (!factorise(L, e, J, hinvGak, maxlen, lane, F)) return 2;
       PROF_STOP(2);
       st.lus++;
       havrate = false;
     }
     // ------------------------------------------------------------------ predictor + simplified Newton (ev.cpp:342-445)
+#ifdef CPT_PROFILE
+    const unsigned long long t_newton0 = clock64();
+    unsigned long long t_inner = 0;
+#endif
     double psi = 0., pred = y;
     {
       const double iga = ndf_invGa(kk - 1);
@@ -949,11 +1064,17 @@ __device__ __forceinline__ int ndf15(const PtParams& P, const Layout& L, const L
       PROF_START();
       fnewton = rhs(P, L, e, Q, M, k, inv_k2, tnew, ynew, lane);
       PROF_STOP(0);
+#ifdef CPT_PROFILE
+      t_inner += clock64() - pf_t0;
+#endif
       st.fevals++;
       const double rhsv = act ? hinvGak * fnewton - (psi + difkp1) : 0.;
       PROF_START();
-      const double del = lu_solve(Am, F, n, S, rhsv, lane);
+      const double del = lu_solve(L, e, F, maxlen, rhsv, lane);
       PROF_STOP(1);
+#ifdef CPT_PROFILE
+      t_inner += clock64() - pf_t0;
+#endif
       st.solves++;
       const double newnrm = wave_max(act ? fabs(del * invwt) : 0.);
       difkp1 += del;
@@ -973,6 +1094,9 @@ __device__ __forceinline__ int ndf15(const PtParams& P, const Layout& L, const L
       }
       oldnrm = newnrm;
     }
+#ifdef CPT_PROFILE
+    prof[5] += clock64() - t_newton0 - t_inner;  // predictor + Newton control without rhs / solve
+#endif
     if (tooslow) {  // ev.cpp:446-479
       st.failed++;
       if (!Jcurrent) { batch = B_JAC; continue; }
@@ -1072,16 +1196,13 @@ __device__ __noinline__ double initial_conditions(DevTables T, int has_cdm, int 
 
 // ---- the kernel: perturb_solve (pm.cpp:2463-2787) for one mode per wavefront ---------------------
 __global__ void __launch_bounds__(64) k_perturb(PtParams P) {
-  extern __shared__ __attribute__((aligned(16))) double lds[];
+  __shared__ __attribute__((aligned(16))) double2 tabw[64 * (BG_NCOL + TH_NCOL)];
   const int lane = threadIdx.x;
   const int ik = P.order[blockIdx.x];
   const double k = P.k[ik];
   const double inv_k2 = 1.0 / (k * k);
-  const int S = P.stride;
-  double* Jm = lds;
-  double* Am = lds + P.rows * S;
-  double2* bgw = (double2*)(lds + 2 * P.rows * S);  // even number of doubles => 16-byte aligned
-  double2* thw = bgw + 64 * BG_NCOL;
+  double2* bgw = tabw;
+  double2* thw = tabw + 64 * BG_NCOL;
 
   Stat st = {0, 0, 0, 0, 0, 0};
   unsigned long long prof[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -1150,7 +1271,7 @@ __global__ void __launch_bounds__(64) k_perturb(PtParams P) {
         L = make_layout(P, f_tca, f_rsa, f_ufa);
         e = make_lane_eq(P, L, lane, k);
         const int src_i = index_of(Lo, e.role, e.ell);
-        double yn = __shfl(y, src_i < 0 ? 0 : src_i, 64);
+        double yn = shfl_all(y, src_i < 0 ? 0 : src_i);
         if (src_i < 0 || e.role == R_NONE) yn = 0.;
         if (Lo.tca && !L.tca) {  // tight coupling switched off: seed shear, l=3 and polarisation (pm.cpp:3893-3916)
           const double sh = M.tca_shear_g, kod = k * Q.tau_c;
@@ -1167,7 +1288,7 @@ __global__ void __launch_bounds__(64) k_perturb(PtParams P) {
         y = yn;
       }
       n_regimes++;
-      const int rc = ndf15(P, L, e, Q, M, k, inv_k2, ik, ta, tb, y, Jm, Am, st, lane, budget, prof);
+      const int rc = ndf15(P, L, e, Q, M, k, inv_k2, ik, ta, tb, y, st, lane, budget, prof);
       if (rc) status = 10 + rc;
     }
   }
@@ -1204,6 +1325,7 @@ __global__ void __launch_bounds__(64) k_dbg_lookup(PtParams P, const double* tau
   }
 }
 
+// y and dy are exchanged in the REFERENCE's ordering of the regime (pm.cpp:3302-3481)
 __global__ void __launch_bounds__(64) k_dbg_derivs(PtParams P, double k, double tau, int tca, int rsa, int ufa, const double* y,
                                                    double* dy, int* neq) {
   __shared__ __attribute__((aligned(16))) double2 w[64 * (BG_NCOL + TH_NCOL)];
@@ -1215,10 +1337,42 @@ __global__ void __launch_bounds__(64) k_dbg_derivs(PtParams P, double k, double 
   M.tca_shear_g = 0.; M.rsa_dg = M.rsa_tg = 0.;
   Layout L = make_layout(P, tca, rsa, ufa);
   LaneEq e = make_lane_eq(P, L, lane, k);
-  const double yl = (lane < L.neq) ? y[lane] : 0.;
+  const int ri = ref_index_of(P, tca, rsa, ufa, e.role, e.ell);
+  const double yl = (lane < L.neq && ri >= 0) ? y[ri] : 0.;
   const double d = rhs(P, L, e, Q, M, k, 1.0 / (k * k), tau, yl, lane);
-  if (lane < L.neq) dy[lane] = d;
+  if (lane < L.neq && ri >= 0) dy[ri] = d;
   if (lane == 0) *neq = L.neq;
+}
+
+// (I - hg J(tau)) x = b through the structured factorisation, in the reference's ordering: unit test of the linear algebra
+__global__ void __launch_bounds__(64) k_dbg_solve(PtParams P, double k, double tau, int tca, int rsa, int ufa, double hg,
+                                                  const double* b, double* x) {
+  __shared__ __attribute__((aligned(16))) double2 w[64 * (BG_NCOL + TH_NCOL)];
+  const int lane = threadIdx.x;
+  Lookup Q;
+  lookup_init(P, Q, w, w + 64 * BG_NCOL, lane);
+  Metric M;
+  M.hp = M.etap = M.alpha = M.alphap = M.delta_m = 0.;
+  M.tca_shear_g = 0.; M.rsa_dg = M.rsa_tg = 0.;
+  Layout L = make_layout(P, tca, rsa, ufa);
+  LaneEq e = make_lane_eq(P, L, lane, k);
+  const double inv_k2 = 1.0 / (k * k);
+  Jac J;
+#pragma unroll
+  for (int j = 0; j < 16; j++) J.Jc[j] = 0.;
+  for (int r = 0; r < L.nc; r++) {
+    const double col = rhs(P, L, e, Q, M, k, inv_k2, tau, (lane == r) ? 1.0 : 0.0, lane);
+#pragma unroll
+    for (int j = 0; j < 16; j++) if (j == r) J.Jc[j] = (lane < L.nc) ? col : 0.;
+  }
+  J.jdiag = -(e.D * Q.th.dkappa + e.G * Q.inv_tau);
+  LuReg F;
+  const int maxlen = max(L.gN, max(L.qN, L.uN));
+  const bool ok = factorise(L, e, J, hg, maxlen, lane, F);
+  const int ri = ref_index_of(P, tca, rsa, ufa, e.role, e.ell);
+  const double bl = (lane < L.neq && ri >= 0) ? b[ri] : 0.;
+  const double xl = lu_solve(L, e, F, maxlen, bl, lane);
+  if (lane < L.neq && ri >= 0) x[ri] = ok ? xl : nan("");
 }
 
 void fill_params(const cpt_handle* h, PtParams& P) {
@@ -1238,15 +1392,8 @@ void fill_params(const cpt_handle* h, PtParams& P) {
   P.rsa_trig = c.radiation_streaming_trigger_tau_over_tau_k; P.ufa_trig = c.ur_fluid_trigger_tau_over_tau_k;
   P.curvature_ini = c.curvature_ini; P.rtol = c.tol_perturb_integration; P.tol_tau_approx = c.tol_tau_approx;
   P.min_var = c.smallest_allowed_variation;
-  int neq_max = 3 + c.l_max_g - 2 + c.l_max_pol_g + 1 + 2 + (c.has_cdm ? 1 : 0) + (c.has_ur ? 3 + c.l_max_ur - 2 : 0) + 1;
-  P.rows = (neq_max + 7) & ~7;   // identity padding to a multiple of 8 (see factorise)
-  P.stride = P.rows | 1;  // odd => lane i accessing row i hits 64 distinct bank pairs
   P.max_steps = 400000;
   P.k = nullptr; P.tau_s = nullptr; P.order = nullptr; P.nk = 0; P.ntau = 0; P.src = nullptr; P.stats = nullptr; P.status = nullptr;
-}
-
-size_t perturb_lds_bytes(const PtParams& P) {
-  return (size_t)2 * P.rows * P.stride * sizeof(double) + (size_t)64 * (BG_NCOL + TH_NCOL) * sizeof(double2);
 }
 
 }  // namespace
@@ -1261,8 +1408,6 @@ int cpt_perturb_impl(cpt_handle* h, const double* k, int nk, const double* tau, 
   if (!(tau[ntau - 1] <= c.tau0 * (1. + 1e-12))) return cpt_fail(h, CPT_ERR_INVALID, "tau_sampling exceeds the conformal age");
   PtParams P;
   fill_params(h, P);
-  const size_t lds = perturb_lds_bytes(P);
-  if (lds > 160 * 1024) return cpt_fail(h, CPT_ERR_UNSUPPORTED, "LDS need %zu B exceeds 160 KB", lds);
   const int ntp = c.tp_size;
   const size_t nsrc = (size_t)ntp * nk * ntau;
   int rc;
@@ -1287,9 +1432,8 @@ int cpt_perturb_impl(cpt_handle* h, const double* k, int nk, const double* tau, 
   CPT_HIP(h, hipMemcpyAsync(d_order, order.data(), nk * sizeof(int), hipMemcpyHostToDevice, h->stream));
   CPT_HIP(h, hipMemsetAsync(h->d_src, 0, nsrc * sizeof(double), h->stream));  // pm.cpp:2767-2771 zero tail
   P.k = d_k; P.tau_s = d_tau; P.order = d_order; P.nk = nk; P.ntau = ntau; P.src = h->d_src; P.stats = d_stats; P.status = d_status;
-  CPT_HIP(h, hipFuncSetAttribute((const void*)k_perturb, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   CPT_HIP(h, hipEventRecord(h->t_perturb.a, h->stream));
-  hipLaunchKernelGGL(k_perturb, dim3(nk), dim3(64), lds, h->stream, P);
+  hipLaunchKernelGGL(k_perturb, dim3(nk), dim3(64), 0, h->stream, P);
   CPT_HIP(h, hipGetLastError());
   CPT_HIP(h, hipEventRecord(h->t_perturb.b, h->stream));
   h->src_nk = nk; h->src_ntau = ntau;
@@ -1371,5 +1515,25 @@ int cpt_dbg_derivs_impl(cpt_handle* h, double k, double tau, int tca_on, int rsa
   (void)hipFree(d_y);
   (void)hipFree(d_dy);
   (void)hipFree(d_neq);
+  return CPT_OK;
+}
+
+int cpt_dbg_solve_impl(cpt_handle* h, double k, double tau, int tca_on, int rsa_on, int ufa_on, double hg, const double* b,
+                       double* x) {
+  PtParams P;
+  fill_params(h, P);
+  if (!(k > 0.) || !(tau > 0.)) return cpt_fail(h, CPT_ERR_INVALID, "k and tau must be positive");
+  double *d_b = nullptr, *d_x = nullptr;
+  CPT_HIP(h, hipMalloc((void**)&d_b, 64 * sizeof(double)));
+  CPT_HIP(h, hipMalloc((void**)&d_x, 64 * sizeof(double)));
+  CPT_HIP(h, hipMemset(d_x, 0, 64 * sizeof(double)));
+  CPT_HIP(h, hipMemcpy(d_b, b, 64 * sizeof(double), hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(k_dbg_solve, dim3(1), dim3(64), 0, h->stream, P, k, tau, tca_on ? 1 : 0, rsa_on ? 1 : 0, ufa_on ? 1 : 0, hg,
+                     d_b, d_x);
+  CPT_HIP(h, hipGetLastError());
+  CPT_HIP(h, hipStreamSynchronize(h->stream));
+  CPT_HIP(h, hipMemcpy(x, d_x, 64 * sizeof(double), hipMemcpyDeviceToHost));
+  (void)hipFree(d_b);
+  (void)hipFree(d_x);
   return CPT_OK;
 }

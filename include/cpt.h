@@ -203,6 +203,10 @@ int cpt_dbg_lookup(cpt_handle* h, const double* tau, int n, double* out);
  * y[neq] in the reference's index order for that regime (pm.cpp:3302-3481); returns dy[neq] and neq       */
 int cpt_dbg_derivs(cpt_handle* h, double k, double tau, int tca_on, int rsa_on, int ufa_on, const double* y,
                    double* dy, int* neq);
+/* solve (I - hg J(tau)) x = b for wavenumber k in the regime (tca_on, rsa_on, ufa_on) with the kernel's structured
+ * factorisation; b[neq], x[neq] in the reference's index order (arrays of 64 doubles) */
+int cpt_dbg_solve(cpt_handle* h, double k, double tau, int tca_on, int rsa_on, int ufa_on, double hg, const double* b,
+                  double* x);
 /* flat spherical Bessel table phi[nl][nx], dphi[nl][nx] and chi_at_phimin[nl] as built for (l, xmax) */
 int cpt_dbg_bessel(cpt_handle* h, const int* l, int nl, double xmax, int* nx, double* phi, double* dphi,
                    double* chi_at_phimin, int cap_nx);

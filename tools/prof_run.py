@@ -20,7 +20,7 @@ out = (C.c_ulonglong * 8)()
 L = capi.lib()
 L.cpt_dbg_profile.argtypes = [C.POINTER(C.c_ulonglong)]
 L.cpt_dbg_profile(out)
-names = ["rhs(newton)", "lu_solve", "factorise", "jacobian", "sampling", "adjust", "schedule", "total"]
+names = ["rhs(newton)", "lu_solve", "factorise", "jacobian+init", "sampling", "newton-control", "schedule", "total"]
 tot = max(out[7], 1)
 s = stats[len(stats) - 1]
 print("heaviest mode: steps", s.steps, "fevals", s.fevals, "lus", s.factorisations, "solves", s.solves, "jacs", s.jacobians)
