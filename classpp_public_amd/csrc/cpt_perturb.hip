@@ -65,13 +65,31 @@ __device__ inline double dpp_keep(double v) {
   hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xf, 0xf, false);
   return __hiloint2double(hi, lo);
 }
-// max over the 64 lanes without touching LDS: 4 DPP steps inside each row of 16 + 4 readlanes (wave-uniform result)
+// max over the 64 lanes of a NON-NEGATIVE quantity (an error norm).  The reduction runs in single precision, where
+// v_max_f32 takes a DPP operand directly: 4 row_shr steps + row_bcast:15 + row_bcast:31 = six VALU instructions
+// (the double-precision version needs ~35: v_max_f64 is VOP3-only, so every step is copy + 2 DPP movs + max).
+// The value is rounded UP to float first, so the result is >= the exact maximum and <= (1 + 2^-23) times it - the
+// norms only steer the step size and the Newton stopping test (ev.cpp:367-444), at rtol-level thresholds.
 __device__ inline double wave_max(double v) {
-  v = fmax(v, dpp_keep<0x111>(v));  // row_shr:1
-  v = fmax(v, dpp_keep<0x112>(v));  // row_shr:2
-  v = fmax(v, dpp_keep<0x114>(v));  // row_shr:4
-  v = fmax(v, dpp_keep<0x118>(v));  // row_shr:8
-  return fmax(fmax(bcast(v, 15), bcast(v, 31)), fmax(bcast(v, 47), bcast(v, 63)));
+  float f = __double2float_ru(v);
+  int x = __float_as_int(f), t;
+  asm volatile(
+      "s_nop 1\n\t"
+      "v_max_f32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+      "s_nop 1\n\t"
+      "v_max_f32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+      "s_nop 1\n\t"
+      "v_max_f32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+      "s_nop 1\n\t"
+      "v_max_f32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+      "s_nop 1\n\t"
+      "v_max_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+      "s_nop 1\n\t"
+      "v_max_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+      "s_nop 1\n\t"
+      "v_readlane_b32 %1, %0, 63"
+      : "+v"(x), "=s"(t));
+  return (double)__int_as_float(t);
 }
 // Cross-lane reads must execute with EVERY lane active: a DPP / bpermute source lane that is masked off by EXEC
 // yields 0.  Never call these inside a lane-dependent branch or the lazy arm of a ?: - hoist the call into its own
@@ -96,7 +114,8 @@ __device__ inline double lane_above(double v) {  // value of lane+1
 // ds_bpermute with a per-lane source index, pinned for the same reason
 __device__ inline double shfl_all(double v, int src) { return pin(__shfl(v, src, 64)); }
 // x^p for the step-size heuristics (ev.cpp:497-505, 580-625): single precision is ample (the result only steers h)
-__device__ inline double fast_pow(double x, double p) { return (double)exp2f((float)p * log2f((float)x)); }
+__device__ inline double fast_root(double x, int n) { return (double)exp2f(log2f((float)x) * __frcp_rn((float)n)); }  // x^(1/n)
+__device__ inline double fast_powi(double x, int n) { return (double)exp2f(log2f((float)x) * (float)n); }                // x^n
 // 1/x: hardware v_rcp_f64 seed + two Newton-Raphson refinements (full double accuracy to ~1 ulp, no IEEE division
 // expansion with its denormal/scale handling on the critical path)
 // Hide a lane-dependent integer from loop-invariant code motion: without this, hipcc hoists the dozens of
@@ -123,90 +142,71 @@ enum Role : int {
   R_DELTA_B, R_THETA_B, R_DELTA_CDM, R_DELTA_UR, R_THETA_UR, R_SHEAR_UR, R_LUR /* l>=3 ur */, R_ETA
 };
 
-// Regime layout (all members wave-uniform).  The equations of pm.cpp:3302-3481 are placed CORE FIRST: the (at most 13)
-// densely coupled variables - densities, velocities, shears, polarisation l<=2, metric - occupy lanes 0..nc-1, then
-// the three free-streaming hierarchy tails (photon temperature l>=3, polarisation l>=3, ur l>=3) in ascending l.
+// Lane map.  One lane per equation of pm.cpp:3302-3481, at a FIXED lane whatever the approximation scheme: the (at most
+// 13) densely coupled variables - densities, velocities, shears, polarisation l<=2, metric - are the CORE in lanes
+// 0..12, followed by the three free-streaming hierarchy tails (photon temperature l>=3, polarisation l>=3, ur l>=3)
+// in ascending l.  A variable that the current scheme does not evolve keeps its lane with y = 0 and dy = 0 (an identity
+// row of the Newton matrix).  Fixed lanes make every broadcast of a named component a v_readlane with an immediate
+// lane number - no index arithmetic, no SGPRs holding a layout - and the hand-over between schemes the identity.
 // A tail is a tridiagonal chain that touches the core only through its l=3 element (l3 <-> shear / pol2): that
 // structure, fixed per regime and shared by all modes, is what the linear algebra below exploits.
+enum Lane : int { LN_DG = 0, LN_TG, LN_SG, LN_P0, LN_P1, LN_P2, LN_DB, LN_TB, LN_DC, LN_DUR, LN_TUR, LN_SUR, LN_ETA, NC = 13 };
+
 struct Layout {
-  int tca, rsa, ufa, neq, nc;
-  int dg, tg, sg, p0, p1, p2, db, tb, dc, dur, tur, sur, eta;  // core slots, -1 = absent
-  int g3, gN, q3, qN, u3, uN;                                  // tails: lane of l=3 and length (0 = absent)
+  int tca, rsa, ufa;
+  int g3, gN, q3, qN, u3, uN;  // tails: lane of l=3 and length (lengths are 0 when the scheme drops the tail)
   int lmg, lmp, lmu;
+  int maxlen;                  // longest tail present
 };
 
 __device__ __forceinline__ Layout make_layout(const PtParams& P, int tca, int rsa, int ufa) {
   Layout L;
   L.tca = tca; L.rsa = rsa; L.ufa = ufa;
-  L.dg = L.tg = L.sg = L.p0 = L.p1 = L.p2 = L.dc = L.dur = L.tur = L.sur = -1;
-  L.g3 = L.q3 = L.u3 = -1; L.gN = L.qN = L.uN = 0;
   L.lmg = P.l_max_g; L.lmp = P.l_max_pol_g; L.lmu = P.l_max_ur;
-  int i = 0;
-  if (!rsa) {
-    L.dg = i++; L.tg = i++;
-    if (!tca) { L.sg = i++; L.p0 = i++; L.p1 = i++; L.p2 = i++; }
-  }
-  L.db = i++; L.tb = i++;
-  if (P.has_cdm) L.dc = i++;
-  if (P.has_ur && !rsa) { L.dur = i++; L.tur = i++; L.sur = i++; }
-  L.eta = i++;
-  L.nc = i;
-  if (!rsa && !tca) {
-    L.g3 = i; L.gN = P.l_max_g - 2; i += L.gN;
-    L.q3 = i; L.qN = P.l_max_pol_g - 2; i += L.qN;
-  }
-  if (P.has_ur && !rsa && !ufa) { L.u3 = i; L.uN = P.l_max_ur - 2; i += L.uN; }
-  L.neq = i;
+  L.g3 = NC; L.q3 = L.g3 + (P.l_max_g - 2); L.u3 = L.q3 + (P.l_max_pol_g - 2);
+  const bool hi = !rsa && !tca;
+  L.gN = hi ? P.l_max_g - 2 : 0;
+  L.qN = hi ? P.l_max_pol_g - 2 : 0;
+  L.uN = (P.has_ur && !rsa && !ufa) ? P.l_max_ur - 2 : 0;
+  L.maxlen = max(L.gN, max(L.qN, L.uN));
   return L;
 }
 
-// (role, multipole) of equation i in layout L
-__device__ __forceinline__ void role_of(const Layout& L, int i, int* role, int* ell) {
-  *role = R_NONE; *ell = 0;
-  if (i < 0 || i >= L.neq) return;
-  if (i == L.dg) { *role = R_DELTA_G; return; }
-  if (i == L.tg) { *role = R_THETA_G; *ell = 1; return; }
-  if (i == L.sg) { *role = R_SHEAR_G; *ell = 2; return; }
-  if (i == L.p0) { *role = R_POL; *ell = 0; return; }
-  if (i == L.p1) { *role = R_POL; *ell = 1; return; }
-  if (i == L.p2) { *role = R_POL; *ell = 2; return; }
-  if (i == L.db) { *role = R_DELTA_B; return; }
-  if (i == L.tb) { *role = R_THETA_B; return; }
-  if (i == L.dc) { *role = R_DELTA_CDM; return; }
-  if (i == L.dur) { *role = R_DELTA_UR; return; }
-  if (i == L.tur) { *role = R_THETA_UR; *ell = 1; return; }
-  if (i == L.sur) { *role = R_SHEAR_UR; *ell = 2; return; }
-  if (i == L.eta) { *role = R_ETA; return; }
-  if (L.gN > 0 && i >= L.g3 && i < L.g3 + L.gN) { *role = R_LG; *ell = 3 + (i - L.g3); return; }
-  if (L.qN > 0 && i >= L.q3 && i < L.q3 + L.qN) { *role = R_POL; *ell = 3 + (i - L.q3); return; }
-  if (L.uN > 0 && i >= L.u3 && i < L.u3 + L.uN) { *role = R_LUR; *ell = 3 + (i - L.u3); return; }
-}
-// inverse: lane of (role, ell) in layout L, -1 if absent
-__device__ __forceinline__ int index_of(const Layout& L, int role, int ell) {
-  switch (role) {
-    case R_DELTA_G: return L.dg;
-    case R_THETA_G: return L.tg;
-    case R_SHEAR_G: return L.sg;
-    case R_LG: return (L.gN > 0 && ell >= 3 && ell <= L.lmg) ? L.g3 + ell - 3 : -1;
-    case R_POL:
-      if (ell == 0) return L.p0;
-      if (ell == 1) return L.p1;
-      if (ell == 2) return L.p2;
-      return (L.qN > 0 && ell <= L.lmp) ? L.q3 + ell - 3 : -1;
-    case R_DELTA_B: return L.db;
-    case R_THETA_B: return L.tb;
-    case R_DELTA_CDM: return L.dc;
-    case R_DELTA_UR: return L.dur;
-    case R_THETA_UR: return L.tur;
-    case R_SHEAR_UR: return L.sur;
-    case R_LUR: return (L.uN > 0 && ell >= 3 && ell <= L.lmu) ? L.u3 + ell - 3 : -1;
-    case R_ETA: return L.eta;
-    default: return -1;
+// is core variable `i` evolved in this scheme?  (i wave-uniform)
+__device__ __forceinline__ bool core_present(const PtParams& P, const Layout& L, int i) {
+  switch (i) {
+    case LN_DG: case LN_TG: return !L.rsa;
+    case LN_SG: case LN_P0: case LN_P1: case LN_P2: return !L.rsa && !L.tca;
+    case LN_DC: return P.has_cdm != 0;
+    case LN_DUR: case LN_TUR: case LN_SUR: return P.has_ur && !L.rsa;
+    default: return true;  // delta_b, theta_b, eta
   }
 }
-// index of (role, ell) in the REFERENCE's ordering of the same regime (pm.cpp:3302-3481): only the unit-test hook
-// cpt_dbg_derivs needs it, to exchange y / dy with the oracle in the reference's order
-__device__ __forceinline__ int ref_index_of(const PtParams& P, int tca, int rsa, int ufa, int role, int ell) {
+
+// (role, multipole) of lane i in the current scheme; R_NONE = not evolved
+__device__ __forceinline__ void role_of(const PtParams& P, const Layout& L, int i, int* role, int* ell) {
+  *role = R_NONE; *ell = 0;
+  const bool g = !L.rsa, hi = !L.rsa && !L.tca, ur = P.has_ur && !L.rsa;
+  if (i == LN_DG) { if (g) *role = R_DELTA_G; return; }
+  if (i == LN_TG) { if (g) { *role = R_THETA_G; *ell = 1; } return; }
+  if (i == LN_SG) { if (hi) { *role = R_SHEAR_G; *ell = 2; } return; }
+  if (i == LN_P0) { if (hi) { *role = R_POL; *ell = 0; } return; }
+  if (i == LN_P1) { if (hi) { *role = R_POL; *ell = 1; } return; }
+  if (i == LN_P2) { if (hi) { *role = R_POL; *ell = 2; } return; }
+  if (i == LN_DB) { *role = R_DELTA_B; return; }
+  if (i == LN_TB) { *role = R_THETA_B; return; }
+  if (i == LN_DC) { if (P.has_cdm) *role = R_DELTA_CDM; return; }
+  if (i == LN_DUR) { if (ur) *role = R_DELTA_UR; return; }
+  if (i == LN_TUR) { if (ur) { *role = R_THETA_UR; *ell = 1; } return; }
+  if (i == LN_SUR) { if (ur) { *role = R_SHEAR_UR; *ell = 2; } return; }
+  if (i == LN_ETA) { *role = R_ETA; return; }
+  if (i >= L.g3 && i < L.g3 + L.gN) { *role = R_LG; *ell = 3 + (i - L.g3); return; }
+  if (i >= L.q3 && i < L.q3 + L.qN) { *role = R_POL; *ell = 3 + (i - L.q3); return; }
+  if (i >= L.u3 && i < L.u3 + L.uN) { *role = R_LUR; *ell = 3 + (i - L.u3); return; }
+}
+// index of (role, ell) in the REFERENCE's ordering of the same regime (pm.cpp:3302-3481): only the unit-test hooks
+// cpt_dbg_derivs / cpt_dbg_solve need it, to exchange vectors with the oracle in the reference's order
+__device__ __forceinline__ int ref_index_of(const PtParams& P, int tca, int rsa, int ufa, int role, int ell, int* neq) {
   int i = 0, dg = -1, tg = -1, sg = -1, l3g = -1, pol0 = -1, db, tb, dc = -1, dur = -1, tur = -1, sur = -1, l3ur = -1, eta;
   if (!rsa) {
     dg = i++; tg = i++;
@@ -216,6 +216,7 @@ __device__ __forceinline__ int ref_index_of(const PtParams& P, int tca, int rsa,
   if (P.has_cdm) dc = i++;
   if (P.has_ur && !rsa) { dur = i++; tur = i++; sur = i++; if (!ufa) { l3ur = i; i += P.l_max_ur - 2; } }
   eta = i++;
+  *neq = i;
   switch (role) {
     case R_DELTA_G: return dg;
     case R_THETA_G: return tg;
@@ -233,6 +234,17 @@ __device__ __forceinline__ int ref_index_of(const PtParams& P, int tca, int rsa,
     default: return -1;
   }
 }
+
+#ifdef CPT_PROFILE
+__device__ unsigned long long g_prof[16];
+#define PROF_DECL unsigned long long pf_t0 = 0
+#define PROF_START() pf_t0 = clock64()
+#define PROF_STOP(slot) prof[slot] += clock64() - pf_t0
+#else
+#define PROF_DECL
+#define PROF_START()
+#define PROF_STOP(slot)
+#endif
 
 // ---- spline tables ------------------------------------------------------------------------------
 struct BgV { double a, H, Hp, rg, rb, rc, ru; };
@@ -287,31 +299,57 @@ struct Lookup {
   double2* bgw;                    // LDS [64][BG_NCOL]
   double2* thw;                    // LDS [64][TH_NCOL]
   double tau_cached;
-  BgV bg;
-  ThV th;
+  // lane c: column c of the background / thermodynamics row at tau_cached.  Values only the sampler needs (a, H',
+  // e^-kappa, g, g') are extracted from these on demand instead of occupying registers through the step loop.
+  double vbg, vth;
+  double rg, rb, rc, ru, kap, ddkappa, cb2;  // what every RHS evaluation needs (wave-uniform)
   // derived, tau-only
-  double a2, aH, two_over_aH, R, inv_1pR, inv_R, tau_c, dtau_c, F, Fp, app, inv_tau, aHp;
+  double a2, aH, two_over_aH, R, inv_1pR, inv_R, tau_c, dtau_c, F, Fp, app, inv_tau, rg43, ru43;
+  double zmax, xe_last, taud_last;  // last row of the thermodynamics table (analytic continuation beyond it)
+#ifdef CPT_PROFILE
+  unsigned long long* prof;
+#endif
 };
 
-__device__ __forceinline__ void window_stage(const double* __restrict__ x, const double2* __restrict__ rows, int n, int ncol,
-                                             int base, int lane, double* xw, double2* w) {
+// All NCOL loads are issued before the first LDS store (one HBM/L2 round trip per restage, not NCOL of them); rows past
+// the end of the table are clamped to the last row - their abscissa is +huge, so they are never selected.
+template <int NCOL>
+__device__ __forceinline__ void window_stage(const double* __restrict__ x, const double2* __restrict__ rows, int n, int base, int lane,
+                                             double* xw, double2* w) {
   const int i = base + lane;
-  *xw = (i < n) ? x[i] : 1e300;
-  const size_t g0 = (size_t)base * ncol, gend = (size_t)n * ncol;
-  for (int e = lane; e < 64 * ncol; e += 64) w[e] = (g0 + e < gend) ? rows[g0 + e] : make_double2(0., 0.);
+  const double xv = x[min(i, n - 1)];
+  const size_t g0 = (size_t)base * NCOL, glast = (size_t)n * NCOL - 1;
+  double2 tmp[NCOL];
+#pragma unroll
+  for (int c = 0; c < NCOL; c++) tmp[c] = rows[min(g0 + (size_t)(lane + 64 * c), glast)];
+  *xw = (i < n) ? xv : 1e300;
+#pragma unroll
+  for (int c = 0; c < NCOL; c++) w[lane + 64 * c] = tmp[c];
 }
 
-// returns inf with x[inf] <= v <= x[inf+1] (x ascending), re-staging the 64-row window when v leaves it
-__device__ __forceinline__ int window_find(const double* __restrict__ x, const double2* __restrict__ rows, int n, int ncol, double v,
+// returns inf with x[inf] <= v <= x[inf+1] (x ascending), re-staging the 64-row window when v leaves it.
+// The integration walks through the tables monotonically, so the window that v left is almost always adjacent to the
+// one it entered: slide by one window (keeping `bias` rows on the side the wave comes from) and only fall back to the
+// binary search - 15 dependent global loads, microseconds - after a jump (first lookup, hand-over to a new mode).
+template <int NCOL>
+__device__ __forceinline__ int window_find(const double* __restrict__ x, const double2* __restrict__ rows, int n, double v,
                                            int lane, double* xw, double2* w, int* base, int bias) {
-  const double lo = bcast(*xw, 0), hi = bcast(*xw, 63);
+  double lo = bcast(*xw, 0), hi = bcast(*xw, 63);
   if (!(v >= lo && v < hi)) {
-    int inf = bsearch_up(x, n, v);  // uniform
-    int nb = inf - bias;
+    int nb = (v >= hi) ? *base + 63 - bias : *base - 63 + (63 - bias);   // slide up / down
     if (nb > n - 64) nb = n - 64;
     if (nb < 0) nb = 0;
     *base = nb;
-    window_stage(x, rows, n, ncol, nb, lane, xw, w);
+    window_stage<NCOL>(x, rows, n, nb, lane, xw, w);
+    lo = bcast(*xw, 0); hi = bcast(*xw, 63);
+    if (!(v >= lo && v < hi) && !(nb == 0 && v < lo) && !(nb == n - 64 && v >= hi)) {
+      const int inf = bsearch_up(x, n, v);  // uniform
+      nb = inf - bias;
+      if (nb > n - 64) nb = n - 64;
+      if (nb < 0) nb = 0;
+      *base = nb;
+      window_stage<NCOL>(x, rows, n, nb, lane, xw, w);
+    }
   }
   const unsigned long long m = __ballot(*xw <= v);
   int inf = *base + __popcll(m) - 1;
@@ -323,9 +361,13 @@ __device__ __forceinline__ int window_find(const double* __restrict__ x, const d
 __device__ __forceinline__ void lookup_init(const PtParams& P, Lookup& Q, double2* bgw, double2* thw, int lane) {
   Q.bgw = bgw; Q.thw = thw;
   Q.bg_base = 0; Q.th_base = 0; Q.bg_inf = -1; Q.th_inf = -1; Q.tau_cached = -1.;
-  window_stage(P.tabs.tau_table, (const double2*)P.tabs.bg, P.tabs.bt_size, BG_NCOL, 0, lane, &Q.bgx, bgw);
-  window_stage(P.tabs.z_table, (const double2*)P.tabs.th, P.tabs.tt_size, TH_NCOL, 0, lane, &Q.thx, thw);
+  window_stage<BG_NCOL>(P.tabs.tau_table, (const double2*)P.tabs.bg, P.tabs.bt_size, 0, lane, &Q.bgx, bgw);
+  window_stage<TH_NCOL>(P.tabs.z_table, (const double2*)P.tabs.th, P.tabs.tt_size, 0, lane, &Q.thx, thw);
   Q.bg_lo = Q.bg_hi = Q.th_lo = Q.th_hi = make_double2(0., 0.);
+  const double2* last = (const double2*)P.tabs.th + (size_t)(P.tabs.tt_size - 1) * TH_NCOL;
+  Q.zmax = P.tabs.z_table[P.tabs.tt_size - 1];
+  Q.xe_last = last[TH_XE].x;
+  Q.taud_last = last[TH_TAU_D].x;
 }
 
 // background_at_tau (normal_info, source/background_module.cpp:125-199) + thermodynamics_at_z (th.cpp:114-285)
@@ -333,7 +375,7 @@ __device__ __forceinline__ void lookup(const PtParams& P, Lookup& Q, double tau,
   if (tau == Q.tau_cached) return;
   Q.tau_cached = tau;
   const DevTables& T = P.tabs;
-  const int inf = window_find(T.tau_table, (const double2*)T.bg, T.bt_size, BG_NCOL, tau, lane, &Q.bgx, Q.bgw, &Q.bg_base, 8);
+  const int inf = window_find<BG_NCOL>(T.tau_table, (const double2*)T.bg, T.bt_size, tau, lane, &Q.bgx, Q.bgw, &Q.bg_base, 8);
   if (inf != Q.bg_inf) {
     Q.bg_inf = inf;
     if (lane < BG_NCOL) {
@@ -344,30 +386,28 @@ __device__ __forceinline__ void lookup(const PtParams& P, Lookup& Q, double tau,
   }
   {
     const double x0 = bcast(Q.bgx, inf - Q.bg_base), x1 = bcast(Q.bgx, inf - Q.bg_base + 1);
-    const double h = x1 - x0, b = (tau - x0) / h, a = 1. - b;
-    const double v = spl2(Q.bg_lo, Q.bg_hi, a, b, h * h / 6.);
-    Q.bg.a = bcast(v, BG_A); Q.bg.H = bcast(v, BG_H); Q.bg.Hp = bcast(v, BG_HP); Q.bg.rg = bcast(v, BG_RHO_G);
-    Q.bg.rb = bcast(v, BG_RHO_B); Q.bg.rc = bcast(v, BG_RHO_CDM); Q.bg.ru = bcast(v, BG_RHO_UR);
+    const double h = x1 - x0, b = (tau - x0) * fast_rcp(h), a = 1. - b;
+    Q.vbg = spl2(Q.bg_lo, Q.bg_hi, a, b, h * h / 6.);
   }
-  const double inv_a = 1. / Q.bg.a;
+  const double bg_a = bcast(Q.vbg, BG_A), bg_H = bcast(Q.vbg, BG_H), bg_Hp = bcast(Q.vbg, BG_HP);
+  Q.rg = bcast(Q.vbg, BG_RHO_G); Q.rb = bcast(Q.vbg, BG_RHO_B); Q.rc = bcast(Q.vbg, BG_RHO_CDM); Q.ru = bcast(Q.vbg, BG_RHO_UR);
+  const double inv_a = fast_rcp(bg_a);
   const double z = inv_a - 1.;
-  const double zmax = T.z_table[T.tt_size - 1];
-  ThV& t = Q.th;
+  const double zmax = Q.zmax;
   if (z >= zmax) {  // analytic extrapolation, th.cpp:128-219
-    const double2* last = (const double2*)T.th + (size_t)(T.tt_size - 1) * TH_NCOL;
-    const double x0 = last[TH_XE].x;
-    t.xe = x0;
-    t.dkappa = (1. + z) * (1. + z) * P.n_e * x0 * SIGMA_T * MPC_OVER_M;
+    const double x0 = Q.xe_last, inv_1pz = fast_rcp(1. + z);
+    const double dk = (1. + z) * (1. + z) * P.n_e * x0 * SIGMA_T * MPC_OVER_M;
     const double r = (1. + z) / (1. + zmax);
-    t.tau_d = last[TH_TAU_D].x * r * r;
-    t.ddkappa = -Q.bg.H * 2. / (1. + z) * t.dkappa;
-    t.dddkappa = (Q.bg.H * Q.bg.H / (1. + z) - Q.bg.Hp) * 2. / (1. + z) * t.dkappa;
-    t.expmk = 0.; t.g = 0.; t.dg = 0.;
+    const double ddk = -bg_H * 2. * inv_1pz * dk;
+    const double dddk = (bg_H * bg_H * inv_1pz - bg_Hp) * 2. * inv_1pz * dk;
     const double wb = K_B / (C_LIGHT * C_LIGHT * M_H) * (1. + (1. / NOT4 - 1.) * P.YHe + x0 * (1. - P.YHe)) * P.T_cmb * (1. + z);
-    t.cb2 = wb * 4. / 3.;
+    Q.kap = dk; Q.ddkappa = ddk; Q.cb2 = wb * 4. / 3.;
+    const int c = opaque(lane);
+    Q.vth = (c == TH_XE) ? x0 : (c == TH_DKAPPA) ? dk : (c == TH_TAU_D) ? Q.taud_last * r * r : (c == TH_DDKAPPA) ? ddk :
+            (c == TH_DDDKAPPA) ? dddk : (c == TH_CB2) ? Q.cb2 : 0.;   // e^-kappa = g = g' = 0
     Q.th_inf = -1;
   } else {
-    const int iz = window_find(T.z_table, (const double2*)T.th, T.tt_size, TH_NCOL, z, lane, &Q.thx, Q.thw, &Q.th_base, 54);
+    const int iz = window_find<TH_NCOL>(T.z_table, (const double2*)T.th, T.tt_size, z, lane, &Q.thx, Q.thw, &Q.th_base, 54);
     if (iz != Q.th_inf) {
       Q.th_inf = iz;
       if (lane < TH_NCOL) {
@@ -377,70 +417,125 @@ __device__ __forceinline__ void lookup(const PtParams& P, Lookup& Q, double tau,
       }
     }
     const double x0 = bcast(Q.thx, iz - Q.th_base), x1 = bcast(Q.thx, iz - Q.th_base + 1);
-    const double h = x1 - x0, b = (z - x0) / h, a = 1. - b;
-    const double v = spl2(Q.th_lo, Q.th_hi, a, b, h * h / 6.);
-    t.xe = bcast(v, TH_XE); t.dkappa = bcast(v, TH_DKAPPA); t.tau_d = bcast(v, TH_TAU_D); t.ddkappa = bcast(v, TH_DDKAPPA);
-    t.dddkappa = bcast(v, TH_DDDKAPPA); t.expmk = bcast(v, TH_EXPMK); t.g = bcast(v, TH_G); t.dg = bcast(v, TH_DG);
-    t.cb2 = bcast(v, TH_CB2);
+    const double h = x1 - x0, b = (z - x0) * fast_rcp(h), a = 1. - b;
+    Q.vth = spl2(Q.th_lo, Q.th_hi, a, b, h * h / 6.);
+    Q.kap = bcast(Q.vth, TH_DKAPPA); Q.ddkappa = bcast(Q.vth, TH_DDKAPPA); Q.cb2 = bcast(Q.vth, TH_CB2);
   }
-  // tau-only derived quantities (one division each, shared by every RHS evaluation at this tau)
-  const BgV& bg = Q.bg;
-  Q.a2 = bg.a * bg.a;
-  Q.aH = bg.a * bg.H;
-  Q.two_over_aH = 2.0 / Q.aH;
-  Q.R = 4. / 3. * bg.rg / bg.rb;
-  Q.inv_1pR = 1.0 / (1.0 + Q.R);
-  Q.inv_R = 1.0 / Q.R;
-  Q.tau_c = 1.0 / t.dkappa;                      // pm.cpp:9290-9297
-  Q.dtau_c = -t.ddkappa * Q.tau_c * Q.tau_c;
+  // tau-only derived quantities (shared by every RHS evaluation at this tau); reciprocals by v_rcp_f64 + Newton
+  Q.a2 = bg_a * bg_a;
+  Q.aH = bg_a * bg_H;
+  Q.two_over_aH = 2.0 * fast_rcp(Q.aH);
+  Q.rg43 = 4. / 3. * Q.rg;
+  Q.ru43 = 4. / 3. * Q.ru;
+  Q.R = Q.rg43 * fast_rcp(Q.rb);
+  Q.inv_1pR = fast_rcp(1.0 + Q.R);
+  Q.inv_R = fast_rcp(Q.R);
+  Q.tau_c = fast_rcp(Q.kap);                     // pm.cpp:9290-9297
+  Q.dtau_c = -Q.ddkappa * Q.tau_c * Q.tau_c;
   Q.F = Q.tau_c * Q.inv_1pR;
   Q.Fp = Q.dtau_c * Q.inv_1pR + Q.tau_c * Q.aH * Q.R * Q.inv_1pR * Q.inv_1pR;
-  Q.app = bg.Hp * bg.a + 2. * Q.aH * Q.aH;       // a''/a
-  Q.aHp = bg.Hp * bg.a + Q.aH * Q.aH;            // (a'/a)'
-  Q.inv_tau = 1.0 / tau;
+  Q.app = bg_Hp * bg_a + 2. * Q.aH * Q.aH;       // a''/a
+  Q.inv_tau = fast_rcp(tau);
 }
 
 // ---- physics ------------------------------------------------------------------------------------
-// Per-lane description of the current regime.
-//   tails:  dy_l = A y_{l-1} - B y_{l+1} - (D kappa' + G/tau) y_l     (y_{l-1} of the l=3 element is a core variable)
-//   core:   explicit equations, computed wave-uniformly and selected by role
-// chain: 0 = core, 1 = photon temperature tail, 2 = polarisation tail, 3 = ur tail.
+// Per-lane description of the current regime.  EVERY equation of the scalar system has the shape
+//   dy = A y[dn] - B y[up] - (D kappa' + G/tau) y + Xmc h'/2 + Xms k^2 alpha + XP kappa' Pi/8... + X4 S4 + Xeta eta' + Xtb theta_b'
+// with per-lane constants (A, B, D, G, X*, dn, up) fixed by the regime and a handful of wave-uniform scalars (the
+// metric perturbations, the polarisation source, the baryon-photon coupling) that depend on (tau, y):
+//   * the streaming terms A y[dn] - B y[up] couple neighbours of one multipole ladder (delta, theta, shear, l=3, ...);
+//     dn / up are lane addresses, so a ladder may jump from its core part (lanes < nc) to its tail;
+//   * the RHS is then two ds_bpermute, a dozen v_readlane, the wave-uniform Einstein / tight-coupling algebra and
+//     nine fused multiply-adds: no lane-dependent branch at all.
+// chain: 0 = core, 1 = photon temperature tail, 2 = polarisation tail, 3 = ur tail (l >= 3 elements).
 struct LaneEq {
   int role, ell, chain;
-  bool first, last;  // l == 3 / l == l_max of a tail
+  bool first, last;    // l == 3 / l == l_max of a tail
+  int dn, up;          // byte address (lane * 4) of the lanes holding y_{l-1} / y_{l+1}
+  int first_addr;      // core parents of a tail (shear_g, pol2, shear_ur): byte address of the tail's l=3 lane; else own lane
+  int parent_addr;     // tail lanes: byte address of the core parent; else own lane
+  double Bpar;         // core parents of a present tail: B (their coupling to the tail's l=3 element); else 0
   double A, B, D, G;
+  double Xmc, Xms, XP, X4, Xeta, Xtb;
 };
 
 __device__ __forceinline__ LaneEq make_lane_eq(const PtParams& P, const Layout& L, int lane, double k) {
   LaneEq e;
-  role_of(L, lane, &e.role, &e.ell);
+  role_of(P, L, lane, &e.role, &e.ell);
   e.A = e.B = e.D = e.G = 0.;
+  e.Xmc = e.Xms = e.XP = e.X4 = e.Xeta = e.Xtb = 0.;
   e.chain = 0; e.first = false; e.last = false;
+  int dn = lane, up = lane;
   const int l = e.ell;
-  int lm = 0;
-  if (e.role == R_LG) { e.chain = 1; lm = L.lmg; e.D = 1.; }
-  else if (e.role == R_POL && l >= 3) { e.chain = 2; lm = L.lmp; e.D = 1.; }
-  else if (e.role == R_LUR) { e.chain = 3; lm = L.lmu; }
+  const double k2 = k * k, c3 = P.three_ceff2_ur, v3 = P.three_cvis2_ur;
+  int lm = 0, parent = lane;
+  if (e.role == R_LG) { e.chain = 1; lm = L.lmg; e.D = 1.; parent = LN_SG; }
+  else if (e.role == R_POL && l >= 3) { e.chain = 2; lm = L.lmp; e.D = 1.; parent = LN_P2; }
+  else if (e.role == R_LUR) { e.chain = 3; lm = L.lmu; parent = LN_SUR; }
   if (e.chain) {
     e.first = (l == 3); e.last = (l == lm);
+    dn = e.first ? parent : lane - 1;
+    up = e.last ? lane : lane + 1;
     if (l == 3 && e.chain != 2) { e.A = 6. * k / 7.; e.B = 4. * k / 7.; }     // pm.cpp:8158-8161: F_2 = 2 shear
     else if (l < lm) { e.A = k * l / (2. * l + 1.); e.B = k * (l + 1.) / (2. * l + 1.); }
     else { e.A = k; e.G = 1. + l; }                                             // pm.cpp:8171-8176, cotKgen = 1/(k tau)
   } else {
-    // coupling of the core "parent" of a tail to the tail's first element: -B y_{l=3}
-    if (e.role == R_SHEAR_G) e.B = 0.3 * k;                                     // pm.cpp:8151-8155
-    else if (e.role == R_POL && l == 2) e.B = 3. * k / 5.;                      // pm.cpp:8191-8193
-    else if (e.role == R_SHEAR_UR && !L.ufa) e.B = 0.3 * k;                     // pm.cpp:8645-8651
+    switch (e.role) {
+      case R_DELTA_G: e.B = 4. / 3.; up = LN_TG; e.Xmc = -4. / 3.; break;                                 // pm.cpp:8095
+      case R_THETA_G:
+        if (!L.tca) { e.A = 0.25 * k2; dn = LN_DG; e.B = k2; up = LN_SG; e.D = 1.; }                       // pm.cpp:8145-8148
+        e.X4 = 1.;                           // S4 = kappa' theta_b, or the whole tight-coupling expression (pm.cpp:8214-8217)
+        break;
+      case R_SHEAR_G:                                                                                    // pm.cpp:8151-8155
+        e.A = 4. / 15.; dn = LN_TG; e.D = 1.; e.Xms = 4. / 15.; e.XP = 0.4;
+        if (L.gN > 0) { e.B = 0.3 * k; up = L.g3; }
+        break;
+      case R_POL:
+        if (l == 0) { e.B = k; up = LN_P1; e.D = 1.; e.XP = 4.; }                                         // pm.cpp:8179-8181
+        else if (l == 1) { e.A = k / 3.; dn = LN_P0; e.B = 2. * k / 3.; up = LN_P2; e.D = 1.; }            // pm.cpp:8184-8186
+        else { e.A = 2. * k / 5.; dn = LN_P1; e.D = 1.; e.XP = 0.8; if (L.qN > 0) { e.B = 3. * k / 5.; up = L.q3; } }  // :8189-8191
+        break;
+      case R_DELTA_B: e.B = 1.; up = LN_TB; e.Xmc = -1.; break;                                           // pm.cpp:8101
+      case R_THETA_B: e.Xtb = 1.; break;
+      case R_DELTA_CDM: e.Xmc = -1.; break;                                                              // pm.cpp:8240
+      case R_DELTA_UR: e.B = 4. / 3.; up = LN_TUR; e.Xmc = -4. / 3.; break;                               // pm.cpp:8630-8634
+      case R_THETA_UR: e.A = 0.25 * c3 * k2; dn = LN_DUR; e.B = k2; up = LN_SUR; break;                    // pm.cpp:8637-8641
+      case R_SHEAR_UR:
+        dn = LN_TUR;
+        if (!L.ufa) { e.A = 4. / 15. * v3; e.Xms = 4. / 15. * v3; if (L.uN > 0) { e.B = 0.3 * k; up = L.u3; } }  // pm.cpp:8645-8651
+        else {                                                                                           // pm.cpp:8704-8708
+          e.A = 2. / 3.;
+          if (P.ufa_method == CPT_UFA_CLASS) { e.G = 3.; e.Xmc = 2. / 3.; }
+          else if (P.ufa_method == CPT_UFA_MB) { e.G = 3.; e.Xms = 2. / 3.; }
+          else e.Xms = 2. / 3.;                                                 // ufa_hu: -3 a'/a shear added in rhs
+        }
+        break;
+      case R_ETA: e.Xeta = 1.; break;                                                                    // pm.cpp:8896
+      default: break;
+    }
   }
+  e.dn = dn * 4;
+  e.up = up * 4;
+  e.parent_addr = parent * 4;
+  const bool is_parent = (lane < NC) && (up >= NC);   // its ladder continues in a tail
+  e.first_addr = (is_parent ? up : lane) * 4;
+  e.Bpar = is_parent ? e.B : 0.;
   return e;
 }
 
 // metric + fluid summary left behind by the last RHS evaluation (struct perturb_workspace of the reference)
 struct Metric {
-  double hp, etap, alpha, alphap, delta_m;
+  double hp, etap, alpha, alphap;
   double rsa_dg, rsa_tg;
   double tca_shear_g;
 };
+
+// y of another lane (per-lane byte address): two ds_bpermute_b32, executed by every lane
+__device__ __forceinline__ double gather(double v, int addr) {
+  const int lo = __builtin_amdgcn_ds_bpermute(addr, __double2loint(v));
+  const int hi = __builtin_amdgcn_ds_bpermute(addr, __double2hiint(v));
+  return pin(__hiloint2double(hi, lo));
+}
 
 // perturb_derivs (pm.cpp:7861-9218) with perturb_total_stress_energy + perturb_einstein (pm.cpp:6047-6703, 5840-6045),
 // perturb_rsa_delta_and_theta (pm.cpp:9530-9636) and perturb_tca_slip_and_shear (pm.cpp:9229-9516) folded in;
@@ -448,27 +543,35 @@ struct Metric {
 // Returns dy of this lane and leaves M describing the state (tau, y).
 __device__ __forceinline__ double rhs(const PtParams& P, const Layout& L, const LaneEq& e, Lookup& Q, Metric& M, double k,
                                       double inv_k2, double tau, double y, int lane) {
+#ifdef CPT_PROFILE
+  unsigned long long* prof = Q.prof;
+  PROF_DECL;
+  PROF_START();
+#endif
   lookup(P, Q, tau, lane);
-  const BgV& bg = Q.bg; const ThV& th = Q.th;
-  const double a2 = Q.a2, aH = Q.aH, k2 = k * k, R = Q.R, kap = th.dkappa;
+#ifdef CPT_PROFILE
+  PROF_STOP(8); PROF_START();
+#endif
+  // neighbours on the multipole ladders: issued first, their LDS-crossbar latency hides behind the scalar algebra
+  const double ym = gather(y, e.dn);
+  const double yp = gather(y, e.up);
+  const double a2 = Q.a2, aH = Q.aH, k2 = k * k, R = Q.R, kap = Q.kap;
   // ---- named components ----
-  double dg = 0., tg = 0., sg = 0., p0 = 0., p1 = 0., p2 = 0., dur = 0., tur = 0., sur = 0.;
-  double g3 = 0., q3 = 0., u3 = 0.;  // first elements of the tails
-  if (!L.rsa) {
-    dg = bcast(y, L.dg); tg = bcast(y, L.tg);
-    if (!L.tca) { sg = bcast(y, L.sg); p0 = bcast(y, L.p0); p1 = bcast(y, L.p1); p2 = bcast(y, L.p2); g3 = bcast(y, L.g3); q3 = bcast(y, L.q3); }
-  }
-  if (P.has_ur && !L.rsa) { dur = bcast(y, L.dur); tur = bcast(y, L.tur); sur = bcast(y, L.sur); if (!L.ufa) u3 = bcast(y, L.u3); }
-  const double db = bcast(y, L.db), tb = bcast(y, L.tb), eta = bcast(y, L.eta);
-  const double dc = P.has_cdm ? bcast(y, L.dc) : 0.;
-  const double cb2 = th.cb2;
+  // (a variable the scheme does not evolve reads as 0 from its idle lane)
+  double dg = bcast(y, LN_DG), tg = bcast(y, LN_TG);
+  const double sg = bcast(y, LN_SG), p0 = bcast(y, LN_P0), p2 = bcast(y, LN_P2);
+  const double dur = bcast(y, LN_DUR), tur = bcast(y, LN_TUR), sur = bcast(y, LN_SUR);
+  const double db = bcast(y, LN_DB), tb = bcast(y, LN_TB), eta = bcast(y, LN_ETA), dc = bcast(y, LN_DC);
+  const double cb2 = Q.cb2;
+#ifdef CPT_PROFILE
+  PROF_STOP(9); PROF_START();
+#endif
   // ---- stress-energy sums ----
-  double delta_rho = bg.rg * dg + bg.rb * db;
-  double rpt = 4. / 3. * bg.rg * tg + bg.rb * tb;
-  double rps = 4. / 3. * bg.rg * sg;
-  double delta_rho_m = bg.rb * db, rho_m = bg.rb;
-  if (P.has_cdm) { delta_rho += bg.rc * dc; delta_rho_m += bg.rc * dc; rho_m += bg.rc; }
-  if (P.has_ur) { delta_rho += bg.ru * dur; rpt += 4. / 3. * bg.ru * tur; rps += 4. / 3. * bg.ru * sur; }
+  double delta_rho = Q.rg * dg + Q.rb * db;
+  double rpt = Q.rg43 * tg + Q.rb * tb;
+  double rps = Q.rg43 * sg;
+  if (P.has_cdm) delta_rho += Q.rc * dc;
+  if (P.has_ur) { delta_rho += Q.ru * dur; rpt += Q.ru43 * tur; rps += Q.ru43 * sur; }
   // ---- Einstein equations ----
   const double hp = (k2 * eta + 1.5 * a2 * delta_rho) * Q.two_over_aH;
   if (L.rsa) {
@@ -476,83 +579,66 @@ __device__ __forceinline__ double rhs(const PtParams& P, const Layout& L, const 
     if (P.rsa_method != CPT_RSA_NULL) { rdg = 4. * inv_k2 * (aH * hp - k2 * eta); rtg = -0.5 * hp; }
     if (P.rsa_method == CPT_RSA_MD_WITH_REIO) {
       rdg += -4. * inv_k2 * kap * (tb + 0.5 * hp);
-      rtg += 3. * inv_k2 * (th.ddkappa * (tb + 0.5 * hp) + kap * (-aH * tb + cb2 * k2 * db - aH * hp + k2 * eta));
+      rtg += 3. * inv_k2 * (Q.ddkappa * (tb + 0.5 * hp) + kap * (-aH * tb + cb2 * k2 * db - aH * hp + k2 * eta));
     }
     if (P.has_ur && P.rsa_method != CPT_RSA_NULL) { rdur = 4. * inv_k2 * (aH * hp - k2 * eta); rtur = -0.5 * hp; }
-    delta_rho += bg.rg * rdg;
-    rpt += 4. / 3. * bg.rg * rtg;
-    if (P.has_ur) { delta_rho += bg.ru * rdur; rpt += 4. / 3. * bg.ru * rtur; }
+    delta_rho += Q.rg * rdg;
+    rpt += Q.rg43 * rtg;
+    if (P.has_ur) { delta_rho += Q.ru * rdur; rpt += Q.ru43 * rtur; }
     M.rsa_dg = rdg; M.rsa_tg = rtg;
     dg = rdg; tg = rtg;  // pm.cpp:8085-8088: the equations below use the streaming values
   }
   const double etap = 1.5 * a2 * rpt * inv_k2;
   const double alpha = (hp + 6. * etap) * 0.5 * inv_k2;
-  if (L.tca) rps += 4. / 3. * bg.rg * (16. / 45. * Q.tau_c * (tg + k2 * alpha));
+  if (L.tca) rps += Q.rg43 * (16. / 45. * Q.tau_c * (tg + k2 * alpha));
   const double alphap = -2. * aH * alpha + eta - 4.5 * (a2 * inv_k2) * rps;
   M.hp = hp; M.etap = etap; M.alpha = alpha; M.alphap = alphap;
-  M.delta_m = (delta_rho_m + 3. * aH * (bg.rb * tb) * inv_k2) / rho_m;  // pm.cpp:6573, 5979-5981
   const double mc = 0.5 * hp;   // metric_continuity
   const double ms = k2 * alpha; // metric_shear
   // ---- baryon velocity / tight coupling ----
-  double dtb, tca_shear = 0.;
+  double dtb, S4;
   if (!L.tca) {
     dtb = -aH * tb + k2 * cb2 * db + R * kap * (tg - tb);  // pm.cpp:8108-8113
+    S4 = kap * tb;
   } else {
     const double tau_c = Q.tau_c, dtau_c = Q.dtau_c, F = Q.F;
     double slip = (dtau_c * kap - 2. * aH * Q.inv_1pR) * (tb - tg) +
-                  F * (-Q.app * tb + k2 * (-aH * dg * 0.5 + cb2 * (-tb - mc) - (-tg - mc) / 3.));
+                  F * (-Q.app * tb + k2 * (-aH * dg * 0.5 + cb2 * (-tb - mc) - (-tg - mc) * (1. / 3.)));
     double shear = 16. / 45. * tau_c * (tg + ms);
     const double theta_prime = (-aH * tb + k2 * (cb2 * db + R * 0.25 * dg)) * Q.inv_1pR;
     const double msp = k2 * alphap;
     const double shear_prime = 16. / 45. * (tau_c * (theta_prime + msp) + dtau_c * (tg + ms));
     if (P.tca_method == CPT_TCA_COMPROMISE_CLASS) {
       slip = (1. - 2. * aH * F) * slip + F * k2 * (2. * aH * shear + shear_prime - (1. / 3. - cb2) * (F * theta_prime + 2. * Q.Fp * tb));
-      shear = (1. - 11. / 6. * dtau_c) * shear - 11. / 6. * tau_c * 16. / 45. * tau_c * (theta_prime + msp);
+      shear = (1. - 11. / 6. * dtau_c) * shear - (11. / 6. * 16. / 45.) * tau_c * tau_c * (theta_prime + msp);
     }
-    tca_shear = shear;
     M.tca_shear_g = shear;
     dtb = (-aH * tb + k2 * (cb2 * db + R * (dg * 0.25 - shear)) + R * slip) * Q.inv_1pR;  // pm.cpp:8123-8129
+    S4 = -(dtb + aH * tb - k2 * cb2 * db) * Q.inv_R + k2 * (0.25 * dg - shear);          // pm.cpp:8214-8217
   }
-  // ---- tails: one formula for every lane; the l=3 element takes its lower neighbour from the core ----
-  const int chain = opaque(e.chain);
-  const double core_below = (chain == 1) ? sg : (chain == 2) ? p2 : sur;
-  const double ylow = lane_below(y);  // NOT inside the ?: below - the operator is lazy, the l=3 lane would be masked off
-  const double ym = e.first ? core_below : ylow;
-  const double yp = lane_above(y);
+  const double SP = kap * (p0 + p2 + 2. * sg) * 0.125;  // kappa' Pi,  Pi = (G_gamma0 + G_gamma2 + F_gamma2)/8 (pm.cpp:8142)
+#ifdef CPT_PROFILE
+  PROF_STOP(10); PROF_START();
+#endif
+  // ---- every equation: streaming + damping + sources ----
   double dy = e.A * ym - e.B * yp - (e.D * kap + e.G * Q.inv_tau) * y;
-  if (chain == 0) {
-    // ---- core equations (wave-uniform values, selected per lane) ----
-    const double P0 = (p0 + p2 + 2. * sg) * 0.125;  // Pi = G_gamma0 + G_gamma2 + F_gamma2 (pm.cpp:8142)
-    const double c3 = P.three_ceff2_ur, v3 = P.three_cvis2_ur;
-    double v = 0.;
-    switch (opaque(e.role)) {
-      case R_DELTA_G: v = -4. / 3. * (tg + mc); break;                                             // pm.cpp:8095
-      case R_THETA_G:
-        if (!L.tca) v = k2 * (0.25 * dg - sg) + kap * (tb - tg);                                   // pm.cpp:8145-8148
-        else v = -(dtb + aH * tb - k2 * cb2 * db) * Q.inv_R + k2 * (0.25 * dg - tca_shear);        // pm.cpp:8214-8217
-        break;
-      case R_SHEAR_G: v = 4. / 15. * (tg + ms) - 0.3 * k * g3 - kap * (sg - 0.4 * P0); break;      // pm.cpp:8151-8155
-      case R_POL:
-        if (e.ell == 0) v = -k * p1 - kap * (p0 - 4. * P0);                                        // pm.cpp:8179-8181
-        else if (e.ell == 1) v = k / 3. * (p0 - 2. * p2) - kap * p1;                               // pm.cpp:8184-8186
-        else v = k / 5. * (2. * p1 - 3. * q3) - kap * (p2 - 0.8 * P0);                             // pm.cpp:8189-8191
-        break;
-      case R_DELTA_B: v = -(tb + mc); break;                                                       // pm.cpp:8101
-      case R_THETA_B: v = dtb; break;
-      case R_DELTA_CDM: v = -mc; break;                                                            // pm.cpp:8240
-      case R_DELTA_UR: v = -4. / 3. * (tur + mc) + (1. - c3) * aH * (dur + 4. * aH * tur * inv_k2); break;  // pm.cpp:8630-8634
-      case R_THETA_UR: v = k2 * (c3 * 0.25 * dur - sur) - (1. - c3) * aH * tur; break;             // pm.cpp:8637-8641
-      case R_SHEAR_UR:
-        if (!L.ufa) v = 4. / 15. * v3 * (tur + ms) - 0.3 * k * u3;                                 // pm.cpp:8645-8651
-        else if (P.ufa_method == CPT_UFA_CLASS) v = -3. * Q.inv_tau * sur + 2. / 3. * (tur + mc);  // pm.cpp:8704-8708
-        else if (P.ufa_method == CPT_UFA_MB) v = -3. * Q.inv_tau * sur + 2. / 3. * (tur + ms);
-        else v = -3. * aH * sur + 2. / 3. * (tur + ms);                                            // ufa_hu
-        break;
-      case R_ETA: v = etap; break;                                                                 // pm.cpp:8896
-      default: v = 0.; break;
-    }
-    dy = v;
+  dy = fma(e.Xmc, mc, dy);
+  dy = fma(e.Xms, ms, dy);
+  dy = fma(e.XP, SP, dy);
+  dy = fma(e.X4, S4, dy);
+  dy = fma(e.Xeta, etap, dy);
+  dy = fma(e.Xtb, dtb, dy);
+  // rarely used variants: non-standard ur sound speed (pm.cpp:8630-8641), ufa_hu (pm.cpp:8711-8716)
+  const double c3 = P.three_ceff2_ur;
+  if (c3 != 1. || (L.ufa && P.ufa_method == CPT_UFA_HU)) {
+    const int role = opaque(e.role);
+    if (role == R_DELTA_UR) dy += (1. - c3) * aH * (dur + 4. * aH * tur * inv_k2);
+    if (role == R_THETA_UR) dy -= (1. - c3) * aH * tur;
+    if (role == R_SHEAR_UR && L.ufa && P.ufa_method == CPT_UFA_HU) dy -= 3. * aH * sur;
   }
+#ifdef CPT_PROFILE
+  PROF_STOP(11);
+#endif
   return dy;
 }
 
@@ -560,17 +646,25 @@ __device__ __forceinline__ double rhs(const PtParams& P, const Layout& L, const 
 // dy is the dense-output derivative (only theta_b' is used, pm.cpp:6883). Lane 0 stores the tp_size values.
 __device__ __forceinline__ void store_sources(const PtParams& P, const Layout& L, const Lookup& Q, const Metric& M, double k,
                                               double inv_k2, double y, double dy, double tca_shear_prev, int it, int ik, int lane) {
-  const BgV& bg = Q.bg; const ThV& th = Q.th;
-  const double z = P.a_today / bg.a - 1.;
-  const double aH = Q.aH, aHp = Q.aHp;
+  struct { double g, dg, expmk; } th;
+  th.g = bcast(Q.vth, TH_G); th.dg = bcast(Q.vth, TH_DG); th.expmk = bcast(Q.vth, TH_EXPMK);
+  const double bg_a = bcast(Q.vbg, BG_A);
+  const double z = P.a_today / bg_a - 1.;
+  const double aH = Q.aH, aHp = bcast(Q.vbg, BG_HP) * bg_a + aH * aH;   // (a'/a)'
   double delta_g, Pi;
   if (L.rsa) { delta_g = M.rsa_dg; Pi = 0.; }
   else {
-    delta_g = bcast(y, L.dg);
+    delta_g = bcast(y, LN_DG);
     if (L.tca) Pi = 5. * tca_shear_prev / 8.;  // left over from the last derivs call of the evolver (pm.cpp:6810)
-    else Pi = (bcast(y, L.p0) + bcast(y, L.p2) + 2. * bcast(y, L.sg)) / 8.;
+    else Pi = (bcast(y, LN_P0) + bcast(y, LN_P2) + 2. * bcast(y, LN_SG)) / 8.;
   }
-  const double eta = bcast(y, L.eta), tb = bcast(y, L.tb), dtb = bcast(dy, L.tb);
+  const double eta = bcast(y, LN_ETA), tb = bcast(y, LN_TB), dtb = bcast(dy, LN_TB);
+  double delta_m = 0.;
+  if (P.tp_dm >= 0) {  // gauge-invariant matter density contrast, pm.cpp:6573, 5979-5981
+    double drm = Q.rb * bcast(y, LN_DB), rho_m = Q.rb;
+    if (P.has_cdm) { drm += Q.rc * bcast(y, LN_DC); rho_m += Q.rc; }
+    delta_m = (drm + 3. * aH * (Q.rb * tb) * inv_k2) / rho_m;
+  }
   int switch_isw = 1;
   if ((P.switch_eisw == 0) && (z >= P.eisw_lisw_split_z)) switch_isw = 0;
   if ((P.switch_lisw == 0) && (z < P.eisw_lisw_split_z)) switch_isw = 0;
@@ -585,7 +679,7 @@ __device__ __forceinline__ void store_sources(const PtParams& P, const Layout& L
     if (P.tp_t2 >= 0) P.src[P.tp_t2 * tstride + base] = P.switch_pol * th.g * Pi;
     if (P.tp_p >= 0) P.src[P.tp_p * tstride + base] = sqrt(6.) * th.g * Pi;
     if (P.tp_pp >= 0) P.src[P.tp_pp * tstride + base] = eta + M.alphap;
-    if (P.tp_dm >= 0) P.src[P.tp_dm * tstride + base] = M.delta_m;
+    if (P.tp_dm >= 0) P.src[P.tp_dm * tstride + base] = delta_m;
   }
 }
 
@@ -642,17 +736,18 @@ __device__ __forceinline__ double search_flip(const PtParams& P, double k, doubl
 //     registers, one row per lane, and is factorised with threshold-diagonal pivoting (tools/sparse.c:171) by
 //     fully unrolled readlane/fma code.
 struct Jac {
-  double Jc[16];   // lane i < nc: row i of J_cc
+  double* Jc;      // LDS [NC][64]: Jc[j * 64 + i] = J_cc(i, j) for lane i < NC, 0 on the other lanes.  Only the (rare)
+                   // Jacobian refresh writes it and only the factorisation reads it: no reason to pin 26 VGPRs
   double jdiag;    // tail lanes: J_ll = -(D kappa' + G/tau) frozen at the time of the Jacobian (ev.cpp keeps J fixed)
 };
 struct LuReg {
-  double Ac[16];   // lane i < nc: row i of the core factors (L below / unit-diagonal U above the diagonal)
+  double Ac[NC];   // lane i < NC: row i of the core factors (L below / unit-diagonal U above the diagonal)
   double rpivc;    // lane j < nc: reciprocal of the j-th core pivot
   int rowperm;     // lane i < nc: original row now at position i (identity on tail lanes)
-  double a, c;     // tail lanes: sub-/super-diagonal of (I - hg J);   core parents: c = coupling to the tail's l=3
-  double rinv;     // tail lanes: 1 / d'_l
-  double r;        // tail lanes: a_l / d'_l
-  int first_lane;  // core parents: lane of the l=3 element of their tail (-1: none)
+  double rinv;     // tail lanes: 1 / d'_l   (0 on core lanes)
+  double g;        // tail lanes: c_l / d'_{l+1}, the downward-sweep multiplier (0 on the l_max element and on core lanes)
+  double r;        // tail lanes: a_l / d'_l, the upward-sweep multiplier
+  double cpar;     // core parents of a tail: coupling to the tail's l=3 element (0 elsewhere)
 };
 
 template <int N>
@@ -663,137 +758,110 @@ __device__ __forceinline__ double reg_get(const double (&a)[N], int i) {
   return v;
 }
 
-__device__ __forceinline__ bool factorise(const Layout& L, const LaneEq& e, const Jac& J, double hg, int maxlen, int lane, LuReg& F) {
+__device__ __forceinline__ bool factorise(const LaneEq& e, const Jac& J, double hg, int maxlen, int lane, LuReg& F) {
   lane = opaque(lane);
-  const int nc = L.nc;
   const int chain = opaque(e.chain);
   // ---- tails ----
-  const double a = chain ? -hg * e.A : 0.;            // coefficient of x_{l-1} in row l
-  const double c = chain ? hg * e.B : 0.;             // coefficient of x_{l+1}
+  const double a = chain ? -hg * e.A : 0.;             // coefficient of x_{l-1} in row l
+  const double c = (chain && !e.last) ? hg * e.B : 0.; // coefficient of x_{l+1}
   const double d = 1.0 - hg * J.jdiag;
   double dp = d, r = 0.;
   for (int s = 0; s < maxlen; s++) {
     r = a * fast_rcp(dp);
     const double r_up = lane_above(r);
-    dp = e.last ? d : d - c * r_up;
+    dp = fma(-c, r_up, d);
   }
   const double rinv = fast_rcp(dp);
   r = a * rinv;
-  F.a = a; F.rinv = chain ? rinv : 0.; F.r = chain ? r : 0.;
+  const double rinv_up = lane_above(rinv);
+  F.rinv = chain ? rinv : 0.; F.r = chain ? r : 0.;
+  F.g = c * rinv_up;
   // ---- core: A_cc = I - hg J_cc, Schur-corrected on the diagonal of the parents of the tails ----
-  int first_lane = -1;
-  double cpar = 0.;
-  if (!chain) {
-    const int role = opaque(e.role);
-    if (role == R_SHEAR_G && L.gN > 0) first_lane = L.g3;
-    else if (role == R_POL && e.ell == 2 && L.qN > 0) first_lane = L.q3;
-    else if (role == R_SHEAR_UR && L.uN > 0) first_lane = L.u3;
-    if (first_lane >= 0) cpar = hg * e.B;  // row parent, column l3:  -hg * (-B)
-  }
-  F.first_lane = first_lane;
-  F.c = chain ? c : cpar;
-  const double r3 = shfl_all(r, first_lane < 0 ? 0 : first_lane);
-  const double schur = (first_lane >= 0) ? cpar * r3 : 0.;
-  double A[16];
+  const double cpar = hg * e.Bpar;               // row parent, column l3:  -hg * (-B);  0 on every other lane
+  F.cpar = cpar;
+  const double r3 = gather(r, e.first_addr);
+  const double schur = cpar * r3;
+  double A[NC];
 #pragma unroll
-  for (int j = 0; j < 16; j++) A[j] = (lane < nc && j < nc) ? ((j == lane ? 1.0 : 0.0) - hg * J.Jc[j]) : ((j == lane) ? 1.0 : 0.0);
-#pragma unroll
-  for (int j = 0; j < 16; j++) if (j == lane) A[j] -= schur;
+  for (int j = 0; j < NC; j++) A[j] = ((j == lane) ? 1.0 - schur : 0.0) - hg * J.Jc[j * 64 + lane];   // J.Jc = 0 outside the core
   int rowperm = lane;
   double rpivc = 1.;
   bool ok = true;
 #pragma unroll
-  for (int j = 0; j < 16; j++) {
-    if (j < nc) {
-      const double mag = (lane >= j && lane < nc) ? fabs(A[j]) : 0.;
-      const double diag = bcast(mag, j);
-      if (__ballot(mag > 1e3 * diag) != 0ull || diag == 0.) {  // rare: the diagonal is not an acceptable pivot
-        const double big = wave_max(mag);
-        if (big == 0.) ok = false;
-        const int p = __ffsll((long long)__ballot(mag == big && big > 0.)) - 1;
-        if (p > j) {
-          // exchange rows p and j (register rows of two lanes) and the row bookkeeping
+  for (int j = 0; j < NC; j++) {
+    const double mag = (lane >= j) ? fabs(A[j]) : 0.;      // rows >= NC hold zeros in the core columns
+    const double diag = bcast(mag, j);
+    if (__ballot(mag > 1e3 * diag) != 0ull || diag == 0.) {  // rare: the diagonal is not an acceptable pivot
+      const double big = wave_max(mag);
+      if (big == 0.) ok = false;
+      const int p = __ffsll((long long)__ballot((double)__double2float_ru(mag) == big && big > 0.)) - 1;  // wave_max rounds up to float
+      if (p > j) {
+        // exchange rows p and j (register rows of two lanes) and the row bookkeeping
 #pragma unroll
-          for (int cidx = 0; cidx < 16; cidx++) {
-            const double vp = bcast(A[cidx], p), vj = bcast(A[cidx], j);
-            if (lane == p) A[cidx] = vj;
-            if (lane == j) A[cidx] = vp;
-          }
-          const int rp_p = __builtin_amdgcn_readlane(rowperm, p), rp_j = __builtin_amdgcn_readlane(rowperm, j);
-          if (lane == p) rowperm = rp_j;
-          if (lane == j) rowperm = rp_p;
+        for (int cidx = 0; cidx < NC; cidx++) {
+          const double vp = bcast(A[cidx], p), vj = bcast(A[cidx], j);
+          if (lane == p) A[cidx] = vj;
+          if (lane == j) A[cidx] = vp;
         }
+        const int rp_p = __builtin_amdgcn_readlane(rowperm, p), rp_j = __builtin_amdgcn_readlane(rowperm, j);
+        if (lane == p) rowperm = rp_j;
+        if (lane == j) rowperm = rp_p;
       }
-      const double rp = fast_rcp(bcast(A[j], j));
-      if (lane == j) rpivc = rp;
-      const double m = (lane > j && lane < nc) ? A[j] * rp : 0.;
-      if (lane > j && lane < nc) A[j] = m;
+    }
+    const double rp = fast_rcp(bcast(A[j], j));
+    if (lane == j) rpivc = rp;
+    const double m = (lane > j) ? A[j] * rp : 0.;
+    if (lane > j) A[j] = m;
 #pragma unroll
-      for (int cidx = j + 1; cidx < 16; cidx++) {
-        const double pj = bcast(A[cidx], j);
-        A[cidx] = fma(-m, pj, A[cidx]);   // m = 0 on rows <= j
-      }
+    for (int cidx = j + 1; cidx < NC; cidx++) {
+      const double pj = bcast(A[cidx], j);
+      A[cidx] = fma(-m, pj, A[cidx]);   // m = 0 on rows <= j
     }
   }
   // unit-diagonal U: scale the upper part of every row by its reciprocal pivot
 #pragma unroll
-  for (int j = 0; j < 16; j++) {
-    F.Ac[j] = (j > lane) ? A[j] * rpivc : A[j];
-  }
+  for (int j = 0; j < NC; j++) F.Ac[j] = (j > lane) ? A[j] * rpivc : A[j];
   F.rpivc = rpivc;
   F.rowperm = rowperm;
   return ok;
 }
 
 // solve (I - hg J) x = b; lane i holds b_i on entry and x_i on return
-__device__ __forceinline__ double lu_solve(const Layout& L, const LaneEq& e, const LuReg& F, int maxlen, double b, int lane) {
+__device__ __forceinline__ double lu_solve(const LaneEq& e, const LuReg& F, int maxlen, double b, int lane) {
   lane = opaque(lane);
-  const int nc = L.nc;
   const int chain = opaque(e.chain);
-  // 1. tails, downward sweep: b'_l = b_l - c_l b'_{l+1} / d'_{l+1}
+  // 1. tails, downward sweep: b'_l = b_l - (c_l / d'_{l+1}) b'_{l+1}; the l_max element is final at once
   double bp = b;
-  if (maxlen > 0) {
-    for (int s = 0; s < maxlen; s++) {
-      const double t_up = lane_above(bp * F.rinv);
-      bp = (chain && !e.last) ? b - F.c * t_up : b;
-    }
-  }
+  for (int s = 1; s < maxlen; s++) bp = fma(-F.g, lane_above(bp), b);
   // 2. core right-hand side: parents of the tails see b'_3 / d'_3
-  const double t3 = shfl_all(bp * F.rinv, F.first_lane < 0 ? 0 : F.first_lane);  // executed by every lane
-  const double bc = (F.first_lane >= 0) ? b - F.c * t3 : b;
-  // 3. core solve with the register-resident factors
-  double x = shfl_all(chain ? 0. : bc, F.rowperm);
-  if (chain) x = 0.;
+  const double u = bp * F.rinv;                       // 0 on core lanes
+  const double t3 = gather(u, e.first_addr);          // executed by every lane
+  const double bc = fma(-F.cpar, t3, b);
+  // 3. core solve with the register-resident factors (idle rows / lanes >= NC are identity rows: x = b there)
+  double x = gather(chain ? 0. : bc, F.rowperm * 4);
 #pragma unroll
-  for (int j = 0; j < 16; j++) {   // forward, unit lower
-    if (j < nc) {
-      const double xj = bcast(x, j);
-      const double m = (lane > j && lane < nc) ? F.Ac[j] : 0.;
-      x = fma(-m, xj, x);
-    }
+  for (int j = 0; j < NC; j++) {   // forward, unit lower
+    const double xj = bcast(x, j);
+    const double m = (lane > j) ? F.Ac[j] : 0.;
+    x = fma(-m, xj, x);
   }
-  x *= (lane < nc) ? F.rpivc : 1.0;
+  x *= F.rpivc;   // 1 outside the core
 #pragma unroll
-  for (int j = 15; j >= 0; j--) {  // backward, unit upper
-    if (j < nc) {
-      const double xj = bcast(x, j);
-      const double u = (lane < j) ? F.Ac[j] : 0.;
-      x = fma(-u, xj, x);
-    }
+  for (int j = NC - 1; j >= 0; j--) {  // backward, unit upper
+    const double xj = bcast(x, j);
+    const double uj = (lane < j) ? F.Ac[j] : 0.;
+    x = fma(-uj, xj, x);
   }
-  // 4. tails, upward sweep: x_l = (b'_l - a_l x_{l-1}) / d'_l, the l=3 element takes x_{l-1} from its core parent
+  // 4. tails, upward sweep: x_l = b'_l / d'_l - (a_l / d'_l) x_{l-1}; the l=3 element takes x_{l-1} from its core parent
   if (maxlen > 0) {
-    const int parent = (chain == 1) ? L.sg : (chain == 2) ? L.p2 : L.sur;
-    const double xpar = shfl_all(x, (chain && parent >= 0) ? parent : 0);
-    double xt = 0.;
-    for (int s = 0; s < maxlen; s++) {
-      const double xlow = lane_below(xt);
-      const double below = e.first ? xpar : xlow;
-      xt = (bp - F.a * below) * F.rinv;
-    }
+    const double xpar = gather(x, e.parent_addr);
+    const double u0 = e.first ? fma(-F.r, xpar, u) : u;
+    const double rr = e.first ? 0. : F.r;
+    double xt = u0;
+    for (int s = 1; s < maxlen; s++) xt = fma(-rr, lane_below(xt), u0);
     if (chain) x = xt;
   }
-  return (lane < L.neq) ? x : 0.;
+  return x;
 }
 
 // adjust_stepsize (ev.cpp:907-943): dif[0..k-1] <- dif[0..k-1] * RU(r); every index static => registers only
@@ -828,16 +896,6 @@ __device__ __forceinline__ void adjust_stepsize(double* dif, double r, int k) {
 
 struct Stat { int steps, failed, fevals, jacs, lus, solves; };
 
-#ifdef CPT_PROFILE
-__device__ unsigned long long g_prof[8];
-#define PROF_DECL unsigned long long pf_t0 = 0
-#define PROF_START() pf_t0 = clock64()
-#define PROF_STOP(slot) prof[slot] += clock64() - pf_t0
-#else
-#define PROF_DECL
-#define PROF_START()
-#define PROF_STOP(slot)
-#endif
 
 // register selects on the backward-difference array (static indices only => no scratch)
 __device__ __forceinline__ double dif_get(const double* dif, int i) {
@@ -852,25 +910,25 @@ __device__ __forceinline__ double dif_get(const double* dif, int i) {
 // final evaluation) and the Newton slot.  Returns 0 / error code (1 step too small, 2 singular, 4 budget).
 __device__ __forceinline__ int ndf15(const PtParams& P, const Layout& L, const LaneEq& e, Lookup& Q, Metric& M, double k,
                                      double inv_k2, int ik, double t0, double tfinal, double& y_io, Stat& st, int lane,
-                                     int& budget, unsigned long long* prof) {
+                                     int& budget, double* jac_lds, unsigned long long* prof) {
   PROF_DECL;
   const double eps = 1e-16, threshold = 1e-15, rtol = P.rtol;
-  const int maxit = 4, maxk = 5, n = L.neq;
-  const bool act = lane < n;
+  const int maxit = 4, maxk = 5;
+  // (idle lanes carry y = dy = dif = 0 and identity rows: they drop out of every norm by themselves)
   const double* ts = P.tau_s;
   const int tres = P.ntau;
   const double htspan = fabs(tfinal - t0), hmax = (tfinal - t0) / 10.0;
-  const int maxlen = max(L.gN, max(L.qN, L.uN));
+  const int maxlen = L.maxlen;
   enum { B_NONE = 0, B_JAC, B_F0, B_F1, B_JF0, B_SAMPLE, B_FINAL };
 
   Jac J;
-#pragma unroll
-  for (int j = 0; j < 16; j++) J.Jc[j] = 0.;
+  J.Jc = jac_lds;
+  for (int j = 0; j < NC; j++) J.Jc[j * 64 + lane] = 0.;
   J.jdiag = 0.;
   LuReg F;
 #pragma unroll
-  for (int j = 0; j < 16; j++) F.Ac[j] = 0.;
-  F.rpivc = 1.; F.rowperm = lane; F.a = F.c = F.rinv = F.r = 0.; F.first_lane = -1;
+  for (int j = 0; j < NC; j++) F.Ac[j] = 0.;
+  F.rpivc = 1.; F.rowperm = lane; F.rinv = F.r = F.g = F.cpar = 0.;
   double y = y_io, ynew = y_io, f0 = 0., f1 = 0., fnewton = 0., wt = 0., tdel = 0.;
   double dif[7] = {0., 0., 0., 0., 0., 0., 0.};
   int next = 0;
@@ -888,15 +946,17 @@ __device__ __forceinline__ int ndf15(const PtParams& P, const Layout& L, const L
     tn = ts[next];
     if (tnew == tn) { yi = ynew; ypi = fnewton; }
     else {
-      const double s = (tn - tnew) / h;
-      double prod = 1.0, sumfrac = 0., fact = 1.0;
+      const double inv_h = fast_rcp(h), s = (tn - tnew) * inv_h;
+      double prod = 1.0, sumfrac = 0.;
       yi = ynew; ypi = 0.;
 #pragma unroll
       for (int j = 0; j < 5; j++) {
         if (j < kk) {
-          prod *= (s + j); fact *= (j + 1); sumfrac += 1.0 / (s + j);
-          yi += (prod / fact) * dif[j];
-          ypi += (prod * sumfrac / (h * fact)) * dif[j];
+          const double inv_fact = (j == 0) ? 1.0 : (j == 1) ? 0.5 : (j == 2) ? 1.0 / 6.0 : (j == 3) ? 1.0 / 24.0 : 1.0 / 120.0;
+          prod *= (s + j); sumfrac += fast_rcp(s + j);
+          const double c = prod * inv_fact;
+          yi = fma(c, dif[j], yi);
+          ypi = fma(c * sumfrac * inv_h, dif[j], ypi);
         }
       }
     }
@@ -907,11 +967,14 @@ __device__ __forceinline__ int ndf15(const PtParams& P, const Layout& L, const L
     // ------------------------------------------------------------------ service slot
     if (batch != B_NONE) {
       PROF_START();
-      const int nreq = (batch == B_JAC) ? L.nc : 1;
+      const int nreq = (batch == B_JAC) ? NC : 1;
       const double tca_keep = M.tca_shear_g;
       for (int r = 0; r < nreq; r++) {
         double tq, yq;
-        if (batch == B_JAC) { tq = t; yq = (lane == r) ? 1.0 : 0.0; }  // J e_r = f(t, e_r): exact, the system is linear
+        if (batch == B_JAC) {  // J e_r = f(t, e_r): exact, the system is linear; idle variables have no column
+          if (!core_present(P, L, r)) continue;
+          tq = t; yq = (lane == r) ? 1.0 : 0.0;
+        }
         else if (batch == B_F0) { tq = t; yq = y; }
         else if (batch == B_F1) { tq = t + tdel; yq = y; }
         else if (batch == B_JF0) { tq = t; yq = f0; }                  // J f0 = f(t, f0)
@@ -919,10 +982,8 @@ __device__ __forceinline__ int ndf15(const PtParams& P, const Layout& L, const L
         else { tq = tnew; yq = ynew; }
         const double dyq = rhs(P, L, e, Q, M, k, inv_k2, tq, yq, lane);
         st.fevals++;
-        if (batch == B_JAC) {
-#pragma unroll
-          for (int j = 0; j < 16; j++) if (j == r) J.Jc[j] = (lane < L.nc) ? dyq : 0.;
-        } else if (batch == B_F0) f0 = dyq;
+        if (batch == B_JAC) J.Jc[r * 64 + lane] = (lane < NC) ? dyq : 0.;
+        else if (batch == B_F0) f0 = dyq;
         else if (batch == B_F1) f1 = dyq;
         else if (batch == B_JF0) fnewton = dyq;  // temporarily J f0
         else if (batch == B_SAMPLE) store_sources(P, L, Q, M, k, inv_k2, yi, ypi, tca_keep, next, ik, lane);
@@ -930,7 +991,7 @@ __device__ __forceinline__ int ndf15(const PtParams& P, const Layout& L, const L
       if (batch == B_FINAL) { PROF_STOP(3); break; }  // ev.cpp:653-662: M, Q left at (tfinal, y) for the hand-over
       if (batch == B_JAC) {
         // the tails' diagonal is analytic: freeze kappa' and 1/tau at the time of this Jacobian
-        J.jdiag = -(e.D * Q.th.dkappa + e.G * Q.inv_tau);
+        J.jdiag = -(e.D * Q.kap + e.G * Q.inv_tau);
         st.jacs++;
         M.tca_shear_g = tca_keep;
         Jcurrent = true;
@@ -942,7 +1003,7 @@ __device__ __forceinline__ int ndf15(const PtParams& P, const Layout& L, const L
       } else if (batch == B_F0) {
         // first guess of h (ev.cpp:225-250)
         wt = fmax(fabs(y), threshold);
-        const double rh = wave_max(act ? 1.25 / sqrt(rtol) * fabs(f0 / wt) : 0.);
+        const double rh = wave_max(1.25 / sqrt(rtol) * fabs(f0 / wt));
         absh = fmin(hmax, htspan);
         if (absh * rh > 1.0) absh = 1.0 / rh;
         absh = fmax(absh, hmin);
@@ -958,7 +1019,7 @@ __device__ __forceinline__ int ndf15(const PtParams& P, const Layout& L, const L
       } else if (batch == B_JF0) {
         // ddfddt = J f0 + (f(t+tdel) - f0)/tdel  (ev.cpp:261-283)
         const double acc = fnewton + (f1 - f0) / tdel;
-        const double rh = wave_max(act ? 1.25 * sqrt(0.5 * fabs(acc / wt) / rtol) : 0.);
+        const double rh = wave_max(1.25 * sqrt(0.5 * fabs(acc / wt) / rtol));
         absh = fmin(hmax, htspan);
         if (absh * rh > 1.0) absh = 1.0 / rh;
         absh = fmax(absh, hmin);
@@ -990,23 +1051,25 @@ __device__ __forceinline__ int ndf15(const PtParams& P, const Layout& L, const L
     if (post_step) {
       post_step = false;
       if (done) { batch = B_FINAL; continue; }
+      PROF_START();
       klast = kk;
       abshlast = absh;
       nconhk = min(nconhk + 1, maxk + 2);
       if (nconhk >= kk + 2) {
-        double temp = 1.2 * fast_pow((err / rtol), (1.0 / (kk + 1.0)));
-        double hopt = temp > 0.1 ? absh / temp : 10 * absh;
+        const double inv_rtol = 1.0 / rtol;  // loop invariant
+        double temp = 1.2 * fast_root(err * inv_rtol, kk + 1);
+        double hopt = temp > 0.1 ? absh * fast_rcp(temp) : 10 * absh;
         int kopt = kk;
         if (kk > 1) {
-          const double errkm1 = wave_max(act ? fabs(dif_get(dif, kk - 1) * invwt) : 0.) * ndf_erconst(kk - 2);
-          temp = 1.3 * fast_pow((errkm1 / rtol), (1.0 / kk));
-          const double hkm1 = temp > 0.1 ? absh / temp : 10 * absh;
+          const double errkm1 = wave_max(fabs(dif_get(dif, kk - 1) * invwt)) * ndf_erconst(kk - 2);
+          temp = 1.3 * fast_root(errkm1 * inv_rtol, kk);
+          const double hkm1 = temp > 0.1 ? absh * fast_rcp(temp) : 10 * absh;
           if (hkm1 > hopt) { hopt = hkm1; kopt = kk - 1; }
         }
         if (kk < maxk) {
-          const double errkp1 = wave_max(act ? fabs(dif_get(dif, kk + 1) * invwt) : 0.) * ndf_erconst(kk);
-          temp = 1.4 * fast_pow((errkp1 / rtol), (1.0 / (kk + 2.0)));
-          const double hkp1 = temp > 0.1 ? absh / temp : 10 * absh;
+          const double errkp1 = wave_max(fabs(dif_get(dif, kk + 1) * invwt)) * ndf_erconst(kk);
+          temp = 1.4 * fast_root(errkp1 * inv_rtol, kk + 2);
+          const double hkp1 = temp > 0.1 ? absh * fast_rcp(temp) : 10 * absh;
           if (hkp1 > hopt) { hopt = hkp1; kopt = kk + 1; }
         }
         if (hopt > absh) { absh = hopt; kk = kopt; }
@@ -1015,10 +1078,12 @@ __device__ __forceinline__ int ndf15(const PtParams& P, const Layout& L, const L
       y = ynew;
       Jcurrent = false;
       new_step = true;
+      PROF_STOP(12);
     }
     // ------------------------------------------------------------------ start of a step (ev.cpp:299-334)
     if (new_step) {
       new_step = false;
+      PROF_START();
       hmin = P.min_var;
       absh = fmin(hmax, fmax(hmin, absh));
       if (fabs(absh - hmin) < 100 * eps) { if (at_hmin) absh = abshlast; at_hmin = true; } else at_hmin = false;
@@ -1031,11 +1096,12 @@ __device__ __forceinline__ int ndf15(const PtParams& P, const Layout& L, const L
         need_fact = true;
       }
       nofailed = true;
+      PROF_STOP(13);
     }
     if (need_fact) {
       need_fact = false;
       PROF_START();
-      if (!factorise(L, e, J, hinvGak, maxlen, lane, F)) return 2;
+      if (!factorise(e, J, hinvGak, maxlen, lane, F)) return 2;
       PROF_STOP(2);
       st.lus++;
       havrate = false;
@@ -1058,7 +1124,7 @@ __device__ __forceinline__ int ndf15(const PtParams& P, const Layout& L, const L
     ynew = pred;
     difkp1 = 0.;
     invwt = fast_rcp(fmax(fmax(fabs(ynew), fabs(y)), threshold));
-    const double minnrm = wave_max(act ? 100 * eps * fabs(ynew * invwt) : 0.);
+    const double minnrm = wave_max(100 * eps * fabs(ynew * invwt));
     bool tooslow = false;
     for (int iter = 1; iter <= maxit; iter++) {
       PROF_START();
@@ -1068,29 +1134,29 @@ __device__ __forceinline__ int ndf15(const PtParams& P, const Layout& L, const L
       t_inner += clock64() - pf_t0;
 #endif
       st.fevals++;
-      const double rhsv = act ? hinvGak * fnewton - (psi + difkp1) : 0.;
+      const double rhsv = hinvGak * fnewton - (psi + difkp1);
       PROF_START();
-      const double del = lu_solve(L, e, F, maxlen, rhsv, lane);
+      const double del = lu_solve(e, F, maxlen, rhsv, lane);
       PROF_STOP(1);
 #ifdef CPT_PROFILE
       t_inner += clock64() - pf_t0;
 #endif
       st.solves++;
-      const double newnrm = wave_max(act ? fabs(del * invwt) : 0.);
+      const double newnrm = wave_max(fabs(del * invwt));
       difkp1 += del;
       ynew = pred + difkp1;
       if (newnrm <= minnrm) break;
       else if (iter == 1) {
-        if (havrate) { const double errit = newnrm * rate / (1.0 - rate); if (errit <= 0.05 * rtol) break; }
+        if (havrate) { const double errit = newnrm * rate * fast_rcp(1.0 - rate); if (errit <= 0.05 * rtol) break; }
         else rate = 0.0;
       } else if (newnrm > 0.9 * oldnrm) { tooslow = true; break; }
       else {
-        rate = fmax(0.9 * rate, newnrm / oldnrm);
+        rate = fmax(0.9 * rate, newnrm * fast_rcp(oldnrm));
         havrate = true;
-        const double errit = newnrm * rate / (1.0 - rate);
+        const double errit = newnrm * rate * fast_rcp(1.0 - rate);
         if (errit <= 0.5 * rtol) break;
         else if (iter == maxit) { tooslow = true; break; }
-        else if (0.5 * rtol < errit * fast_pow(rate, (double)(maxit - iter))) { tooslow = true; break; }
+        else if (0.5 * rtol < errit * fast_powi(rate, maxit - iter)) { tooslow = true; break; }
       }
       oldnrm = newnrm;
     }
@@ -1112,17 +1178,18 @@ __device__ __forceinline__ int ndf15(const PtParams& P, const Layout& L, const L
       continue;
     }
     // ------------------------------------------------------------------ error test (ev.cpp:483-532)
-    err = wave_max(act ? fabs(difkp1 * invwt) : 0.) * ndf_erconst(kk - 1);
+    PROF_START();
+    err = wave_max(fabs(difkp1 * invwt)) * ndf_erconst(kk - 1);
     if (err > rtol) {
       st.failed++;
       if (absh <= hmin) return 1;
       abshlast = absh;
       if (nofailed) {
         nofailed = false;
-        double hopt = absh * fmax(0.1, 0.833 * fast_pow((rtol / err), (1.0 / (kk + 1))));
+        double hopt = absh * fmax(0.1, 0.833 * fast_root(rtol / err, kk + 1));
         if (kk > 1) {
-          const double errkm1 = wave_max(act ? fabs((dif_get(dif, kk - 1) + difkp1) * invwt) : 0.) * ndf_erconst(kk - 2);
-          const double hkm1 = absh * fmax(0.1, 0.769 * fast_pow((rtol / errkm1), (1.0 / kk)));
+          const double errkm1 = wave_max(fabs((dif_get(dif, kk - 1) + difkp1) * invwt)) * ndf_erconst(kk - 2);
+          const double hkm1 = absh * fmax(0.1, 0.769 * fast_root(rtol / errkm1, kk));
           if (hkm1 > hopt) { hopt = fmin(absh, hkm1); kk = kk - 1; }
         }
         absh = fmax(hmin, hopt);
@@ -1149,6 +1216,7 @@ __device__ __forceinline__ int ndf15(const PtParams& P, const Layout& L, const L
     }
     if ((next < tres) && (tnew - ts[next] >= 0.0)) { batch = B_SAMPLE; prepare_sample(); }
     else post_step = true;
+    PROF_STOP(14);
   }
   y_io = ynew;
   return 0;
@@ -1197,6 +1265,7 @@ __device__ __noinline__ double initial_conditions(DevTables T, int has_cdm, int 
 // ---- the kernel: perturb_solve (pm.cpp:2463-2787) for one mode per wavefront ---------------------
 __global__ void __launch_bounds__(64) k_perturb(PtParams P) {
   __shared__ __attribute__((aligned(16))) double2 tabw[64 * (BG_NCOL + TH_NCOL)];
+  __shared__ double jacw[NC * 64];
   const int lane = threadIdx.x;
   const int ik = P.order[blockIdx.x];
   const double k = P.k[ik];
@@ -1205,7 +1274,7 @@ __global__ void __launch_bounds__(64) k_perturb(PtParams P) {
   double2* thw = tabw + 64 * BG_NCOL;
 
   Stat st = {0, 0, 0, 0, 0, 0};
-  unsigned long long prof[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long prof[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #ifdef CPT_PROFILE
   const unsigned long long t_begin = clock64();
 #endif
@@ -1250,8 +1319,11 @@ __global__ void __launch_bounds__(64) k_perturb(PtParams P) {
   if (status == 0) {
     Lookup Q;
     lookup_init(P, Q, bgw, thw, lane);
+#ifdef CPT_PROFILE
+    Q.prof = prof;
+#endif
     Metric M;
-    M.hp = M.etap = M.alpha = M.alphap = M.delta_m = 0.;
+    M.hp = M.etap = M.alpha = M.alphap = 0.;
     M.tca_shear_g = 0.; M.rsa_dg = M.rsa_tg = 0.;
     int f_tca = fi0, f_rsa = fi1, f_ufa = fi2;
     Layout L = make_layout(P, f_tca, f_rsa, f_ufa);
@@ -1264,19 +1336,18 @@ __global__ void __launch_bounds__(64) k_perturb(PtParams P) {
       const double ta = (iv == 0) ? tau_ini : (iv == 1 ? sw0 : (iv == 2 ? sw1 : sw2));
       const double tb = (iv == nsw) ? tau_end : (iv == 0 ? sw0 : (iv == 1 ? sw1 : sw2));
       if (iv > 0) {
-        // hand-over to the new scheme: pm.cpp:3777-4260
-        const Layout Lo = L;
+        // hand-over to the new scheme (pm.cpp:3777-4260): every variable keeps its lane; the ones the new scheme
+        // drops are zeroed, the ones it adds are seeded
+        const int was_tca = L.tca;
         const int ap = (iv == 1) ? ap0 : (iv == 2 ? ap1 : ap2);
         if (ap == 0) f_tca ^= 1; else if (ap == 1) f_rsa ^= 1; else f_ufa ^= 1;
         L = make_layout(P, f_tca, f_rsa, f_ufa);
         e = make_lane_eq(P, L, lane, k);
-        const int src_i = index_of(Lo, e.role, e.ell);
-        double yn = shfl_all(y, src_i < 0 ? 0 : src_i);
-        if (src_i < 0 || e.role == R_NONE) yn = 0.;
-        if (Lo.tca && !L.tca) {  // tight coupling switched off: seed shear, l=3 and polarisation (pm.cpp:3893-3916)
+        double yn = (e.role == R_NONE) ? 0. : y;
+        if (was_tca && !L.tca) {  // tight coupling switched off: seed shear, l=3 and polarisation (pm.cpp:3893-3916)
           const double sh = M.tca_shear_g, kod = k * Q.tau_c;
           if (e.role == R_SHEAR_G) yn = sh;
-          if (e.role == R_LG && e.ell == 3) yn = 6. / 7. * kod * sh;
+          if (e.role == R_LG) yn = (e.ell == 3) ? 6. / 7. * kod * sh : 0.;
           if (e.role == R_POL) {
             if (e.ell == 0) yn = 2.5 * sh;
             else if (e.ell == 1) yn = kod * (5. - 2.) / 6. * sh;
@@ -1288,14 +1359,14 @@ __global__ void __launch_bounds__(64) k_perturb(PtParams P) {
         y = yn;
       }
       n_regimes++;
-      const int rc = ndf15(P, L, e, Q, M, k, inv_k2, ik, ta, tb, y, st, lane, budget, prof);
+      const int rc = ndf15(P, L, e, Q, M, k, inv_k2, ik, ta, tb, y, st, lane, budget, jacw, prof);
       if (rc) status = 10 + rc;
     }
   }
 #ifdef CPT_PROFILE
   prof[7] = clock64() - t_begin;
   if (lane == 0 && blockIdx.x == 0)  // the heaviest mode = the critical path
-    for (int i = 0; i < 8; i++) g_prof[i] = prof[i];
+    for (int i = 0; i < 16; i++) g_prof[i] = prof[i];
 #endif
   if (lane == 0) {
     if (P.status) P.status[ik] = status;
@@ -1314,13 +1385,17 @@ __global__ void __launch_bounds__(64) k_dbg_lookup(PtParams P, const double* tau
   const int lane = threadIdx.x;
   Lookup Q;
   lookup_init(P, Q, w, w + 64 * BG_NCOL, lane);
+#ifdef CPT_PROFILE
+  unsigned long long dbg_prof[16];
+  Q.prof = dbg_prof;
+#endif
   for (int i = 0; i < n; i++) {
     lookup(P, Q, tau[i], lane);
     if (lane == 0) {
       double* o = out + (size_t)i * 16;
-      o[0] = Q.bg.a; o[1] = Q.bg.H; o[2] = Q.bg.Hp; o[3] = Q.bg.rg; o[4] = Q.bg.rb; o[5] = Q.bg.rc; o[6] = Q.bg.ru;
-      o[7] = Q.th.xe; o[8] = Q.th.dkappa; o[9] = Q.th.tau_d; o[10] = Q.th.ddkappa; o[11] = Q.th.dddkappa; o[12] = Q.th.expmk;
-      o[13] = Q.th.g; o[14] = Q.th.dg; o[15] = Q.th.cb2;
+      o[0] = bcast(Q.vbg, BG_A); o[1] = bcast(Q.vbg, BG_H); o[2] = bcast(Q.vbg, BG_HP); o[3] = Q.rg; o[4] = Q.rb; o[5] = Q.rc; o[6] = Q.ru;
+      o[7] = bcast(Q.vth, TH_XE); o[8] = Q.kap; o[9] = bcast(Q.vth, TH_TAU_D); o[10] = Q.ddkappa; o[11] = bcast(Q.vth, TH_DDDKAPPA);
+      o[12] = bcast(Q.vth, TH_EXPMK); o[13] = bcast(Q.vth, TH_G); o[14] = bcast(Q.vth, TH_DG); o[15] = Q.cb2;
     }
   }
 }
@@ -1332,16 +1407,21 @@ __global__ void __launch_bounds__(64) k_dbg_derivs(PtParams P, double k, double 
   const int lane = threadIdx.x;
   Lookup Q;
   lookup_init(P, Q, w, w + 64 * BG_NCOL, lane);
+#ifdef CPT_PROFILE
+  unsigned long long dbg_prof[16];
+  Q.prof = dbg_prof;
+#endif
   Metric M;
-  M.hp = M.etap = M.alpha = M.alphap = M.delta_m = 0.;
+  M.hp = M.etap = M.alpha = M.alphap = 0.;
   M.tca_shear_g = 0.; M.rsa_dg = M.rsa_tg = 0.;
   Layout L = make_layout(P, tca, rsa, ufa);
   LaneEq e = make_lane_eq(P, L, lane, k);
-  const int ri = ref_index_of(P, tca, rsa, ufa, e.role, e.ell);
-  const double yl = (lane < L.neq && ri >= 0) ? y[ri] : 0.;
+  int nref;
+  const int ri = ref_index_of(P, tca, rsa, ufa, e.role, e.ell, &nref);
+  const double yl = (ri >= 0) ? y[ri] : 0.;
   const double d = rhs(P, L, e, Q, M, k, 1.0 / (k * k), tau, yl, lane);
-  if (lane < L.neq && ri >= 0) dy[ri] = d;
-  if (lane == 0) *neq = L.neq;
+  if (ri >= 0) dy[ri] = d;
+  if (lane == 0) *neq = nref;
 }
 
 // (I - hg J(tau)) x = b through the structured factorisation, in the reference's ordering: unit test of the linear algebra
@@ -1351,28 +1431,33 @@ __global__ void __launch_bounds__(64) k_dbg_solve(PtParams P, double k, double t
   const int lane = threadIdx.x;
   Lookup Q;
   lookup_init(P, Q, w, w + 64 * BG_NCOL, lane);
+#ifdef CPT_PROFILE
+  unsigned long long dbg_prof[16];
+  Q.prof = dbg_prof;
+#endif
   Metric M;
-  M.hp = M.etap = M.alpha = M.alphap = M.delta_m = 0.;
+  M.hp = M.etap = M.alpha = M.alphap = 0.;
   M.tca_shear_g = 0.; M.rsa_dg = M.rsa_tg = 0.;
   Layout L = make_layout(P, tca, rsa, ufa);
   LaneEq e = make_lane_eq(P, L, lane, k);
   const double inv_k2 = 1.0 / (k * k);
+  __shared__ double jacw[NC * 64];
   Jac J;
-#pragma unroll
-  for (int j = 0; j < 16; j++) J.Jc[j] = 0.;
-  for (int r = 0; r < L.nc; r++) {
+  J.Jc = jacw;
+  for (int j = 0; j < NC; j++) J.Jc[j * 64 + lane] = 0.;
+  for (int r = 0; r < NC; r++) {
+    if (!core_present(P, L, r)) continue;
     const double col = rhs(P, L, e, Q, M, k, inv_k2, tau, (lane == r) ? 1.0 : 0.0, lane);
-#pragma unroll
-    for (int j = 0; j < 16; j++) if (j == r) J.Jc[j] = (lane < L.nc) ? col : 0.;
+    J.Jc[r * 64 + lane] = (lane < NC) ? col : 0.;
   }
-  J.jdiag = -(e.D * Q.th.dkappa + e.G * Q.inv_tau);
+  J.jdiag = -(e.D * Q.kap + e.G * Q.inv_tau);
   LuReg F;
-  const int maxlen = max(L.gN, max(L.qN, L.uN));
-  const bool ok = factorise(L, e, J, hg, maxlen, lane, F);
-  const int ri = ref_index_of(P, tca, rsa, ufa, e.role, e.ell);
-  const double bl = (lane < L.neq && ri >= 0) ? b[ri] : 0.;
-  const double xl = lu_solve(L, e, F, maxlen, bl, lane);
-  if (lane < L.neq && ri >= 0) x[ri] = ok ? xl : nan("");
+  const bool ok = factorise(e, J, hg, L.maxlen, lane, F);
+  int nref;
+  const int ri = ref_index_of(P, tca, rsa, ufa, e.role, e.ell, &nref);
+  const double bl = (ri >= 0) ? b[ri] : 0.;
+  const double xl = lu_solve(e, F, L.maxlen, bl, lane);
+  if (ri >= 0) x[ri] = ok ? xl : nan("");
 }
 
 void fill_params(const cpt_handle* h, PtParams& P) {
@@ -1469,7 +1554,7 @@ int cpt_perturb_impl(cpt_handle* h, const double* k, int nk, const double* tau, 
 // adjust_stepsize, schedule, total.  Zeros unless built with -DCPT_PROFILE (diagnostic builds only, tools/prof_run.py).
 extern "C" int cpt_dbg_profile(unsigned long long* out) {
 #ifdef CPT_PROFILE
-  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_prof), 8 * sizeof(unsigned long long)) == hipSuccess ? 0 : 3;
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_prof), 16 * sizeof(unsigned long long)) == hipSuccess ? 0 : 3;
 #else
   for (int i = 0; i < 8; i++) out[i] = 0;
   return 0;

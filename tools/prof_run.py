@@ -16,7 +16,7 @@ be = Backend(inp)
 for i in range(2):
     src, stats, status = be.perturb_solve(want_sources=False)
 print("kernel ms", be.kernel_ms(0))
-out = (C.c_ulonglong * 8)()
+out = (C.c_ulonglong * 16)()
 L = capi.lib()
 L.cpt_dbg_profile.argtypes = [C.POINTER(C.c_ulonglong)]
 L.cpt_dbg_profile(out)
@@ -26,5 +26,7 @@ s = stats[len(stats) - 1]
 print("heaviest mode: steps", s.steps, "fevals", s.fevals, "lus", s.factorisations, "solves", s.solves, "jacs", s.jacobians)
 for n, v in zip(names, out):
     print("%-12s %12d cycles %5.1f%%" % (n, v, 100.0 * v / tot))
+print("inside every rhs call (all slots): lookup %d  gather+bcast %d  algebra %d  combine %d   [calls %d]" % (out[8], out[9], out[10], out[11], s.fevals))
+print("post_step %d  new_step %d  errtest+accept %d" % (out[12], out[13], out[14]))
 print("cycles/step %.0f  rhs cycles/call %.0f  solve cycles/call %.0f  factorise cycles/call %.0f  jac cycles/call %.0f" % (
     tot / s.steps, out[0] / s.solves, out[1] / s.solves, out[2] / max(s.factorisations, 1), out[3] / max(s.jacobians, 1)))
