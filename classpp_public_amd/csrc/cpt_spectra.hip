@@ -4,85 +4,111 @@
 // _SPLINE_EST_DERIV_) and array_integrate_all_trapzd_or_spline (:1382-1423), and NonlinearModule::nonlinear_pk_linear
 // (source/nonlinear_module.cpp:1886-2040).
 #include "cpt_internal.h"
+#include <cmath>
+#include <vector>
 
 struct ClParams {
   const double* tr;  // [tt][nl][nq]
-  const double* q;
+  const double* w;   // [nq]: quadrature weight of the integrand spline x primordial spectrum x 4 pi / q
   double* cl;        // [nl][ct]
-  double* scratch;   // [nl*ct][2][nq]: integrand y and spline work array
-  const double* splc; // [3][nq]: c, sig, p of the q grid
   int nq, nl, ct_size;
   int tt_t0, tt_t1, tt_t2, tt_e, tt_lcmb;
   int ct_tt, ct_ee, ct_te, ct_bb, ct_pp, ct_tp, ct_ep;
-  double A_s, n_s, alpha_s, k_pivot;
 };
 
-__device__ static inline double primordial(const ClParams& P, double k) {  // primordial_module.cpp:911-925
-  const double lk = log(k / P.k_pivot);
-  return P.A_s * exp((P.n_s - 1.) * lk + 0.5 * P.alpha_s * lk * lk);
-}
-
-// one thread per (l, ct): build the integrand over q, spline it (natural order, sequential sweeps), integrate
-__global__ void __launch_bounds__(64) k_cl(ClParams P) {
-  const int id = blockIdx.x * blockDim.x + threadIdx.x;
-  if (id >= P.nl * P.ct_size) return;
-  const int il = id / P.ct_size, ct = id - il * P.ct_size;
-  const int nq = P.nq;
-  double* y = P.scratch + (size_t)id * 2 * nq;
-  double* dd = y + nq;
-  const double* x = P.q;
-  // which product of transfer functions is this spectrum? (spectra_module.cpp:1027-1185)
-  int kind = -1;
-  if (ct == P.ct_tt) kind = 0; else if (ct == P.ct_ee) kind = 1; else if (ct == P.ct_te) kind = 2;
-  else if (ct == P.ct_pp) kind = 4; else if (ct == P.ct_tp) kind = 5; else if (ct == P.ct_ep) kind = 6;
-  if (kind < 0) { P.cl[id] = 0.; return; }  // bb vanishes for scalar modes (spectra_module.cpp:1262-1270)
+// C_l = int dq/q 4 pi P(q) Delta_l^X(q) Delta_l^Y(q), the integral being that of the cubic spline through the integrand
+// (spectra_module.cpp:1027-1323).  For a fixed q grid that integral is a LINEAR functional of the integrand samples,
+// sum_q W_q y_q: the host folds the whole spline construction (arrays.c array_spline, _SPLINE_EST_DERIV_) and its
+// integration (array_integrate_all_trapzd_or_spline, arrays.c:1382-1423) into the weights W_q once per grid (adjoint
+// of the two sweeps, spline_integration_weights below), and the kernel is a coalesced dot product: one workgroup per
+// l, the 6 spectra share the transfer rows.  The sequential per-(l,ct) sweeps this replaces took 3.5 ms.
+__global__ void __launch_bounds__(256) k_cl(ClParams P) {
+  const int il = blockIdx.x, tid = threadIdx.x, nq = P.nq;
   const size_t st = (size_t)P.nl * nq, row = (size_t)il * nq;
-  const double PI = 3.1415926535897932384626433832795e0;
-  for (int iq = 0; iq < nq; iq++) {
-    const double k = x[iq];
+  double acc[6] = {0., 0., 0., 0., 0., 0.};  // tt, ee, te, pp, tp, ep
+  for (int iq = tid; iq < nq; iq += 256) {
     double temp = 0., e = 0., lc = 0.;
     if (P.tt_t0 >= 0) temp = P.tr[P.tt_t0 * st + row + iq] + P.tr[P.tt_t1 * st + row + iq] + P.tr[P.tt_t2 * st + row + iq];
     if (P.tt_e >= 0) e = P.tr[P.tt_e * st + row + iq];
     if (P.tt_lcmb >= 0) lc = P.tr[P.tt_lcmb * st + row + iq];
-    double prod;
-    switch (kind) {
-      case 0: prod = temp * temp; break;
-      case 1: prod = e * e; break;
-      case 2: prod = 0.5 * (temp * e + e * temp); break;
-      case 4: prod = lc * lc; break;
-      case 5: prod = 0.5 * (temp * lc + lc * temp); break;
-      default: prod = 0.5 * (e * lc + lc * e); break;
-    }
-    y[iq] = primordial(P, k) * prod * (4. * PI / k);
+    const double w = P.w[iq];
+    acc[0] = fma(w, temp * temp, acc[0]);
+    acc[1] = fma(w, e * e, acc[1]);
+    acc[2] = fma(w, temp * e, acc[2]);
+    acc[3] = fma(w, lc * lc, acc[3]);
+    acc[4] = fma(w, temp * lc, acc[4]);
+    acc[5] = fma(w, e * lc, acc[5]);
   }
-  // spline, _SPLINE_EST_DERIV_: the elimination factors c, sig, p depend on the q grid only (host, P.splc);
-  // forward sweep stores u_i in dd, the backward sweep finishes dd and integrates on the fly (arrays.c:1413-1421)
-  const int n = nq;
-  const double* cc = P.splc;
-  const double* sg = P.splc + n;
-  const double* pp = P.splc + 2 * n;
-  const double dy_first = ((x[2] - x[0]) * (x[2] - x[0]) * (y[1] - y[0]) - (x[1] - x[0]) * (x[1] - x[0]) * (y[2] - y[0])) /
-                          ((x[2] - x[0]) * (x[1] - x[0]) * (x[2] - x[1]));
-  double u = (3. / (x[1] - x[0])) * ((y[1] - y[0]) / (x[1] - x[0]) - dy_first);
-  dd[0] = u;
+  __shared__ double red[4][6];
+#pragma unroll
+  for (int c = 0; c < 6; c++) {
+    double v = acc[c];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    if ((tid & 63) == 0) red[tid >> 6][c] = v;
+  }
+  __syncthreads();
+  if (tid < P.ct_size) {
+    const int ct = tid;
+    int kind = -1;
+    if (ct == P.ct_tt) kind = 0; else if (ct == P.ct_ee) kind = 1; else if (ct == P.ct_te) kind = 2;
+    else if (ct == P.ct_pp) kind = 3; else if (ct == P.ct_tp) kind = 4; else if (ct == P.ct_ep) kind = 5;
+    double v = 0.;  // bb vanishes for scalar modes (spectra_module.cpp:1262-1270)
+    if (kind >= 0) v = red[0][kind] + red[1][kind] + red[2][kind] + red[3][kind];
+    P.cl[(size_t)il * P.ct_size + ct] = v;
+  }
+}
+
+// W with  sum_i W_i y_i == integral of the _SPLINE_EST_DERIV_ cubic spline through (x_i, y_i)  (arrays.c:1382-1423).
+// Forward algorithm (what the reference runs per spectrum):
+//   u_0 = 3/h_0 ((y_1-y_0)/h_0 - y'_first);  u_i = (6 d_i/(x_{i+1}-x_{i-1}) - sig_i u_{i-1})/p_i,  d_i = second divided difference
+//   dd_{n-1} = (u_n - u_{n-2}/2)/(c_{n-2}/2 + 1);  dd_i = c_i dd_{i+1} + u_i;  I = sum_i (y_i+y_{i+1}) h_i/2 + (dd_i+dd_{i+1}) h_i^3/24
+// run here in reverse (adjoint) mode: O(n), exact up to the order of the floating-point additions.
+static void spline_integration_weights(const double* x, int n, double* W) {
+  std::vector<double> c(n), sig(n), p(n), mu(n), nu(n);
+  c[0] = -0.5; sig[0] = 0.; p[0] = 1.;
   for (int i = 1; i < n - 1; i++) {
-    const double ui = (y[i + 1] - y[i]) / (x[i + 1] - x[i]) - (y[i] - y[i - 1]) / (x[i] - x[i - 1]);
-    u = (6.0 * ui / (x[i + 1] - x[i - 1]) - sg[i] * u) / pp[i];
-    dd[i] = u;
+    sig[i] = (x[i] - x[i - 1]) / (x[i + 1] - x[i - 1]);
+    p[i] = sig[i] * c[i - 1] + 2.0;
+    c[i] = (sig[i] - 1.0) / p[i];
   }
-  const double dy_last = ((x[n - 3] - x[n - 1]) * (x[n - 3] - x[n - 1]) * (y[n - 2] - y[n - 1]) -
-                          (x[n - 2] - x[n - 1]) * (x[n - 2] - x[n - 1]) * (y[n - 3] - y[n - 1])) /
-                         ((x[n - 3] - x[n - 1]) * (x[n - 2] - x[n - 1]) * (x[n - 3] - x[n - 2]));
-  const double un = (3. / (x[n - 1] - x[n - 2])) * (dy_last - (y[n - 1] - y[n - 2]) / (x[n - 1] - x[n - 2]));
-  double dd_next = (un - 0.5 * u) / (0.5 * cc[n - 2] + 1.0);  // dd[n-1]
-  double sum = 0.;
-  for (int i = n - 2; i >= 0; i--) {
-    const double ddi = cc[i] * dd_next + dd[i];
-    const double h = x[i + 1] - x[i];
-    sum += (y[i] + y[i + 1]) * h / 2. + (ddi + dd_next) * h * h * h / 24.;
-    dd_next = ddi;
+  auto h = [&](int i) { return x[i + 1] - x[i]; };
+  for (int i = 0; i < n; i++) W[i] = 0.;
+  for (int i = 0; i < n - 1; i++) { W[i] += 0.5 * h(i); W[i + 1] += 0.5 * h(i); }
+  // d I / d dd_i, including the chain dd_i -> dd_{i-1} -> ...
+  for (int i = 0; i < n; i++) {
+    double g = 0.;
+    if (i >= 1) g += h(i - 1) * h(i - 1) * h(i - 1) / 24.;
+    if (i <= n - 2) g += h(i) * h(i) * h(i) / 24.;
+    mu[i] = g + (i >= 1 ? c[i - 1] * mu[i - 1] : 0.);
   }
-  P.cl[id] = sum;
+  const double D = 0.5 * c[n - 2] + 1.0;
+  const double a_un = mu[n - 1] / D;
+  // d I / d u_i, including the chain u_i -> u_{i+1} -> ...
+  nu[n - 2] = mu[n - 2] - 0.5 * mu[n - 1] / D;
+  for (int i = n - 3; i >= 0; i--) nu[i] = mu[i] - sig[i + 1] / p[i + 1] * nu[i + 1];
+  for (int i = 1; i <= n - 2; i++) {
+    const double kap = 6. * nu[i] / ((x[i + 1] - x[i - 1]) * p[i]);
+    W[i + 1] += kap / h(i);
+    W[i] -= kap * (1. / h(i) + 1. / h(i - 1));
+    W[i - 1] += kap / h(i - 1);
+  }
+  {  // u_0 with the estimated first derivative at x_0
+    const double den = (x[2] - x[0]) * (x[1] - x[0]) * (x[2] - x[1]);
+    const double A = (x[2] - x[0]) * (x[2] - x[0]) / den, B = (x[1] - x[0]) * (x[1] - x[0]) / den;
+    const double c0 = nu[0] * 3. / h(0);
+    W[1] += c0 * (1. / h(0) - A);
+    W[0] += c0 * (-1. / h(0) + A - B);
+    W[2] += c0 * B;
+  }
+  {  // u_n with the estimated first derivative at x_{n-1}
+    const double den = (x[n - 3] - x[n - 1]) * (x[n - 2] - x[n - 1]) * (x[n - 3] - x[n - 2]);
+    const double A = (x[n - 3] - x[n - 1]) * (x[n - 3] - x[n - 1]) / den, B = (x[n - 2] - x[n - 1]) * (x[n - 2] - x[n - 1]) / den;
+    const double cn = a_un * 3. / h(n - 2);
+    W[n - 2] += cn * (A + 1. / h(n - 2));
+    W[n - 1] += cn * (-A + B - 1. / h(n - 2));
+    W[n - 3] -= cn * B;
+  }
 }
 
 __global__ void k_pk(const double* __restrict__ src, const double* __restrict__ k, double* __restrict__ pk, int nk, int ntau,
@@ -111,33 +137,25 @@ int cpt_cl_impl(cpt_handle* h, const cpt_spectra_params* sp, const double* trans
     return cpt_fail(h, CPT_ERR_INVALID, "lensing C_l requested without lensing transfer functions");
   for (int i = 1; i < nq; i++)
     if (!(q[i] > q[i - 1])) return cpt_fail(h, CPT_ERR_INVALID, "q grid must be strictly increasing");
+  if (nq < 4) return cpt_fail(h, CPT_ERR_INVALID, "need at least 4 q values for the integrand spline");
   int rc;
   if ((rc = cpt_reserve(h, &h->d_q, &h->grid_cap_q, (size_t)4 * nq))) return rc;
-  std::vector<double> hq((size_t)4 * nq);
-  memcpy(hq.data(), q, nq * sizeof(double));
-  {
-    double* cc = hq.data() + nq; double* sg = cc + nq; double* pp = sg + nq;
-    cc[0] = -0.5; sg[0] = 0.; pp[0] = 1.;
-    for (int i = 1; i < nq - 1; i++) {
-      sg[i] = (q[i] - q[i - 1]) / (q[i + 1] - q[i - 1]);
-      pp[i] = sg[i] * cc[i - 1] + 2.0;
-      cc[i] = (sg[i] - 1.0) / pp[i];
-    }
-    cc[nq - 1] = 0.; sg[nq - 1] = 0.; pp[nq - 1] = 1.;
+  std::vector<double> W(nq);
+  spline_integration_weights(q, nq, W.data());
+  const double PI = 3.1415926535897932384626433832795e0;
+  for (int i = 0; i < nq; i++) {  // primordial_module.cpp:911-925 (analytic spectrum) and the 4 pi / k of the measure
+    const double lk = log(q[i] / sp->k_pivot);
+    W[i] *= sp->A_s * exp((sp->n_s - 1.) * lk + 0.5 * sp->alpha_s * lk * lk) * (4. * PI / q[i]);
   }
-  const size_t need = (size_t)nl * sp->ct_size * 2 * nq;
-  if ((rc = cpt_reserve(h, &h->d_u, &h->u_cap, need))) return rc;
-  CPT_HIP(h, hipMemcpy(h->d_q, hq.data(), hq.size() * sizeof(double), hipMemcpyHostToDevice));
+  CPT_HIP(h, hipMemcpyAsync(h->d_q, W.data(), (size_t)nq * sizeof(double), hipMemcpyHostToDevice, h->stream));
   ClParams P;
-  P.tr = transfer_dev; P.q = h->d_q; P.cl = cl_dev; P.scratch = h->d_u; P.splc = h->d_q + nq; P.nq = nq; P.nl = nl; P.ct_size = sp->ct_size;
+  P.tr = transfer_dev; P.w = h->d_q; P.cl = cl_dev; P.nq = nq; P.nl = nl; P.ct_size = sp->ct_size;
   P.tt_t0 = c.index_tt_t0; P.tt_t1 = c.index_tt_t1; P.tt_t2 = c.index_tt_t2; P.tt_e = c.index_tt_e; P.tt_lcmb = c.index_tt_lcmb;
   P.ct_tt = sp->index_ct_tt; P.ct_ee = sp->index_ct_ee; P.ct_te = sp->index_ct_te; P.ct_bb = sp->index_ct_bb;
   P.ct_pp = sp->index_ct_pp; P.ct_tp = sp->index_ct_tp; P.ct_ep = sp->index_ct_ep;
-  P.A_s = sp->A_s; P.n_s = sp->n_s; P.alpha_s = sp->alpha_s; P.k_pivot = sp->k_pivot;
-  const int nthreads = nl * sp->ct_size;
-  hipLaunchKernelGGL(k_cl, dim3((nthreads + 63) / 64), dim3(64), 0, h->stream, P);
+  hipLaunchKernelGGL(k_cl, dim3(nl), dim3(256), 0, h->stream, P);
   CPT_HIP(h, hipGetLastError());
-  CPT_HIP(h, hipStreamSynchronize(h->stream));
+  CPT_HIP(h, hipStreamSynchronize(h->stream));  // W is a stack vector: the copy above must have completed
   return CPT_OK;
 }
 
