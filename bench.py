@@ -108,6 +108,8 @@ def main():
         torch.cuda.synchronize()
 
     has_pk = inp.config.index_tp_delta_m >= 0
+    has_lensing = "le.l_unlensed_max" in inp.d   # the .ini asks for lensed C_l (explanatory.ini; lcdm.ini has lensing = no)
+    lens_args = (int(inp.d["le.l_unlensed_max"][0]), int(inp.d["le.delta_l_max"][0])) if has_lensing else None
 
     def step():
         # tables-in -> C_l (and P(k)) out, nothing leaves HBM in between
@@ -115,6 +117,8 @@ def main():
             be.perturb_solve(want_sources=False)      # sources stay resident, k-major, in HBM
             tr = be.transfer(None)
             cl = be.cl(tr)
+            if has_lensing:
+                cl = be.lensed_cl(cl, *lens_args)
             pk = be.pk_linear() if has_pk else None
             return cl, pk
         out, _ = sharded_step(comp, k_all, inp.l, rank, world, device, k_size_cl)
@@ -170,7 +174,8 @@ def main():
                                    "%d q x %d l x %d transfer types%s" % (
                                        args.config, "+mPk" if inp.config.index_tp_delta_m >= 0 else "+lCl", nk_total, inp.ntau,
                                        inp.q.size, inp.l.size, inp.config.tt_size,
-                                       "" if world == 1 else "; k grid densified %dx and sharded round-robin" % world),
+                                       ("; lensed C_l" if has_lensing else "") +
+                                       ("" if world == 1 else "; k grid densified %dx and sharded round-robin" % world)),
                        "inputs": "background/thermodynamics spline tables and grids from tests/golden (dumped from the reference)",
                        "parallelism": "k-sharded x%d, l-sharded transfer, 2 RCCL exchanges" % world if world > 1 else "1 GPU"},
             "stage_ms": {"perturb_kernel": k_ms, "los_kernel": t_ms, "step_wall": ms_step},

@@ -104,6 +104,20 @@ class Backend:
                                           C.c_void_p(out.data_ptr())))
         return out
 
+    def lensed_cl(self, cl, l_unlensed_max, delta_l_max=500, accurate=False, num_mu_minus_lmax=70, tol_gauss_legendre=0.0, l=None):
+        """unlensed C_l table [nl][ct] (device) -> lensed table [l_size][ct] on device (cpt_lensing_batch)"""
+        from .capi import CptLensingParams
+        l = np.ascontiguousarray(self.inp.l if l is None else l, dtype=np.int32)
+        lp = CptLensingParams(int(l_unlensed_max), int(delta_l_max), int(bool(accurate)), int(num_mu_minus_lmax), float(tol_gauss_legendre))
+        lptr = l.ctypes.data_as(C.POINTER(C.c_int))
+        n = self.lib.cpt_lensing_l_size(lptr, l.size, C.byref(lp))
+        if n < 1:
+            raise CptInputError("cpt_lensing_l_size failed")
+        out = torch.empty((n, self.inp.spectra.ct_size), dtype=torch.float64, device=self.device)
+        self._check(self.lib.cpt_lensing_batch(self.h, C.byref(self.inp.spectra), C.byref(lp), lptr, l.size, C.c_void_p(cl.data_ptr()),
+                                               C.c_void_p(out.data_ptr())))
+        return out
+
     def pk_linear(self, k=None):
         k = np.ascontiguousarray(self.inp.k if k is None else k, dtype=np.float64)
         out = torch.empty(k.size, dtype=torch.float64, device=self.device)

@@ -75,11 +75,17 @@ class CptSpectraParams(C.Structure):
                 ("index_ct_tp", _i), ("index_ct_ep", _i)]
 
 
+class CptLensingParams(C.Structure):
+    _fields_ = [("l_unlensed_max", _i), ("delta_l_max", _i), ("accurate_lensing", _i), ("num_mu_minus_lmax", _i),
+                ("tol_gauss_legendre", _d)]
+
+
 # every symbol include/cpt.h declares (tests check that the built library exports all of them)
 EXPORTS = [
     "cpt_create", "cpt_destroy", "cpt_last_error", "cpt_create_error", "cpt_perturb_solve_batch",
     "cpt_transfer_batch", "cpt_get_sources", "cpt_last_kernel_ms", "cpt_last_transfer_work",
     "cpt_dbg_lookup", "cpt_dbg_derivs", "cpt_dbg_solve", "cpt_dbg_bessel", "cpt_cl_batch", "cpt_pk_linear",
+    "cpt_lensing_l_size", "cpt_lensing_batch",
 ]
 
 _lib = None
@@ -121,6 +127,10 @@ def lib():
     L.cpt_cl_batch.restype = _i
     L.cpt_pk_linear.argtypes = [vp, C.POINTER(CptSpectraParams), _pd, _i, vp]
     L.cpt_pk_linear.restype = _i
+    L.cpt_lensing_l_size.argtypes = [pi, _i, C.POINTER(CptLensingParams)]
+    L.cpt_lensing_l_size.restype = _i
+    L.cpt_lensing_batch.argtypes = [vp, C.POINTER(CptSpectraParams), C.POINTER(CptLensingParams), pi, _i, vp, vp]
+    L.cpt_lensing_batch.restype = _i
     L.cpt_dbg_lookup.argtypes = [vp, _pd, _i, _pd]
     L.cpt_dbg_lookup.restype = _i
     L.cpt_dbg_derivs.argtypes = [vp, _d, _d, _i, _i, _i, _pd, _pd, pi]

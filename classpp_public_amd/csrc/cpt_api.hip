@@ -155,7 +155,7 @@ void cpt_destroy(cpt_handle* h) {
   if (!h) return;
   // (d_splc and d_ik are interior pointers into d_k / d_q and must not be freed)
   void* ptrs[] = {h->d_tau_table, h->d_bg, h->d_z_table, h->d_th, h->d_src, h->d_dd, h->d_u, h->d_k, h->d_tau, h->d_q,
-                  h->d_l, h->d_bes, h->d_chi_min, h->d_work, h->d_pt_scratch};
+                  h->d_l, h->d_bes, h->d_chi_min, h->d_work, h->d_pt_scratch, h->d_lens, h->d_lens_w, h->d_lens_l};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   for (Timer* tm : {&h->t_perturb, &h->t_transfer}) {
@@ -199,6 +199,19 @@ int cpt_pk_linear(cpt_handle* h, const cpt_spectra_params* sp, const double* k, 
   h->err.clear();
   if (!sp || !k || !pk_dev || nk < 1) return cpt_fail(h, CPT_ERR_INVALID, "bad arguments to cpt_pk_linear");
   return cpt_pk_impl(h, sp, k, nk, pk_dev);
+}
+
+int cpt_lensing_l_size(const int* l, int nl, const cpt_lensing_params* lp) {
+  if (!l || !lp || nl < 1) return -1;
+  return cpt_lensing_l_size_impl(l, nl, lp);
+}
+
+int cpt_lensing_batch(cpt_handle* h, const cpt_spectra_params* sp, const cpt_lensing_params* lp, const int* l, int nl,
+                      const double* cl_dev, double* cl_lensed_dev) {
+  if (!h) return CPT_ERR_INVALID;
+  h->err.clear();
+  if (!sp || !lp || !l || !cl_dev || !cl_lensed_dev) return cpt_fail(h, CPT_ERR_INVALID, "bad arguments to cpt_lensing_batch");
+  return cpt_lensing_impl(h, sp, lp, l, nl, cl_dev, cl_lensed_dev);
 }
 
 int cpt_get_sources(cpt_handle* h, double* sources_dev) {

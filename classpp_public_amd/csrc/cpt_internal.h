@@ -61,6 +61,16 @@ struct cpt_handle {
   double bes_dx = 0;
   unsigned long long* d_work = nullptr;  // [3] integrals, per-type samples, fused samples
   long long work_integrals = 0, work_samples = 0, work_fused = 0;
+  // lensing: Wigner-d table cache [12][num_mu][lmax+1] + coefficient / angle / work arrays (cpt_lensing.hip)
+  double* d_lens = nullptr;
+  size_t lens_cap = 0;
+  double *lens_d = nullptr, *lens_fac = nullptr, *lens_mu = nullptr, *lens_w8 = nullptr, *lens_cgl = nullptr, *lens_ksi = nullptr,
+         *lens_work = nullptr;
+  int lens_num_mu = -1, lens_accurate = -1, lens_lmax = -1;
+  double* d_lens_w = nullptr;
+  size_t lens_w_cap = 0;
+  int* d_lens_l = nullptr;
+  size_t lens_l_cap = 0;
   // perturb scratch
   void* d_pt_scratch = nullptr;
   size_t pt_scratch_cap = 0;
@@ -92,6 +102,9 @@ int cpt_reserve(cpt_handle* h, T** p, size_t* cap, size_t n) {
 int cpt_transfer_impl(cpt_handle* h, const double* sources_dev, const double* k, int nk, int k_size_cl,
                       const double* tau_sampling, int ntau, const double* q, int nq, const int* l, int nl,
                       double* transfer_dev);
+int cpt_lensing_l_size_impl(const int* l, int nl, const cpt_lensing_params* lp);
+int cpt_lensing_impl(cpt_handle* h, const cpt_spectra_params* sp, const cpt_lensing_params* lp, const int* l, int nl,
+                     const double* cl_dev, double* cl_lensed_dev);
 int cpt_bessel_build(cpt_handle* h, const int* l, int nl, double xmax);
 int cpt_perturb_impl(cpt_handle* h, const double* k, int nk, const double* tau_sampling, int ntau, double* sources_dev,
                      cpt_stepstat* stats, int* status);

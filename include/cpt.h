@@ -184,6 +184,23 @@ int cpt_cl_batch(cpt_handle* h, const cpt_spectra_params* sp, const double* tran
  * (NonlinearModule::nonlinear_pk_linear, source/nonlinear_module.cpp:1886-2040); pk_dev device [nk]               */
 int cpt_pk_linear(cpt_handle* h, const cpt_spectra_params* sp, const double* k, int nk, double* pk_dev);
 
+/* ---- CMB lensing of the C_l's (LensingModule::lensing_init, source/lensing_module.cpp:149-854) ----
+ * precision parameters of include/precisions.h:492-495 plus SpectraModule::l_max_tot_ */
+typedef struct cpt_lensing_params {
+  int l_unlensed_max;        /* last multipole of the unlensed spectra (l_max_scalars + delta_l_max when lensing = yes) */
+  int delta_l_max;           /* lensed spectra are returned up to l_unlensed_max - delta_l_max (default 500) */
+  int accurate_lensing;      /* 0: Riemann sum of the correlation-function difference on (0, pi/16] (default); 1: Gauss-Legendre */
+  int num_mu_minus_lmax;     /* accurate mode: number of nodes - l_max (default 70) */
+  double tol_gauss_legendre; /* accurate mode: tolerance on the Legendre roots (<= 0: 1e-14) */
+} cpt_lensing_params;
+/* number of rows of the lensed table for this l grid (LensingModule::lensing_indices, lensing_module.cpp:983-993) */
+int cpt_lensing_l_size(const int* l, int nl, const cpt_lensing_params* lp);
+/* cl_dev device [nl][ct_size] (unlensed, from cpt_cl_batch) on the l grid l[nl] (host)
+ *   -> cl_lensed_dev device [cpt_lensing_l_size][ct_size] = LensingModule::cl_lens_: TT, TE, EE, BB lensed, the other
+ *      types copied.  Replaces the body of LensingModule::lensing_init.                                               */
+int cpt_lensing_batch(cpt_handle* h, const cpt_spectra_params* sp, const cpt_lensing_params* lp, const int* l, int nl,
+                      const double* cl_dev, double* cl_lensed_dev);
+
 /* Device-side copy of the resident sources into the reference layout [tp_size][ntau][nk] (device pointer). */
 int cpt_get_sources(cpt_handle* h, double* sources_dev);
 

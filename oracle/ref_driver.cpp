@@ -49,6 +49,7 @@
 #include "nonlinear_module.h"
 #include "transfer_module.h"
 #include "spectra_module.h"
+#include "lensing_module.h"
 #undef private
 #undef protected
 
@@ -244,6 +245,25 @@ static int do_dump(const char* ini, const char* outpath) {
     put_i("sp.index_ct_pp", sp->has_pp_ ? sp->index_ct_pp_ : -1);
     put_i("sp.index_ct_tp", sp->has_tp_ ? sp->index_ct_tp_ : -1);
     put_i("sp.index_ct_ep", sp->has_ep_ ? sp->index_ct_ep_ : -1);
+    put_i("sp.index_ct_bb", sp->has_bb_ ? sp->index_ct_bb_ : -1);
+
+    // ---- lensed C_l table on the lensing module's l grid (source/lensing_module.cpp:149-854) ----
+    const lensing* ple = &inp->lensing_;
+    if (ple->has_lensed_cls == _TRUE_) {
+      auto le = cosmo.GetLensingModule();
+      put_i("le.l_unlensed_max", le->l_unlensed_max_); put_i("le.l_lensed_max", le->l_lensed_max_);
+      put_i("le.l_size", le->l_size_); put_i("le.lt_size", le->lt_size_);
+      put_f8("le.l", le->l_, {le->l_size_});
+      put_f8("le.cl_lens", le->cl_lens_, {le->l_size_, le->lt_size_});
+      put_i4("le.l_max_lt", le->l_max_lt_, {le->lt_size_});
+      put_i("le.accurate_lensing", (int)ppr->accurate_lensing); put_i("le.delta_l_max", (int)ppr->delta_l_max);
+      put_i("le.num_mu_minus_lmax", (int)ppr->num_mu_minus_lmax);
+      auto lcls = le->cl_output(le->l_lensed_max_);
+      for (auto& kv : lcls) {
+        std::string nm = "le.cl_" + kv.first;
+        put_f8(nm.c_str(), kv.second.data(), {(long)kv.second.size()});
+      }
+    }
   }
 
   // ---- linear P(k, z=0) on the module's own k grid (source/nonlinear_module.cpp:1886-2040) ----

@@ -166,3 +166,18 @@ def pk_linear(inp, delta_m_today):
     out = np.zeros(inp.k.size)
     assert L.orc_pk(C.byref(inp.spectra), dptr(inp.k), inp.k.size, dptr(dm), dptr(out)) == 0
     return out
+
+
+def lensing(inp, cl, l_unlensed_max, delta_l_max=500, accurate=0, num_mu_minus_lmax=70, tol_gl=1e-14):
+    """unlensed cl table [nl][ct] on inp.l -> lensed table [l_size][ct] (oracle/restate/lensing_oracle.cpp)"""
+    from classpp_public_amd.capi import CptSpectraParams
+    L = lib()
+    L.orc_lensing_l_size.argtypes = [_pi, _i, _i, _i]
+    L.orc_lensing.argtypes = [C.POINTER(CptSpectraParams), _pi, _i, _pd, _i, _i, _i, _i, C.c_double, _pd]
+    cl = np.ascontiguousarray(cl, dtype=np.float64)
+    l = np.ascontiguousarray(inp.l, dtype=np.int32)
+    n = L.orc_lensing_l_size(iptr(l), l.size, l_unlensed_max, delta_l_max)
+    out = np.zeros((n, cl.shape[1]))
+    assert L.orc_lensing(C.byref(inp.spectra), iptr(l), l.size, dptr(cl), l_unlensed_max, delta_l_max, accurate,
+                         num_mu_minus_lmax, tol_gl, dptr(out)) == 0
+    return out
