@@ -56,8 +56,8 @@ int cpt_transpose_from_kmajor(cpt_handle* h, const double* src, double* dst, int
 // ---------------------------------------------------------------------------------------------
 static int validate(const cpt_config* c) {
   // physics branches of the reference that this backend does not implement (SURVEY.md S8f "not planned"/later)
-  if (c->sgnK != 0 || c->K != 0. || c->has_curvature)
-    return cpt_fail(nullptr, CPT_ERR_UNSUPPORTED, "non-flat space (K=%g) is not implemented by this backend", c->K);
+  if ((c->sgnK == 0) != (c->K == 0.) || (c->sgnK != 0 && (c->sgnK > 0) != (c->K > 0.)))
+    return cpt_fail(nullptr, CPT_ERR_INVALID, "inconsistent curvature: K=%g, sgnK=%d", c->K, c->sgnK);
   if (c->has_ncdm) return cpt_fail(nullptr, CPT_ERR_UNSUPPORTED, "non-cold dark matter species are not implemented");
   if (c->has_fld) return cpt_fail(nullptr, CPT_ERR_UNSUPPORTED, "dark-energy fluid perturbations are not implemented");
   if (!c->has_cdm && c->gauge == CPT_GAUGE_SYNCHRONOUS)
@@ -183,6 +183,9 @@ int cpt_transfer_batch(cpt_handle* h, const double* sources_dev, const double* k
       k_size_cl > nk)
     return cpt_fail(h, CPT_ERR_INVALID, "bad arguments to cpt_transfer_batch");
   if (h->cfg.tt_size < 1 || h->cfg.tt_size > 5) return cpt_fail(h, CPT_ERR_INVALID, "tt_size=%d out of range", h->cfg.tt_size);
+  if (h->cfg.K != 0.)
+    return cpt_fail(h, CPT_ERR_UNSUPPORTED, "non-flat space (K=%g): the per-q hyperspherical Bessel tables of the transfer stage "
+                    "(hyperspherical.c:11-246 with nu = q/sqrt|K|) are not implemented yet; the perturbation stage is", h->cfg.K);
   return cpt_transfer_impl(h, sources_dev, k, nk, k_size_cl, tau_sampling, ntau, q, nq, l, nl, transfer_dev);
 }
 
@@ -191,6 +194,7 @@ int cpt_cl_batch(cpt_handle* h, const cpt_spectra_params* sp, const double* tran
   if (!h) return CPT_ERR_INVALID;
   h->err.clear();
   if (!sp || !transfer_dev || !q || !cl_dev || nq < 3 || nl < 1) return cpt_fail(h, CPT_ERR_INVALID, "bad arguments to cpt_cl_batch");
+  if (h->cfg.K != 0.) return cpt_fail(h, CPT_ERR_UNSUPPORTED, "non-flat space: the C_l integral over nu (spectra_module.cpp:1290-1323) is not implemented yet");
   return cpt_cl_impl(h, sp, transfer_dev, q, nq, nl, cl_dev);
 }
 

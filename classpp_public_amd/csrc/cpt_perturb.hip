@@ -30,6 +30,7 @@ struct PtParams {
   // config scalars
   int has_cdm, has_ur, tca_method, rsa_method, ufa_method, l_max_g, l_max_pol_g, l_max_ur;
   double T_cmb, a_today, YHe, n_e, tau_free_streaming;
+  double K;  // spatial curvature (pba->K); 0 in flat space
   int switch_sw, switch_eisw, switch_lisw, switch_dop, switch_pol;
   double eisw_lisw_split_z, three_ceff2_ur, three_cvis2_ur;
   int tp_size, tp_t0, tp_t1, tp_t2, tp_p, tp_dm, tp_pp;
@@ -306,6 +307,7 @@ struct Lookup {
   // derived, tau-only
   double a2, aH, two_over_aH, R, inv_1pR, inv_R, tau_c, dtau_c, F, Fp, app, inv_tau, rg43, ru43;
   double zmax, xe_last, taud_last;  // last row of the thermodynamics table (analytic continuation beyond it)
+  double k2s2, inv_k2s2, s2, s2sq, kcot;  // per-mode curvature factors (set_mode) and k cotK_gen(tau_cached); flat: k^2, 1/k^2, 1, 1, 1/tau
 #ifdef CPT_PROFILE
   unsigned long long* prof;
 #endif
@@ -368,6 +370,15 @@ __device__ __forceinline__ void lookup_init(const PtParams& P, Lookup& Q, double
   Q.zmax = P.tabs.z_table[P.tabs.tt_size - 1];
   Q.xe_last = last[TH_XE].x;
   Q.taud_last = last[TH_TAU_D].x;
+}
+
+// per-mode constants of the curved-space equations (pm.cpp:2530-2533, 5856): s_2, s_2^2 = 1 - 3K/k^2
+__device__ __forceinline__ void lookup_set_mode(const PtParams& P, Lookup& Q, double k) {
+  const double k2 = k * k;
+  Q.s2sq = 1. - 3. * P.K / k2;
+  Q.s2 = (P.K == 0.) ? 1. : sqrt(fmax(Q.s2sq, 0.));
+  Q.k2s2 = k2 * Q.s2sq;
+  Q.inv_k2s2 = 1. / Q.k2s2;
 }
 
 // background_at_tau (normal_info, source/background_module.cpp:125-199) + thermodynamics_at_z (th.cpp:114-285)
@@ -436,11 +447,16 @@ __device__ __forceinline__ void lookup(const PtParams& P, Lookup& Q, double tau,
   Q.Fp = Q.dtau_c * Q.inv_1pR + Q.tau_c * Q.aH * Q.R * Q.inv_1pR * Q.inv_1pR;
   Q.app = bg_Hp * bg_a + 2. * Q.aH * Q.aH;       // a''/a
   Q.inv_tau = fast_rcp(tau);
+  if (P.K == 0.) Q.kcot = Q.inv_tau;                       // k cotK_gen = 1/tau (pm.cpp:7969)
+  else {                                                    // pm.cpp:7972-7977
+    const double sq = sqrt(fabs(P.K));
+    Q.kcot = (P.K < 0.) ? sq / tanh(sq * tau) : sq / tan(sq * tau);
+  }
 }
 
 // ---- physics ------------------------------------------------------------------------------------
 // Per-lane description of the current regime.  EVERY equation of the scalar system has the shape
-//   dy = A y[dn] - B y[up] - (D kappa' + G/tau) y + Xmc h'/2 + Xms k^2 alpha + XP kappa' Pi/8... + X4 S4 + Xeta eta' + Xtb theta_b'
+//   dy = A y[dn] - B y[up] - (D kappa' + G k cotK(tau) + Gt/tau) y + Xmc h'/2 + Xms k^2 alpha + XP kappa' Pi/8... + X4 S4 + Xeta eta' + Xtb theta_b'
 // with per-lane constants (A, B, D, G, X*, dn, up) fixed by the regime and a handful of wave-uniform scalars (the
 // metric perturbations, the polarisation source, the baryon-photon coupling) that depend on (tau, y):
 //   * the streaming terms A y[dn] - B y[up] couple neighbours of one multipole ladder (delta, theta, shear, l=3, ...);
@@ -455,19 +471,22 @@ struct LaneEq {
   int first_addr;      // core parents of a tail (shear_g, pol2, shear_ur): byte address of the tail's l=3 lane; else own lane
   int parent_addr;     // tail lanes: byte address of the core parent; else own lane
   double Bpar;         // core parents of a present tail: B (their coupling to the tail's l=3 element); else 0
-  double A, B, D, G;
+  double A, B, D, G, Gt;   // G multiplies k cotK_gen(tau) (hierarchy truncation), Gt multiplies 1/tau (ur fluid): equal in flat space
   double Xmc, Xms, XP, X4, Xeta, Xtb;
 };
 
 __device__ __forceinline__ LaneEq make_lane_eq(const PtParams& P, const Layout& L, int lane, double k) {
   LaneEq e;
   role_of(P, L, lane, &e.role, &e.ell);
-  e.A = e.B = e.D = e.G = 0.;
+  e.A = e.B = e.D = e.G = e.Gt = 0.;
   e.Xmc = e.Xms = e.XP = e.X4 = e.Xeta = e.Xtb = 0.;
   e.chain = 0; e.first = false; e.last = false;
   int dn = lane, up = lane;
   const int l = e.ell;
   const double k2 = k * k, c3 = P.three_ceff2_ur, v3 = P.three_cvis2_ur;
+  // curvature factors s_l = sqrt(1 - K (l^2-1)/k^2) of the multipole ladders (pm.cpp:2530-2533); all 1 in flat space
+  auto S = [&](int ll) { const double v = 1.0 - P.K * (ll * ll - 1.0) / k2; return (P.K == 0.) ? 1.0 : sqrt(fmax(v, 0.)); };
+  const double s2 = S(2), s3 = S(3), s2sq = 1. - 3. * P.K / k2;
   int lm = 0, parent = lane;
   if (e.role == R_LG) { e.chain = 1; lm = L.lmg; e.D = 1.; parent = LN_SG; }
   else if (e.role == R_POL && l >= 3) { e.chain = 2; lm = L.lmp; e.D = 1.; parent = LN_P2; }
@@ -476,37 +495,37 @@ __device__ __forceinline__ LaneEq make_lane_eq(const PtParams& P, const Layout& 
     e.first = (l == 3); e.last = (l == lm);
     dn = e.first ? parent : lane - 1;
     up = e.last ? lane : lane + 1;
-    if (l == 3 && e.chain != 2) { e.A = 6. * k / 7.; e.B = 4. * k / 7.; }     // pm.cpp:8158-8161: F_2 = 2 shear
-    else if (l < lm) { e.A = k * l / (2. * l + 1.); e.B = k * (l + 1.) / (2. * l + 1.); }
-    else { e.A = k; e.G = 1. + l; }                                             // pm.cpp:8171-8176, cotKgen = 1/(k tau)
+    if (l == 3 && e.chain != 2) { e.A = 6. * k * s3 * s2 / 7.; e.B = 4. * k * S(4) / 7.; }   // pm.cpp:8158-8161: F_2 = 2 s_2 shear
+    else if (l < lm) { e.A = k * l * S(l) / (2. * l + 1.); e.B = k * (l + 1.) * S(l + 1) / (2. * l + 1.); }
+    else { e.A = k * S(l); e.G = 1. + l; }                                     // pm.cpp:8171-8176: -(l+1) k cotKgen y_l
   } else {
     switch (e.role) {
       case R_DELTA_G: e.B = 4. / 3.; up = LN_TG; e.Xmc = -4. / 3.; break;                                 // pm.cpp:8095
       case R_THETA_G:
-        if (!L.tca) { e.A = 0.25 * k2; dn = LN_DG; e.B = k2; up = LN_SG; e.D = 1.; }                       // pm.cpp:8145-8148
+        if (!L.tca) { e.A = 0.25 * k2; dn = LN_DG; e.B = k2 * s2sq; up = LN_SG; e.D = 1.; }              // pm.cpp:8145-8148
         e.X4 = 1.;                           // S4 = kappa' theta_b, or the whole tight-coupling expression (pm.cpp:8214-8217)
         break;
       case R_SHEAR_G:                                                                                    // pm.cpp:8151-8155
-        e.A = 4. / 15.; dn = LN_TG; e.D = 1.; e.Xms = 4. / 15.; e.XP = 0.4;
-        if (L.gN > 0) { e.B = 0.3 * k; up = L.g3; }
+        e.A = 4. / 15.; dn = LN_TG; e.D = 1.; e.Xms = 4. / 15.; e.XP = 0.4 / s2;
+        if (L.gN > 0) { e.B = 0.3 * k * s3 / s2; up = L.g3; }
         break;
       case R_POL:
-        if (l == 0) { e.B = k; up = LN_P1; e.D = 1.; e.XP = 4.; }                                         // pm.cpp:8179-8181
-        else if (l == 1) { e.A = k / 3.; dn = LN_P0; e.B = 2. * k / 3.; up = LN_P2; e.D = 1.; }            // pm.cpp:8184-8186
-        else { e.A = 2. * k / 5.; dn = LN_P1; e.D = 1.; e.XP = 0.8; if (L.qN > 0) { e.B = 3. * k / 5.; up = L.q3; } }  // :8189-8191
+        if (l == 0) { e.B = k; up = LN_P1; e.D = 1.; e.XP = 4.; }                                        // pm.cpp:8179-8181
+        else if (l == 1) { e.A = k / 3.; dn = LN_P0; e.B = 2. * k * s2 / 3.; up = LN_P2; e.D = 1.; }     // pm.cpp:8184-8186
+        else { e.A = 2. * k * s2 / 5.; dn = LN_P1; e.D = 1.; e.XP = 0.8; if (L.qN > 0) { e.B = 3. * k * s3 / 5.; up = L.q3; } }  // :8189-8191
         break;
-      case R_DELTA_B: e.B = 1.; up = LN_TB; e.Xmc = -1.; break;                                           // pm.cpp:8101
+      case R_DELTA_B: e.B = 1.; up = LN_TB; e.Xmc = -1.; break;                                          // pm.cpp:8101
       case R_THETA_B: e.Xtb = 1.; break;
       case R_DELTA_CDM: e.Xmc = -1.; break;                                                              // pm.cpp:8240
-      case R_DELTA_UR: e.B = 4. / 3.; up = LN_TUR; e.Xmc = -4. / 3.; break;                               // pm.cpp:8630-8634
-      case R_THETA_UR: e.A = 0.25 * c3 * k2; dn = LN_DUR; e.B = k2; up = LN_SUR; break;                    // pm.cpp:8637-8641
+      case R_DELTA_UR: e.B = 4. / 3.; up = LN_TUR; e.Xmc = -4. / 3.; break;                              // pm.cpp:8630-8634
+      case R_THETA_UR: e.A = 0.25 * c3 * k2; dn = LN_DUR; e.B = k2 * s2sq; up = LN_SUR; break;           // pm.cpp:8637-8641
       case R_SHEAR_UR:
         dn = LN_TUR;
-        if (!L.ufa) { e.A = 4. / 15. * v3; e.Xms = 4. / 15. * v3; if (L.uN > 0) { e.B = 0.3 * k; up = L.u3; } }  // pm.cpp:8645-8651
+        if (!L.ufa) { e.A = 4. / 15. * v3; e.Xms = 4. / 15. * v3; if (L.uN > 0) { e.B = 0.3 * k * s3 / s2; up = L.u3; } }  // pm.cpp:8645-8651
         else {                                                                                           // pm.cpp:8704-8708
           e.A = 2. / 3.;
-          if (P.ufa_method == CPT_UFA_CLASS) { e.G = 3.; e.Xmc = 2. / 3.; }
-          else if (P.ufa_method == CPT_UFA_MB) { e.G = 3.; e.Xms = 2. / 3.; }
+          if (P.ufa_method == CPT_UFA_CLASS) { e.Gt = 3.; e.Xmc = 2. / 3.; }
+          else if (P.ufa_method == CPT_UFA_MB) { e.Gt = 3.; e.Xms = 2. / 3.; }
           else e.Xms = 2. / 3.;                                                 // ufa_hu: -3 a'/a shear added in rhs
         }
         break;
@@ -573,7 +592,7 @@ __device__ __forceinline__ double rhs(const PtParams& P, const Layout& L, const 
   if (P.has_cdm) delta_rho += Q.rc * dc;
   if (P.has_ur) { delta_rho += Q.ru * dur; rpt += Q.ru43 * tur; rps += Q.ru43 * sur; }
   // ---- Einstein equations ----
-  const double hp = (k2 * eta + 1.5 * a2 * delta_rho) * Q.two_over_aH;
+  const double hp = (Q.k2s2 * eta + 1.5 * a2 * delta_rho) * Q.two_over_aH;          // pm.cpp:5913-5914, k2s2 = k^2 (1 - 3K/k^2)
   if (L.rsa) {
     double rdg = 0., rtg = 0., rdur = 0., rtur = 0.;
     if (P.rsa_method != CPT_RSA_NULL) { rdg = 4. * inv_k2 * (aH * hp - k2 * eta); rtg = -0.5 * hp; }
@@ -588,7 +607,7 @@ __device__ __forceinline__ double rhs(const PtParams& P, const Layout& L, const 
     M.rsa_dg = rdg; M.rsa_tg = rtg;
     dg = rdg; tg = rtg;  // pm.cpp:8085-8088: the equations below use the streaming values
   }
-  const double etap = 1.5 * a2 * rpt * inv_k2;
+  const double etap = (1.5 * a2 * rpt + 0.5 * P.K * hp) * Q.inv_k2s2;                 // pm.cpp:5938
   const double alpha = (hp + 6. * etap) * 0.5 * inv_k2;
   if (L.tca) rps += Q.rg43 * (16. / 45. * Q.tau_c * (tg + k2 * alpha));
   const double alphap = -2. * aH * alpha + eta - 4.5 * (a2 * inv_k2) * rps;
@@ -609,19 +628,19 @@ __device__ __forceinline__ double rhs(const PtParams& P, const Layout& L, const 
     const double msp = k2 * alphap;
     const double shear_prime = 16. / 45. * (tau_c * (theta_prime + msp) + dtau_c * (tg + ms));
     if (P.tca_method == CPT_TCA_COMPROMISE_CLASS) {
-      slip = (1. - 2. * aH * F) * slip + F * k2 * (2. * aH * shear + shear_prime - (1. / 3. - cb2) * (F * theta_prime + 2. * Q.Fp * tb));
+      slip = (1. - 2. * aH * F) * slip + F * k2 * (Q.s2sq * (2. * aH * shear + shear_prime) - (1. / 3. - cb2) * (F * theta_prime + 2. * Q.Fp * tb));  // pm.cpp:9501
       shear = (1. - 11. / 6. * dtau_c) * shear - (11. / 6. * 16. / 45.) * tau_c * tau_c * (theta_prime + msp);
     }
     M.tca_shear_g = shear;
-    dtb = (-aH * tb + k2 * (cb2 * db + R * (dg * 0.25 - shear)) + R * slip) * Q.inv_1pR;  // pm.cpp:8123-8129
-    S4 = -(dtb + aH * tb - k2 * cb2 * db) * Q.inv_R + k2 * (0.25 * dg - shear);          // pm.cpp:8214-8217
+    dtb = (-aH * tb + k2 * (cb2 * db + R * (dg * 0.25 - Q.s2sq * shear)) + R * slip) * Q.inv_1pR;  // pm.cpp:8123-8129
+    S4 = -(dtb + aH * tb - k2 * cb2 * db) * Q.inv_R + k2 * (0.25 * dg - Q.s2sq * shear);          // pm.cpp:8214-8217
   }
-  const double SP = kap * (p0 + p2 + 2. * sg) * 0.125;  // kappa' Pi,  Pi = (G_gamma0 + G_gamma2 + F_gamma2)/8 (pm.cpp:8142)
+  const double SP = kap * (p0 + p2 + 2. * Q.s2 * sg) * 0.125;  // kappa' Pi,  Pi = (G_gamma0 + G_gamma2 + F_gamma2)/8 (pm.cpp:8142)
 #ifdef CPT_PROFILE
   PROF_STOP(10); PROF_START();
 #endif
   // ---- every equation: streaming + damping + sources ----
-  double dy = e.A * ym - e.B * yp - (e.D * kap + e.G * Q.inv_tau) * y;
+  double dy = e.A * ym - e.B * yp - (e.D * kap + e.G * Q.kcot + e.Gt * Q.inv_tau) * y;
   dy = fma(e.Xmc, mc, dy);
   dy = fma(e.Xms, ms, dy);
   dy = fma(e.XP, SP, dy);
@@ -655,8 +674,8 @@ __device__ __forceinline__ void store_sources(const PtParams& P, const Layout& L
   if (L.rsa) { delta_g = M.rsa_dg; Pi = 0.; }
   else {
     delta_g = bcast(y, LN_DG);
-    if (L.tca) Pi = 5. * tca_shear_prev / 8.;  // left over from the last derivs call of the evolver (pm.cpp:6810)
-    else Pi = (bcast(y, LN_P0) + bcast(y, LN_P2) + 2. * bcast(y, LN_SG)) / 8.;
+    if (L.tca) Pi = 5. * Q.s2 * tca_shear_prev / 8.;  // left over from the last derivs call of the evolver (pm.cpp:6810)
+    else Pi = (bcast(y, LN_P0) + bcast(y, LN_P2) + 2. * Q.s2 * bcast(y, LN_SG)) / 8.;
   }
   const double eta = bcast(y, LN_ETA), tb = bcast(y, LN_TB), dtb = bcast(dy, LN_TB);
   double delta_m = 0.;
@@ -991,7 +1010,7 @@ __device__ __forceinline__ int ndf15(const PtParams& P, const Layout& L, const L
       if (batch == B_FINAL) { PROF_STOP(3); break; }  // ev.cpp:653-662: M, Q left at (tfinal, y) for the hand-over
       if (batch == B_JAC) {
         // the tails' diagonal is analytic: freeze kappa' and 1/tau at the time of this Jacobian
-        J.jdiag = -(e.D * Q.kap + e.G * Q.inv_tau);
+        J.jdiag = -(e.D * Q.kap + e.G * Q.kcot + e.Gt * Q.inv_tau);
         st.jacs++;
         M.tca_shear_g = tca_keep;
         Jcurrent = true;
@@ -1223,7 +1242,7 @@ __device__ __forceinline__ int ndf15(const PtParams& P, const Layout& L, const L
 }
 
 // perturb_initial_conditions (pm.cpp:4723-5408): adiabatic, synchronous gauge, flat. Returns this lane's y.
-__device__ __noinline__ double initial_conditions(DevTables T, int has_cdm, int has_ur, double ci, int role, int ell,
+__device__ __noinline__ double initial_conditions(DevTables T, int has_cdm, int has_ur, double ci, double K, int role, int ell,
                                                   double k, double tau) {
   // background row at tau (scalar lookup: executed once per mode)
   const int inf = bsearch_up(T.tau_table, T.bt_size, tau);
@@ -1239,14 +1258,15 @@ __device__ __noinline__ double initial_conditions(DevTables T, int has_cdm, int 
   const double fracnu = rho_nu / rho_r, fracb = rb / rho_m;
   const double om = a * rho_m / sqrt(rho_r);
   const double kt2 = k * k * tau * tau, kt3 = k * tau * kt2;
-  const double delta_g = -kt2 / 3. * (1. - om * tau / 5.) * ci;
-  const double theta_g = -k * kt3 / 36. * (1. - 3. * (1. + 5. * fracb - fracnu) / 20. / (1. - fracnu) * om * tau) * ci;
+  const double s2sq = 1. - 3. * K / (k * k);   // pm.cpp:4838: the curvature factors of the super-horizon series
+  const double delta_g = -kt2 / 3. * (1. - om * tau / 5.) * ci * s2sq;
+  const double theta_g = -k * kt3 / 36. * (1. - 3. * (1. + 5. * fracb - fracnu) / 20. / (1. - fracnu) * om * tau) * ci * s2sq;
   const double theta_ur = -k * kt3 / 36. / (4. * fracnu + 15.) *
-                          (4. * fracnu + 11. + 12. - 3. * (8. * fracnu * fracnu + 50. * fracnu + 275.) / 20. / (2. * fracnu + 15.) * tau * om) * ci;
-  const double shear_ur = kt2 / (45. + 12. * fracnu) * 2. * (1. + (4. * fracnu - 5.) / 4. / (2. * fracnu + 15.) * tau * om) * ci;
+                          (4. * fracnu + 11. + 12. * s2sq - 3. * (8. * fracnu * fracnu + 50. * fracnu + 275.) / 20. / (2. * fracnu + 15.) * tau * om) * ci * s2sq;
+  const double shear_ur = kt2 / (45. + 12. * fracnu) * (3. * s2sq - 1.) * (1. + (4. * fracnu - 5.) / 4. / (2. * fracnu + 15.) * tau * om) * ci;
   const double l3_ur = kt3 * 2. / 7. / (12. * fracnu + 45.) * ci;
   const double eta = ci * (1. - kt2 / 12. / (15. + 4. * fracnu) *
-                                    (5. + 4. * fracnu - (16. * fracnu * fracnu + 280. * fracnu + 325) / 10. / (2. * fracnu + 15.) * tau * om));
+                                    (5. + 4. * s2sq * fracnu - (16. * fracnu * fracnu + 280. * fracnu + 325) / 10. / (2. * fracnu + 15.) * tau * om));
   switch (role) {
     case R_DELTA_G: return delta_g;
     case R_THETA_G: return theta_g;
@@ -1319,6 +1339,7 @@ __global__ void __launch_bounds__(64) k_perturb(PtParams P) {
   if (status == 0) {
     Lookup Q;
     lookup_init(P, Q, bgw, thw, lane);
+    lookup_set_mode(P, Q, k);
 #ifdef CPT_PROFILE
     Q.prof = prof;
 #endif
@@ -1328,7 +1349,7 @@ __global__ void __launch_bounds__(64) k_perturb(PtParams P) {
     int f_tca = fi0, f_rsa = fi1, f_ufa = fi2;
     Layout L = make_layout(P, f_tca, f_rsa, f_ufa);
     LaneEq e = make_lane_eq(P, L, lane, k);
-    double y = initial_conditions(P.tabs, P.has_cdm, P.has_ur, P.curvature_ini, e.role, e.ell, k, tau_ini);
+    double y = initial_conditions(P.tabs, P.has_cdm, P.has_ur, P.curvature_ini, P.K, e.role, e.ell, k, tau_ini);
 #ifdef CPT_PROFILE
     prof[6] = clock64() - t_begin;  // schedule search + initial conditions
 #endif
@@ -1347,12 +1368,13 @@ __global__ void __launch_bounds__(64) k_perturb(PtParams P) {
         if (was_tca && !L.tca) {  // tight coupling switched off: seed shear, l=3 and polarisation (pm.cpp:3893-3916)
           const double sh = M.tca_shear_g, kod = k * Q.tau_c;
           if (e.role == R_SHEAR_G) yn = sh;
-          if (e.role == R_LG) yn = (e.ell == 3) ? 6. / 7. * kod * sh : 0.;
+          const double s3 = (P.K == 0.) ? 1. : sqrt(fmax(1. - 8. * P.K / (k * k), 0.));
+          if (e.role == R_LG) yn = (e.ell == 3) ? 6. / 7. * kod * s3 * sh : 0.;
           if (e.role == R_POL) {
             if (e.ell == 0) yn = 2.5 * sh;
-            else if (e.ell == 1) yn = kod * (5. - 2.) / 6. * sh;
+            else if (e.ell == 1) yn = kod * (5. - 2. * Q.s2) / 6. * sh;
             else if (e.ell == 2) yn = 0.5 * sh;
-            else if (e.ell == 3) yn = kod * 3. / 14. * sh;
+            else if (e.ell == 3) yn = kod * 3. * s3 / 14. * sh;
             else yn = 0.;
           }
         }
@@ -1389,6 +1411,7 @@ __global__ void __launch_bounds__(64) k_dbg_lookup(PtParams P, const double* tau
   unsigned long long dbg_prof[16];
   Q.prof = dbg_prof;
 #endif
+  lookup_set_mode(P, Q, 1.0);
   for (int i = 0; i < n; i++) {
     lookup(P, Q, tau[i], lane);
     if (lane == 0) {
@@ -1414,6 +1437,7 @@ __global__ void __launch_bounds__(64) k_dbg_derivs(PtParams P, double k, double 
   Metric M;
   M.hp = M.etap = M.alpha = M.alphap = 0.;
   M.tca_shear_g = 0.; M.rsa_dg = M.rsa_tg = 0.;
+  lookup_set_mode(P, Q, k);
   Layout L = make_layout(P, tca, rsa, ufa);
   LaneEq e = make_lane_eq(P, L, lane, k);
   int nref;
@@ -1438,6 +1462,7 @@ __global__ void __launch_bounds__(64) k_dbg_solve(PtParams P, double k, double t
   Metric M;
   M.hp = M.etap = M.alpha = M.alphap = 0.;
   M.tca_shear_g = 0.; M.rsa_dg = M.rsa_tg = 0.;
+  lookup_set_mode(P, Q, k);
   Layout L = make_layout(P, tca, rsa, ufa);
   LaneEq e = make_lane_eq(P, L, lane, k);
   const double inv_k2 = 1.0 / (k * k);
@@ -1450,7 +1475,7 @@ __global__ void __launch_bounds__(64) k_dbg_solve(PtParams P, double k, double t
     const double col = rhs(P, L, e, Q, M, k, inv_k2, tau, (lane == r) ? 1.0 : 0.0, lane);
     J.Jc[r * 64 + lane] = (lane < NC) ? col : 0.;
   }
-  J.jdiag = -(e.D * Q.kap + e.G * Q.inv_tau);
+  J.jdiag = -(e.D * Q.kap + e.G * Q.kcot + e.Gt * Q.inv_tau);
   LuReg F;
   const bool ok = factorise(e, J, hg, L.maxlen, lane, F);
   int nref;
@@ -1466,7 +1491,7 @@ void fill_params(const cpt_handle* h, PtParams& P) {
   P.has_cdm = c.has_cdm; P.has_ur = c.has_ur; P.tca_method = c.tight_coupling_approximation;
   P.rsa_method = c.radiation_streaming_approximation; P.ufa_method = c.ur_fluid_approximation;
   P.l_max_g = c.l_max_g; P.l_max_pol_g = c.l_max_pol_g; P.l_max_ur = c.l_max_ur;
-  P.T_cmb = c.T_cmb; P.a_today = c.a_today; P.YHe = c.YHe; P.n_e = c.n_e; P.tau_free_streaming = c.tau_free_streaming;
+  P.K = c.K; P.T_cmb = c.T_cmb; P.a_today = c.a_today; P.YHe = c.YHe; P.n_e = c.n_e; P.tau_free_streaming = c.tau_free_streaming;
   P.switch_sw = c.switch_sw; P.switch_eisw = c.switch_eisw; P.switch_lisw = c.switch_lisw; P.switch_dop = c.switch_dop;
   P.switch_pol = c.switch_pol; P.eisw_lisw_split_z = c.eisw_lisw_split_z;
   P.three_ceff2_ur = c.three_ceff2_ur; P.three_cvis2_ur = c.three_cvis2_ur;

@@ -27,7 +27,8 @@ class Inputs:
     def __init__(self, name, golden_dir=GOLDEN):
         self.name = name
         self.d = dict(np.load(os.path.join(golden_dir, name + ".npz")))
-        self.t = dict(np.load(os.path.join(golden_dir, "tables_lcdm.npz")))
+        tname = "tables_%s.npz" % name
+        self.t = dict(np.load(os.path.join(golden_dir, tname if os.path.exists(os.path.join(golden_dir, tname)) else "tables_lcdm.npz")))
         d, t = self.d, self.t
         c = CptConfig()
         c.H0 = _s(d, "pba.H0"); c.K = _s(d, "pba.K"); c.sgnK = int(_s(d, "pba.sgnK"))

@@ -92,6 +92,15 @@ def main():
                 out["tr.transfer_l_index"] = ls.astype(np.int32)
                 out["tr.transfer_at_q"] = np.ascontiguousarray(t[:, :, qs])
                 out["tr.transfer_at_l"] = np.ascontiguousarray(t[:, ls, :])
+        if cfg == "curved":
+            # non-flat cosmology: its own table file; only perturbation-stage vectors are kept (the curved transfer
+            # stage is not built yet), thermodynamics table thinned to the columns the path reads
+            for key in [k for k in out if k.startswith(("tr.transfer", "sp.", "le.", "nl."))]:
+                del out[key]
+            np.savez_compressed(os.path.join(GOLD, cfg + ".npz"), **out)
+            np.savez_compressed(os.path.join(GOLD, "tables_curved.npz"), **tables)
+            print(cfg, {k: v.shape for k, v in out.items() if v.size > 1000})
+            continue
         np.savez_compressed(os.path.join(GOLD, cfg + ".npz"), **out)
         # the three configs share one cosmology -> one table file; verified identical below
         tpath = os.path.join(GOLD, "tables_lcdm.npz")

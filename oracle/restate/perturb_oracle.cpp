@@ -126,6 +126,18 @@ Layout make_layout(const cpt_config& c, int tca, int rsa, int ufa) {
   return L;
 }
 
+// s_l[l] = sqrt(1 - K (l^2-1)/k^2) (pm.cpp:2530-2533); 1 in flat space
+inline double s_l(const cpt_config& c, double k, int l) {
+  if (c.K == 0.) return 1.;
+  double v = 1.0 - c.K * (l * l - 1.0) / k / k;
+  return std::sqrt(v > 0. ? v : 0.);
+}
+inline double cot_K_gen(const cpt_config& c, double k, double tau) {  // pm.cpp:7969-7977
+  if (c.K == 0.) return 1.0 / (k * tau);
+  double sq = std::sqrt(std::fabs(c.K));
+  return c.K < 0 ? sq / k / std::tanh(sq * tau) : sq / k / std::tan(sq * tau);
+}
+
 // ---- per-mode workspace (struct perturb_workspace, source/perturbations.h:300-420) ----
 struct Work {
   Bg bg; Th th;
@@ -218,11 +230,12 @@ void einstein(const Model& m, double k, const double* y, const Layout& L, Work& 
   }
   w.delta_m = delta_rho_m / rho_m;
   w.theta_m = rho_plus_p_theta_m / rho_plus_p_m;
-  // Einstein equations, synchronous gauge, K = 0 (s2_squared = 1): pm.cpp:5906-5971
-  w.h_prime = (k2 * y[L.eta] + 1.5 * a2 * w.delta_rho) / (0.5 * a_prime_over_a);
+  // Einstein equations, synchronous gauge: pm.cpp:5906-5971
+  const double s2_squared = 1. - 3. * c.K / k2;
+  w.h_prime = (k2 * s2_squared * y[L.eta] + 1.5 * a2 * w.delta_rho) / (0.5 * a_prime_over_a);
   if (L.rsa) rsa_delta_and_theta(m, k, y, L, a_prime_over_a, w);
-  w.eta_prime = (1.5 * a2 * w.rho_plus_p_theta) / k2;
-  w.h_prime_prime = -2. * a_prime_over_a * w.h_prime + 2. * k2 * y[L.eta] - 9. * a2 * w.delta_p;
+  w.eta_prime = (1.5 * a2 * w.rho_plus_p_theta + 0.5 * c.K * w.h_prime) / k2 / s2_squared;
+  w.h_prime_prime = -2. * a_prime_over_a * w.h_prime + 2. * k2 * s2_squared * y[L.eta] - 9. * a2 * w.delta_p;
   w.alpha = (w.h_prime + 6. * w.eta_prime) / 2. / k2;
   if (L.tca) {
     double sg = 16. / 45. / w.th.dkappa * (y[L.theta_g] + k2 * w.alpha);
@@ -256,8 +269,9 @@ void tca_slip_and_shear(const Model& m, double k, const double* y, const Layout&
   double theta_prime = (-a_prime_over_a * theta_b + k2 * (cb2 * delta_b + R / 4. * delta_g)) / (1. + R) + metric_euler;
   double shear_g_prime = 16. / 45. * (tau_c * (theta_prime + metric_shear_prime) + dtau_c * (theta_g + metric_shear));
   if (c.tight_coupling_approximation == CPT_TCA_COMPROMISE_CLASS) {
+    const double s2_squared = 1. - 3. * c.K / k2;
     slip = (1. - 2. * a_prime_over_a * F) * slip +
-           F * k2 * (2. * a_prime_over_a * shear_g + shear_g_prime - (1. / 3. - cb2) * (F * theta_prime + 2. * F_prime * theta_b));
+           F * k2 * (2. * a_prime_over_a * s2_squared * shear_g + s2_squared * shear_g_prime - (1. / 3. - cb2) * (F * theta_prime + 2. * F_prime * theta_b));
     shear_g = (1. - 11. / 6. * dtau_c) * shear_g - 11. / 6. * tau_c * 16. / 45. * tau_c * (theta_prime + metric_shear_prime);
   }
   w.tca_shear_g = shear_g;
@@ -274,7 +288,8 @@ void derivs(const Model& m, double k, double tau, const double* y, double* dy, c
   const Bg& bg = w.bg; const Th& th = w.th;
   double k2 = k * k, a = bg.a, a_prime_over_a = bg.H * a;
   double R = 4. / 3. * bg.rho_g / bg.rho_b;
-  double cotKgen = 1.0 / (k * tau);
+  const double cotKgen = cot_K_gen(c, k, tau), s2_squared = 1. - 3. * c.K / k2;
+  auto S = [&](int l) { return s_l(c, k, l); };
   double delta_g = 0, theta_g = 0;
   if (!L.rsa) { delta_g = y[L.delta_g]; theta_g = y[L.theta_g]; }
   double delta_b = y[L.delta_b], theta_b = y[L.theta_b];
@@ -287,44 +302,45 @@ void derivs(const Model& m, double k, double tau, const double* y, double* dy, c
     dy[L.theta_b] = -a_prime_over_a * theta_b + metric_euler + k2 * delta_p_b_over_rho_b + R * th.dkappa * (theta_g - theta_b);
   } else {
     tca_slip_and_shear(m, k, y, L, w);
-    dy[L.theta_b] = (-a_prime_over_a * theta_b + k2 * (delta_p_b_over_rho_b + R * (delta_g / 4. - w.tca_shear_g)) + R * w.tca_slip) / (1. + R) + metric_euler;
+    dy[L.theta_b] = (-a_prime_over_a * theta_b + k2 * (delta_p_b_over_rho_b + R * (delta_g / 4. - s2_squared * w.tca_shear_g)) + R * w.tca_slip) / (1. + R) + metric_euler;
   }
   if (!L.rsa) {
     if (!L.tca) {
-      double P0 = (y[L.pol0_g] + y[L.pol2_g] + 2. * y[L.shear_g]) / 8.;
-      dy[L.theta_g] = k2 * (delta_g / 4. - y[L.shear_g]) + metric_euler + th.dkappa * (theta_b - theta_g);
-      dy[L.shear_g] = 0.5 * (8. / 15. * (theta_g + metric_shear) - 3. / 5. * k * y[L.l3_g] - th.dkappa * (2. * y[L.shear_g] - 4. / 5. * P0));
+      double P0 = (y[L.pol0_g] + y[L.pol2_g] + 2. * S(2) * y[L.shear_g]) / 8.;
+      dy[L.theta_g] = k2 * (delta_g / 4. - s2_squared * y[L.shear_g]) + metric_euler + th.dkappa * (theta_b - theta_g);
+      dy[L.shear_g] = 0.5 * (8. / 15. * (theta_g + metric_shear) - 3. / 5. * k * S(3) / S(2) * y[L.l3_g] -
+                             th.dkappa * (2. * y[L.shear_g] - 4. / 5. / S(2) * P0));
       int l = 3;
-      dy[L.l3_g] = k / (2.0 * l + 1.0) * (l * 2. * y[L.shear_g] - (l + 1.) * y[L.l3_g + 1]) - th.dkappa * y[L.l3_g];
+      dy[L.l3_g] = k / (2.0 * l + 1.0) * (l * S(l) * 2. * S(2) * y[L.shear_g] - (l + 1.) * S(l + 1) * y[L.l3_g + 1]) - th.dkappa * y[L.l3_g];
       for (l = 4; l < L.l_max_g; l++)
-        dy[L.delta_g + l] = k / (2.0 * l + 1.0) * (l * y[L.delta_g + l - 1] - (l + 1) * y[L.delta_g + l + 1]) - th.dkappa * y[L.delta_g + l];
+        dy[L.delta_g + l] = k / (2.0 * l + 1.0) * (l * S(l) * y[L.delta_g + l - 1] - (l + 1) * S(l + 1) * y[L.delta_g + l + 1]) - th.dkappa * y[L.delta_g + l];
       l = L.l_max_g;
-      dy[L.delta_g + l] = k * (y[L.delta_g + l - 1] - (1. + l) * cotKgen * y[L.delta_g + l]) - th.dkappa * y[L.delta_g + l];
+      dy[L.delta_g + l] = k * (S(l) * y[L.delta_g + l - 1] - (1. + l) * cotKgen * y[L.delta_g + l]) - th.dkappa * y[L.delta_g + l];
       dy[L.pol0_g] = -k * y[L.pol0_g + 1] - th.dkappa * (y[L.pol0_g] - 4. * P0);
-      dy[L.pol1_g] = k / 3. * (y[L.pol1_g - 1] - 2. * y[L.pol1_g + 1]) - th.dkappa * y[L.pol1_g];
-      dy[L.pol2_g] = k / 5. * (2. * y[L.pol2_g - 1] - 3. * y[L.pol2_g + 1]) - th.dkappa * (y[L.pol2_g] - 4. / 5. * P0);
+      dy[L.pol1_g] = k / 3. * (y[L.pol1_g - 1] - 2. * S(2) * y[L.pol1_g + 1]) - th.dkappa * y[L.pol1_g];
+      dy[L.pol2_g] = k / 5. * (2. * S(2) * y[L.pol2_g - 1] - 3. * S(3) * y[L.pol2_g + 1]) - th.dkappa * (y[L.pol2_g] - 4. / 5. * P0);
       for (l = 3; l < L.l_max_pol_g; l++)
-        dy[L.pol0_g + l] = k / (2. * l + 1) * (l * y[L.pol0_g + l - 1] - (l + 1.) * y[L.pol0_g + l + 1]) - th.dkappa * y[L.pol0_g + l];
+        dy[L.pol0_g + l] = k / (2. * l + 1) * (l * S(l) * y[L.pol0_g + l - 1] - (l + 1.) * S(l + 1) * y[L.pol0_g + l + 1]) - th.dkappa * y[L.pol0_g + l];
       l = L.l_max_pol_g;
-      dy[L.pol0_g + l] = k * (y[L.pol0_g + l - 1] - (l + 1) * cotKgen * y[L.pol0_g + l]) - th.dkappa * y[L.pol0_g + l];
+      dy[L.pol0_g + l] = k * (S(l) * y[L.pol0_g + l - 1] - (l + 1) * cotKgen * y[L.pol0_g + l]) - th.dkappa * y[L.pol0_g + l];
     } else {
-      dy[L.theta_g] = -(dy[L.theta_b] + a_prime_over_a * theta_b - k2 * delta_p_b_over_rho_b) / R + k2 * (0.25 * delta_g - w.tca_shear_g) + (1. + R) / R * metric_euler;
+      dy[L.theta_g] = -(dy[L.theta_b] + a_prime_over_a * theta_b - k2 * delta_p_b_over_rho_b) / R + k2 * (0.25 * delta_g - s2_squared * w.tca_shear_g) + (1. + R) / R * metric_euler;
     }
   }
   if (c.has_cdm) dy[L.delta_cdm] = -metric_continuity;
   if (c.has_ur && !L.rsa) {
     dy[L.delta_ur] = -4. / 3. * (y[L.theta_ur] + metric_continuity) +
                      (1. - c.three_ceff2_ur) * a_prime_over_a * (y[L.delta_ur] + 4. * a_prime_over_a * y[L.theta_ur] / k / k);
-    dy[L.theta_ur] = k2 * (c.three_ceff2_ur * y[L.delta_ur] / 4. - y[L.shear_ur]) + metric_euler - (1. - c.three_ceff2_ur) * a_prime_over_a * y[L.theta_ur];
+    dy[L.theta_ur] = k2 * (c.three_ceff2_ur * y[L.delta_ur] / 4. - s2_squared * y[L.shear_ur]) + metric_euler - (1. - c.three_ceff2_ur) * a_prime_over_a * y[L.theta_ur];
     if (!L.ufa) {
-      dy[L.shear_ur] = 0.5 * (8. / 15. * (y[L.theta_ur] + metric_shear) - 3. / 5. * k * y[L.shear_ur + 1] -
+      dy[L.shear_ur] = 0.5 * (8. / 15. * (y[L.theta_ur] + metric_shear) - 3. / 5. * k * S(3) / S(2) * y[L.shear_ur + 1] -
                               (1. - c.three_cvis2_ur) * (8. / 15. * (y[L.theta_ur] + metric_shear)));
       int l = 3;
-      dy[L.l3_ur] = k / (2. * l + 1.) * (l * 2. * y[L.shear_ur] - (l + 1.) * y[L.l3_ur + 1]);
+      dy[L.l3_ur] = k / (2. * l + 1.) * (l * 2. * S(l) * S(2) * y[L.shear_ur] - (l + 1.) * S(l + 1) * y[L.l3_ur + 1]);
       for (l = 4; l < L.l_max_ur; l++)
-        dy[L.delta_ur + l] = k / (2. * l + 1) * (l * y[L.delta_ur + l - 1] - (l + 1.) * y[L.delta_ur + l + 1]);
+        dy[L.delta_ur + l] = k / (2. * l + 1) * (l * S(l) * y[L.delta_ur + l - 1] - (l + 1.) * S(l + 1) * y[L.delta_ur + l + 1]);
       l = L.l_max_ur;
-      dy[L.delta_ur + l] = k * (y[L.delta_ur + l - 1] - (1. + l) * cotKgen * y[L.delta_ur + l]);
+      dy[L.delta_ur + l] = k * (S(l) * y[L.delta_ur + l - 1] - (1. + l) * cotKgen * y[L.delta_ur + l]);
     } else {
       if (c.ur_fluid_approximation == CPT_UFA_MB) dy[L.shear_ur] = -3. / tau * y[L.shear_ur] + 2. / 3. * (y[L.theta_ur] + metric_shear);
       if (c.ur_fluid_approximation == CPT_UFA_HU) dy[L.shear_ur] = -3. * a_prime_over_a * y[L.shear_ur] + 2. / 3. * (y[L.theta_ur] + metric_shear);
@@ -347,8 +363,8 @@ void sources(const Model& m, double k, double tau, const double* y, const double
   if (L.rsa) { delta_g = w.rsa_delta_g; P = 0.; }
   else {
     delta_g = y[L.delta_g];
-    if (L.tca) P = 5. * w.tca_shear_g / 8.;  // NB: left over from the last derivs call (pm.cpp:6810), see SURVEY "hidden state"
-    else P = (y[L.pol0_g] + y[L.pol2_g] + 2. * y[L.shear_g]) / 8.;
+    if (L.tca) P = 5. * s_l(c, k, 2) * w.tca_shear_g / 8.;  // NB: left over from the last derivs call (pm.cpp:6810), see SURVEY "hidden state"
+    else P = (y[L.pol0_g] + y[L.pol2_g] + 2. * s_l(c, k, 2) * y[L.shear_g]) / 8.;
   }
   int switch_isw = 1;
   if ((c.switch_eisw == 0) && (z >= c.eisw_lisw_split_z)) switch_isw = 0;
@@ -763,7 +779,7 @@ void initial_conditions(const Model& m, double k, double tau, const Layout& L, d
   double fracnu = rho_nu / rho_r, fracb = bg.rho_b / rho_m;
   double om = a * rho_m / std::sqrt(rho_r);
   double ktau_two = k * k * tau * tau, ktau_three = k * tau * ktau_two;
-  double s2_squared = 1.;
+  double s2_squared = 1. - 3. * c.K / k / k;
   for (int i = 0; i < L.neq; i++) y[i] = 0.;
   y[L.delta_g] = -ktau_two / 3. * (1. - om * tau / 5.) * c.curvature_ini * s2_squared;
   y[L.theta_g] = -k * ktau_three / 36. * (1. - 3. * (1. + 5. * fracb - fracnu) / 20. / (1. - fracnu) * om * tau) * c.curvature_ini * s2_squared;
@@ -793,11 +809,11 @@ void handover(const Model& m, double k, const Layout& Lo, const double* yo, cons
   if (Lo.tca && !Ln.tca) {  // pm.cpp:3880-3935
     yn[Ln.delta_g] = yo[Lo.delta_g]; yn[Ln.theta_g] = yo[Lo.theta_g];
     yn[Ln.shear_g] = w.tca_shear_g;
-    yn[Ln.l3_g] = 6. / 7. * k / w.th.dkappa * yn[Ln.shear_g];
+    yn[Ln.l3_g] = 6. / 7. * k / w.th.dkappa * s_l(c, k, 3) * yn[Ln.shear_g];
     yn[Ln.pol0_g] = 2.5 * yn[Ln.shear_g];
-    yn[Ln.pol1_g] = k / w.th.dkappa * (5. - 2.) / 6. * yn[Ln.shear_g];
+    yn[Ln.pol1_g] = k / w.th.dkappa * (5. - 2. * s_l(c, k, 2)) / 6. * yn[Ln.shear_g];
     yn[Ln.pol2_g] = 0.5 * yn[Ln.shear_g];
-    yn[Ln.pol3_g] = k / w.th.dkappa * 3. / 14. * yn[Ln.shear_g];
+    yn[Ln.pol3_g] = k / w.th.dkappa * 3. * s_l(c, k, 3) / 14. * yn[Ln.shear_g];
     if (c.has_ur) {
       yn[Ln.delta_ur] = yo[Lo.delta_ur]; yn[Ln.theta_ur] = yo[Lo.theta_ur]; yn[Ln.shear_ur] = yo[Lo.shear_ur];
       if (!Ln.ufa) for (int l = 3; l <= Ln.l_max_ur; l++) yn[Ln.delta_ur + l] = yo[Lo.delta_ur + l];
