@@ -43,6 +43,7 @@ class CptConfig(C.Structure):
         ("transfer_neglect_delta_k_S_t0", _d), ("transfer_neglect_delta_k_S_t1", _d),
         ("transfer_neglect_delta_k_S_t2", _d), ("transfer_neglect_delta_k_S_e", _d),
         ("transfer_neglect_late_source", _d), ("l_switch_limber", _d),
+        ("ic", _i), ("entropy_ini", _d),
     ]
 
 

@@ -56,6 +56,11 @@ int cpt_transpose_from_kmajor(cpt_handle* h, const double* src, double* dst, int
 // ---------------------------------------------------------------------------------------------
 static int validate(const cpt_config* c) {
   // physics branches of the reference that this backend does not implement (SURVEY.md S8f "not planned"/later)
+  if (c->ic < CPT_IC_AD || c->ic > CPT_IC_NIV) return cpt_fail(nullptr, CPT_ERR_INVALID, "ic=%d is not an initial condition", c->ic);
+  if (c->ic == CPT_IC_CDI && !c->has_cdm)
+    return cpt_fail(nullptr, CPT_ERR_INVALID, "not consistent to ask for CDI in absence of CDM! (pm.cpp:4961)");
+  if ((c->ic == CPT_IC_NID || c->ic == CPT_IC_NIV) && !c->has_ur)
+    return cpt_fail(nullptr, CPT_ERR_INVALID, "not consistent to ask for NID/NIV in absence of ur species! (pm.cpp:5024, 5050)");
   if ((c->sgnK == 0) != (c->K == 0.) || (c->sgnK != 0 && (c->sgnK > 0) != (c->K > 0.)))
     return cpt_fail(nullptr, CPT_ERR_INVALID, "inconsistent curvature: K=%g, sgnK=%d", c->K, c->sgnK);
   if (c->has_ncdm) return cpt_fail(nullptr, CPT_ERR_UNSUPPORTED, "non-cold dark matter species are not implemented");

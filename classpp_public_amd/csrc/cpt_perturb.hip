@@ -31,6 +31,7 @@ struct PtParams {
   int has_cdm, has_ur, tca_method, rsa_method, ufa_method, l_max_g, l_max_pol_g, l_max_ur;
   double T_cmb, a_today, YHe, n_e, tau_free_streaming;
   double K;  // spatial curvature (pba->K); 0 in flat space
+  int ic; double entropy_ini;  // initial condition of the mode (CPT_IC_*), isocurvature normalisation
   int switch_sw, switch_eisw, switch_lisw, switch_dop, switch_pol;
   double eisw_lisw_split_z, three_ceff2_ur, three_cvis2_ur;
   int tp_size, tp_t0, tp_t1, tp_t2, tp_p, tp_dm, tp_pp;
@@ -1242,7 +1243,7 @@ __device__ __forceinline__ int ndf15(const PtParams& P, const Layout& L, const L
 }
 
 // perturb_initial_conditions (pm.cpp:4723-5408): adiabatic, synchronous gauge, flat. Returns this lane's y.
-__device__ __noinline__ double initial_conditions(DevTables T, int has_cdm, int has_ur, double ci, double K, int role, int ell,
+__device__ __noinline__ double initial_conditions(DevTables T, int has_cdm, int has_ur, double ci, double K, int ic, double ei, int role, int ell,
                                                   double k, double tau) {
   // background row at tau (scalar lookup: executed once per mode)
   const int inf = bsearch_up(T.tau_table, T.bt_size, tau);
@@ -1267,17 +1268,63 @@ __device__ __noinline__ double initial_conditions(DevTables T, int has_cdm, int 
   const double l3_ur = kt3 * 2. / 7. / (12. * fracnu + 45.) * ci;
   const double eta = ci * (1. - kt2 / 12. / (15. + 4. * fracnu) *
                                     (5. + 4. * s2sq * fracnu - (16. * fracnu * fracnu + 280. * fracnu + 325) / 10. / (2. * fracnu + 15.) * tau * om));
+  if (ic == CPT_IC_AD) {
+    switch (role) {
+      case R_DELTA_G: return delta_g;
+      case R_THETA_G: return theta_g;
+      case R_DELTA_B: return 0.75 * delta_g;
+      case R_THETA_B: return theta_g;
+      case R_DELTA_CDM: return 0.75 * delta_g;
+      case R_DELTA_UR: return delta_g;
+      case R_THETA_UR: return theta_ur;
+      case R_SHEAR_UR: return shear_ur;
+      case R_LUR: return ell == 3 ? l3_ur : 0.;
+      case R_ETA: return eta;
+      default: return 0.;
+    }
+  }
+  // isocurvature modes (pm.cpp:4956-5083; Bucher, Moodley & Turok 1999 with CLASS normalisation); l3_ur = 0
+  const double fracg = rg / rho_r, fraccdm = 1. - fracb, kt = k * tau;
+  double dg, tg, db, dcdm = 0., dur, tur, sur, et;
+  if (ic == CPT_IC_CDI || ic == CPT_IC_BI) {
+    const double f = (ic == CPT_IC_CDI) ? fraccdm : fracb;
+    dg = ei * f * om * tau * (-2. / 3. + om * tau / 4.);
+    tg = -ei * f * om * kt2 / 12.;
+    db = 0.75 * dg + (ic == CPT_IC_BI ? ei : 0.);
+    dcdm = 0.75 * dg + (ic == CPT_IC_CDI ? ei : 0.);
+    dur = dg; tur = tg;
+    sur = -ei * f * kt2 * tau * om / 6. / (2. * fracnu + 15.);
+    et = -ei * f * om * tau * (1. / 6. - om * tau / 16.);
+  } else if (ic == CPT_IC_NID) {
+    dg = ei * fracnu / fracg * (-1. + kt2 / 6.);
+    tg = -ei * fracnu / fracg * k * k * tau * (1. / 4. - fracb / fracg * 3. / 16. * om * tau);
+    db = ei * fracnu / fracg / 8. * kt2;
+    dcdm = -ei * fracnu * fracb / fracg / 80. * kt2 * om * tau;
+    dur = ei * (1. - kt2 / 6.);
+    tur = ei * k * k * tau / 4.;
+    sur = ei * kt2 / (4. * fracnu + 15.) / 2.;
+    et = -ei * fracnu / (4. * fracnu + 15.) / 6. * kt2;
+  } else {  // CPT_IC_NIV
+    dg = ei * kt * fracnu / fracg * (1. - 3. / 16. * fracb * (2. + fracg) / fracg * om * tau);
+    tg = ei * fracnu / fracg * 3. / 4. * k *
+         (-1. + 3. / 4. * fracb / fracg * om * tau + 3. / 16. * om * om * tau * tau * fracb / fracg / fracg * (fracg - 3. * fracb) + kt2 / 6.);
+    db = 0.75 * dg;
+    dcdm = -ei * 9. / 64. * fracnu * fracb / fracg * kt * om * tau;
+    dur = -ei * kt * (1. + 3. / 16. * fracb * fracnu / fracg * om * tau);
+    tur = ei * 3. / 4. * k * (1. - 1. / 6. * kt2 * (4. * fracnu + 9.) / (4. * fracnu + 5.));
+    sur = ei / (4. * fracnu + 15.) * kt * (1. + 3. * om * tau * fracnu / (4. * fracnu + 15.));
+    et = ei * fracnu * kt * (-1. / (4. * fracnu + 5.) + (-3. / 64. * fracb / fracg + 15. / 4. / (4. * fracnu + 15.) / (4. * fracnu + 5.) * om * tau));
+  }
   switch (role) {
-    case R_DELTA_G: return delta_g;
-    case R_THETA_G: return theta_g;
-    case R_DELTA_B: return 0.75 * delta_g;
-    case R_THETA_B: return theta_g;
-    case R_DELTA_CDM: return 0.75 * delta_g;
-    case R_DELTA_UR: return delta_g;
-    case R_THETA_UR: return theta_ur;
-    case R_SHEAR_UR: return shear_ur;
-    case R_LUR: return ell == 3 ? l3_ur : 0.;
-    case R_ETA: return eta;
+    case R_DELTA_G: return dg;
+    case R_THETA_G: return tg;
+    case R_DELTA_B: return db;
+    case R_THETA_B: return tg;
+    case R_DELTA_CDM: return dcdm;
+    case R_DELTA_UR: return dur;
+    case R_THETA_UR: return tur;
+    case R_SHEAR_UR: return sur;
+    case R_ETA: return et;
     default: return 0.;
   }
 }
@@ -1349,7 +1396,7 @@ __global__ void __launch_bounds__(64) k_perturb(PtParams P) {
     int f_tca = fi0, f_rsa = fi1, f_ufa = fi2;
     Layout L = make_layout(P, f_tca, f_rsa, f_ufa);
     LaneEq e = make_lane_eq(P, L, lane, k);
-    double y = initial_conditions(P.tabs, P.has_cdm, P.has_ur, P.curvature_ini, P.K, e.role, e.ell, k, tau_ini);
+    double y = initial_conditions(P.tabs, P.has_cdm, P.has_ur, P.curvature_ini, P.K, P.ic, P.entropy_ini, e.role, e.ell, k, tau_ini);
 #ifdef CPT_PROFILE
     prof[6] = clock64() - t_begin;  // schedule search + initial conditions
 #endif
@@ -1491,7 +1538,7 @@ void fill_params(const cpt_handle* h, PtParams& P) {
   P.has_cdm = c.has_cdm; P.has_ur = c.has_ur; P.tca_method = c.tight_coupling_approximation;
   P.rsa_method = c.radiation_streaming_approximation; P.ufa_method = c.ur_fluid_approximation;
   P.l_max_g = c.l_max_g; P.l_max_pol_g = c.l_max_pol_g; P.l_max_ur = c.l_max_ur;
-  P.K = c.K; P.T_cmb = c.T_cmb; P.a_today = c.a_today; P.YHe = c.YHe; P.n_e = c.n_e; P.tau_free_streaming = c.tau_free_streaming;
+  P.K = c.K; P.ic = c.ic; P.entropy_ini = c.entropy_ini; P.T_cmb = c.T_cmb; P.a_today = c.a_today; P.YHe = c.YHe; P.n_e = c.n_e; P.tau_free_streaming = c.tau_free_streaming;
   P.switch_sw = c.switch_sw; P.switch_eisw = c.switch_eisw; P.switch_lisw = c.switch_lisw; P.switch_dop = c.switch_dop;
   P.switch_pol = c.switch_pol; P.eisw_lisw_split_z = c.eisw_lisw_split_z;
   P.three_ceff2_ur = c.three_ceff2_ur; P.three_cvis2_ur = c.three_cvis2_ur;

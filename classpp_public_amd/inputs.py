@@ -66,6 +66,12 @@ class Inputs:
                 setattr(c, "index_tt_" + f, int(_s(d, "tr.index_tt_" + f)))
         c.lcmb_rescale = _s(d, "ptr.lcmb_rescale"); c.lcmb_tilt = _s(d, "ptr.lcmb_tilt")
         c.lcmb_pivot = _s(d, "ptr.lcmb_pivot")
+        # initial condition: one mode per handle (ad unless the fixture says otherwise)
+        c.ic = 0
+        for code, key in ((1, "ppt.has_bi"), (2, "ppt.has_cdi"), (3, "ppt.has_nid"), (4, "ppt.has_niv")):
+            if key in d and int(_s(d, key)) and not int(_s(d, "ppt.has_ad")):
+                c.ic = code
+        c.entropy_ini = float(_s(d, "ppr.entropy_ini")) if "ppr.entropy_ini" in d else 1.0
         self.config = c
 
         # tables (keep numpy arrays alive: the struct only holds raw pointers)
@@ -92,6 +98,8 @@ class Inputs:
         # primordial spectrum + C_l slots (struct primordial / SpectraModule index_ct_*)
         sp = CptSpectraParams()
         sp.A_s = _s(d, "ppm.A_s"); sp.n_s = _s(d, "ppm.n_s"); sp.alpha_s = _s(d, "ppm.alpha_s"); sp.k_pivot = _s(d, "ppm.k_pivot")
+        if "ppm.amplitude0" in d:  # effective power law of the (single) initial condition, e.g. A_s f_cdi^2, n_cdi
+            sp.A_s = _s(d, "ppm.amplitude0"); sp.n_s = _s(d, "ppm.tilt0"); sp.alpha_s = _s(d, "ppm.running0")
         sp.ct_size = int(_s(d, "sp.ct_size")) if "sp.ct_size" in d else 0
         for f in ("tt", "ee", "te", "pp", "tp", "ep"):
             setattr(sp, "index_ct_" + f, int(_s(d, "sp.index_ct_" + f)) if ("sp.index_ct_" + f) in d else -1)

@@ -58,6 +58,8 @@ extern "C" {
 
 /* Flat POD with the physics flags / derived scalars / precision parameters the path reads
  * (struct background / thermo / perturbs / precision / transfers of the reference).  */
+enum { CPT_IC_AD = 0, CPT_IC_BI = 1, CPT_IC_CDI = 2, CPT_IC_NID = 3, CPT_IC_NIV = 4 };
+
 typedef struct cpt_config {
   /* --- background (source/background.h) --- */
   double H0;      /* [1/Mpc] */
@@ -102,6 +104,10 @@ typedef struct cpt_config {
       transfer_neglect_delta_k_S_e;
   double transfer_neglect_late_source;
   double l_switch_limber;
+  /* --- initial condition of the (single) mode integrated by this handle (pm.cpp:4846-5083); appended last so that
+   *     zero-initialised older callers get the adiabatic mode --- */
+  int ic;               /* CPT_IC_AD (0), CPT_IC_BI, CPT_IC_CDI, CPT_IC_NID, CPT_IC_NIV */
+  double entropy_ini;   /* ppr->entropy_ini (isocurvature normalisation; default 1) */
 } cpt_config;
 
 /* Spline tables the RHS samples (all HOST pointers, row-major [n_lines][n_columns], copied to HBM by cpt_create):

@@ -147,7 +147,8 @@ static int do_dump(const char* ini, const char* outpath) {
   put_i("pth.reio_parametrization", (int)pth->reio_parametrization);
   put_i("pth.compute_cb2_derivatives", pth->compute_cb2_derivatives);
   put_i("ppt.gauge", (int)ppt->gauge); put_i("ppt.has_scalars", ppt->has_scalars); put_i("ppt.has_tensors", ppt->has_tensors);
-  put_i("ppt.has_ad", ppt->has_ad);
+  put_i("ppt.has_ad", ppt->has_ad); put_i("ppt.has_bi", ppt->has_bi); put_i("ppt.has_cdi", ppt->has_cdi);
+  put_i("ppt.has_nid", ppt->has_nid); put_i("ppt.has_niv", ppt->has_niv);
   put_i("ppt.has_cl_cmb_temperature", ppt->has_cl_cmb_temperature);
   put_i("ppt.has_cl_cmb_polarization", ppt->has_cl_cmb_polarization);
   put_i("ppt.has_cl_cmb_lensing_potential", ppt->has_cl_cmb_lensing_potential);
@@ -161,6 +162,9 @@ static int do_dump(const char* ini, const char* outpath) {
   put_d("ppt.G_eff_ur", ppt->G_eff_ur);
   put_d("ptr.lcmb_rescale", ptr->lcmb_rescale); put_d("ptr.lcmb_tilt", ptr->lcmb_tilt); put_d("ptr.lcmb_pivot", ptr->lcmb_pivot);
   put_d("ppm.A_s", ppm->A_s); put_d("ppm.n_s", ppm->n_s); put_d("ppm.alpha_s", ppm->alpha_s); put_d("ppm.k_pivot", ppm->k_pivot);
+  // effective power law of the first (only) initial condition: amplitude, tilt, running (primordial_module.cpp:684-800)
+  put_d("ppm.amplitude0", prim->amplitude_[0][0]); put_d("ppm.tilt0", prim->tilt_[0][0]); put_d("ppm.running0", prim->running_[0][0]);
+  put_d("ppr.entropy_ini", ppr->entropy_ini);
 
   // ---- background tables (source/background_module.h:166-178) ----
   put_i("bg.bt_size", bg->bt_size_); put_i("bg.bg_size", bg->bg_size_);

@@ -797,6 +797,44 @@ void initial_conditions(const Model& m, double k, double tau, const Layout& L, d
   }
   y[L.eta] = c.curvature_ini * (1. - ktau_two / 12. / (15. + 4. * fracnu) *
                                          (5. + 4. * s2_squared * fracnu - (16. * fracnu * fracnu + 280. * fracnu + 325) / 10. / (2. * fracnu + 15.) * tau * om));
+  if (c.ic == CPT_IC_AD) return;
+  // ---- isocurvature modes, pm.cpp:4956-5083 (l3_ur stays 0) ----
+  const double ei = c.entropy_ini, fracg = bg.rho_g / rho_r, fraccdm = 1. - fracb;
+  double delta_ur = 0., theta_ur = 0., shear_ur = 0., eta = 0.;
+  if (c.ic == CPT_IC_CDI || c.ic == CPT_IC_BI) {
+    const double f = (c.ic == CPT_IC_CDI) ? fraccdm : fracb;
+    y[L.delta_g] = ei * f * om * tau * (-2. / 3. + om * tau / 4.);
+    y[L.theta_g] = -ei * f * om * ktau_two / 12.;
+    y[L.delta_b] = (c.ic == CPT_IC_BI ? ei : 0.) + 3. / 4. * y[L.delta_g];
+    y[L.theta_b] = y[L.theta_g];
+    if (c.has_cdm) y[L.delta_cdm] = (c.ic == CPT_IC_CDI ? ei : 0.) + 3. / 4. * y[L.delta_g];
+    delta_ur = y[L.delta_g]; theta_ur = y[L.theta_g];
+    shear_ur = -ei * f * ktau_two * tau * om / 6. / (2. * fracnu + 15.);
+    eta = -ei * f * om * tau * (1. / 6. - om * tau / 16.);
+  } else if (c.ic == CPT_IC_NID) {
+    y[L.delta_g] = ei * fracnu / fracg * (-1. + ktau_two / 6.);
+    y[L.theta_g] = -ei * fracnu / fracg * k * k * tau * (1. / 4. - fracb / fracg * 3. / 16. * om * tau);
+    y[L.delta_b] = ei * fracnu / fracg / 8. * ktau_two;
+    y[L.theta_b] = y[L.theta_g];
+    if (c.has_cdm) y[L.delta_cdm] = -ei * fracnu * fracb / fracg / 80. * ktau_two * om * tau;
+    delta_ur = ei * (1. - ktau_two / 6.);
+    theta_ur = ei * k * k * tau / 4.;
+    shear_ur = ei * ktau_two / (4. * fracnu + 15.) / 2.;
+    eta = -ei * fracnu / (4. * fracnu + 15.) / 6. * ktau_two;
+  } else {
+    y[L.delta_g] = ei * k * tau * fracnu / fracg * (1. - 3. / 16. * fracb * (2. + fracg) / fracg * om * tau);
+    y[L.theta_g] = ei * fracnu / fracg * 3. / 4. * k *
+                   (-1. + 3. / 4. * fracb / fracg * om * tau + 3. / 16. * om * om * tau * tau * fracb / fracg / fracg * (fracg - 3. * fracb) + ktau_two / 6.);
+    y[L.delta_b] = 3. / 4. * y[L.delta_g];
+    y[L.theta_b] = y[L.theta_g];
+    if (c.has_cdm) y[L.delta_cdm] = -ei * 9. / 64. * fracnu * fracb / fracg * k * tau * om * tau;
+    delta_ur = -ei * k * tau * (1. + 3. / 16. * fracb * fracnu / fracg * om * tau);
+    theta_ur = ei * 3. / 4. * k * (1. - 1. / 6. * ktau_two * (4. * fracnu + 9.) / (4. * fracnu + 5.));
+    shear_ur = ei / (4. * fracnu + 15.) * k * tau * (1. + 3. * om * tau * fracnu / (4. * fracnu + 15.));
+    eta = ei * fracnu * k * tau * (-1. / (4. * fracnu + 5.) + (-3. / 64. * fracb / fracg + 15. / 4. / (4. * fracnu + 15.) / (4. * fracnu + 5.) * om * tau));
+  }
+  if (c.has_ur) { y[L.delta_ur] = delta_ur; y[L.theta_ur] = theta_ur; y[L.shear_ur] = shear_ur; y[L.l3_ur] = 0.; }
+  y[L.eta] = eta;
 }
 
 // hand-over between regimes: pm.cpp:3777-4260

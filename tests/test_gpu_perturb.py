@@ -88,7 +88,7 @@ def test_perturb_small_all_modes(small):
     print("\n[small] perturb kernel %.3f ms for %d modes, %d steps" % (ms, inp.nk, gs))
 
 
-@pytest.mark.parametrize("cfg", ["lcdm", "explanatory"])
+@pytest.mark.parametrize("cfg", ["lcdm", "explanatory", "iso_cdi", "iso_nid"])
 def test_perturb_full_size(cfg):
     """BASELINE configs 1-2: every k-mode integrated on the GPU; the 16 golden columns are compared with the reference."""
     from classpp_public_amd.backend import Backend
@@ -101,8 +101,11 @@ def test_perturb_full_size(cfg):
     ks = inp.d["pt.sources_k_index"]
     check_sources(inp.config, got[:, :, ks], inp.d["pt.sources_subset"])
     if inp.config.index_tp_delta_m >= 0:  # delta_m(k, tau0) for every k: the P(k) input
-        dm = got[inp.config.index_tp_delta_m, -1, :]
-        assert np.max(np.abs(dm / inp.d["pt.delta_m_today"] - 1)) < 1e-5
+        dm, ref_dm = got[inp.config.index_tp_delta_m, -1, :], inp.d["pt.delta_m_today"]
+        if inp.config.ic == 0:
+            assert np.max(np.abs(dm / ref_dm - 1)) < 1e-5
+        else:  # isocurvature delta_m(k) changes sign: relative to the column maximum
+            assert np.max(np.abs(dm - ref_dm)) < 1e-5 * np.max(np.abs(ref_dm))
     ms, n = be.kernel_ms(0)
     steps = np.array([s.steps for s in stats])
     print("\n[%s] perturb kernel %.2f ms, %d modes -> %.0f k-modes/s; steps total %d max %d; fevals %d, LU %d, solves %d" % (
