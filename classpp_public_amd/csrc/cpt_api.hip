@@ -68,17 +68,18 @@ static int validate(const cpt_config* c) {
   if (!c->has_cdm && c->gauge == CPT_GAUGE_SYNCHRONOUS)
     return cpt_fail(nullptr, CPT_ERR_INVALID,
                     "synchronous gauge needs cdm (the reference rejects this too, perturbations_module.cpp:560)");
-  if (c->gauge != CPT_GAUGE_SYNCHRONOUS)
-    return cpt_fail(nullptr, CPT_ERR_UNSUPPORTED, "only the synchronous gauge is implemented");
+  if (c->gauge != CPT_GAUGE_SYNCHRONOUS && c->gauge != CPT_GAUGE_NEWTONIAN)
+    return cpt_fail(nullptr, CPT_ERR_INVALID, "gauge=%d is neither newtonian (0) nor synchronous (1)", c->gauge);
   if (c->tight_coupling_approximation != CPT_TCA_COMPROMISE_CLASS &&
       c->tight_coupling_approximation != CPT_TCA_FIRST_ORDER_CAMB)
     return cpt_fail(nullptr, CPT_ERR_UNSUPPORTED, "tight_coupling_approximation=%d is not implemented",
                     c->tight_coupling_approximation);
   if (c->l_max_g < 4 || c->l_max_pol_g < 4 || (c->has_ur && c->l_max_ur < 4))
     return cpt_fail(nullptr, CPT_ERR_INVALID, "l_max_g, l_max_pol_g, l_max_ur must be at least 4 (pm.cpp:3302-3330)");
-  if (3 + c->l_max_g - 2 + 3 + c->l_max_pol_g - 2 + 3 + (c->has_ur ? 3 + c->l_max_ur - 2 : 0) + 1 > CPT_WAVE)
+  // lane map of cpt_perturb.hip: 14 core lanes + the three l >= 3 tails
+  if (14 + (c->l_max_g - 2) + (c->l_max_pol_g - 2) + (c->has_ur ? c->l_max_ur - 2 : 0) > CPT_WAVE)
     return cpt_fail(nullptr, CPT_ERR_UNSUPPORTED,
-                    "hierarchy too large: one wavefront (64 lanes) owns one k-mode, need neq <= 64");
+                    "hierarchy too large: one wavefront (64 lanes) owns one k-mode, need 14 + tails <= 64 lanes");
   if (c->tp_size < 1 || c->tp_size > 8) return cpt_fail(nullptr, CPT_ERR_INVALID, "tp_size=%d out of range", c->tp_size);
   const int tps[6] = {c->index_tp_t0, c->index_tp_t1, c->index_tp_t2, c->index_tp_p, c->index_tp_delta_m,
                       c->index_tp_phi_plus_psi};

@@ -31,6 +31,7 @@ struct PtParams {
   int has_cdm, has_ur, tca_method, rsa_method, ufa_method, l_max_g, l_max_pol_g, l_max_ur;
   double T_cmb, a_today, YHe, n_e, tau_free_streaming;
   double K;  // spatial curvature (pba->K); 0 in flat space
+  int gauge;                   // CPT_GAUGE_NEWTONIAN / CPT_GAUGE_SYNCHRONOUS
   int ic; double entropy_ini;  // initial condition of the mode (CPT_IC_*), isocurvature normalisation
   int switch_sw, switch_eisw, switch_lisw, switch_dop, switch_pol;
   double eisw_lisw_split_z, three_ceff2_ur, three_cvis2_ur;
@@ -141,9 +142,28 @@ __device__ inline double ndf_erconst(int i) { return ndf_alpha(i) * ndf_G(i) + 1
 
 enum Role : int {
   R_NONE = 0, R_DELTA_G, R_THETA_G, R_SHEAR_G, R_LG /* l>=3 photon temperature */, R_POL /* l>=0 polarisation */,
-  R_DELTA_B, R_THETA_B, R_DELTA_CDM, R_DELTA_UR, R_THETA_UR, R_SHEAR_UR, R_LUR /* l>=3 ur */, R_ETA
+  R_DELTA_B, R_THETA_B, R_DELTA_CDM, R_DELTA_UR, R_THETA_UR, R_SHEAR_UR, R_LUR /* l>=3 ur */, R_ETA, R_THETA_CDM
 };
 
+#ifdef CPT_PROFILE
+__device__ unsigned long long g_prof[16];
+#define PROF_DECL unsigned long long pf_t0 = 0
+#define PROF_START() pf_t0 = clock64()
+#define PROF_STOP(slot) prof[slot] += clock64() - pf_t0
+#else
+#define PROF_DECL
+#define PROF_START()
+#define PROF_STOP(slot)
+#endif
+
+// Everything from the lane map to the kernel bodies is a class template on the gauge: the Newtonian gauge has one more
+// core variable (theta_cdm: NC = 14 instead of 13) and different metric terms; compiled into the synchronous kernel as
+// run-time branches it pushed the step loop over its register budget (672 B/lane of scratch, 21 -> 34 ms).  Two
+// instantiations cost code size only.  The same holds for non-flat space (CURV): the s_l factors, k cotK(tau) and the
+// separate 1/tau coefficient cost the flat kernel 35 % when they were run-time values; in the flat instantiation they fold
+// to 1, 1/tau and nothing.
+template <int GAUGE, int CURV>
+struct PT {
 // Lane map.  One lane per equation of pm.cpp:3302-3481, at a FIXED lane whatever the approximation scheme: the (at most
 // 13) densely coupled variables - densities, velocities, shears, polarisation l<=2, metric - are the CORE in lanes
 // 0..12, followed by the three free-streaming hierarchy tails (photon temperature l>=3, polarisation l>=3, ur l>=3)
@@ -152,7 +172,9 @@ enum Role : int {
 // lane number - no index arithmetic, no SGPRs holding a layout - and the hand-over between schemes the identity.
 // A tail is a tridiagonal chain that touches the core only through its l=3 element (l3 <-> shear / pol2): that
 // structure, fixed per regime and shared by all modes, is what the linear algebra below exploits.
-enum Lane : int { LN_DG = 0, LN_TG, LN_SG, LN_P0, LN_P1, LN_P2, LN_DB, LN_TB, LN_DC, LN_DUR, LN_TUR, LN_SUR, LN_ETA, NC = 13 };
+// LN_ETA holds eta (synchronous gauge) or phi (Newtonian gauge, pm.cpp:3470-3478); LN_TC = theta_cdm exists in the Newtonian gauge only
+enum Lane : int { LN_DG = 0, LN_TG, LN_SG, LN_P0, LN_P1, LN_P2, LN_DB, LN_TB, LN_DC, LN_DUR, LN_TUR, LN_SUR, LN_ETA, LN_TC };
+static constexpr int NC = (GAUGE == CPT_GAUGE_NEWTONIAN) ? 14 : 13;
 
 struct Layout {
   int tca, rsa, ufa;
@@ -161,7 +183,7 @@ struct Layout {
   int maxlen;                  // longest tail present
 };
 
-__device__ __forceinline__ Layout make_layout(const PtParams& P, int tca, int rsa, int ufa) {
+static __device__ __forceinline__ Layout make_layout(const PtParams& P, int tca, int rsa, int ufa) {
   Layout L;
   L.tca = tca; L.rsa = rsa; L.ufa = ufa;
   L.lmg = P.l_max_g; L.lmp = P.l_max_pol_g; L.lmu = P.l_max_ur;
@@ -175,18 +197,19 @@ __device__ __forceinline__ Layout make_layout(const PtParams& P, int tca, int rs
 }
 
 // is core variable `i` evolved in this scheme?  (i wave-uniform)
-__device__ __forceinline__ bool core_present(const PtParams& P, const Layout& L, int i) {
+static __device__ __forceinline__ bool core_present(const PtParams& P, const Layout& L, int i) {
   switch (i) {
     case LN_DG: case LN_TG: return !L.rsa;
     case LN_SG: case LN_P0: case LN_P1: case LN_P2: return !L.rsa && !L.tca;
     case LN_DC: return P.has_cdm != 0;
+    case LN_TC: return GAUGE == CPT_GAUGE_NEWTONIAN && P.has_cdm != 0;   // (lane 13 is the first tail lane in the synchronous kernel)
     case LN_DUR: case LN_TUR: case LN_SUR: return P.has_ur && !L.rsa;
     default: return true;  // delta_b, theta_b, eta
   }
 }
 
 // (role, multipole) of lane i in the current scheme; R_NONE = not evolved
-__device__ __forceinline__ void role_of(const PtParams& P, const Layout& L, int i, int* role, int* ell) {
+static __device__ __forceinline__ void role_of(const PtParams& P, const Layout& L, int i, int* role, int* ell) {
   *role = R_NONE; *ell = 0;
   const bool g = !L.rsa, hi = !L.rsa && !L.tca, ur = P.has_ur && !L.rsa;
   if (i == LN_DG) { if (g) *role = R_DELTA_G; return; }
@@ -202,20 +225,21 @@ __device__ __forceinline__ void role_of(const PtParams& P, const Layout& L, int 
   if (i == LN_TUR) { if (ur) { *role = R_THETA_UR; *ell = 1; } return; }
   if (i == LN_SUR) { if (ur) { *role = R_SHEAR_UR; *ell = 2; } return; }
   if (i == LN_ETA) { *role = R_ETA; return; }
+  if (GAUGE == CPT_GAUGE_NEWTONIAN && i == LN_TC) { if (P.has_cdm) *role = R_THETA_CDM; return; }
   if (i >= L.g3 && i < L.g3 + L.gN) { *role = R_LG; *ell = 3 + (i - L.g3); return; }
   if (i >= L.q3 && i < L.q3 + L.qN) { *role = R_POL; *ell = 3 + (i - L.q3); return; }
   if (i >= L.u3 && i < L.u3 + L.uN) { *role = R_LUR; *ell = 3 + (i - L.u3); return; }
 }
 // index of (role, ell) in the REFERENCE's ordering of the same regime (pm.cpp:3302-3481): only the unit-test hooks
 // cpt_dbg_derivs / cpt_dbg_solve need it, to exchange vectors with the oracle in the reference's order
-__device__ __forceinline__ int ref_index_of(const PtParams& P, int tca, int rsa, int ufa, int role, int ell, int* neq) {
-  int i = 0, dg = -1, tg = -1, sg = -1, l3g = -1, pol0 = -1, db, tb, dc = -1, dur = -1, tur = -1, sur = -1, l3ur = -1, eta;
+static __device__ __forceinline__ int ref_index_of(const PtParams& P, int tca, int rsa, int ufa, int role, int ell, int* neq) {
+  int i = 0, dg = -1, tg = -1, sg = -1, l3g = -1, pol0 = -1, db, tb, dc = -1, tc = -1, dur = -1, tur = -1, sur = -1, l3ur = -1, eta;
   if (!rsa) {
     dg = i++; tg = i++;
     if (!tca) { sg = i++; l3g = i; i += P.l_max_g - 2; pol0 = i; i += P.l_max_pol_g + 1; }
   }
   db = i++; tb = i++;
-  if (P.has_cdm) dc = i++;
+  if (P.has_cdm) { dc = i++; if (GAUGE == CPT_GAUGE_NEWTONIAN) tc = i++; }
   if (P.has_ur && !rsa) { dur = i++; tur = i++; sur = i++; if (!ufa) { l3ur = i; i += P.l_max_ur - 2; } }
   eta = i++;
   *neq = i;
@@ -228,6 +252,7 @@ __device__ __forceinline__ int ref_index_of(const PtParams& P, int tca, int rsa,
     case R_DELTA_B: return db;
     case R_THETA_B: return tb;
     case R_DELTA_CDM: return dc;
+    case R_THETA_CDM: return tc;
     case R_DELTA_UR: return dur;
     case R_THETA_UR: return tur;
     case R_SHEAR_UR: return sur;
@@ -237,23 +262,13 @@ __device__ __forceinline__ int ref_index_of(const PtParams& P, int tca, int rsa,
   }
 }
 
-#ifdef CPT_PROFILE
-__device__ unsigned long long g_prof[16];
-#define PROF_DECL unsigned long long pf_t0 = 0
-#define PROF_START() pf_t0 = clock64()
-#define PROF_STOP(slot) prof[slot] += clock64() - pf_t0
-#else
-#define PROF_DECL
-#define PROF_START()
-#define PROF_STOP(slot)
-#endif
 
 // ---- spline tables ------------------------------------------------------------------------------
 struct BgV { double a, H, Hp, rg, rb, rc, ru; };
 struct ThV { double xe, dkappa, tau_d, ddkappa, dddkappa, expmk, g, dg, cb2; };
 
 // per-thread (scalar) lookup with binary search: used by the schedule search, where every lane probes its own tau
-__device__ __forceinline__ int bsearch_up(const double* __restrict__ x, int n, double v) {  // arrays.c:1586-1594
+static __device__ __forceinline__ int bsearch_up(const double* __restrict__ x, int n, double v) {  // arrays.c:1586-1594
   int inf = 0, sup = n - 1;
   while (sup - inf > 1) {
     int mid = (inf + sup) >> 1;
@@ -261,12 +276,12 @@ __device__ __forceinline__ int bsearch_up(const double* __restrict__ x, int n, d
   }
   return inf;
 }
-__device__ __forceinline__ double spl2(const double2 lo, const double2 hi, double a, double b, double h2) {
+static __device__ __forceinline__ double spl2(const double2 lo, const double2 hi, double a, double b, double h2) {
   return a * lo.x + b * hi.x + ((a * a * a - a) * lo.y + (b * b * b - b) * hi.y) * h2;
 }
 // a, H and dkappa at tau (what perturb_approximations and the start-time search need)
 struct AHK { double a, H, dk; };
-__device__ __noinline__ AHK lookup_aHk(DevTables T, double n_e, double tau) {
+static __device__ __noinline__ AHK lookup_aHk(DevTables T, double n_e, double tau) {
   int inf = bsearch_up(T.tau_table, T.bt_size, tau);
   double h = T.tau_table[inf + 1] - T.tau_table[inf], b = (tau - T.tau_table[inf]) / h, a = 1. - b, h2 = h * h / 6.;
   const double2* r0 = (const double2*)T.bg + (size_t)inf * BG_NCOL;
@@ -317,7 +332,7 @@ struct Lookup {
 // All NCOL loads are issued before the first LDS store (one HBM/L2 round trip per restage, not NCOL of them); rows past
 // the end of the table are clamped to the last row - their abscissa is +huge, so they are never selected.
 template <int NCOL>
-__device__ __forceinline__ void window_stage(const double* __restrict__ x, const double2* __restrict__ rows, int n, int base, int lane,
+static __device__ __forceinline__ void window_stage(const double* __restrict__ x, const double2* __restrict__ rows, int n, int base, int lane,
                                              double* xw, double2* w) {
   const int i = base + lane;
   const double xv = x[min(i, n - 1)];
@@ -335,7 +350,7 @@ __device__ __forceinline__ void window_stage(const double* __restrict__ x, const
 // one it entered: slide by one window (keeping `bias` rows on the side the wave comes from) and only fall back to the
 // binary search - 15 dependent global loads, microseconds - after a jump (first lookup, hand-over to a new mode).
 template <int NCOL>
-__device__ __forceinline__ int window_find(const double* __restrict__ x, const double2* __restrict__ rows, int n, double v,
+static __device__ __forceinline__ int window_find(const double* __restrict__ x, const double2* __restrict__ rows, int n, double v,
                                            int lane, double* xw, double2* w, int* base, int bias) {
   double lo = bcast(*xw, 0), hi = bcast(*xw, 63);
   if (!(v >= lo && v < hi)) {
@@ -361,7 +376,7 @@ __device__ __forceinline__ int window_find(const double* __restrict__ x, const d
   return inf;
 }
 
-__device__ __forceinline__ void lookup_init(const PtParams& P, Lookup& Q, double2* bgw, double2* thw, int lane) {
+static __device__ __forceinline__ void lookup_init(const PtParams& P, Lookup& Q, double2* bgw, double2* thw, int lane) {
   Q.bgw = bgw; Q.thw = thw;
   Q.bg_base = 0; Q.th_base = 0; Q.bg_inf = -1; Q.th_inf = -1; Q.tau_cached = -1.;
   window_stage<BG_NCOL>(P.tabs.tau_table, (const double2*)P.tabs.bg, P.tabs.bt_size, 0, lane, &Q.bgx, bgw);
@@ -374,16 +389,16 @@ __device__ __forceinline__ void lookup_init(const PtParams& P, Lookup& Q, double
 }
 
 // per-mode constants of the curved-space equations (pm.cpp:2530-2533, 5856): s_2, s_2^2 = 1 - 3K/k^2
-__device__ __forceinline__ void lookup_set_mode(const PtParams& P, Lookup& Q, double k) {
+static __device__ __forceinline__ void lookup_set_mode(const PtParams& P, Lookup& Q, double k) {
   const double k2 = k * k;
-  Q.s2sq = 1. - 3. * P.K / k2;
-  Q.s2 = (P.K == 0.) ? 1. : sqrt(fmax(Q.s2sq, 0.));
+  Q.s2sq = CURV ? 1. - 3. * P.K / k2 : 1.;
+  Q.s2 = CURV ? sqrt(fmax(Q.s2sq, 0.)) : 1.;
   Q.k2s2 = k2 * Q.s2sq;
-  Q.inv_k2s2 = 1. / Q.k2s2;
+  Q.inv_k2s2 = 1. / Q.k2s2;   // (flat: k^2 and 1/k^2, the same values as the kernel's k2 / inv_k2)
 }
 
 // background_at_tau (normal_info, source/background_module.cpp:125-199) + thermodynamics_at_z (th.cpp:114-285)
-__device__ __forceinline__ void lookup(const PtParams& P, Lookup& Q, double tau, int lane) {
+static __device__ __forceinline__ void lookup(const PtParams& P, Lookup& Q, double tau, int lane) {
   if (tau == Q.tau_cached) return;
   Q.tau_cached = tau;
   const DevTables& T = P.tabs;
@@ -448,7 +463,7 @@ __device__ __forceinline__ void lookup(const PtParams& P, Lookup& Q, double tau,
   Q.Fp = Q.dtau_c * Q.inv_1pR + Q.tau_c * Q.aH * Q.R * Q.inv_1pR * Q.inv_1pR;
   Q.app = bg_Hp * bg_a + 2. * Q.aH * Q.aH;       // a''/a
   Q.inv_tau = fast_rcp(tau);
-  if (P.K == 0.) Q.kcot = Q.inv_tau;                       // k cotK_gen = 1/tau (pm.cpp:7969)
+  if (!CURV) Q.kcot = Q.inv_tau;                       // k cotK_gen = 1/tau (pm.cpp:7969)
   else {                                                    // pm.cpp:7972-7977
     const double sq = sqrt(fabs(P.K));
     Q.kcot = (P.K < 0.) ? sq / tanh(sq * tau) : sq / tan(sq * tau);
@@ -473,21 +488,21 @@ struct LaneEq {
   int parent_addr;     // tail lanes: byte address of the core parent; else own lane
   double Bpar;         // core parents of a present tail: B (their coupling to the tail's l=3 element); else 0
   double A, B, D, G, Gt;   // G multiplies k cotK_gen(tau) (hierarchy truncation), Gt multiplies 1/tau (ur fluid): equal in flat space
-  double Xmc, Xms, XP, X4, Xeta, Xtb;
+  double Xmc, Xms, XP, X4, Xeta, Xtb, Xeu;   // Xeu multiplies metric_euler = k^2 psi (Newtonian gauge; 0 in synchronous)
 };
 
-__device__ __forceinline__ LaneEq make_lane_eq(const PtParams& P, const Layout& L, int lane, double k) {
+static __device__ __forceinline__ LaneEq make_lane_eq(const PtParams& P, const Layout& L, int lane, double k) {
   LaneEq e;
   role_of(P, L, lane, &e.role, &e.ell);
   e.A = e.B = e.D = e.G = e.Gt = 0.;
-  e.Xmc = e.Xms = e.XP = e.X4 = e.Xeta = e.Xtb = 0.;
+  e.Xmc = e.Xms = e.XP = e.X4 = e.Xeta = e.Xtb = e.Xeu = 0.;
   e.chain = 0; e.first = false; e.last = false;
   int dn = lane, up = lane;
   const int l = e.ell;
   const double k2 = k * k, c3 = P.three_ceff2_ur, v3 = P.three_cvis2_ur;
   // curvature factors s_l = sqrt(1 - K (l^2-1)/k^2) of the multipole ladders (pm.cpp:2530-2533); all 1 in flat space
-  auto S = [&](int ll) { const double v = 1.0 - P.K * (ll * ll - 1.0) / k2; return (P.K == 0.) ? 1.0 : sqrt(fmax(v, 0.)); };
-  const double s2 = S(2), s3 = S(3), s2sq = 1. - 3. * P.K / k2;
+  auto S = [&](int ll) { return CURV ? sqrt(fmax(1.0 - P.K * (ll * ll - 1.0) / k2, 0.)) : 1.0; };
+  const double s2 = S(2), s3 = S(3), s2sq = CURV ? 1. - 3. * P.K / k2 : 1.;
   int lm = 0, parent = lane;
   if (e.role == R_LG) { e.chain = 1; lm = L.lmg; e.D = 1.; parent = LN_SG; }
   else if (e.role == R_POL && l >= 3) { e.chain = 2; lm = L.lmp; e.D = 1.; parent = LN_P2; }
@@ -503,7 +518,7 @@ __device__ __forceinline__ LaneEq make_lane_eq(const PtParams& P, const Layout& 
     switch (e.role) {
       case R_DELTA_G: e.B = 4. / 3.; up = LN_TG; e.Xmc = -4. / 3.; break;                                 // pm.cpp:8095
       case R_THETA_G:
-        if (!L.tca) { e.A = 0.25 * k2; dn = LN_DG; e.B = k2 * s2sq; up = LN_SG; e.D = 1.; }              // pm.cpp:8145-8148
+        if (!L.tca) { e.A = 0.25 * k2; dn = LN_DG; e.B = k2 * s2sq; up = LN_SG; e.D = 1.; e.Xeu = 1.; } // pm.cpp:8145-8148
         e.X4 = 1.;                           // S4 = kappa' theta_b, or the whole tight-coupling expression (pm.cpp:8214-8217)
         break;
       case R_SHEAR_G:                                                                                    // pm.cpp:8151-8155
@@ -517,16 +532,18 @@ __device__ __forceinline__ LaneEq make_lane_eq(const PtParams& P, const Layout& 
         break;
       case R_DELTA_B: e.B = 1.; up = LN_TB; e.Xmc = -1.; break;                                          // pm.cpp:8101
       case R_THETA_B: e.Xtb = 1.; break;
-      case R_DELTA_CDM: e.Xmc = -1.; break;                                                              // pm.cpp:8240
+      case R_DELTA_CDM: e.Xmc = -1.; if (GAUGE == CPT_GAUGE_NEWTONIAN) { e.B = 1.; up = LN_TC; } break;  // pm.cpp:8232-8240
+      case R_THETA_CDM: e.Xeu = 1.; break;                                     // pm.cpp:8235 (-a'/a theta_cdm added in rhs)
       case R_DELTA_UR: e.B = 4. / 3.; up = LN_TUR; e.Xmc = -4. / 3.; break;                              // pm.cpp:8630-8634
-      case R_THETA_UR: e.A = 0.25 * c3 * k2; dn = LN_DUR; e.B = k2 * s2sq; up = LN_SUR; break;           // pm.cpp:8637-8641
+      case R_THETA_UR: e.A = 0.25 * c3 * k2; dn = LN_DUR; e.B = k2 * s2sq; up = LN_SUR; e.Xeu = 1.; break;  // pm.cpp:8637-8641
       case R_SHEAR_UR:
         dn = LN_TUR;
         if (!L.ufa) { e.A = 4. / 15. * v3; e.Xms = 4. / 15. * v3; if (L.uN > 0) { e.B = 0.3 * k * s3 / s2; up = L.u3; } }  // pm.cpp:8645-8651
         else {                                                                                           // pm.cpp:8704-8708
           e.A = 2. / 3.;
-          if (P.ufa_method == CPT_UFA_CLASS) { e.Gt = 3.; e.Xmc = 2. / 3.; }
-          else if (P.ufa_method == CPT_UFA_MB) { e.Gt = 3.; e.Xms = 2. / 3.; }
+          // ufa_class source: h'/2 = metric_continuity (synchronous), -6 phi' = 2 metric_continuity (Newtonian), pm.cpp:8060-8073
+          if (P.ufa_method == CPT_UFA_CLASS) { (CURV ? e.Gt : e.G) = 3.; e.Xmc = (GAUGE == CPT_GAUGE_NEWTONIAN) ? 4. / 3. : 2. / 3.; }
+          else if (P.ufa_method == CPT_UFA_MB) { (CURV ? e.Gt : e.G) = 3.; e.Xms = 2. / 3.; }
           else e.Xms = 2. / 3.;                                                 // ufa_hu: -3 a'/a shear added in rhs
         }
         break;
@@ -546,12 +563,13 @@ __device__ __forceinline__ LaneEq make_lane_eq(const PtParams& P, const Layout& 
 // metric + fluid summary left behind by the last RHS evaluation (struct perturb_workspace of the reference)
 struct Metric {
   double hp, etap, alpha, alphap;
+  double psi, phip;   // Newtonian gauge
   double rsa_dg, rsa_tg;
   double tca_shear_g;
 };
 
 // y of another lane (per-lane byte address): two ds_bpermute_b32, executed by every lane
-__device__ __forceinline__ double gather(double v, int addr) {
+static __device__ __forceinline__ double gather(double v, int addr) {
   const int lo = __builtin_amdgcn_ds_bpermute(addr, __double2loint(v));
   const int hi = __builtin_amdgcn_ds_bpermute(addr, __double2hiint(v));
   return pin(__hiloint2double(hi, lo));
@@ -561,7 +579,7 @@ __device__ __forceinline__ double gather(double v, int addr) {
 // perturb_rsa_delta_and_theta (pm.cpp:9530-9636) and perturb_tca_slip_and_shear (pm.cpp:9229-9516) folded in;
 // synchronous gauge, K = 0.  y: this lane's component (named components are broadcast with v_readlane).
 // Returns dy of this lane and leaves M describing the state (tau, y).
-__device__ __forceinline__ double rhs(const PtParams& P, const Layout& L, const LaneEq& e, Lookup& Q, Metric& M, double k,
+static __device__ __forceinline__ double rhs(const PtParams& P, const Layout& L, const LaneEq& e, Lookup& Q, Metric& M, double k,
                                       double inv_k2, double tau, double y, int lane) {
 #ifdef CPT_PROFILE
   unsigned long long* prof = Q.prof;
@@ -592,62 +610,87 @@ __device__ __forceinline__ double rhs(const PtParams& P, const Layout& L, const 
   double rps = Q.rg43 * sg;
   if (P.has_cdm) delta_rho += Q.rc * dc;
   if (P.has_ur) { delta_rho += Q.ru * dur; rpt += Q.ru43 * tur; rps += Q.ru43 * sur; }
-  // ---- Einstein equations ----
-  const double hp = (Q.k2s2 * eta + 1.5 * a2 * delta_rho) * Q.two_over_aH;          // pm.cpp:5913-5914, k2s2 = k^2 (1 - 3K/k^2)
-  if (L.rsa) {
-    double rdg = 0., rtg = 0., rdur = 0., rtur = 0.;
-    if (P.rsa_method != CPT_RSA_NULL) { rdg = 4. * inv_k2 * (aH * hp - k2 * eta); rtg = -0.5 * hp; }
-    if (P.rsa_method == CPT_RSA_MD_WITH_REIO) {
-      rdg += -4. * inv_k2 * kap * (tb + 0.5 * hp);
-      rtg += 3. * inv_k2 * (Q.ddkappa * (tb + 0.5 * hp) + kap * (-aH * tb + cb2 * k2 * db - aH * hp + k2 * eta));
+  // ---- Einstein equations -> the metric terms of the matter equations (pm.cpp:8049-8074):
+  //      mc = metric_continuity, me = metric_euler, ms = metric_shear, msp = its derivative, mdot = eta' or phi'
+  double mc, me, ms, msp, mdot;
+  if (GAUGE == CPT_GAUGE_SYNCHRONOUS) {
+    const double hp = (Q.k2s2 * eta + 1.5 * a2 * delta_rho) * Q.two_over_aH;          // pm.cpp:5913-5914, k2s2 = k^2 (1 - 3K/k^2)
+    if (L.rsa) {
+      double rdg = 0., rtg = 0., rdur = 0., rtur = 0.;
+      if (P.rsa_method != CPT_RSA_NULL) { rdg = 4. * inv_k2 * (aH * hp - k2 * eta); rtg = -0.5 * hp; }
+      if (P.rsa_method == CPT_RSA_MD_WITH_REIO) {
+        rdg += -4. * inv_k2 * kap * (tb + 0.5 * hp);
+        rtg += 3. * inv_k2 * (Q.ddkappa * (tb + 0.5 * hp) + kap * (-aH * tb + cb2 * k2 * db - aH * hp + k2 * eta));
+      }
+      if (P.has_ur && P.rsa_method != CPT_RSA_NULL) { rdur = 4. * inv_k2 * (aH * hp - k2 * eta); rtur = -0.5 * hp; }
+      delta_rho += Q.rg * rdg;
+      rpt += Q.rg43 * rtg;
+      if (P.has_ur) { delta_rho += Q.ru * rdur; rpt += Q.ru43 * rtur; }
+      M.rsa_dg = rdg; M.rsa_tg = rtg;
+      dg = rdg; tg = rtg;  // pm.cpp:8085-8088: the equations below use the streaming values
     }
-    if (P.has_ur && P.rsa_method != CPT_RSA_NULL) { rdur = 4. * inv_k2 * (aH * hp - k2 * eta); rtur = -0.5 * hp; }
-    delta_rho += Q.rg * rdg;
-    rpt += Q.rg43 * rtg;
-    if (P.has_ur) { delta_rho += Q.ru * rdur; rpt += Q.ru43 * rtur; }
-    M.rsa_dg = rdg; M.rsa_tg = rtg;
-    dg = rdg; tg = rtg;  // pm.cpp:8085-8088: the equations below use the streaming values
+    const double etap = (1.5 * a2 * rpt + (CURV ? 0.5 * P.K * hp : 0.)) * Q.inv_k2s2;                 // pm.cpp:5938
+    const double alpha = (hp + 6. * etap) * 0.5 * inv_k2;
+    if (L.tca) rps += Q.rg43 * (16. / 45. * Q.tau_c * (tg + k2 * alpha));
+    const double alphap = -2. * aH * alpha + eta - 4.5 * (a2 * inv_k2) * rps;
+    M.hp = hp; M.etap = etap; M.alpha = alpha; M.alphap = alphap;
+    mc = 0.5 * hp; me = 0.; ms = k2 * alpha; msp = k2 * alphap; mdot = etap;
+  } else {
+    // Newtonian gauge (pm.cpp:5869-5897): the LN_ETA lane holds phi; cdm has a velocity
+    const double tc = bcast(y, LN_TC);
+    if (P.has_cdm) rpt += Q.rc * tc;
+    if (L.tca) rps += Q.rg43 * (16. / 45. * Q.tau_c * tg);                            // pm.cpp:6134-6136
+    const double psi = eta - 4.5 * (a2 * inv_k2) * rps;
+    const double phip = -aH * psi + 1.5 * (a2 * inv_k2) * rpt;
+    if (L.rsa) {                                                                      // pm.cpp:9549-9592
+      double rdg = 0., rtg = 0.;
+      if (P.rsa_method != CPT_RSA_NULL) { rdg = -4. * eta; rtg = 6. * phip; }
+      if (P.rsa_method == CPT_RSA_MD_WITH_REIO) {
+        rdg += -4. * inv_k2 * kap * tb;
+        rtg += 3. * inv_k2 * (Q.ddkappa * tb + kap * (-aH * tb + cb2 * k2 * db + k2 * eta));
+      }
+      M.rsa_dg = rdg; M.rsa_tg = rtg;
+      dg = rdg; tg = rtg;
+    }
+    M.psi = psi; M.phip = phip;
+    mc = -3. * phip; me = k2 * psi; ms = 0.; msp = 0.; mdot = phip;
   }
-  const double etap = (1.5 * a2 * rpt + 0.5 * P.K * hp) * Q.inv_k2s2;                 // pm.cpp:5938
-  const double alpha = (hp + 6. * etap) * 0.5 * inv_k2;
-  if (L.tca) rps += Q.rg43 * (16. / 45. * Q.tau_c * (tg + k2 * alpha));
-  const double alphap = -2. * aH * alpha + eta - 4.5 * (a2 * inv_k2) * rps;
-  M.hp = hp; M.etap = etap; M.alpha = alpha; M.alphap = alphap;
-  const double mc = 0.5 * hp;   // metric_continuity
-  const double ms = k2 * alpha; // metric_shear
   // ---- baryon velocity / tight coupling ----
   double dtb, S4;
   if (!L.tca) {
-    dtb = -aH * tb + k2 * cb2 * db + R * kap * (tg - tb);  // pm.cpp:8108-8113
+    dtb = -aH * tb + me + k2 * cb2 * db + R * kap * (tg - tb);  // pm.cpp:8108-8113
     S4 = kap * tb;
   } else {
     const double tau_c = Q.tau_c, dtau_c = Q.dtau_c, F = Q.F;
     double slip = (dtau_c * kap - 2. * aH * Q.inv_1pR) * (tb - tg) +
-                  F * (-Q.app * tb + k2 * (-aH * dg * 0.5 + cb2 * (-tb - mc) - (-tg - mc) * (1. / 3.)));
+                  F * (-Q.app * tb + k2 * (-aH * dg * 0.5 + cb2 * (-tb - mc) - (-tg - mc) * (1. / 3.)) - aH * me);
     double shear = 16. / 45. * tau_c * (tg + ms);
-    const double theta_prime = (-aH * tb + k2 * (cb2 * db + R * 0.25 * dg)) * Q.inv_1pR;
-    const double msp = k2 * alphap;
+    const double theta_prime = (-aH * tb + k2 * (cb2 * db + R * 0.25 * dg)) * Q.inv_1pR + me;
     const double shear_prime = 16. / 45. * (tau_c * (theta_prime + msp) + dtau_c * (tg + ms));
     if (P.tca_method == CPT_TCA_COMPROMISE_CLASS) {
       slip = (1. - 2. * aH * F) * slip + F * k2 * (Q.s2sq * (2. * aH * shear + shear_prime) - (1. / 3. - cb2) * (F * theta_prime + 2. * Q.Fp * tb));  // pm.cpp:9501
       shear = (1. - 11. / 6. * dtau_c) * shear - (11. / 6. * 16. / 45.) * tau_c * tau_c * (theta_prime + msp);
     }
     M.tca_shear_g = shear;
-    dtb = (-aH * tb + k2 * (cb2 * db + R * (dg * 0.25 - Q.s2sq * shear)) + R * slip) * Q.inv_1pR;  // pm.cpp:8123-8129
-    S4 = -(dtb + aH * tb - k2 * cb2 * db) * Q.inv_R + k2 * (0.25 * dg - Q.s2sq * shear);          // pm.cpp:8214-8217
+    dtb = (-aH * tb + k2 * (cb2 * db + R * (dg * 0.25 - Q.s2sq * shear)) + R * slip) * Q.inv_1pR + me;  // pm.cpp:8123-8129
+    S4 = -(dtb + aH * tb - k2 * cb2 * db) * Q.inv_R + k2 * (0.25 * dg - Q.s2sq * shear) + (1. + R) * Q.inv_R * me;  // pm.cpp:8214-8222
   }
   const double SP = kap * (p0 + p2 + 2. * Q.s2 * sg) * 0.125;  // kappa' Pi,  Pi = (G_gamma0 + G_gamma2 + F_gamma2)/8 (pm.cpp:8142)
 #ifdef CPT_PROFILE
   PROF_STOP(10); PROF_START();
 #endif
   // ---- every equation: streaming + damping + sources ----
-  double dy = e.A * ym - e.B * yp - (e.D * kap + e.G * Q.kcot + e.Gt * Q.inv_tau) * y;
+  double dy = e.A * ym - e.B * yp - (e.D * kap + e.G * Q.kcot + (CURV ? e.Gt * Q.inv_tau : 0.)) * y;
   dy = fma(e.Xmc, mc, dy);
   dy = fma(e.Xms, ms, dy);
   dy = fma(e.XP, SP, dy);
   dy = fma(e.X4, S4, dy);
-  dy = fma(e.Xeta, etap, dy);
+  dy = fma(e.Xeta, mdot, dy);
   dy = fma(e.Xtb, dtb, dy);
+  if (GAUGE == CPT_GAUGE_NEWTONIAN) {
+    dy = fma(e.Xeu, me, dy);
+    if (opaque(e.role) == R_THETA_CDM) dy -= aH * y;                                  // pm.cpp:8235
+  }
   // rarely used variants: non-standard ur sound speed (pm.cpp:8630-8641), ufa_hu (pm.cpp:8711-8716)
   const double c3 = P.three_ceff2_ur;
   if (c3 != 1. || (L.ufa && P.ufa_method == CPT_UFA_HU)) {
@@ -664,7 +707,7 @@ __device__ __forceinline__ double rhs(const PtParams& P, const Layout& L, const 
 
 // perturb_sources (pm.cpp:6731-7285): the RHS has just been evaluated at (tau, y) => Q and M describe the sample.
 // dy is the dense-output derivative (only theta_b' is used, pm.cpp:6883). Lane 0 stores the tp_size values.
-__device__ __forceinline__ void store_sources(const PtParams& P, const Layout& L, const Lookup& Q, const Metric& M, double k,
+static __device__ __forceinline__ void store_sources(const PtParams& P, const Layout& L, const Lookup& Q, const Metric& M, double k,
                                               double inv_k2, double y, double dy, double tca_shear_prev, int it, int ik, int lane) {
   struct { double g, dg, expmk; } th;
   th.g = bcast(Q.vth, TH_G); th.dg = bcast(Q.vth, TH_DG); th.expmk = bcast(Q.vth, TH_EXPMK);
@@ -682,13 +725,28 @@ __device__ __forceinline__ void store_sources(const PtParams& P, const Layout& L
   double delta_m = 0.;
   if (P.tp_dm >= 0) {  // gauge-invariant matter density contrast, pm.cpp:6573, 5979-5981
     double drm = Q.rb * bcast(y, LN_DB), rho_m = Q.rb;
-    if (P.has_cdm) { drm += Q.rc * bcast(y, LN_DC); rho_m += Q.rc; }
-    delta_m = (drm + 3. * aH * (Q.rb * tb) * inv_k2) / rho_m;
+    double rptm = Q.rb * tb;                       // [(rho+p) theta]_matter: cdm contributes in the Newtonian gauge (pm.cpp:6241-6243)
+    if (P.has_cdm) {
+      drm += Q.rc * bcast(y, LN_DC); rho_m += Q.rc;
+      if (GAUGE == CPT_GAUGE_NEWTONIAN) rptm += Q.rc * bcast(y, LN_TC);
+    }
+    delta_m = (drm + 3. * aH * rptm * inv_k2) / rho_m;
   }
   int switch_isw = 1;
   if ((P.switch_eisw == 0) && (z >= P.eisw_lisw_split_z)) switch_isw = 0;
   if ((P.switch_lisw == 0) && (z < P.eisw_lisw_split_z)) switch_isw = 0;
-  if (lane == 0) {
+  if (lane == 0 && GAUGE == CPT_GAUGE_NEWTONIAN) {  // pm.cpp:6849-6860, 6955-6957 (eta = phi here)
+    const size_t base = (size_t)ik * P.ntau + it, tstride = (size_t)P.nk * P.ntau;
+    if (P.tp_t0 >= 0)
+      P.src[P.tp_t0 * tstride + base] = P.switch_sw * th.g * (delta_g / 4. + M.psi) +
+                                        switch_isw * (th.g * (eta - M.psi) + th.expmk * 2. * M.phip) +
+                                        P.switch_dop * inv_k2 * (th.g * dtb + th.dg * tb);
+    if (P.tp_t1 >= 0) P.src[P.tp_t1 * tstride + base] = switch_isw * th.expmk * k * (M.psi - eta);
+    if (P.tp_t2 >= 0) P.src[P.tp_t2 * tstride + base] = P.switch_pol * th.g * Pi;
+    if (P.tp_p >= 0) P.src[P.tp_p * tstride + base] = sqrt(6.) * th.g * Pi;
+    if (P.tp_pp >= 0) P.src[P.tp_pp * tstride + base] = eta + M.psi;
+    if (P.tp_dm >= 0) P.src[P.tp_dm * tstride + base] = delta_m;
+  } else if (lane == 0) {
     const size_t base = (size_t)ik * P.ntau + it, tstride = (size_t)P.nk * P.ntau;
     if (P.tp_t0 >= 0)
       P.src[P.tp_t0 * tstride + base] =
@@ -704,7 +762,7 @@ __device__ __forceinline__ void store_sources(const PtParams& P, const Layout& L
 }
 
 // perturb_approximations (pm.cpp:5443-5670) evaluated independently by every lane at its own tau
-__device__ __forceinline__ void approx_flags(const PtParams& P, double k, double tau, int* tca, int* rsa, int* ufa) {
+static __device__ __forceinline__ void approx_flags(const PtParams& P, double k, double tau, int* tca, int* rsa, int* ufa) {
   const AHK q = lookup_aHk(P.tabs, P.n_e, tau);
   const double a = q.a, H = q.H, dk = q.dk;
   const double tau_h = 1. / (H * a);
@@ -719,7 +777,7 @@ __device__ __forceinline__ void approx_flags(const PtParams& P, double k, double
 
 // 64-ary search for the time at which a monotone predicate flips between lo (false) and hi (true):
 // kind 0: "no longer early enough to start" (pm.cpp:2590-2635), kind 1..3: approximation ap-1 differs from `ref`
-__device__ __forceinline__ double search_flip(const PtParams& P, double k, double lo, double hi, double tol_abs, double tol_rel,
+static __device__ __forceinline__ double search_flip(const PtParams& P, double k, double lo, double hi, double tol_abs, double tol_rel,
                                            int kind, int ref, int lane) {
   for (int round = 0; round < 64; round++) {
     const double width = hi - lo;
@@ -771,14 +829,14 @@ struct LuReg {
 };
 
 template <int N>
-__device__ __forceinline__ double reg_get(const double (&a)[N], int i) {
+static __device__ __forceinline__ double reg_get(const double (&a)[N], int i) {
   double v = 0.;
 #pragma unroll
   for (int j = 0; j < N; j++) if (j == i) v = a[j];
   return v;
 }
 
-__device__ __forceinline__ bool factorise(const LaneEq& e, const Jac& J, double hg, int maxlen, int lane, LuReg& F) {
+static __device__ __forceinline__ bool factorise(const LaneEq& e, const Jac& J, double hg, int maxlen, int lane, LuReg& F) {
   lane = opaque(lane);
   const int chain = opaque(e.chain);
   // ---- tails ----
@@ -847,7 +905,7 @@ __device__ __forceinline__ bool factorise(const LaneEq& e, const Jac& J, double 
 }
 
 // solve (I - hg J) x = b; lane i holds b_i on entry and x_i on return
-__device__ __forceinline__ double lu_solve(const LaneEq& e, const LuReg& F, int maxlen, double b, int lane) {
+static __device__ __forceinline__ double lu_solve(const LaneEq& e, const LuReg& F, int maxlen, double b, int lane) {
   lane = opaque(lane);
   const int chain = opaque(e.chain);
   // 1. tails, downward sweep: b'_l = b_l - (c_l / d'_{l+1}) b'_{l+1}; the l_max element is final at once
@@ -885,7 +943,7 @@ __device__ __forceinline__ double lu_solve(const LaneEq& e, const LuReg& F, int 
 }
 
 // adjust_stepsize (ev.cpp:907-943): dif[0..k-1] <- dif[0..k-1] * RU(r); every index static => registers only
-__device__ __forceinline__ void adjust_stepsize(double* dif, double r, int k) {
+static __device__ __forceinline__ void adjust_stepsize(double* dif, double r, int k) {
   const double U[5][5] = {{-1, -2, -3, -4, -5}, {0, 1, 3, 6, 10}, {0, 0, -1, -4, -10}, {0, 0, 0, 1, 5}, {0, 0, 0, 0, -1}};
   double R0[5][5], RU[5][5], tv[5];
 #pragma unroll
@@ -918,7 +976,7 @@ struct Stat { int steps, failed, fevals, jacs, lus, solves; };
 
 
 // register selects on the backward-difference array (static indices only => no scratch)
-__device__ __forceinline__ double dif_get(const double* dif, int i) {
+static __device__ __forceinline__ double dif_get(const double* dif, int i) {
   double v = 0.;
 #pragma unroll
   for (int j = 0; j < 7; j++) if (j == i) v = dif[j];
@@ -928,7 +986,7 @@ __device__ __forceinline__ double dif_get(const double* dif, int i) {
 // evolver_ndf15 (ev.cpp:62-705) for one interval of constant approximation scheme, as ONE flat loop so that the RHS
 // is instantiated exactly twice: a "service" slot (Jacobian columns, f(t0), f(t0+tdel), J f0, sampled outputs, the
 // final evaluation) and the Newton slot.  Returns 0 / error code (1 step too small, 2 singular, 4 budget).
-__device__ __forceinline__ int ndf15(const PtParams& P, const Layout& L, const LaneEq& e, Lookup& Q, Metric& M, double k,
+static __device__ __forceinline__ int ndf15(const PtParams& P, const Layout& L, const LaneEq& e, Lookup& Q, Metric& M, double k,
                                      double inv_k2, int ik, double t0, double tfinal, double& y_io, Stat& st, int lane,
                                      int& budget, double* jac_lds, unsigned long long* prof) {
   PROF_DECL;
@@ -1011,7 +1069,7 @@ __device__ __forceinline__ int ndf15(const PtParams& P, const Layout& L, const L
       if (batch == B_FINAL) { PROF_STOP(3); break; }  // ev.cpp:653-662: M, Q left at (tfinal, y) for the hand-over
       if (batch == B_JAC) {
         // the tails' diagonal is analytic: freeze kappa' and 1/tau at the time of this Jacobian
-        J.jdiag = -(e.D * Q.kap + e.G * Q.kcot + e.Gt * Q.inv_tau);
+        J.jdiag = -(e.D * Q.kap + e.G * Q.kcot + (CURV ? e.Gt * Q.inv_tau : 0.));
         st.jacs++;
         M.tca_shear_g = tca_keep;
         Jcurrent = true;
@@ -1243,8 +1301,8 @@ __device__ __forceinline__ int ndf15(const PtParams& P, const Layout& L, const L
 }
 
 // perturb_initial_conditions (pm.cpp:4723-5408): adiabatic, synchronous gauge, flat. Returns this lane's y.
-__device__ __noinline__ double initial_conditions(DevTables T, int has_cdm, int has_ur, double ci, double K, int ic, double ei, int role, int ell,
-                                                  double k, double tau) {
+static __device__ __noinline__ double initial_conditions(DevTables T, int has_cdm, int has_ur, double ci, double K, int ic, double ei, int gauge, int role,
+                                                  int ell, double k, double tau) {
   // background row at tau (scalar lookup: executed once per mode)
   const int inf = bsearch_up(T.tau_table, T.bt_size, tau);
   const double hh = T.tau_table[inf + 1] - T.tau_table[inf], b = (tau - T.tau_table[inf]) / hh, aa = 1. - b, h2 = hh * hh / 6.;
@@ -1268,69 +1326,75 @@ __device__ __noinline__ double initial_conditions(DevTables T, int has_cdm, int 
   const double l3_ur = kt3 * 2. / 7. / (12. * fracnu + 45.) * ci;
   const double eta = ci * (1. - kt2 / 12. / (15. + 4. * fracnu) *
                                     (5. + 4. * s2sq * fracnu - (16. * fracnu * fracnu + 280. * fracnu + 325) / 10. / (2. * fracnu + 15.) * tau * om));
+  // synchronous-gauge values of the named variables (cdm velocity is zero by definition of that gauge)
+  double dg, tg, db, dcdm = 0., dur, tur, sur, l3u = 0., et;
   if (ic == CPT_IC_AD) {
-    switch (role) {
-      case R_DELTA_G: return delta_g;
-      case R_THETA_G: return theta_g;
-      case R_DELTA_B: return 0.75 * delta_g;
-      case R_THETA_B: return theta_g;
-      case R_DELTA_CDM: return 0.75 * delta_g;
-      case R_DELTA_UR: return delta_g;
-      case R_THETA_UR: return theta_ur;
-      case R_SHEAR_UR: return shear_ur;
-      case R_LUR: return ell == 3 ? l3_ur : 0.;
-      case R_ETA: return eta;
-      default: return 0.;
+    dg = delta_g; tg = theta_g; db = 0.75 * delta_g; dcdm = 0.75 * delta_g; dur = delta_g; tur = theta_ur; sur = shear_ur; l3u = l3_ur; et = eta;
+  } else {
+    // isocurvature modes (pm.cpp:4956-5083; Bucher, Moodley & Turok 1999 with CLASS normalisation); l3_ur = 0
+    const double fracg = rg / rho_r, fraccdm = 1. - fracb, kt = k * tau;
+    if (ic == CPT_IC_CDI || ic == CPT_IC_BI) {
+      const double f = (ic == CPT_IC_CDI) ? fraccdm : fracb;
+      dg = ei * f * om * tau * (-2. / 3. + om * tau / 4.);
+      tg = -ei * f * om * kt2 / 12.;
+      db = 0.75 * dg + (ic == CPT_IC_BI ? ei : 0.);
+      dcdm = 0.75 * dg + (ic == CPT_IC_CDI ? ei : 0.);
+      dur = dg; tur = tg;
+      sur = -ei * f * kt2 * tau * om / 6. / (2. * fracnu + 15.);
+      et = -ei * f * om * tau * (1. / 6. - om * tau / 16.);
+    } else if (ic == CPT_IC_NID) {
+      dg = ei * fracnu / fracg * (-1. + kt2 / 6.);
+      tg = -ei * fracnu / fracg * k * k * tau * (1. / 4. - fracb / fracg * 3. / 16. * om * tau);
+      db = ei * fracnu / fracg / 8. * kt2;
+      dcdm = -ei * fracnu * fracb / fracg / 80. * kt2 * om * tau;
+      dur = ei * (1. - kt2 / 6.);
+      tur = ei * k * k * tau / 4.;
+      sur = ei * kt2 / (4. * fracnu + 15.) / 2.;
+      et = -ei * fracnu / (4. * fracnu + 15.) / 6. * kt2;
+    } else {  // CPT_IC_NIV
+      dg = ei * kt * fracnu / fracg * (1. - 3. / 16. * fracb * (2. + fracg) / fracg * om * tau);
+      tg = ei * fracnu / fracg * 3. / 4. * k *
+           (-1. + 3. / 4. * fracb / fracg * om * tau + 3. / 16. * om * om * tau * tau * fracb / fracg / fracg * (fracg - 3. * fracb) + kt2 / 6.);
+      db = 0.75 * dg;
+      dcdm = -ei * 9. / 64. * fracnu * fracb / fracg * kt * om * tau;
+      dur = -ei * kt * (1. + 3. / 16. * fracb * fracnu / fracg * om * tau);
+      tur = ei * 3. / 4. * k * (1. - 1. / 6. * kt2 * (4. * fracnu + 9.) / (4. * fracnu + 5.));
+      sur = ei / (4. * fracnu + 15.) * kt * (1. + 3. * om * tau * fracnu / (4. * fracnu + 15.));
+      et = ei * fracnu * kt * (-1. / (4. * fracnu + 5.) + (-3. / 64. * fracb / fracg + 15. / 4. / (4. * fracnu + 15.) / (4. * fracnu + 5.) * om * tau));
     }
   }
-  // isocurvature modes (pm.cpp:4956-5083; Bucher, Moodley & Turok 1999 with CLASS normalisation); l3_ur = 0
-  const double fracg = rg / rho_r, fraccdm = 1. - fracb, kt = k * tau;
-  double dg, tg, db, dcdm = 0., dur, tur, sur, et;
-  if (ic == CPT_IC_CDI || ic == CPT_IC_BI) {
-    const double f = (ic == CPT_IC_CDI) ? fraccdm : fracb;
-    dg = ei * f * om * tau * (-2. / 3. + om * tau / 4.);
-    tg = -ei * f * om * kt2 / 12.;
-    db = 0.75 * dg + (ic == CPT_IC_BI ? ei : 0.);
-    dcdm = 0.75 * dg + (ic == CPT_IC_CDI ? ei : 0.);
-    dur = dg; tur = tg;
-    sur = -ei * f * kt2 * tau * om / 6. / (2. * fracnu + 15.);
-    et = -ei * f * om * tau * (1. / 6. - om * tau / 16.);
-  } else if (ic == CPT_IC_NID) {
-    dg = ei * fracnu / fracg * (-1. + kt2 / 6.);
-    tg = -ei * fracnu / fracg * k * k * tau * (1. / 4. - fracb / fracg * 3. / 16. * om * tau);
-    db = ei * fracnu / fracg / 8. * kt2;
-    dcdm = -ei * fracnu * fracb / fracg / 80. * kt2 * om * tau;
-    dur = ei * (1. - kt2 / 6.);
-    tur = ei * k * k * tau / 4.;
-    sur = ei * kt2 / (4. * fracnu + 15.) / 2.;
-    et = -ei * fracnu / (4. * fracnu + 15.) / 6. * kt2;
-  } else {  // CPT_IC_NIV
-    dg = ei * kt * fracnu / fracg * (1. - 3. / 16. * fracb * (2. + fracg) / fracg * om * tau);
-    tg = ei * fracnu / fracg * 3. / 4. * k *
-         (-1. + 3. / 4. * fracb / fracg * om * tau + 3. / 16. * om * om * tau * tau * fracb / fracg / fracg * (fracg - 3. * fracb) + kt2 / 6.);
-    db = 0.75 * dg;
-    dcdm = -ei * 9. / 64. * fracnu * fracb / fracg * kt * om * tau;
-    dur = -ei * kt * (1. + 3. / 16. * fracb * fracnu / fracg * om * tau);
-    tur = ei * 3. / 4. * k * (1. - 1. / 6. * kt2 * (4. * fracnu + 9.) / (4. * fracnu + 5.));
-    sur = ei / (4. * fracnu + 15.) * kt * (1. + 3. * om * tau * fracnu / (4. * fracnu + 15.));
-    et = ei * fracnu * kt * (-1. / (4. * fracnu + 5.) + (-3. / 64. * fracb / fracg + 15. / 4. / (4. * fracnu + 15.) / (4. * fracnu + 5.) * om * tau));
+  double tbv = tg, tcdm = 0.;
+  if (!has_cdm) dcdm = 0.;
+  if (!has_ur) { dur = tur = sur = l3u = 0.; }
+  if (gauge == CPT_GAUGE_NEWTONIAN) {  // gauge transformation of the synchronous series, pm.cpp:5095-5198
+    const double H = spl2(r0[BG_H], r1[BG_H], aa, b, h2), aH = a * H, fracg = rg / rho_r, fraccdm = 1. - fracb, rmr = rho_m / rho_r;
+    const double delta_tot = (fracg * dg + fracnu * dur + rmr * (fracb * db + fraccdm * dcdm)) / (1. + rmr);
+    const double velocity_tot = ((4. / 3.) * (fracg * tg + fracnu * tur) + rmr * fracb * tbv) / (1. + rmr);
+    const double alpha = (et + 1.5 * aH * aH / (k * k) / s2sq * (delta_tot + 3. * aH / (k * k) * velocity_tot)) / aH;
+    et -= aH * alpha;   // phi
+    dg -= 4. * aH * alpha; tg += k * k * alpha;
+    db -= 3. * aH * alpha; tbv += k * k * alpha;
+    if (has_cdm) { dcdm -= 3. * aH * alpha; tcdm = k * k * alpha; }
+    if (has_ur) { dur -= 4. * aH * alpha; tur += k * k * alpha; }
   }
   switch (role) {
     case R_DELTA_G: return dg;
     case R_THETA_G: return tg;
     case R_DELTA_B: return db;
-    case R_THETA_B: return tg;
+    case R_THETA_B: return tbv;
     case R_DELTA_CDM: return dcdm;
+    case R_THETA_CDM: return tcdm;
     case R_DELTA_UR: return dur;
     case R_THETA_UR: return tur;
     case R_SHEAR_UR: return sur;
+    case R_LUR: return ell == 3 ? l3u : 0.;
     case R_ETA: return et;
     default: return 0.;
   }
 }
 
 // ---- the kernel: perturb_solve (pm.cpp:2463-2787) for one mode per wavefront ---------------------
-__global__ void __launch_bounds__(64) k_perturb(PtParams P) {
+static __device__ __forceinline__ void body_perturb(const PtParams& P) {
   __shared__ __attribute__((aligned(16))) double2 tabw[64 * (BG_NCOL + TH_NCOL)];
   __shared__ double jacw[NC * 64];
   const int lane = threadIdx.x;
@@ -1396,7 +1460,7 @@ __global__ void __launch_bounds__(64) k_perturb(PtParams P) {
     int f_tca = fi0, f_rsa = fi1, f_ufa = fi2;
     Layout L = make_layout(P, f_tca, f_rsa, f_ufa);
     LaneEq e = make_lane_eq(P, L, lane, k);
-    double y = initial_conditions(P.tabs, P.has_cdm, P.has_ur, P.curvature_ini, P.K, P.ic, P.entropy_ini, e.role, e.ell, k, tau_ini);
+    double y = initial_conditions(P.tabs, P.has_cdm, P.has_ur, P.curvature_ini, P.K, P.ic, P.entropy_ini, GAUGE, e.role, e.ell, k, tau_ini);
 #ifdef CPT_PROFILE
     prof[6] = clock64() - t_begin;  // schedule search + initial conditions
 #endif
@@ -1415,7 +1479,7 @@ __global__ void __launch_bounds__(64) k_perturb(PtParams P) {
         if (was_tca && !L.tca) {  // tight coupling switched off: seed shear, l=3 and polarisation (pm.cpp:3893-3916)
           const double sh = M.tca_shear_g, kod = k * Q.tau_c;
           if (e.role == R_SHEAR_G) yn = sh;
-          const double s3 = (P.K == 0.) ? 1. : sqrt(fmax(1. - 8. * P.K / (k * k), 0.));
+          const double s3 = CURV ? sqrt(fmax(1. - 8. * P.K / (k * k), 0.)) : 1.;
           if (e.role == R_LG) yn = (e.ell == 3) ? 6. / 7. * kod * s3 * sh : 0.;
           if (e.role == R_POL) {
             if (e.ell == 0) yn = 2.5 * sh;
@@ -1449,7 +1513,7 @@ __global__ void __launch_bounds__(64) k_perturb(PtParams P) {
 }
 
 // ---- unit-test kernels -----------------------------------------------------------------------------
-__global__ void __launch_bounds__(64) k_dbg_lookup(PtParams P, const double* tau, int n, double* out) {
+static __device__ __forceinline__ void body_dbg_lookup(const PtParams& P, const double* tau, int n, double* out) {
   __shared__ __attribute__((aligned(16))) double2 w[64 * (BG_NCOL + TH_NCOL)];
   const int lane = threadIdx.x;
   Lookup Q;
@@ -1471,7 +1535,7 @@ __global__ void __launch_bounds__(64) k_dbg_lookup(PtParams P, const double* tau
 }
 
 // y and dy are exchanged in the REFERENCE's ordering of the regime (pm.cpp:3302-3481)
-__global__ void __launch_bounds__(64) k_dbg_derivs(PtParams P, double k, double tau, int tca, int rsa, int ufa, const double* y,
+static __device__ __forceinline__ void body_dbg_derivs(const PtParams& P, double k, double tau, int tca, int rsa, int ufa, const double* y,
                                                    double* dy, int* neq) {
   __shared__ __attribute__((aligned(16))) double2 w[64 * (BG_NCOL + TH_NCOL)];
   const int lane = threadIdx.x;
@@ -1496,7 +1560,7 @@ __global__ void __launch_bounds__(64) k_dbg_derivs(PtParams P, double k, double 
 }
 
 // (I - hg J(tau)) x = b through the structured factorisation, in the reference's ordering: unit test of the linear algebra
-__global__ void __launch_bounds__(64) k_dbg_solve(PtParams P, double k, double tau, int tca, int rsa, int ufa, double hg,
+static __device__ __forceinline__ void body_dbg_solve(const PtParams& P, double k, double tau, int tca, int rsa, int ufa, double hg,
                                                   const double* b, double* x) {
   __shared__ __attribute__((aligned(16))) double2 w[64 * (BG_NCOL + TH_NCOL)];
   const int lane = threadIdx.x;
@@ -1522,7 +1586,7 @@ __global__ void __launch_bounds__(64) k_dbg_solve(PtParams P, double k, double t
     const double col = rhs(P, L, e, Q, M, k, inv_k2, tau, (lane == r) ? 1.0 : 0.0, lane);
     J.Jc[r * 64 + lane] = (lane < NC) ? col : 0.;
   }
-  J.jdiag = -(e.D * Q.kap + e.G * Q.kcot + e.Gt * Q.inv_tau);
+  J.jdiag = -(e.D * Q.kap + e.G * Q.kcot + (CURV ? e.Gt * Q.inv_tau : 0.));
   LuReg F;
   const bool ok = factorise(e, J, hg, L.maxlen, lane, F);
   int nref;
@@ -1532,13 +1596,28 @@ __global__ void __launch_bounds__(64) k_dbg_solve(PtParams P, double k, double t
   if (ri >= 0) x[ri] = ok ? xl : nan("");
 }
 
+};  // struct PT<GAUGE>
+
+template <int GAUGE, int CURV>
+__global__ void __launch_bounds__(64) k_perturb(PtParams P) { PT<GAUGE, CURV>::body_perturb(P); }
+template <int GAUGE, int CURV>
+__global__ void __launch_bounds__(64) k_dbg_lookup(PtParams P, const double* tau, int n, double* out) { PT<GAUGE, CURV>::body_dbg_lookup(P, tau, n, out); }
+template <int GAUGE, int CURV>
+__global__ void __launch_bounds__(64) k_dbg_derivs(PtParams P, double k, double tau, int tca, int rsa, int ufa, const double* y, double* dy, int* neq) {
+  PT<GAUGE, CURV>::body_dbg_derivs(P, k, tau, tca, rsa, ufa, y, dy, neq);
+}
+template <int GAUGE, int CURV>
+__global__ void __launch_bounds__(64) k_dbg_solve(PtParams P, double k, double tau, int tca, int rsa, int ufa, double hg, const double* b, double* x) {
+  PT<GAUGE, CURV>::body_dbg_solve(P, k, tau, tca, rsa, ufa, hg, b, x);
+}
+
 void fill_params(const cpt_handle* h, PtParams& P) {
   const cpt_config& c = h->cfg;
   P.tabs = h->tabs;
   P.has_cdm = c.has_cdm; P.has_ur = c.has_ur; P.tca_method = c.tight_coupling_approximation;
   P.rsa_method = c.radiation_streaming_approximation; P.ufa_method = c.ur_fluid_approximation;
   P.l_max_g = c.l_max_g; P.l_max_pol_g = c.l_max_pol_g; P.l_max_ur = c.l_max_ur;
-  P.K = c.K; P.ic = c.ic; P.entropy_ini = c.entropy_ini; P.T_cmb = c.T_cmb; P.a_today = c.a_today; P.YHe = c.YHe; P.n_e = c.n_e; P.tau_free_streaming = c.tau_free_streaming;
+  P.K = c.K; P.gauge = c.gauge; P.ic = c.ic; P.entropy_ini = c.entropy_ini; P.T_cmb = c.T_cmb; P.a_today = c.a_today; P.YHe = c.YHe; P.n_e = c.n_e; P.tau_free_streaming = c.tau_free_streaming;
   P.switch_sw = c.switch_sw; P.switch_eisw = c.switch_eisw; P.switch_lisw = c.switch_lisw; P.switch_dop = c.switch_dop;
   P.switch_pol = c.switch_pol; P.eisw_lisw_split_z = c.eisw_lisw_split_z;
   P.three_ceff2_ur = c.three_ceff2_ur; P.three_cvis2_ur = c.three_cvis2_ur;
@@ -1552,6 +1631,16 @@ void fill_params(const cpt_handle* h, PtParams& P) {
   P.max_steps = 400000;
   P.k = nullptr; P.tau_s = nullptr; P.order = nullptr; P.nk = 0; P.ntau = 0; P.src = nullptr; P.stats = nullptr; P.status = nullptr;
 }
+
+// the four instantiations (gauge x curvature) behind one launch expression
+#define CPT_PT_DISPATCH(cfg, KERNEL, ...)                                                                         \
+  do {                                                                                                            \
+    const bool newt__ = (cfg).gauge == CPT_GAUGE_NEWTONIAN, curv__ = (cfg).K != 0.;                               \
+    if (newt__ && curv__) hipLaunchKernelGGL((KERNEL<CPT_GAUGE_NEWTONIAN, 1>), __VA_ARGS__);                      \
+    else if (newt__) hipLaunchKernelGGL((KERNEL<CPT_GAUGE_NEWTONIAN, 0>), __VA_ARGS__);                           \
+    else if (curv__) hipLaunchKernelGGL((KERNEL<CPT_GAUGE_SYNCHRONOUS, 1>), __VA_ARGS__);                         \
+    else hipLaunchKernelGGL((KERNEL<CPT_GAUGE_SYNCHRONOUS, 0>), __VA_ARGS__);                                     \
+  } while (0)
 
 }  // namespace
 
@@ -1590,7 +1679,7 @@ int cpt_perturb_impl(cpt_handle* h, const double* k, int nk, const double* tau, 
   CPT_HIP(h, hipMemsetAsync(h->d_src, 0, nsrc * sizeof(double), h->stream));  // pm.cpp:2767-2771 zero tail
   P.k = d_k; P.tau_s = d_tau; P.order = d_order; P.nk = nk; P.ntau = ntau; P.src = h->d_src; P.stats = d_stats; P.status = d_status;
   CPT_HIP(h, hipEventRecord(h->t_perturb.a, h->stream));
-  hipLaunchKernelGGL(k_perturb, dim3(nk), dim3(64), 0, h->stream, P);
+  CPT_PT_DISPATCH(c, k_perturb, dim3(nk), dim3(64), 0, h->stream, P);
   CPT_HIP(h, hipGetLastError());
   CPT_HIP(h, hipEventRecord(h->t_perturb.b, h->stream));
   h->src_nk = nk; h->src_ntau = ntau;
@@ -1642,7 +1731,7 @@ int cpt_dbg_lookup_impl(cpt_handle* h, const double* tau, int n, double* out) {
   CPT_HIP(h, hipMalloc((void**)&d_tau, n * sizeof(double)));
   CPT_HIP(h, hipMalloc((void**)&d_out, (size_t)n * 16 * sizeof(double)));
   CPT_HIP(h, hipMemcpy(d_tau, tau, n * sizeof(double), hipMemcpyHostToDevice));
-  hipLaunchKernelGGL(k_dbg_lookup, dim3(1), dim3(64), 0, h->stream, P, d_tau, n, d_out);
+  CPT_PT_DISPATCH(h->cfg, k_dbg_lookup, dim3(1), dim3(64), 0, h->stream, P, d_tau, n, d_out);
   CPT_HIP(h, hipGetLastError());
   CPT_HIP(h, hipStreamSynchronize(h->stream));
   CPT_HIP(h, hipMemcpy(out, d_out, (size_t)n * 16 * sizeof(double), hipMemcpyDeviceToHost));
@@ -1663,8 +1752,8 @@ int cpt_dbg_derivs_impl(cpt_handle* h, double k, double tau, int tca_on, int rsa
   CPT_HIP(h, hipMalloc((void**)&d_neq, sizeof(int)));
   CPT_HIP(h, hipMemset(d_dy, 0, 64 * sizeof(double)));
   CPT_HIP(h, hipMemcpy(d_y, y, 64 * sizeof(double), hipMemcpyHostToDevice));
-  hipLaunchKernelGGL(k_dbg_derivs, dim3(1), dim3(64), 0, h->stream, P, k, tau, tca_on ? 1 : 0, rsa_on ? 1 : 0, ufa_on ? 1 : 0, d_y,
-                     d_dy, d_neq);
+  CPT_PT_DISPATCH(h->cfg, k_dbg_derivs, dim3(1), dim3(64), 0, h->stream, P, k, tau, tca_on ? 1 : 0, rsa_on ? 1 : 0, ufa_on ? 1 : 0, d_y,
+                  d_dy, d_neq);
   CPT_HIP(h, hipGetLastError());
   CPT_HIP(h, hipStreamSynchronize(h->stream));
   CPT_HIP(h, hipMemcpy(dy, d_dy, 64 * sizeof(double), hipMemcpyDeviceToHost));
@@ -1685,8 +1774,8 @@ int cpt_dbg_solve_impl(cpt_handle* h, double k, double tau, int tca_on, int rsa_
   CPT_HIP(h, hipMalloc((void**)&d_x, 64 * sizeof(double)));
   CPT_HIP(h, hipMemset(d_x, 0, 64 * sizeof(double)));
   CPT_HIP(h, hipMemcpy(d_b, b, 64 * sizeof(double), hipMemcpyHostToDevice));
-  hipLaunchKernelGGL(k_dbg_solve, dim3(1), dim3(64), 0, h->stream, P, k, tau, tca_on ? 1 : 0, rsa_on ? 1 : 0, ufa_on ? 1 : 0, hg,
-                     d_b, d_x);
+  CPT_PT_DISPATCH(h->cfg, k_dbg_solve, dim3(1), dim3(64), 0, h->stream, P, k, tau, tca_on ? 1 : 0, rsa_on ? 1 : 0, ufa_on ? 1 : 0, hg,
+                  d_b, d_x);
   CPT_HIP(h, hipGetLastError());
   CPT_HIP(h, hipStreamSynchronize(h->stream));
   CPT_HIP(h, hipMemcpy(x, d_x, 64 * sizeof(double), hipMemcpyDeviceToHost));

@@ -92,7 +92,7 @@ def main():
                 out["tr.transfer_l_index"] = ls.astype(np.int32)
                 out["tr.transfer_at_q"] = np.ascontiguousarray(t[:, :, qs])
                 out["tr.transfer_at_l"] = np.ascontiguousarray(t[:, ls, :])
-        if cfg.startswith("iso_"):
+        if cfg.startswith("iso_") or cfg == "newt":
             # same cosmology as small/lcdm/explanatory: the tables must be the committed ones
             old = np.load(os.path.join(GOLD, "tables_lcdm.npz"))
             for k in tables:

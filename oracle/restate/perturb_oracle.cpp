@@ -85,8 +85,8 @@ void th_at_z(const Model& m, double z, const Bg& bg, Th& o) {
 struct Layout {
   int tca, rsa, ufa;  // 1 = approximation ON
   int neq;
-  int delta_g, theta_g, shear_g, l3_g, pol0_g, pol1_g, pol2_g, pol3_g, delta_b, theta_b, delta_cdm, delta_ur, theta_ur,
-      shear_ur, l3_ur, eta;
+  int delta_g, theta_g, shear_g, l3_g, pol0_g, pol1_g, pol2_g, pol3_g, delta_b, theta_b, delta_cdm, theta_cdm, delta_ur, theta_ur,
+      shear_ur, l3_ur, eta;  // eta: synchronous eta, or the Newtonian phi (same slot, pm.cpp:3470-3478)
   int l_max_g, l_max_pol_g, l_max_ur;
   std::vector<int> used_in_sources;
 };
@@ -96,7 +96,7 @@ Layout make_layout(const cpt_config& c, int tca, int rsa, int ufa) {
   L.tca = tca; L.rsa = rsa; L.ufa = ufa;
   L.delta_g = L.theta_g = L.shear_g = L.l3_g = L.pol0_g = L.pol1_g = L.pol2_g = L.pol3_g = -1;
   L.delta_ur = L.theta_ur = L.shear_ur = L.l3_ur = -1;
-  L.delta_cdm = -1;
+  L.delta_cdm = L.theta_cdm = -1;
   L.l_max_g = c.l_max_g; L.l_max_pol_g = c.l_max_pol_g; L.l_max_ur = c.l_max_ur;
   int i = 0;
   if (!rsa) {
@@ -107,7 +107,7 @@ Layout make_layout(const cpt_config& c, int tca, int rsa, int ufa) {
     }
   }
   L.delta_b = i++; L.theta_b = i++;
-  if (c.has_cdm) L.delta_cdm = i++;
+  if (c.has_cdm) { L.delta_cdm = i++; if (c.gauge == CPT_GAUGE_NEWTONIAN) L.theta_cdm = i++; }  // pm.cpp:3357-3360
   if (c.has_ur && !rsa) {
     L.delta_ur = i++; L.theta_ur = i++; L.shear_ur = i++;
     if (!ufa) { L.l3_ur = i; i += c.l_max_ur - 2; }
@@ -142,6 +142,7 @@ inline double cot_K_gen(const cpt_config& c, double k, double tau) {  // pm.cpp:
 struct Work {
   Bg bg; Th th;
   double h_prime, eta_prime, h_prime_prime, alpha, alpha_prime;
+  double psi, phi_prime;  // Newtonian gauge
   double delta_rho, rho_plus_p_theta, rho_plus_p_shear, delta_p, rho_plus_p_tot;
   double delta_m, theta_m;
   double rsa_delta_g, rsa_theta_g, rsa_delta_ur, rsa_theta_ur;
@@ -171,6 +172,21 @@ void approximations(const Model& m, double k, double tau, int* tca, int* rsa, in
 void rsa_delta_and_theta(const Model& m, double k, const double* y, const Layout& L, double a_prime_over_a, Work& w) {
   const cpt_config& c = *m.c;
   double k2 = k * k;
+  if (c.gauge == CPT_GAUGE_NEWTONIAN) {  // pm.cpp:9549-9592
+    const bool null = c.radiation_streaming_approximation == CPT_RSA_NULL;
+    w.rsa_delta_g = null ? 0. : -4. * y[L.eta];
+    w.rsa_theta_g = null ? 0. : 6. * w.phi_prime;
+    if (c.radiation_streaming_approximation == CPT_RSA_MD_WITH_REIO) {
+      w.rsa_delta_g += -4. / k2 * w.th.dkappa * y[L.theta_b];
+      w.rsa_theta_g += 3. / k2 * (w.th.ddkappa * y[L.theta_b] +
+                                  w.th.dkappa * (-a_prime_over_a * y[L.theta_b] + w.th.cb2 * k2 * y[L.delta_b] + k2 * y[L.eta]));
+    }
+    if (c.has_ur) { w.rsa_delta_ur = null ? 0. : -4. * y[L.eta]; w.rsa_theta_ur = null ? 0. : 6. * w.phi_prime; }
+    w.delta_rho += w.bg.rho_g * w.rsa_delta_g;
+    w.rho_plus_p_theta += 4. / 3. * w.bg.rho_g * w.rsa_theta_g;
+    if (c.has_ur) { w.delta_rho += w.bg.rho_ur * w.rsa_delta_ur; w.rho_plus_p_theta += 4. / 3. * w.bg.rho_ur * w.rsa_theta_ur; }
+    return;
+  }
   if (c.radiation_streaming_approximation == CPT_RSA_NULL) { w.rsa_delta_g = 0.; w.rsa_theta_g = 0.; }
   else {
     w.rsa_delta_g = 4. / k2 * (a_prime_over_a * w.h_prime - k2 * y[L.eta]);
@@ -205,7 +221,10 @@ void einstein(const Model& m, double k, const double* y, const Layout& L, Work& 
   double delta_g = 0, theta_g = 0, shear_g = 0, delta_ur = 0, theta_ur = 0, shear_ur = 0;
   if (!L.tca) {
     if (!L.rsa) { delta_g = y[L.delta_g]; theta_g = y[L.theta_g]; shear_g = y[L.shear_g]; }
-  } else { delta_g = y[L.delta_g]; theta_g = y[L.theta_g]; shear_g = 0.; }
+  } else {
+    delta_g = y[L.delta_g]; theta_g = y[L.theta_g];
+    shear_g = (c.gauge == CPT_GAUGE_NEWTONIAN) ? 16. / 45. / w.th.dkappa * y[L.theta_g] : 0.;  // pm.cpp:6134-6147
+  }
   if (c.has_ur && !L.rsa) { delta_ur = y[L.delta_ur]; theta_ur = y[L.theta_ur]; shear_ur = y[L.shear_ur]; }
   double delta_p_b_over_rho_b = w.th.cb2 * y[L.delta_b];
   w.delta_rho = bg.rho_g * delta_g + bg.rho_b * y[L.delta_b];
@@ -220,6 +239,10 @@ void einstein(const Model& m, double k, const double* y, const Layout& L, Work& 
     w.rho_plus_p_tot += bg.rho_cdm;
     delta_rho_m += bg.rho_cdm * y[L.delta_cdm]; rho_m += bg.rho_cdm;
     rho_plus_p_m += bg.rho_cdm;
+    if (c.gauge == CPT_GAUGE_NEWTONIAN) {  // pm.cpp:6231-6243
+      w.rho_plus_p_theta += bg.rho_cdm * y[L.theta_cdm];
+      rho_plus_p_theta_m += bg.rho_cdm * y[L.theta_cdm];
+    }
   }
   if (c.has_ur) {
     w.delta_rho += bg.rho_ur * delta_ur;
@@ -230,6 +253,14 @@ void einstein(const Model& m, double k, const double* y, const Layout& L, Work& 
   }
   w.delta_m = delta_rho_m / rho_m;
   w.theta_m = rho_plus_p_theta_m / rho_plus_p_m;
+  if (c.gauge == CPT_GAUGE_NEWTONIAN) {  // pm.cpp:5869-5897
+    w.psi = y[L.eta] - 4.5 * (a2 / k2) * w.rho_plus_p_shear;
+    w.phi_prime = -a_prime_over_a * w.psi + 1.5 * (a2 / k2) * w.rho_plus_p_theta;
+    if (L.rsa) rsa_delta_and_theta(m, k, y, L, a_prime_over_a, w);
+    w.h_prime = w.eta_prime = w.h_prime_prime = w.alpha = w.alpha_prime = 0.;
+    w.delta_m += 3. * bg.a * bg.H * w.theta_m / k2;   // pm.cpp:5979-5981
+    return;
+  }
   // Einstein equations, synchronous gauge: pm.cpp:5906-5971
   const double s2_squared = 1. - 3. * c.K / k2;
   w.h_prime = (k2 * s2_squared * y[L.eta] + 1.5 * a2 * w.delta_rho) / (0.5 * a_prime_over_a);
@@ -260,6 +291,7 @@ void tca_slip_and_shear(const Model& m, double k, const double* y, const Layout&
   double F = tau_c / (1 + R);
   double F_prime = dtau_c / (1 + R) + tau_c * a_prime_over_a * R / (1 + R) / (1 + R);
   double metric_continuity = w.h_prime / 2., metric_euler = 0., metric_shear = k2 * w.alpha, metric_shear_prime = k2 * w.alpha_prime;
+  if (c.gauge == CPT_GAUGE_NEWTONIAN) { metric_continuity = -3. * w.phi_prime; metric_euler = k2 * w.psi; metric_shear = 0.; metric_shear_prime = 0.; }
   double slip = (dtau_c / tau_c - 2. * a_prime_over_a / (1. + R)) * (theta_b - theta_g) +
                 F * (-a_primeprime_over_a * theta_b +
                      k2 * (-a_prime_over_a * delta_g / 2. + cb2 * (-theta_b - metric_continuity) -
@@ -295,6 +327,9 @@ void derivs(const Model& m, double k, double tau, const double* y, double* dy, c
   double delta_b = y[L.delta_b], theta_b = y[L.theta_b];
   double cb2 = th.cb2, delta_p_b_over_rho_b = cb2 * delta_b;
   double metric_continuity = w.h_prime / 2., metric_euler = 0., metric_shear = k2 * w.alpha, metric_ufa_class = w.h_prime / 2.;
+  if (c.gauge == CPT_GAUGE_NEWTONIAN) {  // pm.cpp:8067-8074
+    metric_continuity = -3. * w.phi_prime; metric_euler = k2 * w.psi; metric_shear = 0.; metric_ufa_class = -6. * w.phi_prime;
+  }
   if (L.rsa) { delta_g = w.rsa_delta_g; theta_g = w.rsa_theta_g; }
   if (!L.rsa) dy[L.delta_g] = -4. / 3. * (theta_g + metric_continuity);
   dy[L.delta_b] = -(theta_b + metric_continuity);
@@ -327,7 +362,12 @@ void derivs(const Model& m, double k, double tau, const double* y, double* dy, c
       dy[L.theta_g] = -(dy[L.theta_b] + a_prime_over_a * theta_b - k2 * delta_p_b_over_rho_b) / R + k2 * (0.25 * delta_g - s2_squared * w.tca_shear_g) + (1. + R) / R * metric_euler;
     }
   }
-  if (c.has_cdm) dy[L.delta_cdm] = -metric_continuity;
+  if (c.has_cdm) {  // pm.cpp:8228-8243
+    if (c.gauge == CPT_GAUGE_NEWTONIAN) {
+      dy[L.delta_cdm] = -(y[L.theta_cdm] + metric_continuity);
+      dy[L.theta_cdm] = -a_prime_over_a * y[L.theta_cdm] + metric_euler;
+    } else dy[L.delta_cdm] = -metric_continuity;
+  }
   if (c.has_ur && !L.rsa) {
     dy[L.delta_ur] = -4. / 3. * (y[L.theta_ur] + metric_continuity) +
                      (1. - c.three_ceff2_ur) * a_prime_over_a * (y[L.delta_ur] + 4. * a_prime_over_a * y[L.theta_ur] / k / k);
@@ -347,7 +387,7 @@ void derivs(const Model& m, double k, double tau, const double* y, double* dy, c
       if (c.ur_fluid_approximation == CPT_UFA_CLASS) dy[L.shear_ur] = -3. / tau * y[L.shear_ur] + 2. / 3. * (y[L.theta_ur] + metric_ufa_class);
     }
   }
-  dy[L.eta] = w.eta_prime;
+  dy[L.eta] = (c.gauge == CPT_GAUGE_NEWTONIAN) ? w.phi_prime : w.eta_prime;   // pm.cpp:8892-8902
 }
 
 // perturb_sources, pm.cpp:6731-7285 (scalar types t0,t1,t2,p,delta_m,phi+psi in synchronous gauge)
@@ -369,6 +409,18 @@ void sources(const Model& m, double k, double tau, const double* y, const double
   int switch_isw = 1;
   if ((c.switch_eisw == 0) && (z >= c.eisw_lisw_split_z)) switch_isw = 0;
   if ((c.switch_lisw == 0) && (z < c.eisw_lisw_split_z)) switch_isw = 0;
+  if (c.gauge == CPT_GAUGE_NEWTONIAN) {  // pm.cpp:6849-6860, 6955-6957
+    if (c.index_tp_t0 >= 0)
+      out[c.index_tp_t0] = c.switch_sw * th.g * (delta_g / 4. + w.psi) +
+                           switch_isw * (th.g * (y[L.eta] - w.psi) + th.expmk * 2. * w.phi_prime) +
+                           c.switch_dop / k / k * (th.g * dy[L.theta_b] + th.dg * y[L.theta_b]);
+    if (c.index_tp_t1 >= 0) out[c.index_tp_t1] = switch_isw * th.expmk * k * (w.psi - y[L.eta]);
+    if (c.index_tp_t2 >= 0) out[c.index_tp_t2] = c.switch_pol * th.g * P;
+    if (c.index_tp_p >= 0) out[c.index_tp_p] = std::sqrt(6.) * th.g * P;
+    if (c.index_tp_phi_plus_psi >= 0) out[c.index_tp_phi_plus_psi] = y[L.eta] + w.psi;
+    if (c.index_tp_delta_m >= 0) out[c.index_tp_delta_m] = w.delta_m;
+    return;
+  }
   if (c.index_tp_t0 >= 0)
     out[c.index_tp_t0] = c.switch_sw * th.g * (delta_g / 4. + w.alpha_prime) +
                          switch_isw * (th.g * (y[L.eta] - w.alpha_prime - 2 * a_prime_over_a * w.alpha) +
@@ -797,7 +849,7 @@ void initial_conditions(const Model& m, double k, double tau, const Layout& L, d
   }
   y[L.eta] = c.curvature_ini * (1. - ktau_two / 12. / (15. + 4. * fracnu) *
                                          (5. + 4. * s2_squared * fracnu - (16. * fracnu * fracnu + 280. * fracnu + 325) / 10. / (2. * fracnu + 15.) * tau * om));
-  if (c.ic == CPT_IC_AD) return;
+  if (c.ic != CPT_IC_AD) {
   // ---- isocurvature modes, pm.cpp:4956-5083 (l3_ur stays 0) ----
   const double ei = c.entropy_ini, fracg = bg.rho_g / rho_r, fraccdm = 1. - fracb;
   double delta_ur = 0., theta_ur = 0., shear_ur = 0., eta = 0.;
@@ -835,6 +887,21 @@ void initial_conditions(const Model& m, double k, double tau, const Layout& L, d
   }
   if (c.has_ur) { y[L.delta_ur] = delta_ur; y[L.theta_ur] = theta_ur; y[L.shear_ur] = shear_ur; y[L.l3_ur] = 0.; }
   y[L.eta] = eta;
+  }
+  if (c.gauge == CPT_GAUGE_NEWTONIAN) {  // gauge transformation of the synchronous series, pm.cpp:5095-5198
+    const double a_prime_over_a = bg.a * bg.H, fracg = bg.rho_g / rho_r, fraccdm = 1. - fracb, rho_m_over_rho_r = rho_m / rho_r;
+    const double eta = y[L.eta];
+    const double delta_cdm = c.has_cdm ? y[L.delta_cdm] : 0.;
+    const double delta_ur = c.has_ur ? y[L.delta_ur] : 0., theta_ur = c.has_ur ? y[L.theta_ur] : 0.;
+    const double delta_tot = (fracg * y[L.delta_g] + fracnu * delta_ur + rho_m_over_rho_r * (fracb * y[L.delta_b] + fraccdm * delta_cdm)) / (1. + rho_m_over_rho_r);
+    const double velocity_tot = ((4. / 3.) * (fracg * y[L.theta_g] + fracnu * theta_ur) + rho_m_over_rho_r * fracb * y[L.theta_b]) / (1. + rho_m_over_rho_r);
+    const double alpha = (eta + 3. / 2. * a_prime_over_a * a_prime_over_a / k / k / s2_squared * (delta_tot + 3. * a_prime_over_a / k / k * velocity_tot)) / a_prime_over_a;
+    y[L.eta] = eta - a_prime_over_a * alpha;   // phi
+    y[L.delta_g] -= 4. * a_prime_over_a * alpha; y[L.theta_g] += k * k * alpha;
+    y[L.delta_b] -= 3. * a_prime_over_a * alpha; y[L.theta_b] += k * k * alpha;
+    if (c.has_cdm) { y[L.delta_cdm] -= 3. * a_prime_over_a * alpha; y[L.theta_cdm] = k * k * alpha; }
+    if (c.has_ur) { y[L.delta_ur] -= 4. * a_prime_over_a * alpha; y[L.theta_ur] += k * k * alpha; }
+  }
 }
 
 // hand-over between regimes: pm.cpp:3777-4260
@@ -842,7 +909,7 @@ void handover(const Model& m, double k, const Layout& Lo, const double* yo, cons
   const cpt_config& c = *m.c;
   for (int i = 0; i < Ln.neq; i++) yn[i] = 0.;
   yn[Ln.delta_b] = yo[Lo.delta_b]; yn[Ln.theta_b] = yo[Lo.theta_b];
-  if (c.has_cdm) yn[Ln.delta_cdm] = yo[Lo.delta_cdm];
+  if (c.has_cdm) { yn[Ln.delta_cdm] = yo[Lo.delta_cdm]; if (Ln.theta_cdm >= 0) yn[Ln.theta_cdm] = yo[Lo.theta_cdm]; }
   yn[Ln.eta] = yo[Lo.eta];
   if (Lo.tca && !Ln.tca) {  // pm.cpp:3880-3935
     yn[Ln.delta_g] = yo[Lo.delta_g]; yn[Ln.theta_g] = yo[Lo.theta_g];

@@ -88,7 +88,7 @@ def test_perturb_small_all_modes(small):
     print("\n[small] perturb kernel %.3f ms for %d modes, %d steps" % (ms, inp.nk, gs))
 
 
-@pytest.mark.parametrize("cfg", ["lcdm", "explanatory", "iso_cdi", "iso_nid"])
+@pytest.mark.parametrize("cfg", ["lcdm", "explanatory", "iso_cdi", "iso_nid", "newt"])
 def test_perturb_full_size(cfg):
     """BASELINE configs 1-2: every k-mode integrated on the GPU; the 16 golden columns are compared with the reference."""
     from classpp_public_amd.backend import Backend
@@ -168,3 +168,47 @@ def test_curved_transfer_is_refused_loudly(curved):
     inp, be = curved
     with pytest.raises(CptInputError, match="hyperspherical"):
         be.transfer(None)
+
+
+# ---- Newtonian gauge (pm.cpp:5869-5897, 8049-8074, 8228-8243, 9549-9592, 6849-6860, 5095-5198): phi dynamic in the eta lane,
+# theta_cdm in its own core lane, metric_euler = k^2 psi in every Euler equation
+@pytest.fixture(scope="module")
+def newt():
+    from classpp_public_amd.backend import Backend
+    inp = Inputs("newt")
+    assert inp.config.gauge == 0
+    be = Backend(inp)
+    yield inp, be
+    be.close()
+
+
+@pytest.mark.parametrize("flags", [(1, 0, 0), (0, 0, 0), (0, 0, 1), (0, 1, 1), (1, 0, 1)])
+def test_newtonian_derivs_match_oracle(newt, flags):
+    inp, be = newt
+    rng = np.random.default_rng(4)
+    for k, tau in [(1e-4, 50.0), (0.03, 150.0), (0.03, 290.0), (0.2, 3000.0), (0.5, 13000.0)]:
+        y = rng.normal(size=64)
+        want = oracle_lib.derivs(inp, k, tau, *flags, y)
+        got = be.dbg_derivs(k, tau, *flags, y[: want.size])
+        assert got.size == want.size
+        scale = np.max(np.abs(want))
+        assert np.max(np.abs(got - want)) < 1e-11 * scale, (k, tau, np.max(np.abs(got - want)) / scale)
+
+
+@pytest.mark.parametrize("flags", [(1, 0, 0), (0, 0, 0), (0, 1, 1)])
+def test_newtonian_structured_solve_matches_dense(newt, flags):
+    inp, be = newt
+    rng = np.random.default_rng(5)
+    for k, tau, hg in [(0.03, 150.0, 0.4), (0.2, 3000.0, 1.0), (1e-3, 5000.0, 500.0)]:
+        n = oracle_lib.derivs(inp, k, tau, *flags, np.zeros(64)).size
+        J = np.zeros((n, n))
+        for j in range(n):
+            e = np.zeros(64)
+            e[j] = 1.0
+            J[:, j] = oracle_lib.derivs(inp, k, tau, *flags, e)
+        A = np.eye(n) - hg * J
+        b = rng.normal(size=n)
+        want = np.linalg.solve(A, b)
+        got = be.dbg_solve(k, tau, *flags, hg, b)
+        assert np.all(np.abs(A @ got - b) <= 1e-11 * (np.abs(A) @ np.abs(got) + np.abs(b)))
+        assert np.max(np.abs(got - want)) < 1e-8 * np.max(np.abs(want)), (k, tau, hg)

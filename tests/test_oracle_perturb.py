@@ -44,7 +44,7 @@ def test_perturb_small_all_modes():
     assert all(s.steps > 50 and s.fevals > s.steps for s in stats)
 
 
-@pytest.mark.parametrize("cfg", ["lcdm", "explanatory", "curved", "iso_cdi", "iso_nid"])
+@pytest.mark.parametrize("cfg", ["lcdm", "explanatory", "curved", "iso_cdi", "iso_nid", "newt"])
 def test_perturb_full_size_subset(cfg):
     inp = Inputs(cfg)
     ks = inp.d["pt.sources_k_index"]
