@@ -44,6 +44,8 @@ class CptConfig(C.Structure):
         ("transfer_neglect_delta_k_S_t2", _d), ("transfer_neglect_delta_k_S_e", _d),
         ("transfer_neglect_late_source", _d), ("l_switch_limber", _d),
         ("ic", _i), ("entropy_ini", _d),
+        ("mode", _i), ("l_max_g_ten", _i), ("l_max_pol_g_ten", _i), ("gw_ini", _d), ("evolve_tensor_ur", _i), ("index_tt_b", _i),
+        ("transfer_neglect_delta_k_T_t2", _d), ("transfer_neglect_delta_k_T_e", _d), ("transfer_neglect_delta_k_T_b", _d),
     ]
 
 

@@ -76,6 +76,17 @@ static int validate(const cpt_config* c) {
                     c->tight_coupling_approximation);
   if (c->l_max_g < 4 || c->l_max_pol_g < 4 || (c->has_ur && c->l_max_ur < 4))
     return cpt_fail(nullptr, CPT_ERR_INVALID, "l_max_g, l_max_pol_g, l_max_ur must be at least 4 (pm.cpp:3302-3330)");
+  if (c->mode != CPT_MODE_SCALARS && c->mode != CPT_MODE_TENSORS) return cpt_fail(nullptr, CPT_ERR_INVALID, "mode=%d is neither scalars (0) nor tensors (1)", c->mode);
+  if (c->mode == CPT_MODE_TENSORS) {
+    if (c->l_max_g_ten < 4 || c->l_max_pol_g_ten < 4)
+      return cpt_fail(nullptr, CPT_ERR_INVALID, "ppr->l_max_g_ten / l_max_pol_g_ten should be at least 4 (pm.cpp:3521-3527)");
+    if (c->evolve_tensor_ur && !c->has_ur) return cpt_fail(nullptr, CPT_ERR_INVALID, "evolve_tensor_ur without ur species");
+    // lane map of the tensor kernel: 17 core lanes + the three l >= 5 tails
+    if (17 + (c->l_max_g_ten - 4) + (c->l_max_pol_g_ten - 4) + (c->evolve_tensor_ur ? c->l_max_ur - 4 : 0) > CPT_WAVE)
+      return cpt_fail(nullptr, CPT_ERR_UNSUPPORTED, "tensor hierarchy too large: one wavefront (64 lanes) owns one k-mode");
+    if (c->index_tp_t0 >= 0 || c->index_tp_t1 >= 0 || c->index_tp_delta_m >= 0 || c->index_tp_phi_plus_psi >= 0)
+      return cpt_fail(nullptr, CPT_ERR_INVALID, "tensor modes have the source types t2 and p only (pm.cpp:7243-7280)");
+  }
   // lane map of cpt_perturb.hip: 14 core lanes + the three l >= 3 tails
   if (14 + (c->l_max_g - 2) + (c->l_max_pol_g - 2) + (c->has_ur ? c->l_max_ur - 2 : 0) > CPT_WAVE)
     return cpt_fail(nullptr, CPT_ERR_UNSUPPORTED,

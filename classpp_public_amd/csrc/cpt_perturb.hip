@@ -32,6 +32,7 @@ struct PtParams {
   double T_cmb, a_today, YHe, n_e, tau_free_streaming;
   double K;  // spatial curvature (pba->K); 0 in flat space
   int gauge;                   // CPT_GAUGE_NEWTONIAN / CPT_GAUGE_SYNCHRONOUS
+  int l_max_g_ten, l_max_pol_g_ten, evolve_tensor_ur; double gw_ini;  // tensor modes
   int ic; double entropy_ini;  // initial condition of the mode (CPT_IC_*), isocurvature normalisation
   int switch_sw, switch_eisw, switch_lisw, switch_dop, switch_pol;
   double eisw_lisw_split_z, three_ceff2_ur, three_cvis2_ur;
@@ -142,7 +143,7 @@ __device__ inline double ndf_erconst(int i) { return ndf_alpha(i) * ndf_G(i) + 1
 
 enum Role : int {
   R_NONE = 0, R_DELTA_G, R_THETA_G, R_SHEAR_G, R_LG /* l>=3 photon temperature */, R_POL /* l>=0 polarisation */,
-  R_DELTA_B, R_THETA_B, R_DELTA_CDM, R_DELTA_UR, R_THETA_UR, R_SHEAR_UR, R_LUR /* l>=3 ur */, R_ETA, R_THETA_CDM
+  R_DELTA_B, R_THETA_B, R_DELTA_CDM, R_DELTA_UR, R_THETA_UR, R_SHEAR_UR, R_LUR /* l>=3 ur */, R_ETA, R_THETA_CDM, R_GW, R_GWDOT
 };
 
 #ifdef CPT_PROFILE
@@ -162,7 +163,7 @@ __device__ unsigned long long g_prof[16];
 // instantiations cost code size only.  The same holds for non-flat space (CURV): the s_l factors, k cotK(tau) and the
 // separate 1/tau coefficient cost the flat kernel 35 % when they were run-time values; in the flat instantiation they fold
 // to 1, 1/tau and nothing.
-template <int GAUGE, int CURV>
+template <int GAUGE, int CURV, int MODE>
 struct PT {
 // Lane map.  One lane per equation of pm.cpp:3302-3481, at a FIXED lane whatever the approximation scheme: the (at most
 // 13) densely coupled variables - densities, velocities, shears, polarisation l<=2, metric - are the CORE in lanes
@@ -174,7 +175,12 @@ struct PT {
 // structure, fixed per regime and shared by all modes, is what the linear algebra below exploits.
 // LN_ETA holds eta (synchronous gauge) or phi (Newtonian gauge, pm.cpp:3470-3478); LN_TC = theta_cdm exists in the Newtonian gauge only
 enum Lane : int { LN_DG = 0, LN_TG, LN_SG, LN_P0, LN_P1, LN_P2, LN_DB, LN_TB, LN_DC, LN_DUR, LN_TUR, LN_SUR, LN_ETA, LN_TC };
-static constexpr int NC = (GAUGE == CPT_GAUGE_NEWTONIAN) ? 14 : 13;
+static constexpr int NC = MODE ? 17 : ((GAUGE == CPT_GAUGE_NEWTONIAN) ? 14 : 13);
+// Tensor modes (MODE = 1; pm.cpp:3519-3586): the same three ladders plus the gravitational wave (gw, gw').  The photon
+// source P^(2) reads the l = 4 multipoles of temperature and polarisation and the gravitational-wave source reads the
+// l = 4 multipoles of photons and ur, so the core holds every ladder up to l = 4 and the tails start at l = 5.
+enum TLane : int { TL_DG = 0, TL_TG, TL_SG, TL_G3, TL_G4, TL_P0, TL_P1, TL_P2, TL_P3, TL_P4, TL_DUR, TL_TUR, TL_SUR, TL_U3, TL_U4, TL_GW, TL_GWD };
+static constexpr int LFIRST = MODE ? 5 : 3;   // multipole of the first element of a tail
 
 struct Layout {
   int tca, rsa, ufa;
@@ -186,6 +192,17 @@ struct Layout {
 static __device__ __forceinline__ Layout make_layout(const PtParams& P, int tca, int rsa, int ufa) {
   Layout L;
   L.tca = tca; L.rsa = rsa; L.ufa = ufa;
+  if (MODE) {  // tensors: photons are evolved when neither approximation is on; ur always (pm.cpp:3529-3560)
+    L.ufa = 0;
+    L.lmg = P.l_max_g_ten; L.lmp = P.l_max_pol_g_ten; L.lmu = P.l_max_ur;
+    const bool hi = !rsa && !tca;
+    L.g3 = NC; L.q3 = L.g3 + (L.lmg - 4); L.u3 = L.q3 + (L.lmp - 4);
+    L.gN = hi ? L.lmg - 4 : 0;
+    L.qN = hi ? L.lmp - 4 : 0;
+    L.uN = P.evolve_tensor_ur ? L.lmu - 4 : 0;
+    L.maxlen = max(L.gN, max(L.qN, L.uN));
+    return L;
+  }
   L.lmg = P.l_max_g; L.lmp = P.l_max_pol_g; L.lmu = P.l_max_ur;
   L.g3 = NC; L.q3 = L.g3 + (P.l_max_g - 2); L.u3 = L.q3 + (P.l_max_pol_g - 2);
   const bool hi = !rsa && !tca;
@@ -198,6 +215,7 @@ static __device__ __forceinline__ Layout make_layout(const PtParams& P, int tca,
 
 // is core variable `i` evolved in this scheme?  (i wave-uniform)
 static __device__ __forceinline__ bool core_present(const PtParams& P, const Layout& L, int i) {
+  if (MODE) return (i <= TL_P4) ? (!L.rsa && !L.tca) : (i <= TL_U4) ? (P.evolve_tensor_ur != 0) : true;
   switch (i) {
     case LN_DG: case LN_TG: return !L.rsa;
     case LN_SG: case LN_P0: case LN_P1: case LN_P2: return !L.rsa && !L.tca;
@@ -211,6 +229,19 @@ static __device__ __forceinline__ bool core_present(const PtParams& P, const Lay
 // (role, multipole) of lane i in the current scheme; R_NONE = not evolved
 static __device__ __forceinline__ void role_of(const PtParams& P, const Layout& L, int i, int* role, int* ell) {
   *role = R_NONE; *ell = 0;
+  if (MODE) {
+    const bool hi = !L.rsa && !L.tca, ur = P.evolve_tensor_ur != 0;
+    if (i < 0) return;
+    if (i <= TL_G4) { if (hi) { *role = (i == TL_DG) ? R_DELTA_G : (i == TL_TG) ? R_THETA_G : (i == TL_SG) ? R_SHEAR_G : R_LG; *ell = i; } return; }
+    if (i <= TL_P4) { if (hi) { *role = R_POL; *ell = i - TL_P0; } return; }
+    if (i <= TL_U4) { if (ur) { const int l = i - TL_DUR; *role = (l == 0) ? R_DELTA_UR : (l == 1) ? R_THETA_UR : (l == 2) ? R_SHEAR_UR : R_LUR; *ell = l; } return; }
+    if (i == TL_GW) { *role = R_GW; return; }
+    if (i == TL_GWD) { *role = R_GWDOT; return; }
+    if (i >= L.g3 && i < L.g3 + L.gN) { *role = R_LG; *ell = 5 + (i - L.g3); return; }
+    if (i >= L.q3 && i < L.q3 + L.qN) { *role = R_POL; *ell = 5 + (i - L.q3); return; }
+    if (i >= L.u3 && i < L.u3 + L.uN) { *role = R_LUR; *ell = 5 + (i - L.u3); return; }
+    return;
+  }
   const bool g = !L.rsa, hi = !L.rsa && !L.tca, ur = P.has_ur && !L.rsa;
   if (i == LN_DG) { if (g) *role = R_DELTA_G; return; }
   if (i == LN_TG) { if (g) { *role = R_THETA_G; *ell = 1; } return; }
@@ -233,6 +264,21 @@ static __device__ __forceinline__ void role_of(const PtParams& P, const Layout& 
 // index of (role, ell) in the REFERENCE's ordering of the same regime (pm.cpp:3302-3481): only the unit-test hooks
 // cpt_dbg_derivs / cpt_dbg_solve need it, to exchange vectors with the oracle in the reference's order
 static __device__ __forceinline__ int ref_index_of(const PtParams& P, int tca, int rsa, int ufa, int role, int ell, int* neq) {
+  if (MODE) {  // pm.cpp:3519-3586
+    int i = 0, dg = -1, pol0 = -1, dur = -1, gw;
+    if (!rsa && !tca) { dg = i; i += P.l_max_g_ten + 1; pol0 = i; i += P.l_max_pol_g_ten + 1; }
+    if (P.evolve_tensor_ur) { dur = i; i += P.l_max_ur + 1; }
+    gw = i; i += 2;
+    *neq = i;
+    switch (role) {
+      case R_DELTA_G: case R_THETA_G: case R_SHEAR_G: case R_LG: return dg >= 0 ? dg + ell : -1;
+      case R_POL: return pol0 >= 0 ? pol0 + ell : -1;
+      case R_DELTA_UR: case R_THETA_UR: case R_SHEAR_UR: case R_LUR: return dur >= 0 ? dur + ell : -1;
+      case R_GW: return gw;
+      case R_GWDOT: return gw + 1;
+      default: return -1;
+    }
+  }
   int i = 0, dg = -1, tg = -1, sg = -1, l3g = -1, pol0 = -1, db, tb, dc = -1, tc = -1, dur = -1, tur = -1, sur = -1, l3ur = -1, eta;
   if (!rsa) {
     dg = i++; tg = i++;
@@ -504,11 +550,39 @@ static __device__ __forceinline__ LaneEq make_lane_eq(const PtParams& P, const L
   auto S = [&](int ll) { return CURV ? sqrt(fmax(1.0 - P.K * (ll * ll - 1.0) / k2, 0.)) : 1.0; };
   const double s2 = S(2), s3 = S(3), s2sq = CURV ? 1. - 3. * P.K / k2 : 1.;
   int lm = 0, parent = lane;
+  if (MODE) {  // ---- tensor modes, pm.cpp:9045-9215: one generic ladder element per lane ----
+    const int role = e.role;
+    const bool photon = (role == R_DELTA_G || role == R_THETA_G || role == R_SHEAR_G || role == R_LG), pol = (role == R_POL),
+               ur = (role == R_DELTA_UR || role == R_THETA_UR || role == R_SHEAR_UR || role == R_LUR);
+    if (photon || pol || ur) {
+      lm = photon ? L.lmg : pol ? L.lmp : L.lmu;
+      const int base = photon ? TL_DG : pol ? TL_P0 : TL_DUR, tail0 = photon ? L.g3 : pol ? L.q3 : L.u3;
+      auto lane_of = [&](int ll) { return ll <= 4 ? base + ll : tail0 + (ll - 5); };
+      e.D = ur ? 0. : 1.;
+      if (l >= 1) dn = lane_of(l - 1);
+      if (l < lm) up = lane_of(l + 1);
+      if (l >= 5) { e.chain = photon ? 1 : pol ? 2 : 3; e.first = (l == 5); e.last = (l == lm); parent = lane_of(4); }
+      if (l == lm) { e.A = k * S(l); e.G = 1. + l; }
+      else if (l == 0) { e.B = pol ? k : 4. / 3.; }
+      else if (pol) { e.A = k * l * S(l) / (2. * l + 1.); e.B = k * (l + 1.) * S(l + 1) / (2. * l + 1.); }
+      else if (l == 1) { e.A = 0.25 * k2; e.B = k2 * (ur ? s2sq : s2); }                    // theta = (3k/4) F_1
+      else if (l == 2) { e.A = 4. / 15. * (ur ? 1. : s2); e.B = 0.3 * k * (ur ? s3 / s2 : s3); }   // shear = F_2/2
+      else if (l == 3) { e.A = 6. * k * s3 * (ur ? s2 : 1.) / 7.; e.B = 4. * k * S(4) / 7.; }
+      else { e.A = k * l * S(l) / (2. * l + 1.); e.B = k * (l + 1.) * S(l + 1) / (2. * l + 1.); }
+      if (l == 0) { e.Xmc = pol ? 0. : 1.; e.XP = photon ? -1. : pol ? 1. : 0.; }           // + sqrt6 gw' ;  -/+ kappa' sqrt6 P2
+    } else if (role == R_GW) { e.A = 1.; dn = TL_GWD; }
+    else if (role == R_GWDOT) e.Xtb = 1.;
+    e.dn = dn * 4; e.up = up * 4; e.parent_addr = parent * 4;
+    const bool is_parent = (lane < NC) && (up >= NC);
+    e.first_addr = (is_parent ? up : lane) * 4;
+    e.Bpar = is_parent ? e.B : 0.;
+    return e;
+  }
   if (e.role == R_LG) { e.chain = 1; lm = L.lmg; e.D = 1.; parent = LN_SG; }
   else if (e.role == R_POL && l >= 3) { e.chain = 2; lm = L.lmp; e.D = 1.; parent = LN_P2; }
   else if (e.role == R_LUR) { e.chain = 3; lm = L.lmu; parent = LN_SUR; }
   if (e.chain) {
-    e.first = (l == 3); e.last = (l == lm);
+    e.first = (l == LFIRST); e.last = (l == lm);
     dn = e.first ? parent : lane - 1;
     up = e.last ? lane : lane + 1;
     if (l == 3 && e.chain != 2) { e.A = 6. * k * s3 * s2 / 7.; e.B = 4. * k * S(4) / 7.; }   // pm.cpp:8158-8161: F_2 = 2 s_2 shear
@@ -575,12 +649,50 @@ static __device__ __forceinline__ double gather(double v, int addr) {
   return pin(__hiloint2double(hi, lo));
 }
 
+// tensor modes: gw_source (pm.cpp:6616-6660), the Einstein equation for gw'' (:6036-6040) and perturb_derivs :9045-9215
+static __device__ __forceinline__ double rhs_tensor(const PtParams& P, const Layout& L, const LaneEq& e, Lookup& Q, Metric& M, double k,
+                                                    double tau, double y, int lane) {
+  lookup(P, Q, tau, lane);
+  const double ym = gather(y, e.dn), yp = gather(y, e.up);
+  const double SQRT6 = 2.449489742783178;
+  // (lanes the scheme does not evolve read as 0)
+  const double dg = bcast(y, TL_DG), sg = bcast(y, TL_SG), g4 = bcast(y, TL_G4), p0 = bcast(y, TL_P0), p2 = bcast(y, TL_P2), p4 = bcast(y, TL_P4);
+  const double dur = bcast(y, TL_DUR), sur = bcast(y, TL_SUR), u4 = bcast(y, TL_U4), gw = bcast(y, TL_GW), gwd = bcast(y, TL_GWD);
+  const double P2 = -1.0 / SQRT6 * (0.1 * dg + 2. / 7. * sg + 3. / 70. * g4 - 0.6 * p0 + 6. / 7. * p2 - 3. / 70. * p4);
+  double gw_source = -SQRT6 * 4. * Q.a2 * Q.rg * (1. / 15. * dg + 4. / 21. * sg + 1. / 35. * g4);
+  if (P.evolve_tensor_ur) gw_source += -SQRT6 * 4. * Q.a2 * Q.ru * (1. / 15. * dur + 4. / 21. * sur + 1. / 35. * u4);
+  const double gwpp = -2. * Q.aH * gwd - (k * k + (CURV ? 2. * P.K : 0.)) * gw + gw_source;
+  double dy = e.A * ym - e.B * yp - (e.D * Q.kap + e.G * Q.kcot) * y;
+  dy = fma(e.XP, Q.kap * SQRT6 * P2, dy);
+  dy = fma(e.Xmc, SQRT6 * gwd, dy);
+  dy = fma(e.Xtb, gwpp, dy);
+  return dy;
+}
+
+// perturb_sources for tensor modes (pm.cpp:7243-7280)
+static __device__ __forceinline__ void store_sources_tensor(const PtParams& P, const Layout& L, const Lookup& Q, double y, int it, int ik, int lane) {
+  const double g = bcast(Q.vth, TH_G), expmk = bcast(Q.vth, TH_EXPMK), gwd = bcast(y, TL_GWD);
+  double Pi = 0.;
+  if (!L.rsa) {
+    if (!L.tca)
+      Pi = -(0.1 * bcast(y, TL_DG) + 2. / 7. * bcast(y, TL_SG) + 3. / 70. * bcast(y, TL_G4) - 0.6 * bcast(y, TL_P0) + 6. / 7. * bcast(y, TL_P2) -
+             3. / 70. * bcast(y, TL_P4)) / 2.449489742783178;
+    else Pi = 0.4 * 2.449489742783178 * gwd / Q.kap;
+  }
+  if (lane == 0) {
+    const size_t base = (size_t)ik * P.ntau + it, tstride = (size_t)P.nk * P.ntau;
+    if (P.tp_t2 >= 0) P.src[P.tp_t2 * tstride + base] = -gwd * expmk + g * Pi;
+    if (P.tp_p >= 0) P.src[P.tp_p * tstride + base] = 2.449489742783178 * g * Pi;
+  }
+}
+
 // perturb_derivs (pm.cpp:7861-9218) with perturb_total_stress_energy + perturb_einstein (pm.cpp:6047-6703, 5840-6045),
 // perturb_rsa_delta_and_theta (pm.cpp:9530-9636) and perturb_tca_slip_and_shear (pm.cpp:9229-9516) folded in;
 // synchronous gauge, K = 0.  y: this lane's component (named components are broadcast with v_readlane).
 // Returns dy of this lane and leaves M describing the state (tau, y).
 static __device__ __forceinline__ double rhs(const PtParams& P, const Layout& L, const LaneEq& e, Lookup& Q, Metric& M, double k,
                                       double inv_k2, double tau, double y, int lane) {
+  if (MODE) return rhs_tensor(P, L, e, Q, M, k, tau, y, lane);
 #ifdef CPT_PROFILE
   unsigned long long* prof = Q.prof;
   PROF_DECL;
@@ -709,6 +821,7 @@ static __device__ __forceinline__ double rhs(const PtParams& P, const Layout& L,
 // dy is the dense-output derivative (only theta_b' is used, pm.cpp:6883). Lane 0 stores the tp_size values.
 static __device__ __forceinline__ void store_sources(const PtParams& P, const Layout& L, const Lookup& Q, const Metric& M, double k,
                                               double inv_k2, double y, double dy, double tca_shear_prev, int it, int ik, int lane) {
+  if (MODE) { store_sources_tensor(P, L, Q, y, it, ik, lane); return; }
   struct { double g, dg, expmk; } th;
   th.g = bcast(Q.vth, TH_G); th.dg = bcast(Q.vth, TH_DG); th.expmk = bcast(Q.vth, TH_EXPMK);
   const double bg_a = bcast(Q.vbg, BG_A);
@@ -772,7 +885,7 @@ static __device__ __forceinline__ void approx_flags(const PtParams& P, double k,
     *tca = ((tau_c / tau_h < P.tca_trig_h) && (tau_c * k < P.tca_trig_k)) ? 1 : 0;
   }
   *rsa = ((tau * k > P.rsa_trig) && (tau > P.tau_free_streaming) && (P.rsa_method != CPT_RSA_NONE)) ? 1 : 0;
-  *ufa = (P.has_ur && (tau * k > P.ufa_trig) && (P.ufa_method != CPT_UFA_NONE)) ? 1 : 0;
+  *ufa = (!MODE && P.has_ur && (tau * k > P.ufa_trig) && (P.ufa_method != CPT_UFA_NONE)) ? 1 : 0;   // no ur fluid for tensors
 }
 
 // 64-ary search for the time at which a monotone predicate flips between lo (false) and hi (true):
@@ -1460,7 +1573,19 @@ static __device__ __forceinline__ void body_perturb(const PtParams& P) {
     int f_tca = fi0, f_rsa = fi1, f_ufa = fi2;
     Layout L = make_layout(P, f_tca, f_rsa, f_ufa);
     LaneEq e = make_lane_eq(P, L, lane, k);
-    double y = initial_conditions(P.tabs, P.has_cdm, P.has_ur, P.curvature_ini, P.K, P.ic, P.entropy_ini, GAUGE, e.role, e.ell, k, tau_ini);
+    double y;
+    if (MODE) {  // tensors (pm.cpp:5386-5403): only the gravitational wave starts non-zero
+      y = 0.;
+      if (e.role == R_GW) {
+        const double k2 = k * k;
+        y = P.gw_ini / 2.449489742783178;
+        if (CURV) {
+          y *= sqrt(k2 * (k2 - P.K) / (k2 + 3. * P.K) / (k2 + 2. * P.K));
+          if (P.K < 0.) y = (k2 + 3. * P.K >= 0.) ? y * sqrt(tanh(1.5707963267948966 * sqrt(k2 + 3. * P.K) / sqrt(-P.K))) : 0.;
+        }
+      }
+    } else
+      y = initial_conditions(P.tabs, P.has_cdm, P.has_ur, P.curvature_ini, P.K, P.ic, P.entropy_ini, GAUGE, e.role, e.ell, k, tau_ini);
 #ifdef CPT_PROFILE
     prof[6] = clock64() - t_begin;  // schedule search + initial conditions
 #endif
@@ -1476,6 +1601,14 @@ static __device__ __forceinline__ void body_perturb(const PtParams& P) {
         L = make_layout(P, f_tca, f_rsa, f_ufa);
         e = make_lane_eq(P, L, lane, k);
         double yn = (e.role == R_NONE) ? 0. : y;
+        if (MODE) {  // tensors (pm.cpp:4640-4648): photons re-enter with delta_g = -4/3 gw'/kappa', pol0 = gw'/(3 kappa')
+          if (was_tca && !L.tca) {
+            const double gwd = bcast(y, TL_GWD);
+            if (e.role == R_DELTA_G) yn = -4. / 3. * gwd * Q.tau_c;
+            else if (e.role == R_POL && e.ell == 0) yn = 1. / 3. * gwd * Q.tau_c;
+            else if (lane <= TL_P4 || e.chain == 1 || e.chain == 2) yn = 0.;
+          }
+        } else
         if (was_tca && !L.tca) {  // tight coupling switched off: seed shear, l=3 and polarisation (pm.cpp:3893-3916)
           const double sh = M.tca_shear_g, kod = k * Q.tau_c;
           if (e.role == R_SHEAR_G) yn = sh;
@@ -1598,17 +1731,17 @@ static __device__ __forceinline__ void body_dbg_solve(const PtParams& P, double 
 
 };  // struct PT<GAUGE>
 
-template <int GAUGE, int CURV>
-__global__ void __launch_bounds__(64) k_perturb(PtParams P) { PT<GAUGE, CURV>::body_perturb(P); }
-template <int GAUGE, int CURV>
-__global__ void __launch_bounds__(64) k_dbg_lookup(PtParams P, const double* tau, int n, double* out) { PT<GAUGE, CURV>::body_dbg_lookup(P, tau, n, out); }
-template <int GAUGE, int CURV>
+template <int GAUGE, int CURV, int MODE>
+__global__ void __launch_bounds__(64) k_perturb(PtParams P) { PT<GAUGE, CURV, MODE>::body_perturb(P); }
+template <int GAUGE, int CURV, int MODE>
+__global__ void __launch_bounds__(64) k_dbg_lookup(PtParams P, const double* tau, int n, double* out) { PT<GAUGE, CURV, MODE>::body_dbg_lookup(P, tau, n, out); }
+template <int GAUGE, int CURV, int MODE>
 __global__ void __launch_bounds__(64) k_dbg_derivs(PtParams P, double k, double tau, int tca, int rsa, int ufa, const double* y, double* dy, int* neq) {
-  PT<GAUGE, CURV>::body_dbg_derivs(P, k, tau, tca, rsa, ufa, y, dy, neq);
+  PT<GAUGE, CURV, MODE>::body_dbg_derivs(P, k, tau, tca, rsa, ufa, y, dy, neq);
 }
-template <int GAUGE, int CURV>
+template <int GAUGE, int CURV, int MODE>
 __global__ void __launch_bounds__(64) k_dbg_solve(PtParams P, double k, double tau, int tca, int rsa, int ufa, double hg, const double* b, double* x) {
-  PT<GAUGE, CURV>::body_dbg_solve(P, k, tau, tca, rsa, ufa, hg, b, x);
+  PT<GAUGE, CURV, MODE>::body_dbg_solve(P, k, tau, tca, rsa, ufa, hg, b, x);
 }
 
 void fill_params(const cpt_handle* h, PtParams& P) {
@@ -1617,6 +1750,7 @@ void fill_params(const cpt_handle* h, PtParams& P) {
   P.has_cdm = c.has_cdm; P.has_ur = c.has_ur; P.tca_method = c.tight_coupling_approximation;
   P.rsa_method = c.radiation_streaming_approximation; P.ufa_method = c.ur_fluid_approximation;
   P.l_max_g = c.l_max_g; P.l_max_pol_g = c.l_max_pol_g; P.l_max_ur = c.l_max_ur;
+  P.l_max_g_ten = c.l_max_g_ten; P.l_max_pol_g_ten = c.l_max_pol_g_ten; P.evolve_tensor_ur = c.evolve_tensor_ur; P.gw_ini = c.gw_ini;
   P.K = c.K; P.gauge = c.gauge; P.ic = c.ic; P.entropy_ini = c.entropy_ini; P.T_cmb = c.T_cmb; P.a_today = c.a_today; P.YHe = c.YHe; P.n_e = c.n_e; P.tau_free_streaming = c.tau_free_streaming;
   P.switch_sw = c.switch_sw; P.switch_eisw = c.switch_eisw; P.switch_lisw = c.switch_lisw; P.switch_dop = c.switch_dop;
   P.switch_pol = c.switch_pol; P.eisw_lisw_split_z = c.eisw_lisw_split_z;
@@ -1636,10 +1770,14 @@ void fill_params(const cpt_handle* h, PtParams& P) {
 #define CPT_PT_DISPATCH(cfg, KERNEL, ...)                                                                         \
   do {                                                                                                            \
     const bool newt__ = (cfg).gauge == CPT_GAUGE_NEWTONIAN, curv__ = (cfg).K != 0.;                               \
-    if (newt__ && curv__) hipLaunchKernelGGL((KERNEL<CPT_GAUGE_NEWTONIAN, 1>), __VA_ARGS__);                      \
-    else if (newt__) hipLaunchKernelGGL((KERNEL<CPT_GAUGE_NEWTONIAN, 0>), __VA_ARGS__);                           \
-    else if (curv__) hipLaunchKernelGGL((KERNEL<CPT_GAUGE_SYNCHRONOUS, 1>), __VA_ARGS__);                         \
-    else hipLaunchKernelGGL((KERNEL<CPT_GAUGE_SYNCHRONOUS, 0>), __VA_ARGS__);                                     \
+    if ((cfg).mode == CPT_MODE_TENSORS) { /* the tensor equations are the same in both gauges */                  \
+      if (curv__) hipLaunchKernelGGL((KERNEL<CPT_GAUGE_SYNCHRONOUS, 1, 1>), __VA_ARGS__);                         \
+      else hipLaunchKernelGGL((KERNEL<CPT_GAUGE_SYNCHRONOUS, 0, 1>), __VA_ARGS__);                                \
+    }                                                                                                             \
+    else if (newt__ && curv__) hipLaunchKernelGGL((KERNEL<CPT_GAUGE_NEWTONIAN, 1, 0>), __VA_ARGS__);              \
+    else if (newt__) hipLaunchKernelGGL((KERNEL<CPT_GAUGE_NEWTONIAN, 0, 0>), __VA_ARGS__);                        \
+    else if (curv__) hipLaunchKernelGGL((KERNEL<CPT_GAUGE_SYNCHRONOUS, 1, 0>), __VA_ARGS__);                      \
+    else hipLaunchKernelGGL((KERNEL<CPT_GAUGE_SYNCHRONOUS, 0, 0>), __VA_ARGS__);                                  \
   } while (0)
 
 }  // namespace

@@ -66,6 +66,15 @@ class Inputs:
                 setattr(c, "index_tt_" + f, int(_s(d, "tr.index_tt_" + f)))
         c.lcmb_rescale = _s(d, "ptr.lcmb_rescale"); c.lcmb_tilt = _s(d, "ptr.lcmb_tilt")
         c.lcmb_pivot = _s(d, "ptr.lcmb_pivot")
+        # tensor modes: one mode per handle (a tensors-only reference run dumps pt.mode_tensors = 1)
+        c.mode = int(_s(d, "pt.mode_tensors")) if "pt.mode_tensors" in d else 0
+        c.l_max_g_ten = int(_s(d, "ppr.l_max_g_ten")); c.l_max_pol_g_ten = int(_s(d, "ppr.l_max_pol_g_ten"))
+        c.gw_ini = float(_s(d, "ppr.gw_ini"))
+        c.evolve_tensor_ur = int(_s(d, "pt.evolve_tensor_ur")) if "pt.evolve_tensor_ur" in d else 0
+        c.index_tt_b = int(_s(d, "tr.index_tt_b")) if "tr.index_tt_b" in d else -1
+        for f in ("t2", "e", "b"):
+            key = "ppr.transfer_neglect_delta_k_T_" + f
+            setattr(c, "transfer_neglect_delta_k_T_" + f, float(_s(d, key)) if key in d else 0.0)
         # initial condition: one mode per handle (ad unless the fixture says otherwise)
         c.ic = 0
         for code, key in ((1, "ppt.has_bi"), (2, "ppt.has_cdi"), (3, "ppt.has_nid"), (4, "ppt.has_niv")):

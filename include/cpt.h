@@ -58,6 +58,7 @@ extern "C" {
 
 /* Flat POD with the physics flags / derived scalars / precision parameters the path reads
  * (struct background / thermo / perturbs / precision / transfers of the reference).  */
+enum { CPT_MODE_SCALARS = 0, CPT_MODE_TENSORS = 1 };
 enum { CPT_IC_AD = 0, CPT_IC_BI = 1, CPT_IC_CDI = 2, CPT_IC_NID = 3, CPT_IC_NIV = 4 };
 
 typedef struct cpt_config {
@@ -108,6 +109,13 @@ typedef struct cpt_config {
    *     zero-initialised older callers get the adiabatic mode --- */
   int ic;               /* CPT_IC_AD (0), CPT_IC_BI, CPT_IC_CDI, CPT_IC_NID, CPT_IC_NIV */
   double entropy_ini;   /* ppr->entropy_ini (isocurvature normalisation; default 1) */
+  /* --- tensor modes (one mode per handle; pm.cpp:3519-3586, 9045-9215, 7243-7280; tm.cpp:3494-3529) --- */
+  int mode;                   /* CPT_MODE_SCALARS (0) or CPT_MODE_TENSORS (1) */
+  int l_max_g_ten, l_max_pol_g_ten;   /* precision: multipoles of the tensor photon hierarchies (default 5, 5) */
+  double gw_ini;              /* precision: initial gravitational-wave amplitude (default 1) */
+  int evolve_tensor_ur;       /* PerturbationsModule::evolve_tensor_ur_: massless neutrinos source the gravitational waves */
+  int index_tt_b;             /* transfer slot of the B-mode polarisation type (tensors; -1 = absent) */
+  double transfer_neglect_delta_k_T_t2, transfer_neglect_delta_k_T_e, transfer_neglect_delta_k_T_b;
 } cpt_config;
 
 /* Spline tables the RHS samples (all HOST pointers, row-major [n_lines][n_columns], copied to HBM by cpt_create):

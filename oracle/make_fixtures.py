@@ -71,7 +71,7 @@ def main():
             else:
                 out[k] = v
         src = d["pt.sources"]  # [tp][tau][k]
-        if cfg == "small":
+        if cfg in ("small", "tens"):
             out["pt.sources"] = src
             if "tr.transfer" in d:
                 out["tr.transfer"] = d["tr.transfer"]
@@ -92,7 +92,7 @@ def main():
                 out["tr.transfer_l_index"] = ls.astype(np.int32)
                 out["tr.transfer_at_q"] = np.ascontiguousarray(t[:, :, qs])
                 out["tr.transfer_at_l"] = np.ascontiguousarray(t[:, ls, :])
-        if cfg.startswith("iso_") or cfg == "newt":
+        if cfg.startswith("iso_") or cfg in ("newt", "tens"):
             # same cosmology as small/lcdm/explanatory: the tables must be the committed ones
             old = np.load(os.path.join(GOLD, "tables_lcdm.npz"))
             for k in tables:

@@ -200,15 +200,21 @@ static int do_dump(const char* ini, const char* outpath) {
   put_d("th.n_e", th->n_e_); put_d("th.z_reionization", th->z_reionization_);
 
   // ---- perturbations: grids + sources_ (source/perturbations_module.h:152-178) ----
-  int md = pt->index_md_scalars_;
+  // scalars when present, else the tensor mode (a tensors-only run, modes = t)
+  const bool tens = !ppt->has_scalars && ppt->has_tensors;
+  int md = tens ? pt->index_md_tensors_ : pt->index_md_scalars_;
+  put_i("pt.mode_tensors", tens ? 1 : 0);
+  put_i("ppt.tensor_method", (int)ppt->tensor_method); put_i("pt.evolve_tensor_ur", tens ? (int)pt->evolve_tensor_ur_ : 0);
+  put_d("ppr.transfer_neglect_delta_k_T_t2", ppr->transfer_neglect_delta_k_T_t2); put_d("ppr.transfer_neglect_delta_k_T_e", ppr->transfer_neglect_delta_k_T_e);
+  put_d("ppr.transfer_neglect_delta_k_T_b", ppr->transfer_neglect_delta_k_T_b);
   int nk = pt->k_size_[md], ntau = pt->tau_size_, ntp = pt->tp_size_[md];
   put_i("pt.md_size", pt->md_size_); put_i("pt.ic_size", pt->ic_size_[md]); put_i("pt.tp_size", ntp);
   put_i("pt.k_size", nk); put_i("pt.k_size_cl", pt->k_size_cl_[md]); put_i("pt.k_size_cmb", pt->k_size_cmb_[md]);
   put_i("pt.tau_size", ntau); put_i("pt.ln_tau_size", pt->ln_tau_size_);
   put_f8("pt.k", pt->k_[md], {nk});
   put_f8("pt.tau_sampling", pt->tau_sampling_, {ntau});
-  put_i("pt.index_tp_t0", pt->has_source_t_ ? pt->index_tp_t0_ : -1);
-  put_i("pt.index_tp_t1", pt->has_source_t_ ? pt->index_tp_t1_ : -1);
+  put_i("pt.index_tp_t0", (pt->has_source_t_ && !tens) ? pt->index_tp_t0_ : -1);
+  put_i("pt.index_tp_t1", (pt->has_source_t_ && !tens) ? pt->index_tp_t1_ : -1);
   put_i("pt.index_tp_t2", pt->has_source_t_ ? pt->index_tp_t2_ : -1);
   put_i("pt.index_tp_p", pt->has_source_p_ ? pt->index_tp_p_ : -1);
   put_i("pt.index_tp_phi_plus_psi", pt->has_source_phi_plus_psi_ ? pt->index_tp_phi_plus_psi_ : -1);
@@ -227,11 +233,12 @@ static int do_dump(const char* ini, const char* outpath) {
     put_f8("tr.q", tr->q_, {nq}); put_f8("tr.k", tr->k_[md], {nq});
     put_i4("tr.l", tr->l_, {nl_});
     put_i4("tr.l_size_tt", tr->l_size_tt_[md], {ntt});
-    put_i("tr.index_tt_t0", ppt->has_cl_cmb_temperature ? tr->index_tt_t0_ : -1);
-    put_i("tr.index_tt_t1", ppt->has_cl_cmb_temperature ? tr->index_tt_t1_ : -1);
+    put_i("tr.index_tt_t0", (ppt->has_cl_cmb_temperature && !tens) ? tr->index_tt_t0_ : -1);
+    put_i("tr.index_tt_t1", (ppt->has_cl_cmb_temperature && !tens) ? tr->index_tt_t1_ : -1);
+    put_i("tr.index_tt_b", (ppt->has_cl_cmb_polarization && tens) ? tr->index_tt_b_ : -1);
     put_i("tr.index_tt_t2", ppt->has_cl_cmb_temperature ? tr->index_tt_t2_ : -1);
     put_i("tr.index_tt_e", ppt->has_cl_cmb_polarization ? tr->index_tt_e_ : -1);
-    put_i("tr.index_tt_lcmb", ppt->has_cl_cmb_lensing_potential ? tr->index_tt_lcmb_ : -1);
+    put_i("tr.index_tt_lcmb", (ppt->has_cl_cmb_lensing_potential && !tens) ? tr->index_tt_lcmb_ : -1);
     put_f8("tr.transfer", tr->transfer_[md], {ntt, nl_, nq});
 
     // ---- spectra: the C_l table at the l_ grid and at every integer l (source/spectra_module.cpp:146-218) ----
@@ -305,7 +312,7 @@ static int do_time(const char* ini, const char* threads, int reps) {
     auto t3 = std::chrono::steady_clock::now();
     best_pt = std::min(best_pt, std::chrono::duration<double>(t1 - t0).count());
     best_tr = std::min(best_tr, std::chrono::duration<double>(t3 - t2).count());
-    int md = pt->index_md_scalars_;
+    int md = 0;
     nk = pt->k_size_[md]; nq = tr->q_size_; nl_ = tr->l_size_[md]; ntt = tr->tt_size_[md];
   }
   printf("{\"perturb_s\": %.6f, \"transfer_s\": %.6f, \"k_size\": %d, \"q_size\": %d, \"l_size\": %d, \"tt_size\": %d, \"threads\": %s, \"reps\": %d}\n",

@@ -87,6 +87,7 @@ struct Layout {
   int neq;
   int delta_g, theta_g, shear_g, l3_g, pol0_g, pol1_g, pol2_g, pol3_g, delta_b, theta_b, delta_cdm, theta_cdm, delta_ur, theta_ur,
       shear_ur, l3_ur, eta;  // eta: synchronous eta, or the Newtonian phi (same slot, pm.cpp:3470-3478)
+  int gw, gwdot;         // tensor modes
   int l_max_g, l_max_pol_g, l_max_ur;
   std::vector<int> used_in_sources;
 };
@@ -98,6 +99,21 @@ Layout make_layout(const cpt_config& c, int tca, int rsa, int ufa) {
   L.delta_ur = L.theta_ur = L.shear_ur = L.l3_ur = -1;
   L.delta_cdm = L.theta_cdm = -1;
   L.l_max_g = c.l_max_g; L.l_max_pol_g = c.l_max_pol_g; L.l_max_ur = c.l_max_ur;
+  L.gw = L.gwdot = L.eta = L.delta_b = L.theta_b = -1;
+  if (c.mode == CPT_MODE_TENSORS) {  // pm.cpp:3519-3586
+    int i = 0;
+    L.ufa = 0;
+    L.l_max_g = c.l_max_g_ten; L.l_max_pol_g = c.l_max_pol_g_ten;
+    if (!rsa && !tca) {
+      L.delta_g = i++; L.theta_g = i++; L.shear_g = i++; L.l3_g = i; i += L.l_max_g - 2;
+      L.pol0_g = i++; L.pol1_g = i++; L.pol2_g = i++; L.pol3_g = i; i += L.l_max_pol_g - 2;
+    }
+    if (c.evolve_tensor_ur) { L.delta_ur = i++; L.theta_ur = i++; L.shear_ur = i++; L.l3_ur = i; i += L.l_max_ur - 2; }
+    L.gw = i++; L.gwdot = i++;
+    L.neq = i;
+    L.used_in_sources.assign(L.neq, 1);
+    return L;
+  }
   int i = 0;
   if (!rsa) {
     L.delta_g = i++; L.theta_g = i++;
@@ -143,6 +159,7 @@ struct Work {
   Bg bg; Th th;
   double h_prime, eta_prime, h_prime_prime, alpha, alpha_prime;
   double psi, phi_prime;  // Newtonian gauge
+  double gw_prime_prime;  // tensors
   double delta_rho, rho_plus_p_theta, rho_plus_p_shear, delta_p, rho_plus_p_tot;
   double delta_m, theta_m;
   double rsa_delta_g, rsa_theta_g, rsa_delta_ur, rsa_theta_ur;
@@ -165,7 +182,7 @@ void approximations(const Model& m, double k, double tau, int* tca, int* rsa, in
   *rsa = ((tau / tau_k > c.radiation_streaming_trigger_tau_over_tau_k) && (tau > c.tau_free_streaming) &&
           (c.radiation_streaming_approximation != CPT_RSA_NONE)) ? 1 : 0;
   *ufa = 0;
-  if (c.has_ur) *ufa = ((tau / tau_k > c.ur_fluid_trigger_tau_over_tau_k) && (c.ur_fluid_approximation != CPT_UFA_NONE)) ? 1 : 0;
+  if (c.has_ur && c.mode != CPT_MODE_TENSORS) *ufa = ((tau / tau_k > c.ur_fluid_trigger_tau_over_tau_k) && (c.ur_fluid_approximation != CPT_UFA_NONE)) ? 1 : 0;
 }
 
 // perturb_rsa_delta_and_theta, pm.cpp:9530-9636 (synchronous gauge)
@@ -310,12 +327,60 @@ void tca_slip_and_shear(const Model& m, double k, const double* y, const Layout&
   w.tca_slip = slip;
 }
 
+// tensor modes: perturb_total_stress_energy :6616-6660 (gw_source), perturb_einstein :6036-6040, perturb_derivs :9045-9215
+void tensor_derivs(const Model& m, double k, double tau, const double* y, double* dy, const Layout& L, Work& w) {
+  const cpt_config& c = *m.c;
+  const Bg& bg = w.bg; const Th& th = w.th;
+  const double k2 = k * k, a2 = bg.a * bg.a, a_prime_over_a = bg.H * bg.a, SQRT6 = std::sqrt(6.);
+  const double cotKgen = cot_K_gen(c, k, tau), s2_squared = 1. - 3. * c.K / k2;
+  auto S = [&](int l) { return s_l(c, k, l); };
+  double gw_source = 0.;
+  const bool photons = !L.rsa && !L.tca;
+  if (photons) gw_source += -SQRT6 * 4 * a2 * bg.rho_g * (1. / 15. * y[L.delta_g] + 4. / 21. * y[L.shear_g] + 1. / 35. * y[L.l3_g + 1]);
+  if (c.evolve_tensor_ur)   // tensor_method = massless approximation / exact without ncdm: rho_relativistic = rho_ur
+    gw_source += -SQRT6 * 4 * a2 * bg.rho_ur * (1. / 15. * y[L.delta_ur] + 4. / 21. * y[L.shear_ur] + 1. / 35. * y[L.l3_ur + 1]);
+  w.gw_prime_prime = -2. * a_prime_over_a * y[L.gwdot] - (k2 + 2. * c.K) * y[L.gw] + gw_source;
+  if (photons) {
+    const double delta_g = y[L.delta_g], theta_g = y[L.theta_g], shear_g = y[L.shear_g];
+    const double P2 = -1.0 / SQRT6 * (1. / 10. * delta_g + 2. / 7. * shear_g + 3. / 70. * y[L.delta_g + 4] - 3. / 5. * y[L.pol0_g] +
+                                       6. / 7. * y[L.pol2_g] - 3. / 70. * y[L.pol0_g + 4]);
+    dy[L.delta_g] = -4. / 3. * theta_g - th.dkappa * (delta_g + SQRT6 * P2) + SQRT6 * y[L.gwdot];
+    dy[L.theta_g] = k2 * (delta_g / 4. - S(2) * shear_g) - th.dkappa * theta_g;
+    dy[L.shear_g] = 4. / 15. * S(2) * theta_g - 3. / 10. * k * S(3) * y[L.shear_g + 1] - th.dkappa * shear_g;
+    dy[L.l3_g] = k / 7. * (6. * S(3) * shear_g - 4. * S(4) * y[L.l3_g + 1]) - th.dkappa * y[L.l3_g];
+    int l;
+    for (l = 4; l < L.l_max_g; l++)
+      dy[L.delta_g + l] = k / (2. * l + 1.) * (l * S(l) * y[L.delta_g + l - 1] - (l + 1.) * S(l + 1) * y[L.delta_g + l + 1]) - th.dkappa * y[L.delta_g + l];
+    l = L.l_max_g;
+    dy[L.delta_g + l] = k * (S(l) * y[L.delta_g + l - 1] - (1. + l) * cotKgen * y[L.delta_g + l]) - th.dkappa * y[L.delta_g + l];
+    dy[L.pol0_g] = -k * y[L.pol0_g + 1] - th.dkappa * (y[L.pol0_g] - SQRT6 * P2);
+    for (l = 1; l < L.l_max_pol_g; l++)
+      dy[L.pol0_g + l] = k / (2. * l + 1.) * (l * S(l) * y[L.pol0_g + l - 1] - (l + 1.) * S(l + 1) * y[L.pol0_g + l + 1]) - th.dkappa * y[L.pol0_g + l];
+    l = L.l_max_pol_g;
+    dy[L.pol0_g + l] = k * (S(l) * y[L.pol0_g + l - 1] - (l + 1.) * cotKgen * y[L.pol0_g + l]) - th.dkappa * y[L.pol0_g + l];
+  }
+  if (c.evolve_tensor_ur) {
+    dy[L.delta_ur] = -4. / 3. * y[L.theta_ur] + SQRT6 * y[L.gwdot];
+    dy[L.theta_ur] = k2 * (y[L.delta_ur] / 4. - s2_squared * y[L.shear_ur]);
+    dy[L.shear_ur] = 4. / 15. * y[L.theta_ur] - 3. / 10. * k * S(3) / S(2) * y[L.shear_ur + 1];
+    int l = 3;
+    dy[L.l3_ur] = k / (2. * l + 1.) * (l * 2. * S(l) * S(2) * y[L.shear_ur] - (l + 1.) * S(l + 1) * y[L.l3_ur + 1]);
+    for (l = 4; l < L.l_max_ur; l++)
+      dy[L.delta_ur + l] = k / (2. * l + 1) * (l * S(l) * y[L.delta_ur + l - 1] - (l + 1.) * S(l + 1) * y[L.delta_ur + l + 1]);
+    l = L.l_max_ur;
+    dy[L.delta_ur + l] = k * (S(l) * y[L.delta_ur + l - 1] - (1. + l) * cotKgen * y[L.delta_ur + l]);
+  }
+  dy[L.gw] = y[L.gwdot];
+  dy[L.gwdot] = w.gw_prime_prime;
+}
+
 // perturb_derivs, pm.cpp:7861-9218 (scalars, synchronous, flat, no exotic species)
 void derivs(const Model& m, double k, double tau, const double* y, double* dy, const Layout& L, Work& w) {
   const cpt_config& c = *m.c;
   w.fevals++;
   bg_at_tau(m, tau, w.bg);
   th_at_z(m, 1. / w.bg.a - 1., w.bg, w.th);
+  if (c.mode == CPT_MODE_TENSORS) { tensor_derivs(m, k, tau, y, dy, L, w); return; }
   einstein(m, k, y, L, w);
   const Bg& bg = w.bg; const Th& th = w.th;
   double k2 = k * k, a = bg.a, a_prime_over_a = bg.H * a;
@@ -397,6 +462,18 @@ void sources(const Model& m, double k, double tau, const double* y, const double
   double z = c.a_today / w.bg.a - 1.;
   th_at_z(m, z, w.bg, w.th);
   const Bg& bg = w.bg; const Th& th = w.th;
+  if (c.mode == CPT_MODE_TENSORS) {  // pm.cpp:7243-7280
+    double P = 0.;
+    if (!L.rsa) {
+      if (!L.tca)
+        P = -(1. / 10. * y[L.delta_g] + 2. / 7. * y[L.shear_g] + 3. / 70. * y[L.delta_g + 4] - 3. / 5. * y[L.pol0_g] + 6. / 7. * y[L.pol2_g] -
+              3. / 70. * y[L.pol0_g + 4]) / std::sqrt(6.);
+      else P = 2. / 5. * std::sqrt(6.) * y[L.gwdot] / th.dkappa;
+    }
+    if (c.index_tp_t2 >= 0) out[c.index_tp_t2] = -y[L.gwdot] * th.expmk + th.g * P;
+    if (c.index_tp_p >= 0) out[c.index_tp_p] = std::sqrt(6.) * th.g * P;
+    return;
+  }
   double a_prime_over_a = bg.a * bg.H, a_prime_over_a_prime = bg.Hp * bg.a + std::pow(bg.H * bg.a, 2);
   einstein(m, k, y, L, w);
   double delta_g, P;
@@ -833,6 +910,16 @@ void initial_conditions(const Model& m, double k, double tau, const Layout& L, d
   double ktau_two = k * k * tau * tau, ktau_three = k * tau * ktau_two;
   double s2_squared = 1. - 3. * c.K / k / k;
   for (int i = 0; i < L.neq; i++) y[i] = 0.;
+  if (c.mode == CPT_MODE_TENSORS) {  // pm.cpp:5386-5403
+    y[L.gw] = c.gw_ini / std::sqrt(6.);
+    const double k2 = k * k;
+    if (c.sgnK != 0) y[L.gw] *= std::sqrt(k2 * (k2 - c.K) / (k2 + 3. * c.K) / (k2 + 2. * c.K));
+    if (c.sgnK == -1) {
+      if (k2 + 3 * c.K >= 0.) y[L.gw] *= std::sqrt(std::tanh(3.1415926535897932384626433832795 / 2. * std::sqrt(k2 + 3 * c.K) / std::sqrt(-c.K)));
+      else y[L.gw] = 0.;
+    }
+    return;
+  }
   y[L.delta_g] = -ktau_two / 3. * (1. - om * tau / 5.) * c.curvature_ini * s2_squared;
   y[L.theta_g] = -k * ktau_three / 36. * (1. - 3. * (1. + 5. * fracb - fracnu) / 20. / (1. - fracnu) * om * tau) * c.curvature_ini * s2_squared;
   y[L.delta_b] = 3. / 4. * y[L.delta_g];
@@ -908,6 +995,15 @@ void initial_conditions(const Model& m, double k, double tau, const Layout& L, d
 void handover(const Model& m, double k, const Layout& Lo, const double* yo, const Layout& Ln, double* yn, const Work& w) {
   const cpt_config& c = *m.c;
   for (int i = 0; i < Ln.neq; i++) yn[i] = 0.;
+  if (c.mode == CPT_MODE_TENSORS) {  // pm.cpp:4596-4670
+    yn[Ln.gw] = yo[Lo.gw]; yn[Ln.gwdot] = yo[Lo.gwdot];
+    if (c.evolve_tensor_ur) for (int l = 0; l <= Ln.l_max_ur; l++) yn[Ln.delta_ur + l] = yo[Lo.delta_ur + l];
+    if (Lo.tca && !Ln.tca) {
+      yn[Ln.delta_g] = -4. / 3. * yo[Lo.gwdot] / w.th.dkappa;
+      yn[Ln.pol0_g] = 1. / 3. * yo[Lo.gwdot] / w.th.dkappa;
+    }
+    return;
+  }
   yn[Ln.delta_b] = yo[Lo.delta_b]; yn[Ln.theta_b] = yo[Lo.theta_b];
   if (c.has_cdm) { yn[Ln.delta_cdm] = yo[Lo.delta_cdm]; if (Ln.theta_cdm >= 0) yn[Ln.theta_cdm] = yo[Lo.theta_cdm]; }
   yn[Ln.eta] = yo[Lo.eta];

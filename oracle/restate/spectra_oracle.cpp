@@ -45,14 +45,17 @@ int orc_cl(const cpt_config* c, const cpt_spectra_params* s, const double* tr, c
       int kind = -1;
       if (ct == s->index_ct_tt) kind = 0; else if (ct == s->index_ct_ee) kind = 1; else if (ct == s->index_ct_te) kind = 2;
       else if (ct == s->index_ct_pp) kind = 4; else if (ct == s->index_ct_tp) kind = 5; else if (ct == s->index_ct_ep) kind = 6;
+      const bool tens = c->mode == CPT_MODE_TENSORS;   // tensors: TT, EE, TE and BB only (spectra_module.cpp:1027-1185)
+      if (tens) { if (kind >= 4) kind = -1; if (ct == s->index_ct_bb) kind = 3; }
       if (kind < 0) { cl[(size_t)il * s->ct_size + ct] = 0.; continue; }
       for (int iq = 0; iq < nq; iq++) {
-        double k = q[iq], temp = 0., e = 0., lc = 0.;
+        double k = q[iq], temp = 0., e = 0., lc = 0., bm = 0.;
         size_t o = (size_t)il * nq + iq;
-        if (c->index_tt_t0 >= 0) temp = tr[c->index_tt_t0 * st + o] + tr[c->index_tt_t1 * st + o] + tr[c->index_tt_t2 * st + o];
+        if (tens) { if (c->index_tt_t2 >= 0) temp = tr[c->index_tt_t2 * st + o]; if (c->index_tt_b >= 0) bm = tr[c->index_tt_b * st + o]; }
+        else if (c->index_tt_t0 >= 0) temp = tr[c->index_tt_t0 * st + o] + tr[c->index_tt_t1 * st + o] + tr[c->index_tt_t2 * st + o];
         if (c->index_tt_e >= 0) e = tr[c->index_tt_e * st + o];
-        if (c->index_tt_lcmb >= 0) lc = tr[c->index_tt_lcmb * st + o];
-        double prod = kind == 0 ? temp * temp : kind == 1 ? e * e : kind == 2 ? 0.5 * (temp * e + e * temp)
+        if (!tens && c->index_tt_lcmb >= 0) lc = tr[c->index_tt_lcmb * st + o];
+        double prod = kind == 3 ? bm * bm : kind == 0 ? temp * temp : kind == 1 ? e * e : kind == 2 ? 0.5 * (temp * e + e * temp)
                     : kind == 4 ? lc * lc : kind == 5 ? 0.5 * (temp * lc + lc * temp) : 0.5 * (e * lc + lc * e);
         y[iq] = primordial(*s, k) * prod * (4. * PI / k);
       }

@@ -212,3 +212,61 @@ def test_newtonian_structured_solve_matches_dense(newt, flags):
         got = be.dbg_solve(k, tau, *flags, hg, b)
         assert np.all(np.abs(A @ got - b) <= 1e-11 * (np.abs(A) @ np.abs(got) + np.abs(b)))
         assert np.max(np.abs(got - want)) < 1e-8 * np.max(np.abs(want)), (k, tau, hg)
+
+
+# ---- tensor modes (pm.cpp:3519-3586, 9045-9215, 7243-7280): tests/golden/tens.ini is a tensors-only reference run (modes = t)
+@pytest.fixture(scope="module")
+def tens():
+    from classpp_public_amd.backend import Backend
+    inp = Inputs("tens")
+    assert inp.config.mode == 1
+    be = Backend(inp)
+    yield inp, be
+    be.close()
+
+
+@pytest.mark.parametrize("flags", [(1, 0, 0), (0, 0, 0), (0, 1, 0)])
+def test_tensor_derivs_match_oracle(tens, flags):
+    inp, be = tens
+    rng = np.random.default_rng(6)
+    for k, tau in [(1e-4, 50.0), (0.03, 150.0), (0.03, 290.0), (0.2, 3000.0), (0.5, 13000.0)]:
+        y = rng.normal(size=64)
+        want = oracle_lib.derivs(inp, k, tau, *flags, y)
+        got = be.dbg_derivs(k, tau, *flags, y[: want.size])
+        assert got.size == want.size
+        scale = np.max(np.abs(want))
+        assert np.max(np.abs(got - want)) < 1e-11 * scale, (k, tau, np.max(np.abs(got - want)) / scale)
+
+
+@pytest.mark.parametrize("flags", [(1, 0, 0), (0, 0, 0)])
+def test_tensor_structured_solve_matches_dense(tens, flags):
+    inp, be = tens
+    rng = np.random.default_rng(7)
+    for k, tau, hg in [(0.03, 150.0, 0.4), (0.2, 3000.0, 1.0), (1e-3, 5000.0, 500.0)]:
+        n = oracle_lib.derivs(inp, k, tau, *flags, np.zeros(64)).size
+        J = np.zeros((n, n))
+        for j in range(n):
+            e = np.zeros(64)
+            e[j] = 1.0
+            J[:, j] = oracle_lib.derivs(inp, k, tau, *flags, e)
+        A = np.eye(n) - hg * J
+        b = rng.normal(size=n)
+        want = np.linalg.solve(A, b)
+        got = be.dbg_solve(k, tau, *flags, hg, b)
+        assert np.all(np.abs(A @ got - b) <= 1e-11 * (np.abs(A) @ np.abs(got) + np.abs(b)))
+        assert np.max(np.abs(got - want)) < 1e-8 * np.max(np.abs(want)), (k, tau, hg)
+
+
+def test_tensor_sources_match_reference(tens):
+    inp, be = tens
+    src, stats, status = be.perturb_solve()
+    assert not status.any()
+    got = src.cpu().numpy()
+    ref = inp.d["pt.sources"]
+    for tp, tol in ((inp.config.index_tp_t2, 2e-4), (inp.config.index_tp_p, 2e-4)):
+        scale = np.max(np.abs(ref[tp]), axis=0, keepdims=True)
+        scale[scale == 0] = 1
+        assert np.max(np.abs(got[tp] - ref[tp]) / scale) < tol, tp
+    osrc, ostats, _, _ = oracle_lib.perturb(inp)
+    gs, os_ = sum(s.steps for s in stats), sum(s.steps for s in ostats)
+    assert abs(gs - os_) < 0.02 * os_, (gs, os_)
