@@ -12,7 +12,8 @@ struct ClParams {
   const double* w;   // [nq]: quadrature weight of the integrand spline x primordial spectrum x 4 pi / q
   double* cl;        // [nl][ct]
   int nq, nl, ct_size;
-  int tt_t0, tt_t1, tt_t2, tt_e, tt_lcmb;
+  int tt_t0, tt_t1, tt_t2, tt_e, tt_lcmb, tt_b;
+  int tensors;  // tensor mode: temperature = t2 alone, BB = b b, no lensing-potential spectra (spectra_module.cpp:1027-1185)
   int ct_tt, ct_ee, ct_te, ct_bb, ct_pp, ct_tp, ct_ep;
 };
 
@@ -25,12 +26,15 @@ struct ClParams {
 __global__ void __launch_bounds__(256) k_cl(ClParams P) {
   const int il = blockIdx.x, tid = threadIdx.x, nq = P.nq;
   const size_t st = (size_t)P.nl * nq, row = (size_t)il * nq;
-  double acc[6] = {0., 0., 0., 0., 0., 0.};  // tt, ee, te, pp, tp, ep
+  double acc[7] = {0., 0., 0., 0., 0., 0., 0.};  // tt, ee, te, pp, tp, ep, bb
   for (int iq = tid; iq < nq; iq += 256) {
-    double temp = 0., e = 0., lc = 0.;
-    if (P.tt_t0 >= 0) temp = P.tr[P.tt_t0 * st + row + iq] + P.tr[P.tt_t1 * st + row + iq] + P.tr[P.tt_t2 * st + row + iq];
+    double temp = 0., e = 0., lc = 0., bm = 0.;
+    if (P.tensors) {
+      if (P.tt_t2 >= 0) temp = P.tr[P.tt_t2 * st + row + iq];
+      if (P.tt_b >= 0) bm = P.tr[P.tt_b * st + row + iq];
+    } else if (P.tt_t0 >= 0) temp = P.tr[P.tt_t0 * st + row + iq] + P.tr[P.tt_t1 * st + row + iq] + P.tr[P.tt_t2 * st + row + iq];
     if (P.tt_e >= 0) e = P.tr[P.tt_e * st + row + iq];
-    if (P.tt_lcmb >= 0) lc = P.tr[P.tt_lcmb * st + row + iq];
+    if (!P.tensors && P.tt_lcmb >= 0) lc = P.tr[P.tt_lcmb * st + row + iq];
     const double w = P.w[iq];
     acc[0] = fma(w, temp * temp, acc[0]);
     acc[1] = fma(w, e * e, acc[1]);
@@ -38,10 +42,11 @@ __global__ void __launch_bounds__(256) k_cl(ClParams P) {
     acc[3] = fma(w, lc * lc, acc[3]);
     acc[4] = fma(w, temp * lc, acc[4]);
     acc[5] = fma(w, e * lc, acc[5]);
+    acc[6] = fma(w, bm * bm, acc[6]);
   }
-  __shared__ double red[4][6];
+  __shared__ double red[4][7];
 #pragma unroll
-  for (int c = 0; c < 6; c++) {
+  for (int c = 0; c < 7; c++) {
     double v = acc[c];
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
@@ -53,6 +58,7 @@ __global__ void __launch_bounds__(256) k_cl(ClParams P) {
     int kind = -1;
     if (ct == P.ct_tt) kind = 0; else if (ct == P.ct_ee) kind = 1; else if (ct == P.ct_te) kind = 2;
     else if (ct == P.ct_pp) kind = 3; else if (ct == P.ct_tp) kind = 4; else if (ct == P.ct_ep) kind = 5;
+    if (P.tensors) { if (kind >= 3) kind = -1; if (ct == P.ct_bb) kind = 6; }
     double v = 0.;  // bb vanishes for scalar modes (spectra_module.cpp:1262-1270)
     if (kind >= 0) v = red[0][kind] + red[1][kind] + red[2][kind] + red[3][kind];
     P.cl[(size_t)il * P.ct_size + ct] = v;
@@ -129,7 +135,11 @@ int cpt_cl_impl(cpt_handle* h, const cpt_spectra_params* sp, const double* trans
   const int cts[7] = {sp->index_ct_tt, sp->index_ct_ee, sp->index_ct_te, sp->index_ct_bb, sp->index_ct_pp, sp->index_ct_tp, sp->index_ct_ep};
   for (int i = 0; i < 7; i++)
     if (cts[i] >= sp->ct_size) return cpt_fail(h, CPT_ERR_INVALID, "index_ct_* >= ct_size");
-  if ((sp->index_ct_tt >= 0 || sp->index_ct_te >= 0 || sp->index_ct_tp >= 0) && (c.index_tt_t0 < 0 || c.index_tt_t1 < 0 || c.index_tt_t2 < 0))
+  const bool tens = c.mode == CPT_MODE_TENSORS;
+  if (tens && (sp->index_ct_pp >= 0 || sp->index_ct_tp >= 0 || sp->index_ct_ep >= 0))
+    return cpt_fail(h, CPT_ERR_INVALID, "tensor modes have no lensing-potential spectra");
+  if (tens && sp->index_ct_bb >= 0 && c.index_tt_b < 0) return cpt_fail(h, CPT_ERR_INVALID, "BB requested without B transfer functions");
+  if ((sp->index_ct_tt >= 0 || sp->index_ct_te >= 0 || sp->index_ct_tp >= 0) && (tens ? c.index_tt_t2 < 0 : (c.index_tt_t0 < 0 || c.index_tt_t1 < 0 || c.index_tt_t2 < 0)))
     return cpt_fail(h, CPT_ERR_INVALID, "temperature C_l requested without temperature transfer functions");
   if ((sp->index_ct_ee >= 0 || sp->index_ct_te >= 0 || sp->index_ct_ep >= 0) && c.index_tt_e < 0)
     return cpt_fail(h, CPT_ERR_INVALID, "polarisation C_l requested without E transfer functions");
@@ -151,6 +161,7 @@ int cpt_cl_impl(cpt_handle* h, const cpt_spectra_params* sp, const double* trans
   ClParams P;
   P.tr = transfer_dev; P.w = h->d_q; P.cl = cl_dev; P.nq = nq; P.nl = nl; P.ct_size = sp->ct_size;
   P.tt_t0 = c.index_tt_t0; P.tt_t1 = c.index_tt_t1; P.tt_t2 = c.index_tt_t2; P.tt_e = c.index_tt_e; P.tt_lcmb = c.index_tt_lcmb;
+  P.tt_b = c.index_tt_b; P.tensors = (c.mode == CPT_MODE_TENSORS) ? 1 : 0;
   P.ct_tt = sp->index_ct_tt; P.ct_ee = sp->index_ct_ee; P.ct_te = sp->index_ct_te; P.ct_bb = sp->index_ct_bb;
   P.ct_pp = sp->index_ct_pp; P.ct_tp = sp->index_ct_tp; P.ct_ep = sp->index_ct_ep;
   hipLaunchKernelGGL(k_cl, dim3(nl), dim3(256), 0, h->stream, P);

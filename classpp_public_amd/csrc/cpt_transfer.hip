@@ -234,7 +234,8 @@ struct LosParams {
   unsigned long long* work;
   int nk, ntau, nq, nl, nx;
   double bes_xmin, bes_dx, bes_xmax;
-  int tts[5], tps[5];
+  int tts[5], tps[5];   // slots 0..3: scalars t0,t1,t2,e | tensors t2,e,b,-;  slot 4: lensing potential (scalars)
+  int tensors;          // radial functions of the tensor types (tm.cpp:3494-3529) in slots 0..2
   double dk[4];
   double tau0, tau_rec, ra_rec, t0mt_cut, late_l, l_switch_limber;
   double lcmb_fac_rescale, lcmb_tilt, lcmb_pivot;
@@ -409,7 +410,13 @@ __global__ void __launch_bounds__(256) k_los(LosParams P) {
         const double w = wt[i];
         const double ix = 1.0 / x;
         // radial functions, tm.cpp:3413-3445 with sqrt_absK_over_k = 1, s2 = 1
-        const double R[4] = {Phi, dPhi, 0.5 * (3. * d2Phi + Phi), fac_e * ix * ix * Phi};
+        double R[4] = {Phi, dPhi, 0.5 * (3. * d2Phi + Phi), fac_e * ix * ix * Phi};
+        if (P.tensors) {  // tm.cpp:3494-3529 with cscK = cotK = 1/chi, K = 0: tensor temperature, E and B polarisation
+          R[0] = fac_e * ix * ix * Phi;
+          R[1] = 0.25 * (d2Phi + 4.0 * ix * dPhi - (1.0 - 2.0 * ix * ix) * Phi);
+          R[2] = 0.5 * (dPhi + 2.0 * ix * Phi);
+          R[3] = 0.;
+        }
 #pragma unroll
         for (int t = 0; t < 4; t++) {
           if (i <= imax_t[t]) {
@@ -484,8 +491,13 @@ int cpt_transfer_impl(cpt_handle* h, const double* sources_dev, const double* k,
     if (!(q[i] > q[i - 1])) return cpt_fail(h, CPT_ERR_INVALID, "q grid must be strictly increasing");
   if (!(q[0] > 0.) || !(k[0] > 0.)) return cpt_fail(h, CPT_ERR_INVALID, "wavenumbers must be positive");
   if (!(tau[ntau - 1] <= c.tau0)) return cpt_fail(h, CPT_ERR_INVALID, "tau_sampling exceeds conformal age");
-  const int tts[5] = {c.index_tt_t0, c.index_tt_t1, c.index_tt_t2, c.index_tt_e, c.index_tt_lcmb};
-  const int tps[5] = {c.index_tp_t0, c.index_tp_t1, c.index_tp_t2, c.index_tp_p, c.index_tp_phi_plus_psi};
+  const bool tens = c.mode == CPT_MODE_TENSORS;
+  const int tts_s[5] = {c.index_tt_t0, c.index_tt_t1, c.index_tt_t2, c.index_tt_e, c.index_tt_lcmb};
+  const int tps_s[5] = {c.index_tp_t0, c.index_tp_t1, c.index_tp_t2, c.index_tp_p, c.index_tp_phi_plus_psi};
+  const int tts_t[5] = {c.index_tt_t2, c.index_tt_e, c.index_tt_b, -1, -1};   // tm.cpp:455-470: tensor types t2, e, b
+  const int tps_t[5] = {c.index_tp_t2, c.index_tp_p, c.index_tp_p, -1, -1};   // E and B both project the polarisation source
+  const int* tts = tens ? tts_t : tts_s;
+  const int* tps = tens ? tps_t : tps_s;
   for (int t = 0; t < 5; t++) {
     if (tts[t] >= c.tt_size) return cpt_fail(h, CPT_ERR_INVALID, "index_tt_* >= tt_size");
     if (tts[t] >= 0 && (tps[t] < 0 || tps[t] >= ntp))
@@ -565,8 +577,10 @@ int cpt_transfer_impl(cpt_handle* h, const double* sources_dev, const double* k,
   P.nk = nk; P.ntau = ntau; P.nq = nq; P.nl = nl; P.nx = h->bes_nx;
   P.bes_xmin = c.hyper_x_min; P.bes_dx = h->bes_dx; P.bes_xmax = bes_xmax;
   for (int t = 0; t < 5; t++) { P.tts[t] = tts[t]; P.tps[t] = tps[t] < 0 ? 0 : tps[t]; }
+  P.tensors = tens ? 1 : 0;
   P.dk[0] = c.transfer_neglect_delta_k_S_t0; P.dk[1] = c.transfer_neglect_delta_k_S_t1;
   P.dk[2] = c.transfer_neglect_delta_k_S_t2; P.dk[3] = c.transfer_neglect_delta_k_S_e;
+  if (tens) { P.dk[0] = c.transfer_neglect_delta_k_T_t2; P.dk[1] = c.transfer_neglect_delta_k_T_e; P.dk[2] = c.transfer_neglect_delta_k_T_b; P.dk[3] = 0.; }
   P.tau0 = c.tau0; P.tau_rec = c.tau_rec; P.ra_rec = (c.tau0 - c.tau_rec) * c.angular_rescaling;
   P.t0mt_cut = c.tau0 - c.tau_cut; P.late_l = c.transfer_neglect_late_source * c.angular_rescaling;
   P.l_switch_limber = c.l_switch_limber;

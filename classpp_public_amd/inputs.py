@@ -113,9 +113,9 @@ class Inputs:
         for f in ("tt", "ee", "te", "pp", "tp", "ep"):
             setattr(sp, "index_ct_" + f, int(_s(d, "sp.index_ct_" + f)) if ("sp.index_ct_" + f) in d else -1)
         used = {getattr(sp, "index_ct_" + f) for f in ("tt", "ee", "te", "pp", "tp", "ep")}
-        sp.index_ct_bb = -1
-        for i in range(sp.ct_size):  # the remaining slot of a scalar run is BB (identically zero)
-            if i not in used:
+        sp.index_ct_bb = int(_s(d, "sp.index_ct_bb")) if "sp.index_ct_bb" in d else -1
+        for i in range(sp.ct_size):  # older fixtures: the remaining slot of a scalar run is BB (identically zero)
+            if i not in used and sp.index_ct_bb < 0:
                 sp.index_ct_bb = i
         self.spectra = sp
 

@@ -14,7 +14,7 @@ from classpp_public_amd.inputs import Inputs
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("cfg", ["small", "lcdm", "explanatory", "iso_cdi", "iso_nid", "newt"])
+@pytest.mark.parametrize("cfg", ["small", "lcdm", "explanatory", "iso_cdi", "iso_nid", "newt", "tens"])
 def test_cl_and_pk_match_reference(cfg):
     from classpp_public_amd.backend import Backend
     inp = Inputs(cfg)
@@ -30,6 +30,7 @@ def test_cl_and_pk_match_reference(cfg):
     # sampling, 3x coarser k steps): there the reference moves its own C_l^TT by 7.9e-5 when its rtol is halved.
     tol = 1e-4 if cfg in ("lcdm", "explanatory") else 3e-4   # small and iso_* share the coarse precision file
     for name, idx, kind in (("tt", sp.index_ct_tt, "rel"), ("ee", sp.index_ct_ee, "rel"), ("pp", sp.index_ct_pp, "rel"),
+                            ("bb", sp.index_ct_bb if inp.config.mode == 1 else -1, "rel"),
                             ("te", sp.index_ct_te, "abs"), ("tp", sp.index_ct_tp, "abs"), ("ep", sp.index_ct_ep, "abs")):
         if idx < 0:
             continue
@@ -37,7 +38,7 @@ def test_cl_and_pk_match_reference(cfg):
         err = np.max(np.abs(a / b - 1)) if kind == "rel" else np.max(np.abs(a - b)) / np.max(np.abs(b))
         worst[name] = err
         assert err < tol, (name, err)
-    if sp.index_ct_bb >= 0:
+    if sp.index_ct_bb >= 0 and inp.config.mode == 0:
         assert np.all(cl[:, sp.index_ct_bb] == 0)
     # every integer l, as cl_output() returns them (spline in l: host post-processing, here via the checker)
     lmax = int(d["sp.l_max_tot"][0])

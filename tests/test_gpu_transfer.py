@@ -110,3 +110,21 @@ def test_transfer_full_size_vs_reference(cfg):
     ms, n = be.kernel_ms(1)
     print("\n[%s] LOS kernel %.3f ms, %d integrals, %d type-samples, %d fused samples" % (cfg, ms, ints, tsamp, fused))
     be.close()
+
+
+def test_tensor_transfer_vs_reference_and_oracle():
+    """tensor types t2, e, b (radial functions of tm.cpp:3494-3529) from the reference's own tensor sources"""
+    from classpp_public_amd.backend import Backend
+    inp = Inputs("tens")
+    be = Backend(inp)
+    src = inp.d["pt.sources"]
+    got = be.transfer(torch.from_numpy(src).cuda()).cpu().numpy()
+    ref = inp.d["tr.transfer"]
+    orc, work = oracle_lib.transfer(inp, src)
+    assert got.shape == ref.shape == (3, inp.l.size, inp.q.size)
+    assert np.array_equal(got == 0, ref == 0)
+    assert rel_to_rowmax(got, orc) < TOL
+    assert rel_to_rowmax(got, ref) < TOL
+    ints, tsamp, fused = be.transfer_work()
+    assert (ints, tsamp) == work
+    be.close()

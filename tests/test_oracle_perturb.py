@@ -61,3 +61,14 @@ def test_lookup_matches_table_nodes():
     out = oracle_lib.lookup(inp, t["bg.tau_table"][idx])
     assert np.allclose(out[:, 0], t["bg.background_table"][idx, int(t["bg.index_bg_a"][0])], rtol=1e-14)
     assert np.allclose(out[:, 1], t["bg.background_table"][idx, int(t["bg.index_bg_H"][0])], rtol=1e-14)
+
+
+def test_tensor_perturbations_all_modes():
+    """tensor modes (gw, tensor photon / ur ladders; pm.cpp:9045-9215) against the reference's tensor sources t2, p"""
+    inp = Inputs("tens")
+    src, stats, status, rc = oracle_lib.perturb(inp)
+    assert rc == 0 and not status.any()
+    ref = inp.d["pt.sources"]
+    for tp in (inp.config.index_tp_t2, inp.config.index_tp_p):
+        emax, erms = col_errors(src[tp], ref[tp])
+        assert emax < 2e-4 and erms < 5e-5, (tp, emax, erms)

@@ -6,8 +6,12 @@ import oracle_lib
 from classpp_public_amd.inputs import Inputs
 
 
-def test_cl_from_reference_transfer_small():
-    inp = Inputs("small")
+import pytest
+
+
+@pytest.mark.parametrize("cfg", ["small", "tens"])
+def test_cl_from_reference_transfer_small(cfg):
+    inp = Inputs(cfg)
     d = inp.d
     cl = oracle_lib.cl_table(inp, d["tr.transfer"])
     ref = d["sp.cl_table"]
@@ -19,7 +23,7 @@ def test_cl_from_reference_transfer_small():
     full = oracle_lib.cl_at_integer_l(inp, cl, lmax)
     sp = inp.spectra
     for name, idx in (("tt", sp.index_ct_tt), ("ee", sp.index_ct_ee), ("te", sp.index_ct_te), ("pp", sp.index_ct_pp),
-                      ("tp", sp.index_ct_tp), ("ep", sp.index_ct_ep)):
+                      ("tp", sp.index_ct_tp), ("ep", sp.index_ct_ep), ("bb", sp.index_ct_bb if inp.config.mode == 1 else -1)):
         if idx < 0:
             continue
         want = d["sp.cl_" + name]

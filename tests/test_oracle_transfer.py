@@ -15,8 +15,10 @@ def rel_to_rowmax(a, b):
     return np.max(np.abs(a - b) / scale)
 
 
-def test_transfer_small_full_table():
-    inp = Inputs("small")
+@pytest.mark.parametrize("cfg", ["small", "tens"])
+def test_transfer_small_full_table(cfg):
+    """scalar types t0,t1,t2,e,lcmb (small) and tensor types t2,e,b (tens: a tensors-only reference run)"""
+    inp = Inputs(cfg)
     got, work = oracle_lib.transfer(inp, inp.d["pt.sources"])
     ref = inp.d["tr.transfer"]
     assert got.shape == ref.shape
