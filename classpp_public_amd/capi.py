@@ -46,6 +46,8 @@ class CptConfig(C.Structure):
         ("ic", _i), ("entropy_ini", _d),
         ("mode", _i), ("l_max_g_ten", _i), ("l_max_pol_g_ten", _i), ("gw_ini", _d), ("evolve_tensor_ur", _i), ("index_tt_b", _i),
         ("transfer_neglect_delta_k_T_t2", _d), ("transfer_neglect_delta_k_T_e", _d), ("transfer_neglect_delta_k_T_b", _d),
+        ("hyper_sampling_curved_low_nu", _d), ("hyper_sampling_curved_high_nu", _d), ("hyper_nu_sampling_step", _d),
+        ("hyper_flat_approximation_nu", _d),
     ]
 
 

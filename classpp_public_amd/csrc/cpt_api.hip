@@ -172,7 +172,7 @@ void cpt_destroy(cpt_handle* h) {
   if (!h) return;
   // (d_splc and d_ik are interior pointers into d_k / d_q and must not be freed)
   void* ptrs[] = {h->d_tau_table, h->d_bg, h->d_z_table, h->d_th, h->d_src, h->d_dd, h->d_u, h->d_k, h->d_tau, h->d_q,
-                  h->d_l, h->d_bes, h->d_chi_min, h->d_work, h->d_pt_scratch, h->d_lens, h->d_lens_w, h->d_lens_l};
+                  h->d_l, h->d_bes, h->d_chi_min, h->d_work, h->d_pt_scratch, h->d_lens, h->d_lens_w, h->d_lens_l, h->d_his, h->d_his_trig, h->d_his_desc, h->d_kq};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   for (Timer* tm : {&h->t_perturb, &h->t_transfer}) {
@@ -200,9 +200,14 @@ int cpt_transfer_batch(cpt_handle* h, const double* sources_dev, const double* k
       k_size_cl > nk)
     return cpt_fail(h, CPT_ERR_INVALID, "bad arguments to cpt_transfer_batch");
   if (h->cfg.tt_size < 1 || h->cfg.tt_size > 5) return cpt_fail(h, CPT_ERR_INVALID, "tt_size=%d out of range", h->cfg.tt_size);
-  if (h->cfg.K != 0.)
-    return cpt_fail(h, CPT_ERR_UNSUPPORTED, "non-flat space (K=%g): the per-q hyperspherical Bessel tables of the transfer stage "
-                    "(hyperspherical.c:11-246 with nu = q/sqrt|K|) are not implemented yet; the perturbation stage is", h->cfg.K);
+  if (h->cfg.K < 0.)
+    return cpt_fail(h, CPT_ERR_UNSUPPORTED, "open space (K=%g): the l_max search of the per-q hyperspherical tables (WKB/Airy, "
+                    "tm.cpp:3823-3856) is not implemented; flat and closed space are", h->cfg.K);
+  if (h->cfg.K > 0. && h->cfg.mode == CPT_MODE_TENSORS)
+    return cpt_fail(h, CPT_ERR_UNSUPPORTED, "tensor transfer functions in closed space are not implemented");
+  if (h->cfg.K > 0. && sqrt(h->cfg.K) * h->cfg.tau0 >= 1.5707963267948966 - h->cfg.hyper_x_min)
+    return cpt_fail(h, CPT_ERR_UNSUPPORTED, "closed space with sqrt(K) tau0 >= pi/2: the folding of chi onto [0, pi/2] (ClosedModY, "
+                    "hyperspherical.c:1025-1052) is not implemented");
   return cpt_transfer_impl(h, sources_dev, k, nk, k_size_cl, tau_sampling, ntau, q, nq, l, nl, transfer_dev);
 }
 
@@ -211,7 +216,7 @@ int cpt_cl_batch(cpt_handle* h, const cpt_spectra_params* sp, const double* tran
   if (!h) return CPT_ERR_INVALID;
   h->err.clear();
   if (!sp || !transfer_dev || !q || !cl_dev || nq < 3 || nl < 1) return cpt_fail(h, CPT_ERR_INVALID, "bad arguments to cpt_cl_batch");
-  if (h->cfg.K != 0.) return cpt_fail(h, CPT_ERR_UNSUPPORTED, "non-flat space: the C_l integral over nu (spectra_module.cpp:1290-1323) is not implemented yet");
+  if (h->cfg.K < 0.) return cpt_fail(h, CPT_ERR_UNSUPPORTED, "open space is not implemented in the transfer / C_l stages");
   return cpt_cl_impl(h, sp, transfer_dev, q, nq, nl, cl_dev);
 }
 

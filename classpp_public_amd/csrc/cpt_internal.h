@@ -61,6 +61,13 @@ struct cpt_handle {
   double bes_dx = 0;
   unsigned long long* d_work = nullptr;  // [3] integrals, per-type samples, fused samples
   long long work_integrals = 0, work_samples = 0, work_fused = 0;
+  // closed space: per-q hyperspherical tables {Phi, Phi'}, their {sinK, cotK} nodes, descriptors, k(q) (cpt_transfer.hip)
+  double2 *d_his = nullptr, *d_his_trig = nullptr;
+  size_t his_cap = 0, his_trig_cap = 0;
+  void* d_his_desc = nullptr;
+  size_t his_desc_cap = 0;  // bytes
+  double* d_kq = nullptr;
+  size_t kq_cap = 0;
   // lensing: Wigner-d table cache [12][num_mu][lmax+1] + coefficient / angle / work arrays (cpt_lensing.hip)
   double* d_lens = nullptr;
   size_t lens_cap = 0;

@@ -70,7 +70,9 @@ __global__ void __launch_bounds__(256) k_cl(ClParams P) {
 //   u_0 = 3/h_0 ((y_1-y_0)/h_0 - y'_first);  u_i = (6 d_i/(x_{i+1}-x_{i-1}) - sig_i u_{i-1})/p_i,  d_i = second divided difference
 //   dd_{n-1} = (u_n - u_{n-2}/2)/(c_{n-2}/2 + 1);  dd_i = c_i dd_{i+1} + u_i;  I = sum_i (y_i+y_{i+1}) h_i/2 + (dd_i+dd_{i+1}) h_i^3/24
 // run here in reverse (adjoint) mode: O(n), exact up to the order of the floating-point additions.
-static void spline_integration_weights(const double* x, int n, double* W) {
+// Cells below istart are integrated with the trapezoidal rule only (array_integrate_all_trapzd_or_spline, arrays.c:1382-1423;
+// closed space, spectra_module.cpp:1293-1316), the spline itself is still built on all points.
+static void spline_integration_weights(const double* x, int n, int istart, double* W) {
   std::vector<double> c(n), sig(n), p(n), mu(n), nu(n);
   c[0] = -0.5; sig[0] = 0.; p[0] = 1.;
   for (int i = 1; i < n - 1; i++) {
@@ -84,8 +86,8 @@ static void spline_integration_weights(const double* x, int n, double* W) {
   // d I / d dd_i, including the chain dd_i -> dd_{i-1} -> ...
   for (int i = 0; i < n; i++) {
     double g = 0.;
-    if (i >= 1) g += h(i - 1) * h(i - 1) * h(i - 1) / 24.;
-    if (i <= n - 2) g += h(i) * h(i) * h(i) / 24.;
+    if (i >= 1 && i - 1 >= istart) g += h(i - 1) * h(i - 1) * h(i - 1) / 24.;
+    if (i <= n - 2 && i >= istart) g += h(i) * h(i) * h(i) / 24.;
     mu[i] = g + (i >= 1 ? c[i - 1] * mu[i - 1] : 0.);
   }
   const double D = 0.5 * c[n - 2] + 1.0;
@@ -150,12 +152,21 @@ int cpt_cl_impl(cpt_handle* h, const cpt_spectra_params* sp, const double* trans
   if (nq < 4) return cpt_fail(h, CPT_ERR_INVALID, "need at least 4 q values for the integrand spline");
   int rc;
   if ((rc = cpt_reserve(h, &h->d_q, &h->grid_cap_q, (size_t)4 * nq))) return rc;
-  std::vector<double> W(nq);
-  spline_integration_weights(q, nq, W.data());
+  std::vector<double> W(nq), kk(nq);
+  // integration variable k(q) = sqrt(q^2 - K(1+m)) (spectra_module.cpp:990-994); flat: k = q
+  for (int i = 0; i < nq; i++) kk[i] = (c.K == 0.) ? q[i] : sqrt(q[i] * q[i] - c.K * (tens ? 3. : 1.));
+  int index_q_spline = 0;
+  if (c.K > 0.) {  // closed: trapezoidal rule where nu is integer (below the flat-approximation index), spectra_module.cpp:1293-1316
+    const double q_approximation = c.hyper_flat_approximation_nu * sqrt(c.K);
+    for (index_q_spline = 0; index_q_spline < nq - 1; index_q_spline++)
+      if (q[index_q_spline] > q_approximation) break;
+  }
+  spline_integration_weights(kk.data(), nq, index_q_spline, W.data());
+  if (c.K > 0.) W[0] += q[0] / kk[0] * sqrt(c.K) / 2.;   // discrete sum over nu: weight of the first point, spectra_module.cpp:1319-1321
   const double PI = 3.1415926535897932384626433832795e0;
   for (int i = 0; i < nq; i++) {  // primordial_module.cpp:911-925 (analytic spectrum) and the 4 pi / k of the measure
-    const double lk = log(q[i] / sp->k_pivot);
-    W[i] *= sp->A_s * exp((sp->n_s - 1.) * lk + 0.5 * sp->alpha_s * lk * lk) * (4. * PI / q[i]);
+    const double lk = log(kk[i] / sp->k_pivot);
+    W[i] *= sp->A_s * exp((sp->n_s - 1.) * lk + 0.5 * sp->alpha_s * lk * lk) * (4. * PI / kk[i]);
   }
   CPT_HIP(h, hipMemcpyAsync(h->d_q, W.data(), (size_t)nq * sizeof(double), hipMemcpyHostToDevice, h->stream));
   ClParams P;

@@ -476,6 +476,417 @@ __global__ void __launch_bounds__(256) k_los(LosParams P) {
   }
 }
 
+// =============================================================================================
+// Closed space (K > 0): every q below the flat-approximation threshold has its own table of hyperspherical Bessel
+// functions Phi_l^nu(chi), nu = q/sqrt(K) integer (transfer_update_HIS, tm.cpp:3777-3887 -> hyperspherical_HIS_create,
+// hyperspherical.c:11-246).  The reference builds and frees one table per q task; here ALL tables are built by one
+// launch (one thread per (q, x_j), recurrence over l in registers, only the listed l stored) into one HBM buffer
+// - sum_q nl(q) nx(q) 16 B, ~2 GB for the default-precision config - and the LOS kernel of that q reads its slice.
+// =============================================================================================
+struct HisDesc {
+  double nu, dx;
+  int nl, nx, xfwdidx, L, special;  // special: nu == lmax+1, Phi_{lmax+1} := 0 (hyperspherical.c:146-155)
+  unsigned long long off, trig_off; // offsets (in double2) of the table [nl][nx] {Phi, Phi'} and of {sinK, cotK}[nx]
+};
+
+// Lentz continued fraction for Phi_l'/Phi_l, K = 1 (hyperspherical.c:677-716); false if not converged
+__device__ static inline bool cf1_closed(int l, double beta, double cotK, double* CF) {
+  const double tiny = 1e-100, reltol = 2.220446049250313e-16, beta2 = beta * beta;
+  const int maxiter = (int)(beta - l - 10);
+  double bj = l * cotK, fj = bj, Cj = bj, Dj = 0.0;
+  for (int j = 1; j <= maxiter; j++) {
+    const double sqrttmp = sqrt(beta2 - (l + j + 1.) * (l + j + 1.));
+    double aj = -sqrt(beta2 - (double)(l + j) * (l + j)) / sqrttmp;
+    if (j == 1) aj = sqrt(beta2 - (l + 1.) * (l + 1.)) * aj;
+    bj = (2 * (l + j) + 1) / sqrttmp * cotK;
+    Dj = bj + aj * Dj;
+    if (Dj == 0.0) Dj = tiny;
+    Cj = bj + aj / Cj;
+    if (Cj == 0.0) Cj = tiny;
+    Dj = 1.0 / Dj;
+    const double Delj = Cj * Dj;
+    fj = fj * Delj;
+    if (fabs(Delj - 1.0) < reltol) { *CF = fj; return true; }
+  }
+  return false;
+}
+
+// Phi_l'/Phi_l from the Gegenbauer polynomial C_n^{l+1}(cos chi), n = nu - l - 1 (hyperspherical.c:718-780)
+__device__ static inline void cf1_gegenbauer(int l, int beta, double sinK, double cotK, double* CF) {
+  const int n = beta - l - 1;
+  const double alpha = l + 1, x = sinK * cotK;
+  double G, dG;
+  if (n <= 0) { G = 1; dG = 0; }
+  else if (n == 1) { G = 2 * alpha * x; dG = 2 * alpha; }
+  else if (n == 2) { G = -alpha + 2 * alpha * (1 + alpha) * x * x; dG = 4 * x * alpha * (1 + alpha); }
+  else if (n == 3) {
+    G = -2 * alpha * (1 + alpha) * x + 4.0 / 3.0 * alpha * (1 + alpha) * (2 + alpha) * x * x * x;
+    dG = 2 * alpha * (1 + alpha) * (2 * (2 + alpha) * x * x - 1);
+  } else {
+    G = 0.0;
+    double Gkm2 = -alpha + 2 * alpha * (1 + alpha) * x * x;
+    double Gkm1 = -2 * alpha * (1 + alpha) * x + 4.0 / 3.0 * alpha * (1 + alpha) * (2 + alpha) * x * x * x;
+    for (int k = 4; k <= n; k++) {
+      G = (2 * (k + alpha - 1) * x * Gkm1 - (k + 2 * alpha - 2) * Gkm2) / k;
+      if (fabs(G) > 1e200) { Gkm2 = Gkm1 / 1e200; G = G / 1e200; Gkm1 = G; }
+      else { Gkm2 = Gkm1; Gkm1 = G; }
+    }
+    dG = (-n * x * G + (n + 2 * alpha - 1) * Gkm2) / (1.0 - x * x);
+  }
+  *CF = l * cotK - sinK * dG / G;
+}
+
+// one thread per (own-table q, abscissa x_j): blockIdx.y = q index, blockIdx.x * 64 + lane = j
+__global__ void __launch_bounds__(64) k_his_closed(const HisDesc* __restrict__ desc, const int* __restrict__ lvec, double xmin,
+                                                   double2* __restrict__ tab, double2* __restrict__ trig) {
+  const HisDesc D = desc[blockIdx.y];
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= D.nx || D.nl <= 0) return;
+  const int nl = D.nl, nx = D.nx, L = D.L;
+  const double beta = D.nu, beta2 = beta * beta;
+  const double x = xmin + j * D.dx;
+  const double sinK = sin(x), cotK = 1.0 / tan(x);
+  trig[D.trig_off + j] = make_double2(sinK, cotK);
+  double2* out = tab + D.off;
+  auto sk = [&](int l) { return sqrt(beta2 - (double)l * l); };   // sqrtK[l], hyperspherical.c:104-107
+  if (j >= D.xfwdidx) {
+    // forward recurrence, hyperspherical.c:472-514
+    double pm = sin(beta * x) / (beta * sinK);                                 // P[0]
+    double pc = pm * (cotK - beta / tan(beta * x)) / sk(1);                    // P[1]
+    int kk = 0;
+    while (kk < nl && lvec[kk] == 0) { out[(size_t)kk * nx + j] = make_double2(pm, -sk(1) * pc); kk++; }
+    for (int l = 1; l <= L; l++) {
+      // P[l+1] exists up to l+1 = L; beyond (the special case l = L = lmax) it is 0 by definition
+      const double s1 = (l < L) ? sk(l + 1) : 0.;
+      const double pn = (l < L) ? ((2 * l + 1) * cotK * pc - pm * sk(l)) / s1 : 0.;
+      if (kk < nl && lvec[kk] == l) { out[(size_t)kk * nx + j] = make_double2(pc, l * cotK * pc - s1 * pn); kk++; }
+      pm = pc; pc = pn;
+    }
+    return;
+  }
+  // backward recurrence, hyperspherical.c:517-603 (closed: phi1 = 1, no sign bookkeeping)
+  const double phi0 = sin(beta * x) / (beta * sinK);
+  double phipr1 = 0.;
+  bool ok = false;
+  if (beta > 1.5 * L) ok = cf1_closed(L, beta, cotK, &phipr1);
+  if (!ok) cf1_gegenbauer(L, (int)(beta + 0.2), sinK, cotK, &phipr1);
+  const int l_align = L - L % 8;
+  int n_rescale_total = 0;
+  double scaling = 0.;
+  for (int pass = 0; pass < 2; pass++) {
+    double phi = 1.0, ppts = L * cotK * 1.0 - phipr1;  // P[l], sqrtK[l+1] P[l+1]
+    int kk = nl - 1, n_done = 0;
+    auto emit = [&](int l) {  // P[l] = phi, sqrtK[l+1] P[l+1] = ppts, as they stand now
+      if (pass == 1 && kk >= 0 && lvec[kk] == l) {
+        double v = phi, vp = ppts;
+        const int later = n_rescale_total - n_done;
+        for (int r = 0; r < later && r < 8; r++) { v *= 1e-200; vp *= 1e-200; }
+        if (later >= 8) { v = 0.; vp = 0.; }
+        v *= scaling; vp *= scaling;
+        out[(size_t)kk * nx + j] = make_double2(v, l * cotK * v - vp);
+        kk--;
+      }
+    };
+    if (D.special) { const double keep = ppts; ppts = 0.; emit(L); ppts = keep; }   // l = lmax = L is in the list, Phi_{L+1} := 0
+    int l = L;
+    for (; l > l_align; l--) {
+      const double pmv = ((2 * l + 1) * cotK * phi - ppts) / sk(l);
+      ppts = phi * sk(l);
+      phi = pmv;
+      emit(l - 1);
+    }
+    for (int l_ini = l_align; l_ini > 0; l_ini -= 8) {
+      for (l = l_ini; l > l_ini - 8; l--) {
+        const double pmv = ((2 * l + 1) * cotK * phi - ppts) / sk(l);
+        ppts = phi * sk(l);
+        phi = pmv;
+        emit(l - 1);
+      }
+      if (fabs(phi) > 1e200) { phi *= 1e-200; ppts *= 1e-200; n_done++; }
+    }
+    if (pass == 0) { n_rescale_total = n_done; scaling = phi0 / phi; }
+  }
+}
+
+struct LosClosedParams {
+  LosParams b;               // everything of the flat kernel (the flat table serves q >= index_q_flat)
+  const double* kq;          // k(q) = sqrt(q^2 - K), tm.cpp:1106-1167
+  const HisDesc* desc;       // [index_q_flat]
+  const double2* his;        // per-q tables
+  const double2* trig;       // per-q {sinK, cotK} at the table nodes
+  double K, sqrtK, his_xmin, phiminabs;
+  int index_q_flat;
+};
+
+// Hermite interpolation of order 6 on a per-q table (hermite6_interpolation_csource.h), stateless per sample
+__device__ static inline void hermite6_closed(const double2* __restrict__ tl, const double2* __restrict__ tg, int nx, double xmin, double dx,
+                                              double beta, double lxlp1, double x, double* Phi, double* dPhi, double* d2Phi) {
+  const double xmax = xmin + (nx - 1) * dx;
+  if (x < xmin || x > xmax) { *Phi = *dPhi = *d2Phi = 0.; return; }
+  int idx = (int)((x - xmin) / dx) + 1;
+  idx = idx < 1 ? 1 : idx;
+  idx = idx > nx - 1 ? nx - 1 : idx;
+  const double KmB2 = 1.0 - beta * beta, dx2 = dx * dx;
+  double y[2], dy[2], d2y[2], d3y[2], d4y[2];
+#pragma unroll
+  for (int s = 0; s < 2; s++) {
+    const double2 v = tl[idx - 1 + s], g = tg[idx - 1 + s];
+    const double cot = g.y, is2 = 1.0 / (g.x * g.x);
+    y[s] = v.x; dy[s] = v.y;
+    d2y[s] = -2 * dy[s] * cot + y[s] * (lxlp1 * is2 + KmB2);
+    d3y[s] = -2 * cot * d2y[s] - 2 * y[s] * lxlp1 * cot * is2 + dy[s] * (KmB2 + (2 + lxlp1) * is2);
+    d4y[s] = -2 * cot * d3y[s] + d2y[s] * (KmB2 + (4 + lxlp1) * is2) + dy[s] * (-4 * (1 + lxlp1) * cot * is2) +
+             y[s] * (2 * lxlp1 * is2 * (2 * cot * cot + is2));
+  }
+  const double ym = y[0], yp = y[1], dym = dy[0], dyp = dy[1], d2ym = d2y[0], d2yp = d2y[1], d3ym = d3y[0], d3yp = d3y[1],
+               d4ym = d4y[0], d4yp = d4y[1];
+  const double a1 = dym * dx, a2 = 0.5 * d2ym * dx2, a3 = (-1.5 * d2ym + 0.5 * d2yp) * dx2 - (6 * dym + 4 * dyp) * dx - 10 * (ym - yp),
+               a4 = (1.5 * d2ym - d2yp) * dx2 + (8 * dym + 7 * dyp) * dx + 15 * (ym - yp),
+               a5 = (-0.5 * d2ym + 0.5 * d2yp) * dx2 - 3 * (dym + dyp) * dx - 6 * (ym - yp);
+  const double b1 = d2ym * dx, b2 = 0.5 * d3ym * dx2, b3 = (-1.5 * d3ym + 0.5 * d3yp) * dx2 - (6 * d2ym + 4 * d2yp) * dx - 10 * (dym - dyp),
+               b4 = (1.5 * d3ym - d3yp) * dx2 + (8 * d2ym + 7 * d2yp) * dx + 15 * (dym - dyp),
+               b5 = (-0.5 * d3ym + 0.5 * d3yp) * dx2 - 3 * (d2ym + d2yp) * dx - 6 * (dym - dyp);
+  const double c1 = d3ym * dx, c2 = 0.5 * d4ym * dx2, c3 = (-1.5 * d4ym + 0.5 * d4yp) * dx2 - (6 * d3ym + 4 * d3yp) * dx - 10 * (d2ym - d2yp),
+               c4 = (1.5 * d4ym - d4yp) * dx2 + (8 * d3ym + 7 * d3yp) * dx + 15 * (d2ym - d2yp),
+               c5 = (-0.5 * d4ym + 0.5 * d4yp) * dx2 - 3 * (d3ym + d3yp) * dx - 6 * (d2ym - d2yp);
+  const double z = (x - (xmin + (idx - 1) * dx)) / dx, z2 = z * z, z3 = z2 * z, z4 = z2 * z2, z5 = z2 * z3;
+  *Phi = ym + a1 * z + a2 * z2 + a3 * z3 + a4 * z4 + a5 * z5;
+  *dPhi = dym + b1 * z + b2 * z2 + b3 * z3 + b4 * z4 + b5 * z5;
+  *d2Phi = d2ym + c1 * z + c2 * z2 + c3 * z3 + c4 * z4 + c5 * z5;
+}
+
+// Hermite-4 on the flat table (same arithmetic as in k_los)
+__device__ static inline void hermite4_flat(const double2* __restrict__ bl, int nx, double xmin, double dx, double xmax, double lxlp1, double x,
+                                            double* Phi, double* dPhi, double* d2Phi) {
+  *Phi = *dPhi = *d2Phi = 0.;
+  if (!(x >= xmin && x <= xmax)) return;
+  int idx = (int)((x - xmin) / dx) + 1;
+  idx = idx < 1 ? 1 : idx;
+  idx = idx > nx - 1 ? nx - 1 : idx;
+  const double2 vm = bl[idx - 1], vp = bl[idx];
+  const double xm = xmin + (idx - 1) * dx, xp = xmin + idx * dx;
+  const double ym = vm.x, dym = vm.y, yp = vp.x, dyp = vp.y;
+  const double cotm = 1.0 / xm, cotp = 1.0 / xp, ism2 = cotm * cotm, isp2 = cotp * cotp;
+  const double d2ym = -2 * dym * cotm + ym * (lxlp1 * ism2 - 1.0), d2yp = -2 * dyp * cotp + yp * (lxlp1 * isp2 - 1.0);
+  const double d3ym = -2 * cotm * d2ym - 2 * ym * lxlp1 * cotm * ism2 + dym * (-1.0 + (2 + lxlp1) * ism2);
+  const double d3yp = -2 * cotp * d2yp - 2 * yp * lxlp1 * cotp * isp2 + dyp * (-1.0 + (2 + lxlp1) * isp2);
+  const double a0 = dym * dx, a1 = -2 * dym * dx - dyp * dx - 3 * ym + 3 * yp, a2 = dym * dx + dyp * dx + 2 * ym - 2 * yp;
+  const double b0 = d2ym * dx, b1 = -2 * d2ym * dx - d2yp * dx - 3 * dym + 3 * dyp, b2 = d2ym * dx + d2yp * dx + 2 * dym - 2 * dyp;
+  const double c0 = d3ym * dx, c1 = -2 * d3ym * dx - d3yp * dx - 3 * d2ym + 3 * d2yp, c2 = d3ym * dx + d3yp * dx + 2 * d2ym - 2 * d2yp;
+  const double z = (x - xm) / dx, z2 = z * z, z3 = z2 * z;
+  *Phi = ym + a0 * z + a1 * z2 + a2 * z3;
+  *dPhi = dym + b0 * z + b1 * z2 + b2 * z3;
+  *d2Phi = d2ym + c0 * z + c1 * z2 + c2 * z3;
+}
+
+// hyperspherical_get_xmin_from_approx, K = 1 (hyperspherical.c:1419-1450)
+__device__ static inline double xmin_from_approx_closed(double l, double nu, double phiminabs) {
+  const double lph = l + 0.5, lhs = 1.0 / lph * log(2 * phiminabs * lph);
+  const double alpha = -2.0 * lhs / 5.0 * (1.0 + 2.0 * cosh(1.0 / 3.0 * acosh(1.0 + 375.0 / (16.0 * lhs * lhs))));
+  return lph / cosh(alpha) / nu * asin(l / nu) / (l / nu);
+}
+
+// LOS kernel for closed space, scalar types (transfer_compute_for_each_q tm.cpp:1488-1715 with the sgnK = 1 branches of
+// transfer_radial_coordinates :1717-1749, transfer_radial_function :3274-3445, transfer_sources :1905-1964,
+// transfer_integrate :2762-2792, transfer_limber :2930-2968).  Same organisation as k_los: one workgroup per q, sources
+// in LDS, waves pull multipoles from an LDS queue, the CMB types share one interpolation of Phi_l.
+__global__ void __launch_bounds__(256) k_los_closed(LosClosedParams C) {
+  const LosParams& P = C.b;
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  const int ntau = P.ntau, nl = P.nl, nq = P.nq;
+  double* t0mt = lds;
+  double* wt = lds + ntau;
+  double* S = lds + 2 * ntau;        // [5][ntau]
+  double* csc2 = lds + 7 * ntau;     // [ntau] cscK_gen^2 = K / k^2 / sin^2(chi)
+  int& next_l = *(int*)(lds + 8 * ntau);
+
+  const int iq = nq - 1 - blockIdx.x;
+  const double q = P.q[iq], k = C.kq[iq], sqrtK = C.sqrtK, K = C.K;
+  const int ik = P.ik[iq];
+  const int tid = threadIdx.x;
+  if (ik < 0) {
+    for (int e = tid; e < 5 * nl; e += blockDim.x) {
+      int t = e / nl, il = e - t * nl;
+      if (P.tts[t] >= 0) P.out[((size_t)P.tts[t] * nl + il) * nq + iq] = 0.;
+    }
+    return;
+  }
+  const bool own = iq < C.index_q_flat;
+  const double nu = own ? (double)(int)(q / sqrtK + 0.2) : q / sqrtK;   // tm.cpp:3796-3804 / :3331
+  const int nu_int = (int)(q / sqrtK + 0.2);                            // tm.cpp:1636: transfer functions exist for l < nu only
+  HisDesc D;
+  D.nl = 0; D.nx = 0; D.dx = 1.; D.off = 0; D.trig_off = 0;
+  if (own) D = C.desc[iq];
+
+  const double k_lo = P.k[ik], k_hi = P.k[ik + 1], h = k_hi - k_lo;
+  const double b = (k - k_lo) / h, a = 1. - b;
+  const double ca = (a * a * a - a), cb = (b * b * b - b), h2 = h * h / 6.0;
+  const double lfac = (P.tts[4] >= 0) ? P.lcmb_fac_rescale * pow(k / P.lcmb_pivot, P.lcmb_tilt) : 0.;
+  if (tid == 0) next_l = 0;
+  for (int i = tid; i < ntau; i += blockDim.x) {
+    const double tau = P.tau[i], tm = P.tau0 - tau;
+    t0mt[i] = tm;
+    double w;
+    if (i == 0) w = 0.5 * (tm - (P.tau0 - P.tau[1]));
+    else if (i == ntau - 1) w = 0.5 * ((P.tau0 - P.tau[ntau - 2]) - tm);
+    else w = 0.5 * ((P.tau0 - P.tau[i - 1]) - (P.tau0 - P.tau[i + 1]));
+    wt[i] = w;
+    const double sc = sqrtK / k / sin(sqrtK * tm);
+    csc2[i] = sc * sc;
+#pragma unroll
+    for (int t = 0; t < 5; t++) {
+      double v = 0.;
+      if (P.tts[t] >= 0) {
+        const size_t o = ((size_t)P.tps[t] * P.nk + ik) * ntau + i;
+        v = a * P.src[o] + b * P.src[o + ntau] + (ca * P.dd[o] + cb * P.dd[o + ntau]) * h2;
+        if (t == 4) {
+          double resc = 0.;   // tm.cpp:1926-1932
+          if (!(i == ntau - 1 || i < P.imin_lcmb))
+            resc = sqrtK * sin((P.tau_rec - tau) * sqrtK) / sin((P.tau0 - tau) * sqrtK) / sin((P.tau0 - P.tau_rec) * sqrtK);
+          v = v * resc * lfac;
+        }
+      }
+      S[t * ntau + i] = v;
+    }
+  }
+  __syncthreads();
+
+  const int lane = tid & 63;
+  unsigned long long n_int = 0, n_samp = 0, n_fused = 0;
+  const double* S_l = S + 4 * ntau;
+  const int imin = P.imin_lcmb;
+  const int tsz_l = ntau - imin;
+  const double sqrt_absK_over_k = sqrtK / k, absK_over_k2 = sqrt_absK_over_k * sqrt_absK_over_k;
+  const double s2 = sqrt(1.0 - 3.0 * K / (k * k));
+
+  for (;;) {
+    int il = 0;
+    if (lane == 0) il = atomicAdd(&next_l, 1);
+    il = __shfl(il, 0, 64);
+    if (il >= nl) break;
+    const int li = P.l[il];
+    const double l = (double)li;
+    double acc[5] = {0., 0., 0., 0., 0.};
+    int imax_t[5] = {-1, -1, -1, -1, -1};
+    bool trunc_t[5] = {false, false, false, false, false};
+    int imax_all = -1;
+    bool lcmb_limber = false;
+    // closed space: l < nu, and (own table) l within the list the table was built for (tm.cpp:1636-1643)
+    const bool exists = (li < nu_int) && (!own || il < D.nl);
+    double tmin_bessel = 0.;
+    // flat rescaling approximation of this (q, l): tm.cpp:3329-3342
+    double rescale_argument = 1., rescale_amplitude = 1., chi_tp = 0., at = 0.;
+    if (exists) {
+      if (own) tmin_bessel = xmin_from_approx_closed(l, nu, C.phiminabs) / sqrtK;
+      else {
+        chi_tp = asin(sqrt(l * (l + 1.)) / nu);
+        tmin_bessel = P.chi_min[il] / sqrtK * chi_tp / sqrt(l * (l + 1.));   // tm.cpp:2781-2786 (asin(sqrt(l(l+1)) sqrtK / q))
+        rescale_argument = sqrt(l * (l + 1.)) / chi_tp;
+        rescale_amplitude = pow(1. - K * l * (l + 1.) / q / q, -1. / 12.);
+        at = atan(l / nu);
+      }
+      const bool late = l > P.late_l;
+      const int imax_b = (tmin_bessel >= t0mt[0]) ? -1 : last_ge(t0mt, 0, ntau - 1, tmin_bessel);
+#pragma unroll
+      for (int t = 0; t < 4; t++) {
+        if (P.tts[t] < 0) continue;
+        if (l < (q - P.dk[t]) * P.ra_rec) continue;     // tm.cpp:3187-3196, called with q (tm.cpp:1626)
+        if (imax_b < 0) continue;
+        int im = imax_b;
+        const double* St = S + t * ntau;
+        while (im >= 0 && St[im] == 0.) im--;
+        if (im >= 0 && late && t != 0) im = (P.i_cut < im) ? P.i_cut : im;
+        if (im < 0) continue;
+        imax_t[t] = im;
+        trunc_t[t] = (im != ntau - 1) && (im == imax_b);
+        imax_all = im > imax_all ? im : imax_all;
+      }
+      if (P.tts[4] >= 0) {
+        if (l > P.l_switch_limber) lcmb_limber = true;
+        else if (tmin_bessel < t0mt[imin]) {
+          const int imb = last_ge(t0mt, imin, ntau - 1, tmin_bessel);
+          int im = imb;
+          while (im >= imin && S_l[im] == 0.) im--;
+          if (im >= imin) {
+            imax_t[4] = im;
+            trunc_t[4] = (im != ntau - 1) && (im == imb);
+            imax_all = im > imax_all ? im : imax_all;
+          }
+        }
+      }
+    }
+    if (imax_all >= 0) {
+      const double lxlp1 = l * (l + 1.0);
+      const double fac_e = sqrt(3.0 / 8.0 * (l + 2.0) * (l + 1.0) * l * (l - 1.0)) / s2;
+      const double2* tl = own ? C.his + D.off + (size_t)il * D.nx : P.bes + (size_t)il * P.nx;
+      const double2* tg = C.trig + D.trig_off;
+      for (int i = lane; i <= imax_all; i += 64) {
+        const double tm = t0mt[i];
+        const double chi0 = sqrtK * tm;            // tm.cpp:1724
+        double Phi, dPhi, d2Phi, rf = 1.;
+        if (own) hermite6_closed(tl, tg, D.nx, C.his_xmin, D.dx, nu, lxlp1, chi0, &Phi, &dPhi, &d2Phi);
+        else {
+          hermite4_flat(tl, P.nx, P.bes_xmin, P.bes_dx, P.bes_xmax, lxlp1, chi0 * rescale_argument, &Phi, &dPhi, &d2Phi);
+          const double dxx = at * (chi0 - chi_tp);  // tm.cpp:3375-3383
+          rf = fmin(rescale_amplitude * (1 + 0.34 * dxx + 2.00 * dxx * dxx), chi0 / sin(chi0));
+        }
+        const double w = wt[i];
+        const double R[4] = {Phi * rf, sqrt_absK_over_k * dPhi * rescale_argument * rf,
+                             1.0 / (2.0 * s2) * (3 * absK_over_k2 * d2Phi * rescale_argument * rescale_argument + Phi) * rf,
+                             fac_e * csc2[i] * Phi * rf};
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+          if (i <= imax_t[t]) {
+            const double s = S[t * ntau + i];
+            double term = s * R[t] * w;
+            if (trunc_t[t] && i == imax_t[t]) term -= 0.5 * (t0mt[i + 1] - tmin_bessel) * R[t] * s;
+            acc[t] += term;
+          }
+        }
+        if (i >= imin && i <= imax_t[4]) {
+          const double s = S_l[i];
+          const double wl = (i == imin) ? 0.5 * (tm - t0mt[i + 1]) : w;
+          double term = s * R[0] * wl;
+          if (trunc_t[4] && i == imax_t[4]) term -= 0.5 * (t0mt[i + 1] - tmin_bessel) * R[0] * s;
+          acc[4] += term;
+        }
+      }
+#pragma unroll
+      for (int t = 0; t < 5; t++) acc[t] = wave_sum(acc[t]);
+    }
+    if (lane == 0) {
+      if (lcmb_limber) {  // tm.cpp:2930-2968, closed
+        double res = 0.;
+        const double tl = asin(sqrt(l * (l + 1.)) / q * sqrtK) / sqrtK;
+        if (!(tl > t0mt[imin] || tl < t0mt[ntau - 1])) {
+          int j = last_ge(t0mt, imin, ntau - 1, tl) - imin;
+          int it = j + 1;
+          if (j >= 0 && t0mt[imin + j] == tl) it = j;
+          if (it < 1) it = 1;
+          if (it > tsz_l - 2) it = tsz_l - 2;
+          const int o = imin + it;
+          const double y3 = (it < tsz_l - 2) ? S_l[o + 1] * t0mt[o + 1] : S_l[o] * t0mt[o];
+          const double Sv = parabola(t0mt[o - 1], t0mt[o], t0mt[o + 1], tl, S_l[o - 1] * t0mt[o - 1], S_l[o] * t0mt[o], y3);
+          const double IPhiFlat = sqrt(3.1415926535897932384626433832795 / (2. * l)) * (1. - 0.25 / l + 1. / 32. / (l * l));
+          res = IPhiFlat * Sv * pow(1. - K * l * l / q / q, -1. / 4.) / (tl * q);
+        }
+        acc[4] = res;
+      }
+#pragma unroll
+      for (int t = 0; t < 5; t++)
+        if (P.tts[t] >= 0) P.out[((size_t)P.tts[t] * nl + il) * nq + iq] = acc[t];
+      for (int t = 0; t < 5; t++)
+        if (imax_t[t] >= 0) { n_int++; n_samp += (t == 4) ? (imax_t[t] - imin + 1) : (imax_t[t] + 1); }
+      if (imax_all >= 0) n_fused += imax_all + 1;
+    }
+  }
+  if (lane == 0 && P.work) {
+    atomicAdd(&P.work[0], n_int);
+    atomicAdd(&P.work[1], n_samp);
+    atomicAdd(&P.work[2], n_fused);
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 int cpt_transfer_impl(cpt_handle* h, const double* sources_dev, const double* k, int nk, int k_size_cl,
                       const double* tau, int ntau, const double* q, int nq, const int* l, int nl, double* transfer_dev) {
@@ -506,7 +917,7 @@ int cpt_transfer_impl(cpt_handle* h, const double* sources_dev, const double* k,
   if (!sources_dev && (!h->d_src || h->src_nk != nk || h->src_ntau != ntau))
     return cpt_fail(h, CPT_ERR_INVALID, "sources_dev is NULL and the handle holds no resident sources of shape [%d][%d][%d]",
                     ntp, nk, ntau);
-  size_t lds_bytes = (size_t)7 * ntau * sizeof(double) + 16;
+  size_t lds_bytes = (size_t)(c.K > 0. ? 8 : 7) * ntau * sizeof(double) + 16;
   if (lds_bytes > 160 * 1024 - 256) return cpt_fail(h, CPT_ERR_UNSUPPORTED, "ntau=%d too large for the LDS staging (160 KB/CU)", ntau);
 
   const size_t nsrc = (size_t)ntp * nk * ntau;
@@ -521,7 +932,7 @@ int cpt_transfer_impl(cpt_handle* h, const double* sources_dev, const double* k,
   const double xmax = q[nq - 1] * c.tau0;
   if ((rc = cpt_bessel_build(h, l, nl, xmax))) return rc;
   const double bes_xmax = c.hyper_x_min + (h->bes_nx - 1) * h->bes_dx;
-  if (q[nq - 1] > bes_xmax / (c.tau0 - tau[0]))
+  if (c.K == 0. && q[nq - 1] > bes_xmax / (c.tau0 - tau[0]))
     return cpt_fail(h, CPT_ERR_RUNTIME, "q_max exceeds q_max_bessel (tm.cpp:1660): Limber fallback for CMB types not implemented");
 
   // ---- host prep: spline elimination factors of the k grid, bracketing indices ----
@@ -537,13 +948,52 @@ int cpt_transfer_impl(cpt_handle* h, const double* sources_dev, const double* k,
     cc[i] = (sg[i] - 1.0) / pp[i];
   }
   cc[nk - 1] = 0.; sg[nk - 1] = 0.; pp[nk - 1] = 1.;
+  const bool closed = c.K > 0.;
+  std::vector<double> kq(nq);  // k(q) = sqrt(q^2 - K(1+m)), tm.cpp:1106-1167 (scalars: m = 0); flat: k = q
+  for (int i = 0; i < nq; i++) kq[i] = closed ? sqrt(q[i] * q[i] - c.K) : q[i];
   std::vector<int> ik(nq);
   {
     int j = 0;  // tm.cpp:1794-1802 (q ascending -> resume the scan)
     for (int i = 0; i < nq; i++) {
-      if (!(q[i] <= k[k_size_cl - 1])) { ik[i] = -1; continue; }
-      while ((j + 1) < nk && k[j + 1] < q[i]) j++;
+      if (!(kq[i] <= k[k_size_cl - 1])) { ik[i] = -1; continue; }
+      while ((j + 1) < nk && k[j + 1] < kq[i]) j++;
       ik[i] = (j + 1 < nk) ? j : nk - 2;
+    }
+  }
+  // ---- closed space: one hyperspherical table per q below the flat-approximation threshold (tm.cpp:3777-3887, 1081-1088) ----
+  int index_q_flat = 0, his_max_nx = 0;
+  std::vector<HisDesc> desc;
+  size_t his_total = 0, trig_total = 0;
+  if (closed) {
+    const double sqrtK = sqrt(c.K), PI = 3.1415926535897932384626433832795;
+    const double q_approximation = c.hyper_flat_approximation_nu * sqrtK;
+    for (index_q_flat = 0; index_q_flat < nq - 1; index_q_flat++)
+      if (q[index_q_flat] > q_approximation) break;
+    desc.resize(index_q_flat);
+    const double xmin = c.hyper_x_min, xmax = std::min(sqrtK * c.tau0, PI / 2.0 - xmin);
+    for (int i = 0; i < index_q_flat; i++) {
+      HisDesc& D = desc[i];
+      const double nu = (double)(int)(q[i] / sqrtK + 0.2);
+      if (q[i] / sqrtK - nu > 1.e-6)
+        return cpt_fail(h, CPT_ERR_INVALID, "problem in q list definition in closed case for index_q=%d, nu=%e (tm.cpp:3800-3803)", i, q[i] / sqrtK);
+      int nlq = nl;
+      while (nlq > 0 && (double)l[nlq - 1] >= nu) nlq--;
+      const double sampling = (nu > c.hyper_nu_sampling_step) ? c.hyper_sampling_curved_high_nu : c.hyper_sampling_curved_low_nu;
+      int nx = (int)((xmax - xmin) * sampling / (2 * PI / nu));
+      if (nx < 2) nx = 2;
+      D.nu = nu; D.nl = nlq; D.nx = nx; D.dx = (xmax - xmin) / (nx - 1.0);
+      D.off = his_total; D.trig_off = trig_total;
+      D.special = 0; D.L = 0; D.xfwdidx = 0;
+      if (nlq > 0) {
+        const int lmax = l[nlq - 1];
+        D.special = ((int)(nu + 0.2) == lmax + 1) ? 1 : 0;
+        D.L = D.special ? lmax : lmax + 1;
+        const double xfwd = asin(sqrt(lmax * (lmax + 1.0)) / nu);
+        D.xfwdidx = (int)((xfwd - xmin) / D.dx);
+        his_total += (size_t)nlq * nx;
+      }
+      trig_total += (size_t)nx;
+      his_max_nx = std::max(his_max_nx, nx);
     }
   }
   int imin_lcmb = 0;
@@ -591,8 +1041,31 @@ int cpt_transfer_impl(cpt_handle* h, const double* sources_dev, const double* k,
   CPT_HIP(h, hipEventCreate(&ka));
   CPT_HIP(h, hipEventCreate(&kb));
   CPT_HIP(h, hipEventRecord(ka, h->stream));
-  hipLaunchKernelGGL(k_los, dim3(nq), dim3(256), lds_bytes, h->stream, P);
+  if (closed) {
+    if ((rc = cpt_reserve(h, &h->d_his, &h->his_cap, his_total + 1))) return rc;
+    if ((rc = cpt_reserve(h, &h->d_his_trig, &h->his_trig_cap, trig_total + 1))) return rc;
+    if ((rc = cpt_reserve(h, &h->d_kq, &h->kq_cap, (size_t)nq))) return rc;
+    {
+      char* pdesc = (char*)h->d_his_desc;
+      size_t cap = h->his_desc_cap;
+      if ((rc = cpt_reserve(h, &pdesc, &cap, (desc.size() + 1) * sizeof(HisDesc)))) return rc;
+      h->d_his_desc = pdesc; h->his_desc_cap = cap;
+    }
+    CPT_HIP(h, hipMemcpyAsync(h->d_kq, kq.data(), nq * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    if (!desc.empty()) {
+      CPT_HIP(h, hipMemcpyAsync(h->d_his_desc, desc.data(), desc.size() * sizeof(HisDesc), hipMemcpyHostToDevice, h->stream));
+      hipLaunchKernelGGL(k_his_closed, dim3((his_max_nx + 63) / 64, (unsigned)desc.size()), dim3(64), 0, h->stream, (const HisDesc*)h->d_his_desc,
+                         h->d_l, c.hyper_x_min, h->d_his, h->d_his_trig);
+      CPT_HIP(h, hipGetLastError());
+    }
+    LosClosedParams CP;
+    CP.b = P; CP.kq = h->d_kq; CP.desc = (const HisDesc*)h->d_his_desc; CP.his = h->d_his; CP.trig = h->d_his_trig;
+    CP.K = c.K; CP.sqrtK = sqrt(c.K); CP.his_xmin = c.hyper_x_min; CP.phiminabs = c.hyper_phi_min_abs; CP.index_q_flat = index_q_flat;
+    hipLaunchKernelGGL(k_los_closed, dim3(nq), dim3(256), lds_bytes, h->stream, CP);
+  } else
+    hipLaunchKernelGGL(k_los, dim3(nq), dim3(256), lds_bytes, h->stream, P);
   CPT_HIP(h, hipGetLastError());
+  CPT_HIP(h, hipStreamSynchronize(h->stream));   // (desc / kq live in host vectors until the copies have completed)
   CPT_HIP(h, hipEventRecord(kb, h->stream));
   CPT_HIP(h, hipEventRecord(h->t_transfer.b, h->stream));
   CPT_HIP(h, hipStreamSynchronize(h->stream));

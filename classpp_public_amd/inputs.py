@@ -51,7 +51,8 @@ class Inputs:
                   "tight_coupling_trigger_tau_c_over_tau_h", "tight_coupling_trigger_tau_c_over_tau_k",
                   "radiation_streaming_trigger_tau_over_tau_k", "ur_fluid_trigger_tau_over_tau_k", "curvature_ini",
                   "tol_perturb_integration", "tol_tau_approx", "smallest_allowed_variation",
-                  "hyper_x_min", "hyper_sampling_flat", "hyper_phi_min_abs",
+                  "hyper_x_min", "hyper_sampling_flat", "hyper_phi_min_abs", "hyper_sampling_curved_low_nu",
+                  "hyper_sampling_curved_high_nu", "hyper_nu_sampling_step", "hyper_flat_approximation_nu",
                   "transfer_neglect_delta_k_S_t0", "transfer_neglect_delta_k_S_t1",
                   "transfer_neglect_delta_k_S_t2", "transfer_neglect_delta_k_S_e",
                   "transfer_neglect_late_source", "l_switch_limber"):

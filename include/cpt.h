@@ -116,6 +116,8 @@ typedef struct cpt_config {
   int evolve_tensor_ur;       /* PerturbationsModule::evolve_tensor_ur_: massless neutrinos source the gravitational waves */
   int index_tt_b;             /* transfer slot of the B-mode polarisation type (tensors; -1 = absent) */
   double transfer_neglect_delta_k_T_t2, transfer_neglect_delta_k_T_e, transfer_neglect_delta_k_T_b;
+  /* --- non-flat space: per-q hyperspherical tables (tm.cpp:3777-3887; include/precisions.h:341-346) --- */
+  double hyper_sampling_curved_low_nu, hyper_sampling_curved_high_nu, hyper_nu_sampling_step, hyper_flat_approximation_nu;
 } cpt_config;
 
 /* Spline tables the RHS samples (all HOST pointers, row-major [n_lines][n_columns], copied to HBM by cpt_create):

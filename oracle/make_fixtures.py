@@ -101,10 +101,11 @@ def main():
             print(cfg, {k: v.shape for k, v in out.items() if v.size > 1000})
             continue
         if cfg == "curved":
-            # non-flat cosmology: its own table file; only perturbation-stage vectors are kept (the curved transfer
-            # stage is not built yet), thermodynamics table thinned to the columns the path reads
-            for key in [k for k in out if k.startswith(("tr.transfer", "sp.", "le.", "nl."))]:
+            # non-flat cosmology: its own table file; full sources and transfer table (small precision file)
+            for key in [k for k in out if k.startswith(("tr.transfer_at", "pt.sources_subset", "pt.sources_k_index"))]:
                 del out[key]
+            out["pt.sources"] = src
+            out["tr.transfer"] = d["tr.transfer"]
             np.savez_compressed(os.path.join(GOLD, cfg + ".npz"), **out)
             np.savez_compressed(os.path.join(GOLD, "tables_curved.npz"), **tables)
             print(cfg, {k: v.shape for k, v in out.items() if v.size > 1000})

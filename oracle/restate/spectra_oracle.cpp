@@ -38,8 +38,17 @@ extern "C" {
 // transfer [tt][nl][nq] -> cl [nl][ct]
 int orc_cl(const cpt_config* c, const cpt_spectra_params* s, const double* tr, const double* q, int nq, int nl, double* cl) {
   const double PI = 3.1415926535897932384626433832795e0;
-  std::vector<double> y(nq), dd(nq), u(nq);
+  std::vector<double> y(nq), dd(nq), u(nq), kk(nq);
   const size_t st = (size_t)nl * nq;
+  // integration variable: k(q) = sqrt(q^2 - K(1+m)) (tm.cpp:1106-1167; spectra_module.cpp:990-994); flat: k = q
+  for (int iq = 0; iq < nq; iq++) kk[iq] = (c->K == 0.) ? q[iq] : std::sqrt(q[iq] * q[iq] - c->K * (c->mode == CPT_MODE_TENSORS ? 3. : 1.));
+  // closed space: trapezoidal rule below the flat-approximation index (integer nu => uneven dq), spectra_module.cpp:1293-1323
+  int index_q_spline = 0;
+  if (c->sgnK == 1) {
+    const double q_approximation = c->hyper_flat_approximation_nu * std::sqrt(c->K);
+    for (index_q_spline = 0; index_q_spline < nq - 1; index_q_spline++)
+      if (q[index_q_spline] > q_approximation) break;
+  }
   for (int il = 0; il < nl; il++) {
     for (int ct = 0; ct < s->ct_size; ct++) {
       int kind = -1;
@@ -49,7 +58,7 @@ int orc_cl(const cpt_config* c, const cpt_spectra_params* s, const double* tr, c
       if (tens) { if (kind >= 4) kind = -1; if (ct == s->index_ct_bb) kind = 3; }
       if (kind < 0) { cl[(size_t)il * s->ct_size + ct] = 0.; continue; }
       for (int iq = 0; iq < nq; iq++) {
-        double k = q[iq], temp = 0., e = 0., lc = 0., bm = 0.;
+        double k = kk[iq], temp = 0., e = 0., lc = 0., bm = 0.;
         size_t o = (size_t)il * nq + iq;
         if (tens) { if (c->index_tt_t2 >= 0) temp = tr[c->index_tt_t2 * st + o]; if (c->index_tt_b >= 0) bm = tr[c->index_tt_b * st + o]; }
         else if (c->index_tt_t0 >= 0) temp = tr[c->index_tt_t0 * st + o] + tr[c->index_tt_t1 * st + o] + tr[c->index_tt_t2 * st + o];
@@ -59,12 +68,14 @@ int orc_cl(const cpt_config* c, const cpt_spectra_params* s, const double* tr, c
                     : kind == 4 ? lc * lc : kind == 5 ? 0.5 * (temp * lc + lc * temp) : 0.5 * (e * lc + lc * e);
         y[iq] = primordial(*s, k) * prod * (4. * PI / k);
       }
-      spline_est_deriv(q, nq, y.data(), dd.data(), u.data());
+      spline_est_deriv(kk.data(), nq, y.data(), dd.data(), u.data());
       double sum = 0.;
-      for (int i = 0; i < nq - 1; i++) {  // arrays.c:1413-1421
-        double h = q[i + 1] - q[i];
+      for (int i = 0; i < index_q_spline; i++) sum += (y[i] + y[i + 1]) * (kk[i + 1] - kk[i]) / 2.;   // arrays.c:1402-1409
+      for (int i = index_q_spline; i < nq - 1; i++) {  // arrays.c:1413-1421
+        double h = kk[i + 1] - kk[i];
         sum += (y[i] + y[i + 1]) * h / 2. + (dd[i] + dd[i + 1]) * h * h * h / 24.;
       }
+      if (c->sgnK == 1) sum += y[0] * q[0] / kk[0] * std::sqrt(c->K) / 2.;   // discrete sum: weight of the first point, :1319-1321
       cl[(size_t)il * s->ct_size + ct] = sum;
     }
   }

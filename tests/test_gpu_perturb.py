@@ -155,19 +155,51 @@ def test_curved_perturb_matches_reference(curved):
     assert not status.any()
     got = src.cpu().numpy()
     assert np.all(np.isfinite(got))
-    ks = inp.d["pt.sources_k_index"]
-    check_sources(inp.config, got[:, :, ks], inp.d["pt.sources_subset"])
+    check_sources(inp.config, got, inp.d["pt.sources"])
     dm = got[inp.config.index_tp_delta_m, -1, :]
     assert np.max(np.abs(dm / inp.d["pt.delta_m_today"] - 1)) < 1e-5
-    osrc, ostats, _, _ = oracle_lib.perturb(inp, k=inp.k[ks])
-    assert [stats[i].n_regimes for i in ks] == [s.n_regimes for s in ostats]
 
 
-def test_curved_transfer_is_refused_loudly(curved):
-    from classpp_public_amd.backend import CptInputError
+def test_closed_transfer_matches_reference_and_oracle(curved):
+    """closed space: per-q hyperspherical tables (nu integer) + the flat-rescaling approximation above
+    hyper_flat_approximation_nu (lowered to 1500 in curved.ini so that both branches are exercised), from the reference's
+    own sources: transfer_ of the reference and of the oracle to round-off"""
     inp, be = curved
-    with pytest.raises(CptInputError, match="hyperspherical"):
-        be.transfer(None)
+    src = inp.d["pt.sources"]
+    got = be.transfer(torch.from_numpy(src).cuda()).cpu().numpy()
+    ref = inp.d["tr.transfer"]
+    orc, work = oracle_lib.transfer(inp, src)
+    assert np.array_equal(got == 0, ref == 0)
+    scale = np.max(np.abs(ref), axis=-1, keepdims=True)
+    scale[scale == 0] = 1
+    # the first node of every per-q table sits at chi = hyper_x_min = 1e-5 where the Hermite derivatives carry factors
+    # 1/sin^2(chi) ~ 1e10: an ulp of difference in Phi (device sin/tan/sqrt vs libm) becomes ~1e-7 for the two lowest nu
+    assert np.max(np.abs(got - orc) / scale) < 1e-6
+    assert np.max(np.abs(got - ref) / scale) < 1e-6
+    e = np.abs(got - ref) / scale
+    assert np.max(e[:, :, 20:]) < 1e-9     # beyond the lowest nu: round-off
+    ints, tsamp, fused = be.transfer_work()
+    assert (ints, tsamp) == work
+
+
+def test_closed_cl_end_to_end(curved):
+    inp, be = curved
+    be.perturb_solve(want_sources=False)
+    cl = be.cl(be.transfer(None)).cpu().numpy()
+    ref = inp.d["sp.cl_table"]
+    sp = inp.spectra
+    for name, idx in (("tt", sp.index_ct_tt), ("ee", sp.index_ct_ee), ("pp", sp.index_ct_pp)):
+        err = np.max(np.abs(cl[:, idx] / ref[:, idx] - 1))
+        assert err < 3e-4, (name, err)   # coarse precision file (same as `small`)
+    for name, idx in (("te", sp.index_ct_te), ("tp", sp.index_ct_tp), ("ep", sp.index_ct_ep)):
+        err = np.max(np.abs(cl[:, idx] - ref[:, idx])) / np.max(np.abs(ref[:, idx]))
+        assert err < 3e-4, (name, err)
+    # and the quadrature weights against the sequential algorithm on the reference's own table
+    want = oracle_lib.cl_table(inp, inp.d["tr.transfer"])
+    got = be.cl(torch.from_numpy(np.ascontiguousarray(inp.d["tr.transfer"])).cuda()).cpu().numpy()
+    scale = np.max(np.abs(want), axis=0, keepdims=True)
+    scale[scale == 0] = 1
+    assert np.max(np.abs(got - want) / scale) < 1e-11
 
 
 # ---- Newtonian gauge (pm.cpp:5869-5897, 8049-8074, 8228-8243, 9549-9592, 6849-6860, 5095-5198): phi dynamic in the eta lane,
