@@ -79,3 +79,26 @@ def test_lensing_rejects_bad_input(expl):
         be.lensed_cl(cl, 100000)          # beyond the l grid
     with pytest.raises(CptInputError):
         be.lensed_cl(cl, 3000, 3000)      # delta_l_max >= l_max
+
+
+def test_config5_closed_space_lensed_cl_matches_reference():
+    """BASELINE configs[4]: Omega_k = -0.01 (closed) with lensing, default precision - the whole chain on the GPU"""
+    from classpp_public_amd.backend import Backend
+    inp = Inputs("curved_full")
+    d = inp.d
+    be = Backend(inp)
+    be.perturb_solve(want_sources=False)
+    cl = be.cl(be.transfer(None))
+    got = be.lensed_cl(cl, int(d["le.l_unlensed_max"][0]), int(d["le.delta_l_max"][0])).cpu().numpy()
+    want = d["le.cl_lens"]
+    sel = d["le.l"] <= int(d["le.l_lensed_max"][0])
+    sp = inp.spectra
+    worst = {}
+    for name, idx in (("tt", sp.index_ct_tt), ("ee", sp.index_ct_ee), ("bb", sp.index_ct_bb), ("pp", sp.index_ct_pp)):
+        worst[name] = np.max(np.abs(got[sel, idx] / want[sel, idx] - 1))
+        assert worst[name] < 1e-4, (name, worst[name])
+    worst["te"] = np.max(np.abs(got[sel, sp.index_ct_te] - want[sel, sp.index_ct_te])) / np.max(np.abs(want[sel, sp.index_ct_te]))
+    assert worst["te"] < 1e-4
+    print("\n[curved_full, lensed] max errors vs reference: %s; kernels: perturb %.2f ms, los %.2f ms" % (
+        ", ".join("%s %.1e" % kv for kv in worst.items()), be.kernel_ms(0)[0], be.kernel_ms(1)[0]))
+    be.close()
