@@ -200,11 +200,8 @@ int cpt_transfer_batch(cpt_handle* h, const double* sources_dev, const double* k
       k_size_cl > nk)
     return cpt_fail(h, CPT_ERR_INVALID, "bad arguments to cpt_transfer_batch");
   if (h->cfg.tt_size < 1 || h->cfg.tt_size > 5) return cpt_fail(h, CPT_ERR_INVALID, "tt_size=%d out of range", h->cfg.tt_size);
-  if (h->cfg.K < 0.)
-    return cpt_fail(h, CPT_ERR_UNSUPPORTED, "open space (K=%g): the l_max search of the per-q hyperspherical tables (WKB/Airy, "
-                    "tm.cpp:3823-3856) is not implemented; flat and closed space are", h->cfg.K);
-  if (h->cfg.K > 0. && h->cfg.mode == CPT_MODE_TENSORS)
-    return cpt_fail(h, CPT_ERR_UNSUPPORTED, "tensor transfer functions in closed space are not implemented");
+  if (h->cfg.K != 0. && h->cfg.mode == CPT_MODE_TENSORS)
+    return cpt_fail(h, CPT_ERR_UNSUPPORTED, "tensor transfer functions in non-flat space are not implemented");
   if (h->cfg.K > 0. && sqrt(h->cfg.K) * h->cfg.tau0 >= 1.5707963267948966 - h->cfg.hyper_x_min)
     return cpt_fail(h, CPT_ERR_UNSUPPORTED, "closed space with sqrt(K) tau0 >= pi/2: the folding of chi onto [0, pi/2] (ClosedModY, "
                     "hyperspherical.c:1025-1052) is not implemented");
@@ -216,7 +213,6 @@ int cpt_cl_batch(cpt_handle* h, const cpt_spectra_params* sp, const double* tran
   if (!h) return CPT_ERR_INVALID;
   h->err.clear();
   if (!sp || !transfer_dev || !q || !cl_dev || nq < 3 || nl < 1) return cpt_fail(h, CPT_ERR_INVALID, "bad arguments to cpt_cl_batch");
-  if (h->cfg.K < 0.) return cpt_fail(h, CPT_ERR_UNSUPPORTED, "open space is not implemented in the transfer / C_l stages");
   return cpt_cl_impl(h, sp, transfer_dev, q, nq, nl, cl_dev);
 }
 

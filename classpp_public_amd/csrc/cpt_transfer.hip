@@ -489,15 +489,16 @@ struct HisDesc {
   unsigned long long off, trig_off; // offsets (in double2) of the table [nl][nx] {Phi, Phi'} and of {sinK, cotK}[nx]
 };
 
-// Lentz continued fraction for Phi_l'/Phi_l, K = 1 (hyperspherical.c:677-716); false if not converged
-__device__ static inline bool cf1_closed(int l, double beta, double cotK, double* CF) {
+// Lentz continued fraction for Phi_l'/Phi_l, K = +-1 (hyperspherical.c:677-716); false if not converged
+__device__ static inline bool cf1_curved(int K, int l, double beta, double cotK, double* CF, int* isign) {
   const double tiny = 1e-100, reltol = 2.220446049250313e-16, beta2 = beta * beta;
-  const int maxiter = (int)(beta - l - 10);
+  const int maxiter = (K == 1) ? (int)(beta - l - 10) : 1000000;
   double bj = l * cotK, fj = bj, Cj = bj, Dj = 0.0;
+  int sgn = 1;
   for (int j = 1; j <= maxiter; j++) {
-    const double sqrttmp = sqrt(beta2 - (l + j + 1.) * (l + j + 1.));
-    double aj = -sqrt(beta2 - (double)(l + j) * (l + j)) / sqrttmp;
-    if (j == 1) aj = sqrt(beta2 - (l + 1.) * (l + 1.)) * aj;
+    const double sqrttmp = sqrt(beta2 - K * (l + j + 1.) * (l + j + 1.));
+    double aj = -sqrt(beta2 - K * (double)(l + j) * (l + j)) / sqrttmp;
+    if (j == 1) aj = sqrt(beta2 - K * (l + 1.) * (l + 1.)) * aj;
     bj = (2 * (l + j) + 1) / sqrttmp * cotK;
     Dj = bj + aj * Dj;
     if (Dj == 0.0) Dj = tiny;
@@ -506,8 +507,10 @@ __device__ static inline bool cf1_closed(int l, double beta, double cotK, double
     Dj = 1.0 / Dj;
     const double Delj = Cj * Dj;
     fj = fj * Delj;
-    if (fabs(Delj - 1.0) < reltol) { *CF = fj; return true; }
+    if (Dj < 0) sgn = -sgn;
+    if (fabs(Delj - 1.0) < reltol) { *CF = fj; *isign = sgn; return true; }
   }
+  *isign = sgn;
   return false;
 }
 
@@ -537,7 +540,7 @@ __device__ static inline void cf1_gegenbauer(int l, int beta, double sinK, doubl
 }
 
 // one thread per (own-table q, abscissa x_j): blockIdx.y = q index, blockIdx.x * 64 + lane = j
-__global__ void __launch_bounds__(64) k_his_closed(const HisDesc* __restrict__ desc, const int* __restrict__ lvec, double xmin,
+__global__ void __launch_bounds__(64) k_his_curved(const HisDesc* __restrict__ desc, const int* __restrict__ lvec, double xmin, int sgnK,
                                                    double2* __restrict__ tab, double2* __restrict__ trig) {
   const HisDesc D = desc[blockIdx.y];
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
@@ -545,10 +548,10 @@ __global__ void __launch_bounds__(64) k_his_closed(const HisDesc* __restrict__ d
   const int nl = D.nl, nx = D.nx, L = D.L;
   const double beta = D.nu, beta2 = beta * beta;
   const double x = xmin + j * D.dx;
-  const double sinK = sin(x), cotK = 1.0 / tan(x);
+  const double sinK = (sgnK == 1) ? sin(x) : sinh(x), cotK = (sgnK == 1) ? 1.0 / tan(x) : 1.0 / tanh(x);
   trig[D.trig_off + j] = make_double2(sinK, cotK);
   double2* out = tab + D.off;
-  auto sk = [&](int l) { return sqrt(beta2 - (double)l * l); };   // sqrtK[l], hyperspherical.c:104-107
+  auto sk = [&](int l) { return sqrt(beta2 - sgnK * (double)l * l); };   // sqrtK[l], hyperspherical.c:104-121
   if (j >= D.xfwdidx) {
     // forward recurrence, hyperspherical.c:472-514
     double pm = sin(beta * x) / (beta * sinK);                                 // P[0]
@@ -566,15 +569,22 @@ __global__ void __launch_bounds__(64) k_his_closed(const HisDesc* __restrict__ d
   }
   // backward recurrence, hyperspherical.c:517-603 (closed: phi1 = 1, no sign bookkeeping)
   const double phi0 = sin(beta * x) / (beta * sinK);
-  double phipr1 = 0.;
-  bool ok = false;
-  if (beta > 1.5 * L) ok = cf1_closed(L, beta, cotK, &phipr1);
-  if (!ok) cf1_gegenbauer(L, (int)(beta + 0.2), sinK, cotK, &phipr1);
+  double phipr1 = 0., phi1 = 1.0;
+  int isign = 1;
+  if (sgnK == 1) {
+    bool ok = false;
+    if (beta > 1.5 * L) ok = cf1_curved(1, L, beta, cotK, &phipr1, &isign);
+    if (!ok) cf1_gegenbauer(L, (int)(beta + 0.2), sinK, cotK, &phipr1);
+  } else {
+    cf1_curved(-1, L, beta, cotK, &phipr1, &isign);
+    phi1 = (double)isign;
+    phipr1 *= phi1;
+  }
   const int l_align = L - L % 8;
   int n_rescale_total = 0;
   double scaling = 0.;
   for (int pass = 0; pass < 2; pass++) {
-    double phi = 1.0, ppts = L * cotK * 1.0 - phipr1;  // P[l], sqrtK[l+1] P[l+1]
+    double phi = phi1, ppts = L * cotK * phi1 - phipr1;  // P[l], sqrtK[l+1] P[l+1]
     int kk = nl - 1, n_done = 0;
     auto emit = [&](int l) {  // P[l] = phi, sqrtK[l+1] P[l+1] = ppts, as they stand now
       if (pass == 1 && kk >= 0 && lvec[kk] == l) {
@@ -614,19 +624,19 @@ struct LosClosedParams {
   const HisDesc* desc;       // [index_q_flat]
   const double2* his;        // per-q tables
   const double2* trig;       // per-q {sinK, cotK} at the table nodes
-  double K, sqrtK, his_xmin, phiminabs;
-  int index_q_flat;
+  double K, sqrtK, his_xmin, phiminabs;   // sqrtK = sqrt|K|
+  int index_q_flat, sgnK;
 };
 
 // Hermite interpolation of order 6 on a per-q table (hermite6_interpolation_csource.h), stateless per sample
-__device__ static inline void hermite6_closed(const double2* __restrict__ tl, const double2* __restrict__ tg, int nx, double xmin, double dx,
-                                              double beta, double lxlp1, double x, double* Phi, double* dPhi, double* d2Phi) {
+__device__ static inline void hermite6_curved(const double2* __restrict__ tl, const double2* __restrict__ tg, int nx, double xmin, double dx,
+                                              double beta, int sgnK, double lxlp1, double x, double* Phi, double* dPhi, double* d2Phi) {
   const double xmax = xmin + (nx - 1) * dx;
   if (x < xmin || x > xmax) { *Phi = *dPhi = *d2Phi = 0.; return; }
   int idx = (int)((x - xmin) / dx) + 1;
   idx = idx < 1 ? 1 : idx;
   idx = idx > nx - 1 ? nx - 1 : idx;
-  const double KmB2 = 1.0 - beta * beta, dx2 = dx * dx;
+  const double KmB2 = (double)sgnK - beta * beta, dx2 = dx * dx;
   double y[2], dy[2], d2y[2], d3y[2], d4y[2];
 #pragma unroll
   for (int s = 0; s < 2; s++) {
@@ -679,18 +689,21 @@ __device__ static inline void hermite4_flat(const double2* __restrict__ bl, int 
   *d2Phi = d2ym + c0 * z + c1 * z2 + c2 * z3;
 }
 
-// hyperspherical_get_xmin_from_approx, K = 1 (hyperspherical.c:1419-1450)
-__device__ static inline double xmin_from_approx_closed(double l, double nu, double phiminabs) {
+// hyperspherical_get_xmin_from_approx, K = +-1 (hyperspherical.c:1419-1450)
+__device__ static inline double xmin_from_approx_curved(int sgnK, double l, double nu, double phiminabs) {
   const double lph = l + 0.5, lhs = 1.0 / lph * log(2 * phiminabs * lph);
   const double alpha = -2.0 * lhs / 5.0 * (1.0 + 2.0 * cosh(1.0 / 3.0 * acosh(1.0 + 375.0 / (16.0 * lhs * lhs))));
-  return lph / cosh(alpha) / nu * asin(l / nu) / (l / nu);
+  double x = lph / cosh(alpha) / nu;
+  if (sgnK == 1) x *= asin(l / nu) / (l / nu);
+  else { x *= asinh(l / nu) / (l / nu); x *= ((nu + 0.4567) / (nu + 1.24) - 2.209e-3); }
+  return x;
 }
 
 // LOS kernel for closed space, scalar types (transfer_compute_for_each_q tm.cpp:1488-1715 with the sgnK = 1 branches of
 // transfer_radial_coordinates :1717-1749, transfer_radial_function :3274-3445, transfer_sources :1905-1964,
 // transfer_integrate :2762-2792, transfer_limber :2930-2968).  Same organisation as k_los: one workgroup per q, sources
 // in LDS, waves pull multipoles from an LDS queue, the CMB types share one interpolation of Phi_l.
-__global__ void __launch_bounds__(256) k_los_closed(LosClosedParams C) {
+__global__ void __launch_bounds__(256) k_los_curved(LosClosedParams C) {
   const LosParams& P = C.b;
   extern __shared__ __attribute__((aligned(16))) double lds[];
   const int ntau = P.ntau, nl = P.nl, nq = P.nq;
@@ -702,6 +715,9 @@ __global__ void __launch_bounds__(256) k_los_closed(LosClosedParams C) {
 
   const int iq = nq - 1 - blockIdx.x;
   const double q = P.q[iq], k = C.kq[iq], sqrtK = C.sqrtK, K = C.K;
+  const int sgnK = C.sgnK;
+  auto sinKf = [&](double x) { return sgnK == 1 ? sin(x) : sinh(x); };      // sin_K
+  auto asinKf = [&](double x) { return sgnK == 1 ? asin(x) : asinh(x); };
   const int ik = P.ik[iq];
   const int tid = threadIdx.x;
   if (ik < 0) {
@@ -712,8 +728,8 @@ __global__ void __launch_bounds__(256) k_los_closed(LosClosedParams C) {
     return;
   }
   const bool own = iq < C.index_q_flat;
-  const double nu = own ? (double)(int)(q / sqrtK + 0.2) : q / sqrtK;   // tm.cpp:3796-3804 / :3331
-  const int nu_int = (int)(q / sqrtK + 0.2);                            // tm.cpp:1636: transfer functions exist for l < nu only
+  const double nu = (own && sgnK == 1) ? (double)(int)(q / sqrtK + 0.2) : q / sqrtK;   // tm.cpp:3796-3804 / :3331
+  const int nu_int = (sgnK == 1) ? (int)(q / sqrtK + 0.2) : 2147483647;                 // closed (tm.cpp:1636): l < nu only
   HisDesc D;
   D.nl = 0; D.nx = 0; D.dx = 1.; D.off = 0; D.trig_off = 0;
   if (own) D = C.desc[iq];
@@ -731,7 +747,7 @@ __global__ void __launch_bounds__(256) k_los_closed(LosClosedParams C) {
     else if (i == ntau - 1) w = 0.5 * ((P.tau0 - P.tau[ntau - 2]) - tm);
     else w = 0.5 * ((P.tau0 - P.tau[i - 1]) - (P.tau0 - P.tau[i + 1]));
     wt[i] = w;
-    const double sc = sqrtK / k / sin(sqrtK * tm);
+    const double sc = sqrtK / k / sinKf(sqrtK * tm);
     csc2[i] = sc * sc;
 #pragma unroll
     for (int t = 0; t < 5; t++) {
@@ -742,7 +758,7 @@ __global__ void __launch_bounds__(256) k_los_closed(LosClosedParams C) {
         if (t == 4) {
           double resc = 0.;   // tm.cpp:1926-1932
           if (!(i == ntau - 1 || i < P.imin_lcmb))
-            resc = sqrtK * sin((P.tau_rec - tau) * sqrtK) / sin((P.tau0 - tau) * sqrtK) / sin((P.tau0 - P.tau_rec) * sqrtK);
+            resc = sqrtK * sinKf((P.tau_rec - tau) * sqrtK) / sinKf((P.tau0 - tau) * sqrtK) / sinKf((P.tau0 - P.tau_rec) * sqrtK);
           v = v * resc * lfac;
         }
       }
@@ -777,9 +793,9 @@ __global__ void __launch_bounds__(256) k_los_closed(LosClosedParams C) {
     // flat rescaling approximation of this (q, l): tm.cpp:3329-3342
     double rescale_argument = 1., rescale_amplitude = 1., chi_tp = 0., at = 0.;
     if (exists) {
-      if (own) tmin_bessel = xmin_from_approx_closed(l, nu, C.phiminabs) / sqrtK;
+      if (own) tmin_bessel = xmin_from_approx_curved(sgnK, l, nu, C.phiminabs) / sqrtK;
       else {
-        chi_tp = asin(sqrt(l * (l + 1.)) / nu);
+        chi_tp = asinKf(sqrt(l * (l + 1.)) / nu);
         tmin_bessel = P.chi_min[il] / sqrtK * chi_tp / sqrt(l * (l + 1.));   // tm.cpp:2781-2786 (asin(sqrt(l(l+1)) sqrtK / q))
         rescale_argument = sqrt(l * (l + 1.)) / chi_tp;
         rescale_amplitude = pow(1. - K * l * (l + 1.) / q / q, -1. / 12.);
@@ -824,11 +840,12 @@ __global__ void __launch_bounds__(256) k_los_closed(LosClosedParams C) {
         const double tm = t0mt[i];
         const double chi0 = sqrtK * tm;            // tm.cpp:1724
         double Phi, dPhi, d2Phi, rf = 1.;
-        if (own) hermite6_closed(tl, tg, D.nx, C.his_xmin, D.dx, nu, lxlp1, chi0, &Phi, &dPhi, &d2Phi);
+        if (own) hermite6_curved(tl, tg, D.nx, C.his_xmin, D.dx, nu, sgnK, lxlp1, chi0, &Phi, &dPhi, &d2Phi);
         else {
           hermite4_flat(tl, P.nx, P.bes_xmin, P.bes_dx, P.bes_xmax, lxlp1, chi0 * rescale_argument, &Phi, &dPhi, &d2Phi);
           const double dxx = at * (chi0 - chi_tp);  // tm.cpp:3375-3383
-          rf = fmin(rescale_amplitude * (1 + 0.34 * dxx + 2.00 * dxx * dxx), chi0 / sin(chi0));
+          rf = (sgnK == 1) ? fmin(rescale_amplitude * (1 + 0.34 * dxx + 2.00 * dxx * dxx), chi0 / sin(chi0))
+                           : fmax(rescale_amplitude * (1 - 0.38 * dxx + 0.40 * dxx * dxx), chi0 / sinh(chi0));
         }
         const double w = wt[i];
         const double R[4] = {Phi * rf, sqrt_absK_over_k * dPhi * rescale_argument * rf,
@@ -857,7 +874,7 @@ __global__ void __launch_bounds__(256) k_los_closed(LosClosedParams C) {
     if (lane == 0) {
       if (lcmb_limber) {  // tm.cpp:2930-2968, closed
         double res = 0.;
-        const double tl = asin(sqrt(l * (l + 1.)) / q * sqrtK) / sqrtK;
+        const double tl = (sgnK == 1) ? asin(sqrt(l * (l + 1.)) / q * sqrtK) / sqrtK : asinh((l + 0.5) / q * sqrtK) / sqrtK;
         if (!(tl > t0mt[imin] || tl < t0mt[ntau - 1])) {
           int j = last_ge(t0mt, imin, ntau - 1, tl) - imin;
           int it = j + 1;
@@ -917,7 +934,7 @@ int cpt_transfer_impl(cpt_handle* h, const double* sources_dev, const double* k,
   if (!sources_dev && (!h->d_src || h->src_nk != nk || h->src_ntau != ntau))
     return cpt_fail(h, CPT_ERR_INVALID, "sources_dev is NULL and the handle holds no resident sources of shape [%d][%d][%d]",
                     ntp, nk, ntau);
-  size_t lds_bytes = (size_t)(c.K > 0. ? 8 : 7) * ntau * sizeof(double) + 16;
+  size_t lds_bytes = (size_t)(c.K != 0. ? 8 : 7) * ntau * sizeof(double) + 16;
   if (lds_bytes > 160 * 1024 - 256) return cpt_fail(h, CPT_ERR_UNSUPPORTED, "ntau=%d too large for the LDS staging (160 KB/CU)", ntau);
 
   const size_t nsrc = (size_t)ntp * nk * ntau;
@@ -929,7 +946,8 @@ int cpt_transfer_impl(cpt_handle* h, const double* sources_dev, const double* k,
   h->d_ik = (int*)(h->d_q + nq);
 
   // ---- Bessel table (cached on (l list, xmax)); tm.cpp:246-262 ----
-  const double xmax = q[nq - 1] * c.tau0;
+  double xmax = q[nq - 1] * c.tau0;
+  if (c.K < 0.) xmax *= (l[nl - 1] / c.hyper_flat_approximation_nu) / asinh(l[nl - 1] / c.hyper_flat_approximation_nu) * 1.01;   // tm.cpp:247-249
   if ((rc = cpt_bessel_build(h, l, nl, xmax))) return rc;
   const double bes_xmax = c.hyper_x_min + (h->bes_nx - 1) * h->bes_dx;
   if (c.K == 0. && q[nq - 1] > bes_xmax / (c.tau0 - tau[0]))
@@ -948,7 +966,8 @@ int cpt_transfer_impl(cpt_handle* h, const double* sources_dev, const double* k,
     cc[i] = (sg[i] - 1.0) / pp[i];
   }
   cc[nk - 1] = 0.; sg[nk - 1] = 0.; pp[nk - 1] = 1.;
-  const bool closed = c.K > 0.;
+  const bool closed = c.K != 0.;   // (any curved space: closed or open)
+  const int sgnK = (c.K > 0.) ? 1 : (c.K < 0. ? -1 : 0);
   std::vector<double> kq(nq);  // k(q) = sqrt(q^2 - K(1+m)), tm.cpp:1106-1167 (scalars: m = 0); flat: k = q
   for (int i = 0; i < nq; i++) kq[i] = closed ? sqrt(q[i] * q[i] - c.K) : q[i];
   std::vector<int> ik(nq);
@@ -965,19 +984,24 @@ int cpt_transfer_impl(cpt_handle* h, const double* sources_dev, const double* k,
   std::vector<HisDesc> desc;
   size_t his_total = 0, trig_total = 0;
   if (closed) {
-    const double sqrtK = sqrt(c.K), PI = 3.1415926535897932384626433832795;
+    const double sqrtK = sqrt(fabs(c.K)), PI = 3.1415926535897932384626433832795;
     const double q_approximation = c.hyper_flat_approximation_nu * sqrtK;
     for (index_q_flat = 0; index_q_flat < nq - 1; index_q_flat++)
       if (q[index_q_flat] > q_approximation) break;
     desc.resize(index_q_flat);
-    const double xmin = c.hyper_x_min, xmax = std::min(sqrtK * c.tau0, PI / 2.0 - xmin);
+    const double xmin = c.hyper_x_min, xmax = (sgnK == 1) ? std::min(sqrtK * c.tau0, PI / 2.0 - xmin) : sqrtK * c.tau0;
     for (int i = 0; i < index_q_flat; i++) {
       HisDesc& D = desc[i];
-      const double nu = (double)(int)(q[i] / sqrtK + 0.2);
-      if (q[i] / sqrtK - nu > 1.e-6)
-        return cpt_fail(h, CPT_ERR_INVALID, "problem in q list definition in closed case for index_q=%d, nu=%e (tm.cpp:3800-3803)", i, q[i] / sqrtK);
+      double nu = q[i] / sqrtK;
       int nlq = nl;
-      while (nlq > 0 && (double)l[nlq - 1] >= nu) nlq--;
+      if (sgnK == 1) {
+        nu = (double)(int)(q[i] / sqrtK + 0.2);
+        if (q[i] / sqrtK - nu > 1.e-6)
+          return cpt_fail(h, CPT_ERR_INVALID, "problem in q list definition in closed case for index_q=%d, nu=%e (tm.cpp:3800-3803)", i, q[i] / sqrtK);
+        while (nlq > 0 && (double)l[nlq - 1] >= nu) nlq--;
+      }
+      // open space: every l of the list (the reference's WKB/Airy l_max cut, tm.cpp:3823-3856, only drops functions that
+      // stay below hyper_phi_min_abs on the whole range)
       const double sampling = (nu > c.hyper_nu_sampling_step) ? c.hyper_sampling_curved_high_nu : c.hyper_sampling_curved_low_nu;
       int nx = (int)((xmax - xmin) * sampling / (2 * PI / nu));
       if (nx < 2) nx = 2;
@@ -986,9 +1010,9 @@ int cpt_transfer_impl(cpt_handle* h, const double* sources_dev, const double* k,
       D.special = 0; D.L = 0; D.xfwdidx = 0;
       if (nlq > 0) {
         const int lmax = l[nlq - 1];
-        D.special = ((int)(nu + 0.2) == lmax + 1) ? 1 : 0;
+        D.special = (sgnK == 1 && (int)(nu + 0.2) == lmax + 1) ? 1 : 0;
         D.L = D.special ? lmax : lmax + 1;
-        const double xfwd = asin(sqrt(lmax * (lmax + 1.0)) / nu);
+        const double xfwd = (sgnK == 1) ? asin(sqrt(lmax * (lmax + 1.0)) / nu) : asinh(sqrt(lmax * (lmax + 1.0)) / nu);
         D.xfwdidx = (int)((xfwd - xmin) / D.dx);
         his_total += (size_t)nlq * nx;
       }
@@ -1054,14 +1078,14 @@ int cpt_transfer_impl(cpt_handle* h, const double* sources_dev, const double* k,
     CPT_HIP(h, hipMemcpyAsync(h->d_kq, kq.data(), nq * sizeof(double), hipMemcpyHostToDevice, h->stream));
     if (!desc.empty()) {
       CPT_HIP(h, hipMemcpyAsync(h->d_his_desc, desc.data(), desc.size() * sizeof(HisDesc), hipMemcpyHostToDevice, h->stream));
-      hipLaunchKernelGGL(k_his_closed, dim3((his_max_nx + 63) / 64, (unsigned)desc.size()), dim3(64), 0, h->stream, (const HisDesc*)h->d_his_desc,
-                         h->d_l, c.hyper_x_min, h->d_his, h->d_his_trig);
+      hipLaunchKernelGGL(k_his_curved, dim3((his_max_nx + 63) / 64, (unsigned)desc.size()), dim3(64), 0, h->stream, (const HisDesc*)h->d_his_desc,
+                         h->d_l, c.hyper_x_min, sgnK, h->d_his, h->d_his_trig);
       CPT_HIP(h, hipGetLastError());
     }
     LosClosedParams CP;
     CP.b = P; CP.kq = h->d_kq; CP.desc = (const HisDesc*)h->d_his_desc; CP.his = h->d_his; CP.trig = h->d_his_trig;
-    CP.K = c.K; CP.sqrtK = sqrt(c.K); CP.his_xmin = c.hyper_x_min; CP.phiminabs = c.hyper_phi_min_abs; CP.index_q_flat = index_q_flat;
-    hipLaunchKernelGGL(k_los_closed, dim3(nq), dim3(256), lds_bytes, h->stream, CP);
+    CP.K = c.K; CP.sqrtK = sqrt(fabs(c.K)); CP.sgnK = sgnK; CP.his_xmin = c.hyper_x_min; CP.phiminabs = c.hyper_phi_min_abs; CP.index_q_flat = index_q_flat;
+    hipLaunchKernelGGL(k_los_curved, dim3(nq), dim3(256), lds_bytes, h->stream, CP);
   } else
     hipLaunchKernelGGL(k_los, dim3(nq), dim3(256), lds_bytes, h->stream, P);
   CPT_HIP(h, hipGetLastError());

@@ -108,14 +108,14 @@ def main():
             np.savez_compressed(os.path.join(GOLD, cfg + ".npz"), **out)
             print(cfg, {k: v.shape for k, v in out.items() if v.size > 1000})
             continue
-        if cfg == "curved":
+        if cfg in ("curved", "open"):
             # non-flat cosmology: its own table file; full sources and transfer table (small precision file)
             for key in [k for k in out if k.startswith(("tr.transfer_at", "pt.sources_subset", "pt.sources_k_index"))]:
                 del out[key]
             out["pt.sources"] = src
             out["tr.transfer"] = d["tr.transfer"]
             np.savez_compressed(os.path.join(GOLD, cfg + ".npz"), **out)
-            np.savez_compressed(os.path.join(GOLD, "tables_curved.npz"), **tables)
+            np.savez_compressed(os.path.join(GOLD, "tables_%s.npz" % cfg), **tables)
             print(cfg, {k: v.shape for k, v in out.items() if v.size > 1000})
             continue
         np.savez_compressed(os.path.join(GOLD, cfg + ".npz"), **out)

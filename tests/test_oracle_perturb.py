@@ -44,7 +44,7 @@ def test_perturb_small_all_modes():
     assert all(s.steps > 50 and s.fevals > s.steps for s in stats)
 
 
-@pytest.mark.parametrize("cfg", ["lcdm", "explanatory", "curved", "iso_cdi", "iso_nid", "newt", "curved_full"])
+@pytest.mark.parametrize("cfg", ["lcdm", "explanatory", "curved", "open", "iso_cdi", "iso_nid", "newt", "curved_full"])
 def test_perturb_full_size_subset(cfg):
     inp = Inputs(cfg)
     if "pt.sources_k_index" in inp.d:

@@ -15,7 +15,7 @@ def rel_to_rowmax(a, b):
     return np.max(np.abs(a - b) / scale)
 
 
-@pytest.mark.parametrize("cfg", ["small", "tens", "curved"])
+@pytest.mark.parametrize("cfg", ["small", "tens", "curved", "open"])
 def test_transfer_small_full_table(cfg):
     """scalar types t0,t1,t2,e,lcmb (small), tensor types t2,e,b (tens: a tensors-only reference run) and closed space
     (curved: per-q hyperspherical tables with integer nu + flat-rescaling approximation above nu = 1500)"""
@@ -25,5 +25,6 @@ def test_transfer_small_full_table(cfg):
     assert got.shape == ref.shape
     # exact zero pattern (neglect / Limber / no-overlap rules) must match
     assert np.array_equal(got == 0, ref == 0)
-    assert rel_to_rowmax(got, ref) < 1e-9
+    # open space: the tables hold every l (no WKB/Airy l_max cut, see transfer_oracle.cpp) => other recurrence start, 2e-8
+    assert rel_to_rowmax(got, ref) < (1e-7 if cfg == "open" else 1e-9)
     assert work[0] > 0 and work[1] > work[0]
