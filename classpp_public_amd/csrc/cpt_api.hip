@@ -200,8 +200,6 @@ int cpt_transfer_batch(cpt_handle* h, const double* sources_dev, const double* k
       k_size_cl > nk)
     return cpt_fail(h, CPT_ERR_INVALID, "bad arguments to cpt_transfer_batch");
   if (h->cfg.tt_size < 1 || h->cfg.tt_size > 5) return cpt_fail(h, CPT_ERR_INVALID, "tt_size=%d out of range", h->cfg.tt_size);
-  if (h->cfg.K != 0. && h->cfg.mode == CPT_MODE_TENSORS)
-    return cpt_fail(h, CPT_ERR_UNSUPPORTED, "tensor transfer functions in non-flat space are not implemented");
   if (h->cfg.K > 0. && sqrt(h->cfg.K) * h->cfg.tau0 >= 1.5707963267948966 - h->cfg.hyper_x_min)
     return cpt_fail(h, CPT_ERR_UNSUPPORTED, "closed space with sqrt(K) tau0 >= pi/2: the folding of chi onto [0, pi/2] (ClosedModY, "
                     "hyperspherical.c:1025-1052) is not implemented");

@@ -710,8 +710,9 @@ __global__ void __launch_bounds__(256) k_los_curved(LosClosedParams C) {
   double* t0mt = lds;
   double* wt = lds + ntau;
   double* S = lds + 2 * ntau;        // [5][ntau]
-  double* csc2 = lds + 7 * ntau;     // [ntau] cscK_gen^2 = K / k^2 / sin^2(chi)
-  int& next_l = *(int*)(lds + 8 * ntau);
+  double* csc2 = lds + 7 * ntau;     // [ntau] cscK_gen^2 = |K| / k^2 / sin_K^2(chi)
+  double* cotg = lds + 8 * ntau;     // [ntau] cotK_gen = cscK_gen cos_K(chi)  (tensor E and B types)
+  int& next_l = *(int*)(lds + 9 * ntau);
 
   const int iq = nq - 1 - blockIdx.x;
   const double q = P.q[iq], k = C.kq[iq], sqrtK = C.sqrtK, K = C.K;
@@ -749,6 +750,7 @@ __global__ void __launch_bounds__(256) k_los_curved(LosClosedParams C) {
     wt[i] = w;
     const double sc = sqrtK / k / sinKf(sqrtK * tm);
     csc2[i] = sc * sc;
+    cotg[i] = sc * (sgnK == 1 ? cos(sqrtK * tm) : cosh(sqrtK * tm));   // tm.cpp:1726, 1742
 #pragma unroll
     for (int t = 0; t < 5; t++) {
       double v = 0.;
@@ -848,9 +850,17 @@ __global__ void __launch_bounds__(256) k_los_curved(LosClosedParams C) {
                            : fmax(rescale_amplitude * (1 - 0.38 * dxx + 0.40 * dxx * dxx), chi0 / sinh(chi0));
         }
         const double w = wt[i];
-        const double R[4] = {Phi * rf, sqrt_absK_over_k * dPhi * rescale_argument * rf,
-                             1.0 / (2.0 * s2) * (3 * absK_over_k2 * d2Phi * rescale_argument * rescale_argument + Phi) * rf,
-                             fac_e * csc2[i] * Phi * rf};
+        double R[4] = {Phi * rf, sqrt_absK_over_k * dPhi * rescale_argument * rf,
+                       1.0 / (2.0 * s2) * (3 * absK_over_k2 * d2Phi * rescale_argument * rescale_argument + Phi) * rf,
+                       fac_e * csc2[i] * Phi * rf};
+        if (P.tensors) {  // tm.cpp:3494-3529
+          const double Kk2 = K / (k * k), ssqrt2 = sqrt(1.0 - Kk2), si = sqrt(1.0 + 2.0 * Kk2), ssqrt2i = sqrt(1.0 + 3.0 * Kk2), cg = cotg[i];
+          R[0] = fac_e * s2 / si / ssqrt2 * csc2[i] * Phi * rf;   // (fac_e carries the scalar 1/s2: undo it)
+          R[1] = 0.25 / si / ssqrt2 * (absK_over_k2 * d2Phi * rescale_argument * rescale_argument + 4.0 * cg * sqrt_absK_over_k * dPhi * rescale_argument -
+                                       (1.0 + 4 * Kk2 - 2.0 * cg * cg) * Phi) * rf;
+          R[2] = 0.5 * ssqrt2i / ssqrt2 / si * (sqrt_absK_over_k * dPhi * rescale_argument + 2.0 * cg * Phi) * rf;
+          R[3] = 0.;
+        }
 #pragma unroll
         for (int t = 0; t < 4; t++) {
           if (i <= imax_t[t]) {
@@ -934,7 +944,7 @@ int cpt_transfer_impl(cpt_handle* h, const double* sources_dev, const double* k,
   if (!sources_dev && (!h->d_src || h->src_nk != nk || h->src_ntau != ntau))
     return cpt_fail(h, CPT_ERR_INVALID, "sources_dev is NULL and the handle holds no resident sources of shape [%d][%d][%d]",
                     ntp, nk, ntau);
-  size_t lds_bytes = (size_t)(c.K != 0. ? 8 : 7) * ntau * sizeof(double) + 16;
+  size_t lds_bytes = (size_t)(c.K != 0. ? 9 : 7) * ntau * sizeof(double) + 16;
   if (lds_bytes > 160 * 1024 - 256) return cpt_fail(h, CPT_ERR_UNSUPPORTED, "ntau=%d too large for the LDS staging (160 KB/CU)", ntau);
 
   const size_t nsrc = (size_t)ntp * nk * ntau;
@@ -969,7 +979,7 @@ int cpt_transfer_impl(cpt_handle* h, const double* sources_dev, const double* k,
   const bool closed = c.K != 0.;   // (any curved space: closed or open)
   const int sgnK = (c.K > 0.) ? 1 : (c.K < 0. ? -1 : 0);
   std::vector<double> kq(nq);  // k(q) = sqrt(q^2 - K(1+m)), tm.cpp:1106-1167 (scalars: m = 0); flat: k = q
-  for (int i = 0; i < nq; i++) kq[i] = closed ? sqrt(q[i] * q[i] - c.K) : q[i];
+  for (int i = 0; i < nq; i++) kq[i] = closed ? sqrt(q[i] * q[i] - c.K * (tens ? 3. : 1.)) : q[i];   // m = 2 for tensors
   std::vector<int> ik(nq);
   {
     int j = 0;  // tm.cpp:1794-1802 (q ascending -> resume the scan)

@@ -27,7 +27,7 @@ class Inputs:
     def __init__(self, name, golden_dir=GOLDEN):
         self.name = name
         self.d = dict(np.load(os.path.join(golden_dir, name + ".npz")))
-        tname = "tables_%s.npz" % ("curved" if name.startswith("curved") else name)   # (open.ini has its own: tables_open.npz)
+        tname = "tables_%s.npz" % ("curved" if (name.startswith("curved") or name == "tens_curved") else name)   # (open.ini has its own: tables_open.npz)
         self.t = dict(np.load(os.path.join(golden_dir, tname if os.path.exists(os.path.join(golden_dir, tname)) else "tables_lcdm.npz")))
         d, t = self.d, self.t
         c = CptConfig()

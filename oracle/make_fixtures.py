@@ -71,7 +71,7 @@ def main():
             else:
                 out[k] = v
         src = d["pt.sources"]  # [tp][tau][k]
-        if cfg in ("small", "tens"):
+        if cfg in ("small", "tens", "tens_curved"):
             out["pt.sources"] = src
             if "tr.transfer" in d:
                 out["tr.transfer"] = d["tr.transfer"]
@@ -92,7 +92,7 @@ def main():
                 out["tr.transfer_l_index"] = ls.astype(np.int32)
                 out["tr.transfer_at_q"] = np.ascontiguousarray(t[:, :, qs])
                 out["tr.transfer_at_l"] = np.ascontiguousarray(t[:, ls, :])
-        if cfg == "curved_full":
+        if cfg in ("curved_full", "tens_curved"):
             old = np.load(os.path.join(GOLD, "tables_curved.npz"))
             for k in tables:
                 assert np.array_equal(old[k], tables[k]), "tables differ between configs: " + k
@@ -104,7 +104,7 @@ def main():
             np.savez_compressed(os.path.join(GOLD, cfg + ".npz"), **out)
             print(cfg, {k: v.shape for k, v in out.items() if v.size > 1000})
             continue
-        if cfg == "curved_full":
+        if cfg in ("curved_full", "tens_curved"):
             np.savez_compressed(os.path.join(GOLD, cfg + ".npz"), **out)
             print(cfg, {k: v.shape for k, v in out.items() if v.size > 1000})
             continue

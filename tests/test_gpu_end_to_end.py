@@ -14,7 +14,7 @@ from classpp_public_amd.inputs import Inputs
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("cfg", ["small", "lcdm", "explanatory", "iso_cdi", "iso_nid", "newt", "tens", "curved_full"])
+@pytest.mark.parametrize("cfg", ["small", "lcdm", "explanatory", "iso_cdi", "iso_nid", "newt", "tens", "tens_curved", "curved_full"])
 def test_cl_and_pk_match_reference(cfg):
     from classpp_public_amd.backend import Backend
     inp = Inputs(cfg)

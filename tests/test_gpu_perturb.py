@@ -249,10 +249,10 @@ def test_newtonian_structured_solve_matches_dense(newt, flags):
 
 
 # ---- tensor modes (pm.cpp:3519-3586, 9045-9215, 7243-7280): tests/golden/tens.ini is a tensors-only reference run (modes = t)
-@pytest.fixture(scope="module")
-def tens():
+@pytest.fixture(scope="module", params=["tens", "tens_curved"])
+def tens(request):
     from classpp_public_amd.backend import Backend
-    inp = Inputs("tens")
+    inp = Inputs(request.param)
     assert inp.config.mode == 1
     be = Backend(inp)
     yield inp, be

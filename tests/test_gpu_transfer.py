@@ -112,10 +112,12 @@ def test_transfer_full_size_vs_reference(cfg):
     be.close()
 
 
-def test_tensor_transfer_vs_reference_and_oracle():
-    """tensor types t2, e, b (radial functions of tm.cpp:3494-3529) from the reference's own tensor sources"""
+@pytest.mark.parametrize("cfg", ["tens", "tens_curved"])
+def test_tensor_transfer_vs_reference_and_oracle(cfg):
+    """tensor types t2, e, b (radial functions of tm.cpp:3494-3529) from the reference's own tensor sources, in flat and
+    in closed space (per-q hyperspherical tables, k^2 = q^2 - 3K)"""
     from classpp_public_amd.backend import Backend
-    inp = Inputs("tens")
+    inp = Inputs(cfg)
     be = Backend(inp)
     src = inp.d["pt.sources"]
     got = be.transfer(torch.from_numpy(src).cuda()).cpu().numpy()
@@ -123,8 +125,9 @@ def test_tensor_transfer_vs_reference_and_oracle():
     orc, work = oracle_lib.transfer(inp, src)
     assert got.shape == ref.shape == (3, inp.l.size, inp.q.size)
     assert np.array_equal(got == 0, ref == 0)
-    assert rel_to_rowmax(got, orc) < TOL
-    assert rel_to_rowmax(got, ref) < TOL
+    tol = TOL if cfg == "tens" else 1e-6   # (curved: the chi = hyper_x_min node of the lowest-nu tables, see test_gpu_perturb)
+    assert rel_to_rowmax(got, orc) < tol
+    assert rel_to_rowmax(got, ref) < tol
     ints, tsamp, fused = be.transfer_work()
     assert (ints, tsamp) == work
     be.close()

@@ -68,9 +68,10 @@ def test_lookup_matches_table_nodes():
     assert np.allclose(out[:, 1], t["bg.background_table"][idx, int(t["bg.index_bg_H"][0])], rtol=1e-14)
 
 
-def test_tensor_perturbations_all_modes():
-    """tensor modes (gw, tensor photon / ur ladders; pm.cpp:9045-9215) against the reference's tensor sources t2, p"""
-    inp = Inputs("tens")
+@pytest.mark.parametrize("cfg", ["tens", "tens_curved"])
+def test_tensor_perturbations_all_modes(cfg):
+    """tensor modes (gw, tensor photon / ur ladders; pm.cpp:9045-9215) against the reference's tensor sources t2, p; flat and closed"""
+    inp = Inputs(cfg)
     src, stats, status, rc = oracle_lib.perturb(inp)
     assert rc == 0 and not status.any()
     ref = inp.d["pt.sources"]

@@ -9,7 +9,7 @@ from classpp_public_amd.inputs import Inputs
 import pytest
 
 
-@pytest.mark.parametrize("cfg", ["small", "tens", "curved", "open"])
+@pytest.mark.parametrize("cfg", ["small", "tens", "curved", "open", "tens_curved"])
 def test_cl_from_reference_transfer_small(cfg):
     inp = Inputs(cfg)
     d = inp.d

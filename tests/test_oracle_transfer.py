@@ -15,7 +15,7 @@ def rel_to_rowmax(a, b):
     return np.max(np.abs(a - b) / scale)
 
 
-@pytest.mark.parametrize("cfg", ["small", "tens", "curved", "open"])
+@pytest.mark.parametrize("cfg", ["small", "tens", "curved", "open", "tens_curved"])
 def test_transfer_small_full_table(cfg):
     """scalar types t0,t1,t2,e,lcmb (small), tensor types t2,e,b (tens: a tensors-only reference run) and closed space
     (curved: per-q hyperspherical tables with integer nu + flat-rescaling approximation above nu = 1500)"""
