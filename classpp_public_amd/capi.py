@@ -48,10 +48,15 @@ class CptConfig(C.Structure):
         ("transfer_neglect_delta_k_T_t2", _d), ("transfer_neglect_delta_k_T_e", _d), ("transfer_neglect_delta_k_T_b", _d),
         ("hyper_sampling_curved_low_nu", _d), ("hyper_sampling_curved_high_nu", _d), ("hyper_nu_sampling_step", _d),
         ("hyper_flat_approximation_nu", _d),
+        ("N_ncdm", _i), ("l_max_ncdm", _i), ("ncdm_fluid_approximation", _i), ("ncdm_fluid_trigger_tau_over_tau_k", _d),
+        ("tol_ncdm_initial_w", _d), ("index_tp_delta_cb", _i), ("tensor_method", _i),
     ]
 
 
 _pd = C.POINTER(_d)
+
+
+MAX_NCDM = 3
 
 
 class CptTables(C.Structure):
@@ -66,6 +71,9 @@ class CptTables(C.Structure):
         ("index_th_xe", _i), ("index_th_dkappa", _i), ("index_th_tau_d", _i), ("index_th_ddkappa", _i),
         ("index_th_dddkappa", _i), ("index_th_exp_m_kappa", _i), ("index_th_g", _i), ("index_th_dg", _i),
         ("index_th_cb2", _i), ("index_th_rate", _i),
+        ("index_bg_rho_ncdm1", _i), ("index_bg_p_ncdm1", _i), ("index_bg_pseudo_p_ncdm1", _i),
+        ("q_size_ncdm", _i * MAX_NCDM), ("q_ncdm", _pd * MAX_NCDM), ("w_ncdm", _pd * MAX_NCDM),
+        ("dlnf0_dlnq_ncdm", _pd * MAX_NCDM), ("M_ncdm", _d * MAX_NCDM), ("factor_ncdm", _d * MAX_NCDM),
     ]
 
 

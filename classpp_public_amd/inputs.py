@@ -27,7 +27,8 @@ class Inputs:
     def __init__(self, name, golden_dir=GOLDEN):
         self.name = name
         self.d = dict(np.load(os.path.join(golden_dir, name + ".npz")))
-        tname = "tables_%s.npz" % ("curved" if (name.startswith("curved") or name == "tens_curved") else name)   # (open.ini has its own: tables_open.npz)
+        tname = "tables_%s.npz" % ("curved" if (name.startswith("curved") or name == "tens_curved") else
+                                  "ncdm3" if name.startswith("ncdm3") else "ncdm1" if name.startswith("ncdm") else name)   # (open.ini has its own: tables_open.npz)
         self.t = dict(np.load(os.path.join(golden_dir, tname if os.path.exists(os.path.join(golden_dir, tname)) else "tables_lcdm.npz")))
         d, t = self.d, self.t
         c = CptConfig()
@@ -76,6 +77,13 @@ class Inputs:
         for f in ("t2", "e", "b"):
             key = "ppr.transfer_neglect_delta_k_T_" + f
             setattr(c, "transfer_neglect_delta_k_T_" + f, float(_s(d, key)) if key in d else 0.0)
+        # non-cold dark matter (massive neutrinos): momentum grids travel in the tables struct below
+        c.N_ncdm = int(_s(d, "pba.N_ncdm")) if c.has_ncdm else 0
+        c.l_max_ncdm = int(_s(d, "ppr.l_max_ncdm")); c.ncdm_fluid_approximation = int(_s(d, "ppr.ncdm_fluid_approximation"))
+        c.ncdm_fluid_trigger_tau_over_tau_k = float(_s(d, "ppr.ncdm_fluid_trigger_tau_over_tau_k"))
+        c.tol_ncdm_initial_w = float(_s(d, "ppr.tol_ncdm_initial_w")) if "ppr.tol_ncdm_initial_w" in d else 1e-3
+        c.index_tp_delta_cb = int(_s(d, "pt.index_tp_delta_cb")) if "pt.index_tp_delta_cb" in d else -1
+        c.tensor_method = int(_s(d, "ppt.tensor_method")) if "ppt.tensor_method" in d else 1
         # initial condition: one mode per handle (ad unless the fixture says otherwise)
         c.ic = 0
         for code, key in ((1, "ppt.has_bi"), (2, "ppt.has_cdi"), (3, "ppt.has_nid"), (4, "ppt.has_niv")):
@@ -103,6 +111,14 @@ class Inputs:
         tb.d2thermodynamics_dz2_table = ptr(t["th.d2thermodynamics_dz2_table"])
         for f in ("xe", "dkappa", "tau_d", "ddkappa", "dddkappa", "exp_m_kappa", "g", "dg", "cb2", "rate"):
             setattr(tb, "index_th_" + f, int(_s(t, "th.index_th_" + f)))
+        if c.has_ncdm:
+            for f in ("rho_ncdm1", "p_ncdm1", "pseudo_p_ncdm1"):
+                setattr(tb, "index_bg_" + f, int(_s(t, "bg.index_bg_" + f)))
+            for n in range(c.N_ncdm):
+                tb.q_size_ncdm[n] = t["ncdm.q_%d" % n].size
+                tb.q_ncdm[n] = ptr(t["ncdm.q_%d" % n]); tb.w_ncdm[n] = ptr(t["ncdm.w_%d" % n])
+                tb.dlnf0_dlnq_ncdm[n] = ptr(t["ncdm.dlnf0_dlnq_%d" % n])
+                tb.M_ncdm[n] = float(t["ncdm.M"][n]); tb.factor_ncdm[n] = float(t["ncdm.factor"][n])
         self.tables = tb
 
         # primordial spectrum + C_l slots (struct primordial / SpectraModule index_ct_*)

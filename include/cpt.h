@@ -55,6 +55,17 @@ extern "C" {
 #define CPT_UFA_HU 1
 #define CPT_UFA_CLASS 2
 #define CPT_UFA_NONE 3
+/* ncdm_fluid_approximation (enum ncdmfa_method, source/perturbations.h:55) */
+#define CPT_NCDMFA_MB 0
+#define CPT_NCDMFA_HU 1
+#define CPT_NCDMFA_CLASS 2
+#define CPT_NCDMFA_NONE 3
+/* tensor_method (enum tensor_methods, source/perturbations.h:56) */
+#define CPT_TM_PHOTONS_ONLY 0
+#define CPT_TM_MASSLESS_APPROXIMATION 1
+#define CPT_TM_EXACT 2
+#define CPT_MAX_NCDM 3       /* species per handle */
+#define CPT_MAX_Q_NCDM 8     /* momentum bins per species */
 
 /* Flat POD with the physics flags / derived scalars / precision parameters the path reads
  * (struct background / thermo / perturbs / precision / transfers of the reference).  */
@@ -118,6 +129,16 @@ typedef struct cpt_config {
   double transfer_neglect_delta_k_T_t2, transfer_neglect_delta_k_T_e, transfer_neglect_delta_k_T_b;
   /* --- non-flat space: per-q hyperspherical tables (tm.cpp:3777-3887; include/precisions.h:341-346) --- */
   double hyper_sampling_curved_low_nu, hyper_sampling_curved_high_nu, hyper_nu_sampling_step, hyper_flat_approximation_nu;
+  /* --- non-cold dark matter: massive neutrinos etc. (read only when has_ncdm != 0; pm.cpp:3441-3466, 8725-8879, 6317-6432) --- */
+  int N_ncdm;                         /* number of species, <= CPT_MAX_NCDM; momentum grids travel in cpt_tables          */
+  int l_max_ncdm;                     /* precision: multipoles per momentum bin (default 17)                               */
+  int ncdm_fluid_approximation;       /* CPT_NCDMFA_MB / HU / CLASS / NONE (source/perturbations.h:55)                     */
+  double ncdm_fluid_trigger_tau_over_tau_k;
+  double tol_ncdm_initial_w;          /* start-time condition |p/rho - 1/3| of every species (pm.cpp:2574-2603)           */
+  int index_tp_delta_cb;              /* slot of the cdm+baryon density source (requested together with delta_m when ncdm is
+                                         present, pm.cpp:996); -1 = absent                                                 */
+  int tensor_method;                  /* CPT_TM_PHOTONS_ONLY / MASSLESS_APPROXIMATION / EXACT (pm.cpp:590-611): with ncdm and
+                                         the massless approximation the tensor ur hierarchy carries rho_ur + 3 sum p_ncdm  */
 } cpt_config;
 
 /* Spline tables the RHS samples (all HOST pointers, row-major [n_lines][n_columns], copied to HBM by cpt_create):
@@ -138,6 +159,15 @@ typedef struct cpt_tables {
   int index_th_xe, index_th_dkappa, index_th_tau_d, index_th_ddkappa, index_th_dddkappa, index_th_exp_m_kappa,
       index_th_g, index_th_dg, index_th_cb2;
   int index_th_rate; /* only read by the host-side time sampling (include/cpt_host.h), never by the kernels */
+  /* non-cold dark matter (read only when cfg->has_ncdm): background columns of the first species (others contiguous,
+   * source/background_module.h:55-57) and the momentum grids NonColdDarkMatter::q_ncdm_, w_ncdm_, dlnf0_dlnq_ncdm_, M_ncdm_,
+   * factor_ncdm_ (tools/non_cold_dark_matter.h:70-79), host pointers */
+  int index_bg_rho_ncdm1, index_bg_p_ncdm1, index_bg_pseudo_p_ncdm1;
+  int q_size_ncdm[CPT_MAX_NCDM];
+  const double* q_ncdm[CPT_MAX_NCDM];
+  const double* w_ncdm[CPT_MAX_NCDM];
+  const double* dlnf0_dlnq_ncdm[CPT_MAX_NCDM];
+  double M_ncdm[CPT_MAX_NCDM], factor_ncdm[CPT_MAX_NCDM];
 } cpt_tables;
 
 /* per-k-mode work counters = the evolver's stepstat[6] (tools/evolver_ndf15.cpp:29-37) summed over regimes */

@@ -48,7 +48,7 @@ def run_reference(cfg, tmpdir="/tmp"):
     return d
 
 
-TABLE_KEYS = ("bg.", "th.")
+TABLE_KEYS = ("bg.", "th.", "ncdm.")
 
 
 def pick_k_subset(nk, n=16):
@@ -71,7 +71,7 @@ def main():
             else:
                 out[k] = v
         src = d["pt.sources"]  # [tp][tau][k]
-        if cfg in ("small", "tens", "tens_curved"):
+        if cfg in ("small", "tens", "tens_curved", "ncdm_small", "ncdm3_small"):
             out["pt.sources"] = src
             if "tr.transfer" in d:
                 out["tr.transfer"] = d["tr.transfer"]
@@ -106,6 +106,18 @@ def main():
             continue
         if cfg in ("curved_full", "tens_curved"):
             np.savez_compressed(os.path.join(GOLD, cfg + ".npz"), **out)
+            print(cfg, {k: v.shape for k, v in out.items() if v.size > 1000})
+            continue
+        if cfg.startswith("ncdm"):
+            # massive neutrinos (BASELINE configs 3, 4): one table file per cosmology (1 species / 3 species)
+            tname = "tables_ncdm3.npz" if cfg.startswith("ncdm3") else "tables_ncdm1.npz"
+            np.savez_compressed(os.path.join(GOLD, cfg + ".npz"), **out)
+            if cfg in ("ncdm_small", "ncdm3_small"):
+                np.savez_compressed(os.path.join(GOLD, tname), **tables)
+            else:
+                old = np.load(os.path.join(GOLD, tname))
+                for k in tables:
+                    assert np.array_equal(old[k], tables[k]), "tables differ between configs: " + k
             print(cfg, {k: v.shape for k, v in out.items() if v.size > 1000})
             continue
         if cfg in ("curved", "open"):

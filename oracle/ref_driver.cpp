@@ -43,6 +43,7 @@
 #define protected public
 #include "cosmology.h"
 #include "background_module.h"
+#include "non_cold_dark_matter.h"
 #include "thermodynamics_module.h"
 #include "perturbations_module.h"
 #include "primordial_module.h"
@@ -181,6 +182,22 @@ static int do_dump(const char* ini, const char* outpath) {
   put_i("bg.index_bg_Omega_r", bg->index_bg_Omega_r_); put_i("bg.index_bg_rho_crit", bg->index_bg_rho_crit_);
   put_i("bg.index_bg_Omega_m", bg->index_bg_Omega_m_); put_i("bg.index_bg_conf_distance", bg->index_bg_conf_distance_);
   put_i("bg.index_bg_D", bg->index_bg_D_); put_i("bg.index_bg_f", bg->index_bg_f_);
+  if (pba->has_ncdm) {   // non-cold species: momentum grids of the perturbation sampling (tools/non_cold_dark_matter.h:72-79)
+    const auto& nc = *inp->ncdm_;
+    put_i("bg.index_bg_rho_ncdm1", bg->index_bg_rho_ncdm1_); put_i("bg.index_bg_p_ncdm1", bg->index_bg_p_ncdm1_);
+    put_i("bg.index_bg_pseudo_p_ncdm1", bg->index_bg_pseudo_p_ncdm1_);
+    put_d("ppr.tol_ncdm_initial_w", ppr->tol_ncdm_initial_w);
+    std::vector<double> M(nc.N_ncdm_), fac(nc.N_ncdm_);
+    for (int n = 0; n < nc.N_ncdm_; n++) {
+      M[n] = nc.M_ncdm_[n]; fac[n] = nc.factor_ncdm_[n];
+      if (nc.ncdm_types_[n] != NCDMType::standard) { fprintf(stderr, "only standard ncdm species are dumped\n"); exit(3); }
+      char nm[64];
+      snprintf(nm, sizeof nm, "ncdm.q_%d", n); put_f8(nm, nc.q_ncdm_[n], {nc.q_size_ncdm_[n]});
+      snprintf(nm, sizeof nm, "ncdm.w_%d", n); put_f8(nm, nc.w_ncdm_[n], {nc.q_size_ncdm_[n]});
+      snprintf(nm, sizeof nm, "ncdm.dlnf0_dlnq_%d", n); put_f8(nm, nc.dlnf0_dlnq_ncdm_[n], {nc.q_size_ncdm_[n]});
+    }
+    put_f8("ncdm.M", M.data(), {nc.N_ncdm_}); put_f8("ncdm.factor", fac.data(), {nc.N_ncdm_});
+  }
   put_d("bg.conformal_age", bg->conformal_age_); put_d("bg.Omega0_m", bg->Omega0_m_);
 
   // ---- thermodynamics tables (source/thermodynamics_module.h:120-125) ----
@@ -219,6 +236,7 @@ static int do_dump(const char* ini, const char* outpath) {
   put_i("pt.index_tp_p", pt->has_source_p_ ? pt->index_tp_p_ : -1);
   put_i("pt.index_tp_phi_plus_psi", pt->has_source_phi_plus_psi_ ? pt->index_tp_phi_plus_psi_ : -1);
   put_i("pt.index_tp_delta_m", pt->has_source_delta_m_ ? pt->index_tp_delta_m_ : -1);
+  put_i("pt.index_tp_delta_cb", pt->has_source_delta_cb_ ? pt->index_tp_delta_cb_ : -1);
   {
     std::vector<double> s((size_t)ntp * ntau * nk);
     for (int tp = 0; tp < ntp; tp++)

@@ -21,7 +21,7 @@ namespace {
 constexpr double SIGMA_T = 6.6524616e-29, MPC_OVER_M = 3.085677581282e22, K_B = 1.3806504e-23, C_LIGHT = 2.99792458e8,
                  M_H = 1.673575e-27, NOT4 = 3.9715;
 
-struct Bg { double a, H, Hp, rho_g, rho_b, rho_cdm, rho_ur; };
+struct Bg { double a, H, Hp, rho_g, rho_b, rho_cdm, rho_ur; double rho_ncdm[CPT_MAX_NCDM], p_ncdm[CPT_MAX_NCDM], pseudo_p_ncdm[CPT_MAX_NCDM]; };
 struct Th { double xe, dkappa, tau_d, ddkappa, dddkappa, expmk, g, dg, cb2; };
 
 struct Model {
@@ -53,6 +53,9 @@ bool bg_at_tau(const Model& m, double tau, Bg& o) {
   o.a = f(t.index_bg_a); o.H = f(t.index_bg_H); o.Hp = f(t.index_bg_H_prime); o.rho_g = f(t.index_bg_rho_g);
   o.rho_b = f(t.index_bg_rho_b); o.rho_cdm = m.c->has_cdm ? f(t.index_bg_rho_cdm) : 0.;
   o.rho_ur = m.c->has_ur ? f(t.index_bg_rho_ur) : 0.;
+  for (int n = 0; n < (m.c->has_ncdm ? m.c->N_ncdm : 0); n++) {
+    o.rho_ncdm[n] = f(t.index_bg_rho_ncdm1 + n); o.p_ncdm[n] = f(t.index_bg_p_ncdm1 + n); o.pseudo_p_ncdm[n] = f(t.index_bg_pseudo_p_ncdm1 + n);
+  }
   return true;
 }
 
@@ -83,18 +86,21 @@ void th_at_z(const Model& m, double z, const Bg& bg, Th& o) {
 
 // ---- regime layout: pm.cpp:3302-3481 (scalars, synchronous gauge, LambdaCDM + ur) ----
 struct Layout {
-  int tca, rsa, ufa;  // 1 = approximation ON
+  int tca, rsa, ufa, nfa;  // 1 = approximation ON (nfa: ncdm fluid approximation)
   int neq;
   int delta_g, theta_g, shear_g, l3_g, pol0_g, pol1_g, pol2_g, pol3_g, delta_b, theta_b, delta_cdm, theta_cdm, delta_ur, theta_ur,
       shear_ur, l3_ur, eta;  // eta: synchronous eta, or the Newtonian phi (same slot, pm.cpp:3470-3478)
   int gw, gwdot;         // tensor modes
+  int psi0_ncdm1, n_ncdm, l_max_ncdm, q_size_ncdm[CPT_MAX_NCDM], ncdm_start[CPT_MAX_NCDM];  // pm.cpp:3441-3466
+  int ncdm_index(int n, int iq) const { return ncdm_start[n] + iq * (l_max_ncdm + 1); }
   int l_max_g, l_max_pol_g, l_max_ur;
   std::vector<int> used_in_sources;
 };
 
-Layout make_layout(const cpt_config& c, int tca, int rsa, int ufa) {
+Layout make_layout(const cpt_config& c, const cpt_tables& t, int tca, int rsa, int ufa, int nfa) {
   Layout L;
-  L.tca = tca; L.rsa = rsa; L.ufa = ufa;
+  L.tca = tca; L.rsa = rsa; L.ufa = ufa; L.nfa = nfa;
+  L.psi0_ncdm1 = -1; L.n_ncdm = 0; L.l_max_ncdm = 0;
   L.delta_g = L.theta_g = L.shear_g = L.l3_g = L.pol0_g = L.pol1_g = L.pol2_g = L.pol3_g = -1;
   L.delta_ur = L.theta_ur = L.shear_ur = L.l3_ur = -1;
   L.delta_cdm = L.theta_cdm = -1;
@@ -128,6 +134,14 @@ Layout make_layout(const cpt_config& c, int tca, int rsa, int ufa) {
     L.delta_ur = i++; L.theta_ur = i++; L.shear_ur = i++;
     if (!ufa) { L.l3_ur = i; i += c.l_max_ur - 2; }
   }
+  if (c.has_ncdm) {  // pm.cpp:3441-3466: full hierarchy per momentum bin, or (delta, theta, shear) per species in the fluid regime
+    L.psi0_ncdm1 = i; L.n_ncdm = c.N_ncdm; L.l_max_ncdm = nfa ? 2 : c.l_max_ncdm;
+    for (int n = 0; n < c.N_ncdm; n++) {
+      L.q_size_ncdm[n] = nfa ? 1 : t.q_size_ncdm[n];
+      L.ncdm_start[n] = i;
+      i += (L.l_max_ncdm + 1) * L.q_size_ncdm[n];
+    }
+  }
   L.eta = i++;
   L.neq = i;
   // pm.cpp:3597-3640
@@ -139,6 +153,10 @@ Layout make_layout(const cpt_config& c, int tca, int rsa, int ufa) {
   }
   if (c.has_ur && !rsa && !ufa)
     for (int p = L.l3_ur; p <= L.delta_ur + L.l_max_ur; p++) L.used_in_sources[p] = 0;
+  if (c.has_ncdm)   // pm.cpp:3663-3671
+    for (int n = 0; n < L.n_ncdm; n++)
+      for (int iq = 0; iq < L.q_size_ncdm[n]; iq++)
+        for (int l = 3; l <= L.l_max_ncdm; l++) L.used_in_sources[L.ncdm_index(n, iq) + l] = 0;
   return L;
 }
 
@@ -161,14 +179,14 @@ struct Work {
   double psi, phi_prime;  // Newtonian gauge
   double gw_prime_prime;  // tensors
   double delta_rho, rho_plus_p_theta, rho_plus_p_shear, delta_p, rho_plus_p_tot;
-  double delta_m, theta_m;
+  double delta_m, theta_m, delta_cb, theta_cb;
   double rsa_delta_g, rsa_theta_g, rsa_delta_ur, rsa_theta_ur;
   double tca_shear_g, tca_slip;
   long fevals = 0;
 };
 
 // perturb_approximations, pm.cpp:5443-5670
-void approximations(const Model& m, double k, double tau, int* tca, int* rsa, int* ufa) {
+void approximations(const Model& m, double k, double tau, int* tca, int* rsa, int* ufa, int* nfa) {
   const cpt_config& c = *m.c;
   Bg bg; Th th;
   bg_at_tau(m, tau, bg);
@@ -183,6 +201,9 @@ void approximations(const Model& m, double k, double tau, int* tca, int* rsa, in
           (c.radiation_streaming_approximation != CPT_RSA_NONE)) ? 1 : 0;
   *ufa = 0;
   if (c.has_ur && c.mode != CPT_MODE_TENSORS) *ufa = ((tau / tau_k > c.ur_fluid_trigger_tau_over_tau_k) && (c.ur_fluid_approximation != CPT_UFA_NONE)) ? 1 : 0;
+  *nfa = 0;   // pm.cpp:5606-5614
+  if (c.has_ncdm && c.mode != CPT_MODE_TENSORS)
+    *nfa = ((tau / tau_k > c.ncdm_fluid_trigger_tau_over_tau_k) && (c.ncdm_fluid_approximation != CPT_NCDMFA_NONE)) ? 1 : 0;
 }
 
 // perturb_rsa_delta_and_theta, pm.cpp:9530-9636 (synchronous gauge)
@@ -268,6 +289,39 @@ void einstein(const Model& m, double k, const double* y, const Layout& L, Work& 
     w.delta_p += 1. / 3. * bg.rho_ur * delta_ur;
     w.rho_plus_p_tot += 4. / 3. * bg.rho_ur;
   }
+  w.delta_cb = delta_rho_m / rho_m;                 // cdm + baryons only, before ncdm is added (pm.cpp:6309-6315)
+  w.theta_cb = rho_plus_p_theta_m / rho_plus_p_m;
+  if (c.has_ncdm) {  // pm.cpp:6317-6432
+    const cpt_tables& t = *m.t;
+    for (int n = 0; n < L.n_ncdm; n++) {
+      const double rho_bg = bg.rho_ncdm[n], p_bg = bg.p_ncdm[n], rho_plus_p = rho_bg + p_bg;
+      double rho_delta, rho_plus_p_theta, rho_plus_p_shear, delta_p;
+      if (L.nfa) {
+        const int idx = L.ncdm_index(n, 0);
+        const double w_ncdm = p_bg / rho_bg;
+        const double cg2 = w_ncdm * (1.0 - 1.0 / (3.0 + 3.0 * w_ncdm) * (3.0 * w_ncdm - 2.0 + bg.pseudo_p_ncdm[n] / p_bg));
+        rho_delta = rho_bg * y[idx]; rho_plus_p_theta = rho_plus_p * y[idx + 1]; rho_plus_p_shear = rho_plus_p * y[idx + 2];
+        delta_p = cg2 * rho_bg * y[idx];
+      } else {
+        rho_delta = rho_plus_p_theta = rho_plus_p_shear = delta_p = 0.;
+        const double factor = t.factor_ncdm[n] * std::pow(c.a_today / a, 4);
+        for (int iq = 0; iq < L.q_size_ncdm[n]; iq++) {
+          const int idx = L.ncdm_index(n, iq);
+          const double q = t.q_ncdm[n][iq], q2 = q * q, w0 = t.w_ncdm[n][iq];
+          const double epsilon = std::sqrt(q2 + t.M_ncdm[n] * t.M_ncdm[n] * a2);
+          rho_delta += q2 * epsilon * w0 * y[idx];
+          rho_plus_p_theta += q2 * q * w0 * y[idx + 1];
+          rho_plus_p_shear += q2 * q2 / epsilon * w0 * y[idx + 2];
+          delta_p += q2 * q2 / epsilon * w0 * y[idx];
+        }
+        rho_delta *= factor; rho_plus_p_theta *= k * factor; rho_plus_p_shear *= 2.0 / 3.0 * factor; delta_p *= factor / 3.;
+      }
+      w.delta_rho += rho_delta; w.rho_plus_p_theta += rho_plus_p_theta; w.rho_plus_p_shear += rho_plus_p_shear; w.delta_p += delta_p;
+      w.rho_plus_p_tot += rho_plus_p;
+      delta_rho_m += rho_delta; rho_m += rho_bg;                       // delta_ncdm rho_ncdm
+      rho_plus_p_theta_m += rho_plus_p_theta; rho_plus_p_m += rho_plus_p;
+    }
+  }
   w.delta_m = delta_rho_m / rho_m;
   w.theta_m = rho_plus_p_theta_m / rho_plus_p_m;
   if (c.gauge == CPT_GAUGE_NEWTONIAN) {  // pm.cpp:5869-5897
@@ -276,6 +330,7 @@ void einstein(const Model& m, double k, const double* y, const Layout& L, Work& 
     if (L.rsa) rsa_delta_and_theta(m, k, y, L, a_prime_over_a, w);
     w.h_prime = w.eta_prime = w.h_prime_prime = w.alpha = w.alpha_prime = 0.;
     w.delta_m += 3. * bg.a * bg.H * w.theta_m / k2;   // pm.cpp:5979-5981
+    w.delta_cb += 3. * bg.a * bg.H * w.theta_cb / k2;
     return;
   }
   // Einstein equations, synchronous gauge: pm.cpp:5906-5971
@@ -293,6 +348,7 @@ void einstein(const Model& m, double k, const double* y, const Layout& L, Work& 
   // gauge-invariant matter variables pm.cpp:5979-6005 (delta_m always tracked: cheap)
   w.delta_m += 3. * bg.a * bg.H * w.theta_m / k2;
   w.theta_m += w.alpha * k2;
+  w.delta_cb += 3. * bg.a * bg.H * w.theta_cb / k2;   // pm.cpp:5992-5993
 }
 
 // perturb_tca_slip_and_shear, pm.cpp:9229-9516 (first_order_CAMB and compromise_CLASS)
@@ -337,8 +393,10 @@ void tensor_derivs(const Model& m, double k, double tau, const double* y, double
   double gw_source = 0.;
   const bool photons = !L.rsa && !L.tca;
   if (photons) gw_source += -SQRT6 * 4 * a2 * bg.rho_g * (1. / 15. * y[L.delta_g] + 4. / 21. * y[L.shear_g] + 1. / 35. * y[L.l3_g + 1]);
-  if (c.evolve_tensor_ur)   // tensor_method = massless approximation / exact without ncdm: rho_relativistic = rho_ur
-    gw_source += -SQRT6 * 4 * a2 * bg.rho_ur * (1. / 15. * y[L.delta_ur] + 4. / 21. * y[L.shear_ur] + 1. / 35. * y[L.l3_ur + 1]);
+  double rho_relativistic = bg.rho_ur;   // pm.cpp:6640-6657: the massless approximation counts 3 p_ncdm as relativistic density
+  if (c.has_ncdm && c.tensor_method == CPT_TM_MASSLESS_APPROXIMATION) for (int n = 0; n < c.N_ncdm; n++) rho_relativistic += 3. * bg.p_ncdm[n];
+  if (c.evolve_tensor_ur)
+    gw_source += -SQRT6 * 4 * a2 * rho_relativistic * (1. / 15. * y[L.delta_ur] + 4. / 21. * y[L.shear_ur] + 1. / 35. * y[L.l3_ur + 1]);
   w.gw_prime_prime = -2. * a_prime_over_a * y[L.gwdot] - (k2 + 2. * c.K) * y[L.gw] + gw_source;
   if (photons) {
     const double delta_g = y[L.delta_g], theta_g = y[L.theta_g], shear_g = y[L.shear_g];
@@ -452,6 +510,42 @@ void derivs(const Model& m, double k, double tau, const double* y, double* dy, c
       if (c.ur_fluid_approximation == CPT_UFA_CLASS) dy[L.shear_ur] = -3. / tau * y[L.shear_ur] + 2. / 3. * (y[L.theta_ur] + metric_ufa_class);
     }
   }
+  if (c.has_ncdm) {  // pm.cpp:8725-8879
+    const cpt_tables& t = *m.t;
+    const double a2 = a * a;
+    for (int n = 0; n < L.n_ncdm; n++) {
+      if (L.nfa) {
+        const int idx = L.ncdm_index(n, 0);
+        const double rho_bg = bg.rho_ncdm[n], p_bg = bg.p_ncdm[n], pseudo_p_over_p = bg.pseudo_p_ncdm[n] / p_bg;
+        const double w_ncdm = p_bg / rho_bg, ca2 = w_ncdm / 3.0 / (1.0 + w_ncdm) * (5.0 - pseudo_p_over_p);
+        double ceff2 = ca2, cvis2 = 3. * w_ncdm * ca2;
+        if (c.ncdm_fluid_approximation == CPT_NCDMFA_HU) cvis2 = w_ncdm;
+        dy[idx] = -(1.0 + w_ncdm) * (y[idx + 1] + metric_continuity) - 3.0 * a_prime_over_a * (ceff2 - w_ncdm) * y[idx];
+        dy[idx + 1] = -a_prime_over_a * (1.0 - 3.0 * ca2) * y[idx + 1] + ceff2 / (1.0 + w_ncdm) * k2 * y[idx] - k2 * y[idx + 2] + metric_euler;
+        if (c.ncdm_fluid_approximation == CPT_NCDMFA_MB)
+          dy[idx + 2] = -3.0 * (a_prime_over_a * (2. / 3. - ca2 - pseudo_p_over_p / 3.) + 1. / tau) * y[idx + 2] +
+                        8.0 / 3.0 * cvis2 / (1.0 + w_ncdm) * S(2) * (y[idx + 1] + metric_shear);
+        if (c.ncdm_fluid_approximation == CPT_NCDMFA_HU)
+          dy[idx + 2] = -3.0 * a_prime_over_a * ca2 / w_ncdm * y[idx + 2] + 8.0 / 3.0 * cvis2 / (1.0 + w_ncdm) * S(2) * (y[idx + 1] + metric_shear);
+        if (c.ncdm_fluid_approximation == CPT_NCDMFA_CLASS)
+          dy[idx + 2] = -3.0 * (a_prime_over_a * (2. / 3. - ca2 - pseudo_p_over_p / 3.) + 1. / tau) * y[idx + 2] +
+                        8.0 / 3.0 * cvis2 / (1.0 + w_ncdm) * S(2) * (y[idx + 1] + metric_ufa_class);
+      } else {
+        for (int iq = 0; iq < L.q_size_ncdm[n]; iq++) {
+          const int idx = L.ncdm_index(n, iq);
+          const double q = t.q_ncdm[n][iq], dlnf0_dlnq = t.dlnf0_dlnq_ncdm[n][iq];
+          const double epsilon = std::sqrt(q * q + a2 * t.M_ncdm[n] * t.M_ncdm[n]), qk_div_epsilon = k * q / epsilon;
+          dy[idx] = -qk_div_epsilon * y[idx + 1] + metric_continuity * dlnf0_dlnq / 3.;
+          dy[idx + 1] = qk_div_epsilon / 3.0 * (y[idx] - 2 * S(2) * y[idx + 2]) - epsilon * metric_euler / (3 * q * k) * dlnf0_dlnq;
+          dy[idx + 2] = qk_div_epsilon / 5.0 * (2 * S(2) * y[idx + 1] - 3. * S(3) * y[idx + 3]) - S(2) * metric_shear * 2. / 15. * dlnf0_dlnq;
+          int l;
+          for (l = 3; l < L.l_max_ncdm; l++)
+            dy[idx + l] = qk_div_epsilon / (2. * l + 1.0) * (l * S(l) * y[idx + (l - 1)] - (l + 1.) * S(l + 1) * y[idx + (l + 1)]);
+          dy[idx + l] = qk_div_epsilon * y[idx + l - 1] - (1. + l) * k * cotKgen * y[idx + l];
+        }
+      }
+    }
+  }
   dy[L.eta] = (c.gauge == CPT_GAUGE_NEWTONIAN) ? w.phi_prime : w.eta_prime;   // pm.cpp:8892-8902
 }
 
@@ -496,6 +590,7 @@ void sources(const Model& m, double k, double tau, const double* y, const double
     if (c.index_tp_p >= 0) out[c.index_tp_p] = std::sqrt(6.) * th.g * P;
     if (c.index_tp_phi_plus_psi >= 0) out[c.index_tp_phi_plus_psi] = y[L.eta] + w.psi;
     if (c.index_tp_delta_m >= 0) out[c.index_tp_delta_m] = w.delta_m;
+    if (c.has_ncdm && c.index_tp_delta_cb >= 0) out[c.index_tp_delta_cb] = w.delta_cb;
     return;
   }
   if (c.index_tp_t0 >= 0)
@@ -508,6 +603,7 @@ void sources(const Model& m, double k, double tau, const double* y, const double
   if (c.index_tp_p >= 0) out[c.index_tp_p] = std::sqrt(6.) * th.g * P;
   if (c.index_tp_phi_plus_psi >= 0) out[c.index_tp_phi_plus_psi] = y[L.eta] + w.alpha_prime;
   if (c.index_tp_delta_m >= 0) out[c.index_tp_delta_m] = w.delta_m;
+  if (c.has_ncdm && c.index_tp_delta_cb >= 0) out[c.index_tp_delta_cb] = w.delta_cb;   // pm.cpp:7001-7003
 }
 
 // ---- ndf15: ev.cpp:62-705 (+ numjac :1213-1539 in its dense mode, dense LU :1001-1064) ----
@@ -905,6 +1001,7 @@ void initial_conditions(const Model& m, double k, double tau, const Layout& L, d
   double rho_r = bg.rho_g, rho_m = bg.rho_b, rho_nu = 0.;
   if (c.has_cdm) rho_m += bg.rho_cdm;
   if (c.has_ur) { rho_r += bg.rho_ur; rho_nu += bg.rho_ur; }
+  if (c.has_ncdm) for (int n = 0; n < c.N_ncdm; n++) { rho_r += bg.rho_ncdm[n]; rho_nu += bg.rho_ncdm[n]; }   // pm.cpp:4794-4799
   double fracnu = rho_nu / rho_r, fracb = bg.rho_b / rho_m;
   double om = a * rho_m / std::sqrt(rho_r);
   double ktau_two = k * k * tau * tau, ktau_three = k * tau * ktau_two;
@@ -925,14 +1022,16 @@ void initial_conditions(const Model& m, double k, double tau, const Layout& L, d
   y[L.delta_b] = 3. / 4. * y[L.delta_g];
   y[L.theta_b] = y[L.theta_g];
   if (c.has_cdm) y[L.delta_cdm] = 3. / 4. * y[L.delta_g];
-  if (c.has_ur) {
+  double ur0 = 0., ur1 = 0., ur2 = 0., ur3 = 0.;   // relativistic relics: ur and early ncdm share these series (pm.cpp:4922-4943, 5202-5256)
+  if (c.has_ur || c.has_ncdm) {
     double delta_ur = y[L.delta_g];
     double theta_ur = -k * ktau_three / 36. / (4. * fracnu + 15.) *
                       (4. * fracnu + 11. + 12. * s2_squared - 3. * (8. * fracnu * fracnu + 50. * fracnu + 275.) / 20. / (2. * fracnu + 15.) * tau * om) *
                       c.curvature_ini * s2_squared;
     double shear_ur = ktau_two / (45. + 12. * fracnu) * (3. * s2_squared - 1.) * (1. + (4. * fracnu - 5.) / 4. / (2. * fracnu + 15.) * tau * om) * c.curvature_ini;
     double l3_ur = ktau_three * 2. / 7. / (12. * fracnu + 45.) * c.curvature_ini;
-    y[L.delta_ur] = delta_ur; y[L.theta_ur] = theta_ur; y[L.shear_ur] = shear_ur; y[L.l3_ur] = l3_ur;
+    ur0 = delta_ur; ur1 = theta_ur; ur2 = shear_ur; ur3 = l3_ur;
+    if (c.has_ur) { y[L.delta_ur] = delta_ur; y[L.theta_ur] = theta_ur; y[L.shear_ur] = shear_ur; y[L.l3_ur] = l3_ur; }
   }
   y[L.eta] = c.curvature_ini * (1. - ktau_two / 12. / (15. + 4. * fracnu) *
                                          (5. + 4. * s2_squared * fracnu - (16. * fracnu * fracnu + 280. * fracnu + 325) / 10. / (2. * fracnu + 15.) * tau * om));
@@ -973,13 +1072,14 @@ void initial_conditions(const Model& m, double k, double tau, const Layout& L, d
     eta = ei * fracnu * k * tau * (-1. / (4. * fracnu + 5.) + (-3. / 64. * fracb / fracg + 15. / 4. / (4. * fracnu + 15.) / (4. * fracnu + 5.) * om * tau));
   }
   if (c.has_ur) { y[L.delta_ur] = delta_ur; y[L.theta_ur] = theta_ur; y[L.shear_ur] = shear_ur; y[L.l3_ur] = 0.; }
+  ur0 = delta_ur; ur1 = theta_ur; ur2 = shear_ur; ur3 = 0.;
   y[L.eta] = eta;
   }
   if (c.gauge == CPT_GAUGE_NEWTONIAN) {  // gauge transformation of the synchronous series, pm.cpp:5095-5198
     const double a_prime_over_a = bg.a * bg.H, fracg = bg.rho_g / rho_r, fraccdm = 1. - fracb, rho_m_over_rho_r = rho_m / rho_r;
     const double eta = y[L.eta];
     const double delta_cdm = c.has_cdm ? y[L.delta_cdm] : 0.;
-    const double delta_ur = c.has_ur ? y[L.delta_ur] : 0., theta_ur = c.has_ur ? y[L.theta_ur] : 0.;
+    const double delta_ur = ur0, theta_ur = ur1;
     const double delta_tot = (fracg * y[L.delta_g] + fracnu * delta_ur + rho_m_over_rho_r * (fracb * y[L.delta_b] + fraccdm * delta_cdm)) / (1. + rho_m_over_rho_r);
     const double velocity_tot = ((4. / 3.) * (fracg * y[L.theta_g] + fracnu * theta_ur) + rho_m_over_rho_r * fracb * y[L.theta_b]) / (1. + rho_m_over_rho_r);
     const double alpha = (eta + 3. / 2. * a_prime_over_a * a_prime_over_a / k / k / s2_squared * (delta_tot + 3. * a_prime_over_a / k / k * velocity_tot)) / a_prime_over_a;
@@ -988,6 +1088,19 @@ void initial_conditions(const Model& m, double k, double tau, const Layout& L, d
     y[L.delta_b] -= 3. * a_prime_over_a * alpha; y[L.theta_b] += k * k * alpha;
     if (c.has_cdm) { y[L.delta_cdm] -= 3. * a_prime_over_a * alpha; y[L.theta_cdm] = k * k * alpha; }
     if (c.has_ur) { y[L.delta_ur] -= 4. * a_prime_over_a * alpha; y[L.theta_ur] += k * k * alpha; }
+    ur0 -= 4. * a_prime_over_a * alpha; ur1 += k * k * alpha;
+  }
+  if (c.has_ncdm) {  // pm.cpp:5229-5256
+    const cpt_tables& t = *m.t;
+    for (int n = 0; n < L.n_ncdm; n++)
+      for (int iq = 0; iq < L.q_size_ncdm[n]; iq++) {
+        const int idx = L.ncdm_index(n, iq);
+        const double q = t.q_ncdm[n][iq], epsilon = std::sqrt(q * q + a * a * t.M_ncdm[n] * t.M_ncdm[n]), dlnf0_dlnq = t.dlnf0_dlnq_ncdm[n][iq];
+        y[idx] = -0.25 * ur0 * dlnf0_dlnq;
+        y[idx + 1] = -epsilon / 3. / q / k * ur1 * dlnf0_dlnq;
+        y[idx + 2] = -0.5 * ur2 * dlnf0_dlnq;
+        y[idx + 3] = -0.25 * ur3 * dlnf0_dlnq;
+      }
   }
 }
 
@@ -1007,6 +1120,37 @@ void handover(const Model& m, double k, const Layout& Lo, const double* yo, cons
   yn[Ln.delta_b] = yo[Lo.delta_b]; yn[Ln.theta_b] = yo[Lo.theta_b];
   if (c.has_cdm) { yn[Ln.delta_cdm] = yo[Lo.delta_cdm]; if (Ln.theta_cdm >= 0) yn[Ln.theta_cdm] = yo[Lo.theta_cdm]; }
   yn[Ln.eta] = yo[Lo.eta];
+  if (c.has_ncdm && Lo.nfa == Ln.nfa)   // pm.cpp:3968-3975 etc.: the momentum hierarchies ride through the other switches
+    for (int i = 0; i < Ln.eta - Ln.psi0_ncdm1; i++) yn[Ln.psi0_ncdm1 + i] = yo[Lo.psi0_ncdm1 + i];
+  if (c.has_ncdm && !Lo.nfa && Ln.nfa) {  // pm.cpp:4352-4518: integrate the distribution into (delta, theta, shear)
+    const cpt_tables& t = *m.t;
+    const double a = w.bg.a;
+    if (!Ln.rsa) {
+      yn[Ln.delta_g] = yo[Lo.delta_g]; yn[Ln.theta_g] = yo[Lo.theta_g];
+      if (!Ln.tca) {
+        for (int l = 2; l <= Ln.l_max_g; l++) yn[Ln.delta_g + l] = yo[Lo.delta_g + l];
+        for (int l = 0; l <= Ln.l_max_pol_g; l++) yn[Ln.pol0_g + l] = yo[Lo.pol0_g + l];
+      }
+      if (c.has_ur) {
+        yn[Ln.delta_ur] = yo[Lo.delta_ur]; yn[Ln.theta_ur] = yo[Lo.theta_ur]; yn[Ln.shear_ur] = yo[Lo.shear_ur];
+        if (!Ln.ufa) for (int l = 3; l <= Ln.l_max_ur; l++) yn[Ln.delta_ur + l] = yo[Lo.delta_ur + l];
+      }
+    }
+    for (int n = 0; n < Ln.n_ncdm; n++) {
+      const double rho_plus_p = w.bg.rho_ncdm[n] + w.bg.p_ncdm[n], factor = t.factor_ncdm[n] * std::pow(c.a_today / a, 4);
+      double delta = 0., theta = 0., shear = 0.;
+      for (int iq = 0; iq < Lo.q_size_ncdm[n]; iq++) {
+        const int idx = Lo.ncdm_index(n, iq);
+        const double q = t.q_ncdm[n][iq], w0 = t.w_ncdm[n][iq], epsilon = std::sqrt(q * q + a * a * t.M_ncdm[n] * t.M_ncdm[n]);
+        delta += w0 * std::pow(q, 2) * epsilon * yo[idx];
+        theta += w0 * std::pow(q, 3) * yo[idx + 1];
+        shear += w0 * std::pow(q, 4) / epsilon * yo[idx + 2];
+      }
+      delta *= factor / w.bg.rho_ncdm[n]; theta *= k * factor / rho_plus_p; shear *= 2. / 3. * factor / rho_plus_p;
+      const int idn = Ln.ncdm_index(n, 0);
+      yn[idn] = delta; yn[idn + 1] = theta; yn[idn + 2] = shear;
+    }
+  }
   if (Lo.tca && !Ln.tca) {  // pm.cpp:3880-3935
     yn[Ln.delta_g] = yo[Lo.delta_g]; yn[Ln.theta_g] = yo[Lo.theta_g];
     yn[Ln.shear_g] = w.tca_shear_g;
@@ -1047,31 +1191,33 @@ int solve_mode(const Model& m, double k, int ik, int nk, const double* tau_sampl
     th_at_z(m, 1. / bg.a - 1., bg, th);
     if (bg.a * bg.H / th.dkappa > c.start_small_k_at_tau_c_over_tau_h) return 1;
     if (k / bg.a / bg.H > c.start_large_k_at_tau_h_over_tau_k) return 1;
+    if (c.has_ncdm) for (int n = 0; n < c.N_ncdm; n++) if (std::fabs(bg.p_ncdm[n] / bg.rho_ncdm[n] - 1. / 3.) > c.tol_ncdm_initial_w) return 1;   // pm.cpp:2574-2582
   }
   while ((tau_upper - tau_lower) / tau_lower > c.tol_tau_approx) {
     Bg bg; Th th;
     bg_at_tau(m, tau_mid, bg);
     th_at_z(m, 1. / bg.a - 1., bg, th);
     bool early = !((bg.a * bg.H / th.dkappa > c.start_small_k_at_tau_c_over_tau_h) || (k / bg.a / bg.H > c.start_large_k_at_tau_h_over_tau_k));
+    if (c.has_ncdm) for (int n = 0; n < c.N_ncdm; n++) if (std::fabs(bg.p_ncdm[n] / bg.rho_ncdm[n] - 1. / 3.) > c.tol_ncdm_initial_w) early = false;   // pm.cpp:2601-2603
     if (early) tau_lower = tau_mid; else tau_upper = tau_mid;
     tau_mid = 0.5 * (tau_lower + tau_upper);
   }
   const double tau_ini = tau_mid, tau_end = tau_sampling[ntau - 1];
   res->st.tau_ini = tau_ini;
   // ---- regime schedule, pm.cpp:2940-3231 ----
-  int f_ini[3], f_end[3];
-  approximations(m, k, tau_ini, &f_ini[0], &f_ini[1], &f_ini[2]);
-  approximations(m, k, tau_end, &f_end[0], &f_end[1], &f_end[2]);
+  int f_ini[4], f_end[4];
+  approximations(m, k, tau_ini, &f_ini[0], &f_ini[1], &f_ini[2], &f_ini[3]);
+  approximations(m, k, tau_end, &f_end[0], &f_end[1], &f_end[2], &f_end[3]);
   // tca goes 1 -> 0, rsa / ufa go 0 -> 1 (chronological order of the reference's enums)
   std::vector<double> limits{tau_ini};
   std::vector<double> sw;
-  for (int ap = 0; ap < 3; ap++) {
+  for (int ap = 0; ap < 4; ap++) {
     if (f_ini[ap] == f_end[ap]) continue;
     if ((ap == 0 && !(f_ini[0] == 1 && f_end[0] == 0)) || (ap > 0 && !(f_ini[ap] == 0 && f_end[ap] == 1))) return 2;  // would go backward
     double lo = tau_ini, hi = tau_end, mid = 0.5 * (lo + hi);
     while (hi - lo > c.tol_tau_approx) {
-      int f[3];
-      approximations(m, k, mid, &f[0], &f[1], &f[2]);
+      int f[4];
+      approximations(m, k, mid, &f[0], &f[1], &f[2], &f[3]);
       if (f[ap] != f_ini[ap]) hi = mid; else lo = mid;
       mid = 0.5 * (lo + hi);
     }
@@ -1084,26 +1230,26 @@ int solve_mode(const Model& m, double k, int ik, int nk, const double* tau_sampl
   const int n_int = (int)limits.size() - 1;
   res->st.n_regimes = n_int;
 
-  if (f_ini[0] != 1 || f_ini[1] != 0 || f_ini[2] != 0) return 3;  // pm.cpp:3720-3745: ICs assume tca on, rsa/ufa off
+  if (f_ini[0] != 1 || f_ini[1] != 0 || f_ini[2] != 0 || f_ini[3] != 0) return 3;  // pm.cpp:3720-3745: ICs assume tca on, rsa/ufa off
   Work w;
   Layout Lprev;
   std::vector<double> y, yprev;
   Ndf S;
   for (int iv = 0; iv < n_int; iv++) {
-    int f[3];
-    approximations(m, k, iv == 0 ? limits[0] : 0.5 * (limits[iv] + limits[iv + 1]), &f[0], &f[1], &f[2]);
-    if (iv == 0) { f[0] = f_ini[0]; f[1] = f_ini[1]; f[2] = f_ini[2]; }
-    Layout L = make_layout(c, f[0], f[1], f[2]);
+    int f[4];
+    approximations(m, k, iv == 0 ? limits[0] : 0.5 * (limits[iv] + limits[iv + 1]), &f[0], &f[1], &f[2], &f[3]);
+    if (iv == 0) { f[0] = f_ini[0]; f[1] = f_ini[1]; f[2] = f_ini[2]; f[3] = f_ini[3]; }
+    Layout L = make_layout(c, t, f[0], f[1], f[2], f[3]);
     y.assign(L.neq, 0.);
     if (iv == 0) initial_conditions(m, k, limits[0], L, y.data());
     else {
-      int nsw = (f[0] != Lprev.tca) + (f[1] != Lprev.rsa) + (f[2] != Lprev.ufa);
+      int nsw = (f[0] != Lprev.tca) + (f[1] != Lprev.rsa) + (f[2] != Lprev.ufa) + (f[3] != Lprev.nfa);
       if (nsw != 1) return 2;
       handover(m, k, Lprev, yprev.data(), L, y.data(), w);
     }
     auto rhs = [&](double tau, const double* yy, double* dyy) { derivs(m, k, tau, yy, dyy, L, w); };
     auto out = [&](double tau, const double* yy, const double* dyy, int it) {
-      double s[16];
+      double s[16] = {0};
       sources(m, k, tau, yy, dyy, L, w, s);
       for (int tp = 0; tp < c.tp_size; tp++) src[((size_t)tp * ntau + it) * nk + ik] = s[tp];
     };
@@ -1164,7 +1310,7 @@ int orc_lookup(const cpt_config* cfg, const cpt_tables* tabs, const double* tau,
 int orc_derivs(const cpt_config* cfg, const cpt_tables* tabs, double k, double tau, int tca_on, int rsa_on, int ufa_on,
                const double* y, double* dy, int* neq) {
   Model m{cfg, tabs};
-  Layout L = make_layout(*cfg, tca_on, rsa_on, ufa_on);
+  Layout L = make_layout(*cfg, *tabs, tca_on & 1, rsa_on, ufa_on, (tca_on >> 1) & 1);   // bit 1 of tca_on: ncdm fluid approximation
   Work w;
   *neq = L.neq;
   derivs(m, k, tau, y, dy, L, w);

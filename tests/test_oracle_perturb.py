@@ -26,6 +26,8 @@ def col_errors(got, ref):
 def check_sources(cfg, got, ref):
     tol = {cfg.index_tp_t0: (3e-3, 3e-4), cfg.index_tp_t1: (3e-3, 3e-4), cfg.index_tp_t2: (2e-4, 5e-5),
            cfg.index_tp_p: (2e-4, 5e-5), cfg.index_tp_delta_m: (1e-5, 1e-5), cfg.index_tp_phi_plus_psi: (1e-5, 1e-5)}
+    if cfg.has_ncdm:
+        tol[cfg.index_tp_delta_cb] = (1e-5, 1e-5)
     for tp, (tmax, trms) in tol.items():
         if tp < 0:
             continue
@@ -44,8 +46,11 @@ def test_perturb_small_all_modes():
     assert all(s.steps > 50 and s.fevals > s.steps for s in stats)
 
 
-@pytest.mark.parametrize("cfg", ["lcdm", "explanatory", "curved", "open", "iso_cdi", "iso_nid", "newt", "curved_full"])
+@pytest.mark.parametrize("cfg", ["lcdm", "explanatory", "curved", "open", "iso_cdi", "iso_nid", "newt", "curved_full",
+                                 "ncdm_small", "ncdm3_small", "ncdm", "ncdm3"])
 def test_perturb_full_size_subset(cfg):
+    """(ncdm*: massive neutrinos, one and three species -- momentum hierarchies of pm.cpp:8832-8879, fluid regime :8737-8823,
+    stress-energy integrals :6317-6432, relativistic initial conditions :5229-5256; BASELINE configs 3 and 4)"""
     inp = Inputs(cfg)
     if "pt.sources_k_index" in inp.d:
         ks = inp.d["pt.sources_k_index"]
@@ -68,13 +73,19 @@ def test_lookup_matches_table_nodes():
     assert np.allclose(out[:, 1], t["bg.background_table"][idx, int(t["bg.index_bg_H"][0])], rtol=1e-14)
 
 
-@pytest.mark.parametrize("cfg", ["tens", "tens_curved"])
+@pytest.mark.parametrize("cfg", ["tens", "tens_curved", "ncdm3_tens"])
 def test_tensor_perturbations_all_modes(cfg):
-    """tensor modes (gw, tensor photon / ur ladders; pm.cpp:9045-9215) against the reference's tensor sources t2, p; flat and closed"""
+    """tensor modes (gw, tensor photon / ur ladders; pm.cpp:9045-9215) against the reference's tensor sources t2, p; flat and closed;
+    with three massive neutrinos in the massless approximation (3 p_ncdm counted as relativistic, pm.cpp:6640-6657)"""
     inp = Inputs(cfg)
-    src, stats, status, rc = oracle_lib.perturb(inp)
+    if "pt.sources_k_index" in inp.d:
+        ks = inp.d["pt.sources_k_index"]
+        ref = inp.d["pt.sources_subset"]
+        src, stats, status, rc = oracle_lib.perturb(inp, k=inp.k[ks])
+    else:
+        ref = inp.d["pt.sources"]
+        src, stats, status, rc = oracle_lib.perturb(inp)
     assert rc == 0 and not status.any()
-    ref = inp.d["pt.sources"]
     for tp in (inp.config.index_tp_t2, inp.config.index_tp_p):
         emax, erms = col_errors(src[tp], ref[tp])
         assert emax < 2e-4 and erms < 5e-5, (tp, emax, erms)
