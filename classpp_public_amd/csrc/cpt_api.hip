@@ -63,7 +63,21 @@ static int validate(const cpt_config* c) {
     return cpt_fail(nullptr, CPT_ERR_INVALID, "not consistent to ask for NID/NIV in absence of ur species! (pm.cpp:5024, 5050)");
   if ((c->sgnK == 0) != (c->K == 0.) || (c->sgnK != 0 && (c->sgnK > 0) != (c->K > 0.)))
     return cpt_fail(nullptr, CPT_ERR_INVALID, "inconsistent curvature: K=%g, sgnK=%d", c->K, c->sgnK);
-  if (c->has_ncdm) return cpt_fail(nullptr, CPT_ERR_UNSUPPORTED, "non-cold dark matter species are not implemented");
+  if (c->has_ncdm) {
+    if (c->N_ncdm < 1 || c->N_ncdm > CPT_MAX_NCDM)
+      return cpt_fail(nullptr, CPT_ERR_UNSUPPORTED, "N_ncdm=%d: between 1 and %d non-cold species per handle", c->N_ncdm, CPT_MAX_NCDM);
+    if (c->mode == CPT_MODE_TENSORS) {
+      if (c->tensor_method == CPT_TM_EXACT)
+        return cpt_fail(nullptr, CPT_ERR_UNSUPPORTED, "tensor_method = exact with ncdm (tensor ncdm hierarchies, pm.cpp:9158-9201) is not implemented");
+    } else {
+      if (c->gauge != CPT_GAUGE_SYNCHRONOUS) return cpt_fail(nullptr, CPT_ERR_UNSUPPORTED, "ncdm perturbations are implemented in the synchronous gauge only");
+      if (c->l_max_ncdm < 4) return cpt_fail(nullptr, CPT_ERR_INVALID, "ppr->l_max_ncdm=%d should be at least 4 (pm.cpp:3451)", c->l_max_ncdm);
+      if (c->l_max_ncdm + 1 > CPT_WAVE / 2) return cpt_fail(nullptr, CPT_ERR_UNSUPPORTED, "l_max_ncdm=%d: a momentum bin must fit half a wavefront", c->l_max_ncdm);
+      if (c->ncdm_fluid_approximation < CPT_NCDMFA_MB || c->ncdm_fluid_approximation > CPT_NCDMFA_NONE)
+        return cpt_fail(nullptr, CPT_ERR_INVALID, "ncdm_fluid_approximation=%d", c->ncdm_fluid_approximation);
+      if (c->index_tp_delta_cb >= c->tp_size) return cpt_fail(nullptr, CPT_ERR_INVALID, "index_tp_delta_cb >= tp_size");
+    }
+  }
   if (c->has_fld) return cpt_fail(nullptr, CPT_ERR_UNSUPPORTED, "dark-energy fluid perturbations are not implemented");
   if (!c->has_cdm && c->gauge == CPT_GAUGE_SYNCHRONOUS)
     return cpt_fail(nullptr, CPT_ERR_INVALID,
@@ -80,7 +94,7 @@ static int validate(const cpt_config* c) {
   if (c->mode == CPT_MODE_TENSORS) {
     if (c->l_max_g_ten < 4 || c->l_max_pol_g_ten < 4)
       return cpt_fail(nullptr, CPT_ERR_INVALID, "ppr->l_max_g_ten / l_max_pol_g_ten should be at least 4 (pm.cpp:3521-3527)");
-    if (c->evolve_tensor_ur && !c->has_ur) return cpt_fail(nullptr, CPT_ERR_INVALID, "evolve_tensor_ur without ur species");
+    if (c->evolve_tensor_ur && !c->has_ur && !c->has_ncdm) return cpt_fail(nullptr, CPT_ERR_INVALID, "evolve_tensor_ur without ur species");
     // lane map of the tensor kernel: 17 core lanes + the three l >= 5 tails
     if (17 + (c->l_max_g_ten - 4) + (c->l_max_pol_g_ten - 4) + (c->evolve_tensor_ur ? c->l_max_ur - 4 : 0) > CPT_WAVE)
       return cpt_fail(nullptr, CPT_ERR_UNSUPPORTED, "tensor hierarchy too large: one wavefront (64 lanes) owns one k-mode");
@@ -145,6 +159,33 @@ int cpt_create(const cpt_config* cfg, const cpt_tables* t, cpt_handle** out) {
       th[((size_t)r * TH_NCOL + c) * 2 + 0] = have ? t->thermodynamics_table[(size_t)r * t->th_size + thmap[c]] : 0.;
       th[((size_t)r * TH_NCOL + c) * 2 + 1] = have ? t->d2thermodynamics_dz2_table[(size_t)r * t->th_size + thmap[c]] : 0.;
     }
+  // non-cold species: per-species columns {rho, p, pseudo_p} in a table of their own, sharing the background abscissa
+  std::vector<double> ncb;
+  if (cfg->has_ncdm) {
+    if (t->index_bg_rho_ncdm1 < 0 || t->index_bg_p_ncdm1 < 0 || t->index_bg_pseudo_p_ncdm1 < 0 ||
+        t->index_bg_pseudo_p_ncdm1 + cfg->N_ncdm > t->bg_size)
+      return bail(cpt_fail(h, CPT_ERR_INVALID, "ncdm background columns missing from the tables"));
+    for (int n = 0; n < cfg->N_ncdm; n++) {
+      if (cfg->mode == CPT_MODE_SCALARS && (t->q_size_ncdm[n] < 1 || t->q_size_ncdm[n] > CPT_MAX_Q_NCDM || !t->q_ncdm[n] || !t->w_ncdm[n] || !t->dlnf0_dlnq_ncdm[n]))
+        return bail(cpt_fail(h, CPT_ERR_UNSUPPORTED, "ncdm species %d: between 1 and %d momentum bins", n, CPT_MAX_Q_NCDM));
+    }
+    ncb.assign((size_t)t->bt_size * NCB_NCOL * 2, 0.);
+    for (int r = 0; r < t->bt_size; r++)
+      for (int n = 0; n < cfg->N_ncdm; n++) {
+        const int cols[3] = {t->index_bg_rho_ncdm1 + n, t->index_bg_p_ncdm1 + n, t->index_bg_pseudo_p_ncdm1 + n};
+        for (int j = 0; j < 3; j++) {
+          ncb[((size_t)r * NCB_NCOL + 3 * n + j) * 2 + 0] = t->background_table[(size_t)r * t->bg_size + cols[j]];
+          ncb[((size_t)r * NCB_NCOL + 3 * n + j) * 2 + 1] = t->d2background_dtau2_table[(size_t)r * t->bg_size + cols[j]];
+        }
+      }
+    if (cfg->mode == CPT_MODE_TENSORS && cfg->tensor_method == CPT_TM_MASSLESS_APPROXIMATION) {
+      // pm.cpp:6640-6657: the ur hierarchy of the tensor modes carries rho_relativistic = rho_ur + 3 sum_n p_ncdm_n.  A cubic
+      // spline is linear in its ordinates, so the combined column's second derivatives are the combination of the columns'
+      for (int r = 0; r < t->bt_size; r++)
+        for (int n = 0; n < cfg->N_ncdm; n++)
+          for (int j = 0; j < 2; j++) bg[((size_t)r * BG_NCOL + BG_RHO_UR) * 2 + j] += 3. * ncb[((size_t)r * NCB_NCOL + 3 * n + 1) * 2 + j];
+    }
+  }
   auto up = [&](double** d, const double* src, size_t n) -> bool {
     if (hipMalloc((void**)d, n * sizeof(double)) != hipSuccess) return false;
     return hipMemcpy(*d, src, n * sizeof(double), hipMemcpyHostToDevice) == hipSuccess;
@@ -152,6 +193,22 @@ int cpt_create(const cpt_config* cfg, const cpt_tables* t, cpt_handle** out) {
   if (!up(&h->d_tau_table, t->tau_table, t->bt_size) || !up(&h->d_bg, bg.data(), bg.size()) ||
       !up(&h->d_z_table, t->z_table, t->tt_size) || !up(&h->d_th, th.data(), th.size()))
     return bail(cpt_fail(h, CPT_ERR_NO_DEVICE, "table upload failed"));
+  if (cfg->has_ncdm) {
+    if (!up(&h->d_ncb, ncb.data(), ncb.size())) return bail(cpt_fail(h, CPT_ERR_NO_DEVICE, "table upload failed"));
+    h->tabs.ncb = h->d_ncb;
+    NcdmDev& nd = h->ncdm;
+    memset(&nd, 0, sizeof(nd));
+    nd.n_species = cfg->N_ncdm; nd.lmax = cfg->l_max_ncdm;
+    if (cfg->mode == CPT_MODE_SCALARS)
+      for (int n = 0; n < cfg->N_ncdm; n++) {
+        nd.M[n] = t->M_ncdm[n]; nd.factor[n] = t->factor_ncdm[n]; nd.first_chain[n] = nd.nchains;
+        for (int iq = 0; iq < t->q_size_ncdm[n]; iq++) {
+          const int c = nd.nchains++;
+          nd.species[c] = n; nd.q[c] = t->q_ncdm[n][iq]; nd.w[c] = t->w_ncdm[n][iq]; nd.dlnf0[c] = t->dlnf0_dlnq_ncdm[n][iq];
+        }
+      }
+    nd.first_chain[cfg->N_ncdm] = nd.nchains;
+  }
   h->tabs.bt_size = t->bt_size;
   h->tabs.tt_size = t->tt_size;
   h->tabs.tau_table = h->d_tau_table;
@@ -171,7 +228,7 @@ int cpt_create(const cpt_config* cfg, const cpt_tables* t, cpt_handle** out) {
 void cpt_destroy(cpt_handle* h) {
   if (!h) return;
   // (d_splc and d_ik are interior pointers into d_k / d_q and must not be freed)
-  void* ptrs[] = {h->d_tau_table, h->d_bg, h->d_z_table, h->d_th, h->d_src, h->d_dd, h->d_u, h->d_k, h->d_tau, h->d_q,
+  void* ptrs[] = {h->d_ncb, h->d_tau_table, h->d_bg, h->d_z_table, h->d_th, h->d_src, h->d_dd, h->d_u, h->d_k, h->d_tau, h->d_q,
                   h->d_l, h->d_bes, h->d_chi_min, h->d_work, h->d_pt_scratch, h->d_lens, h->d_lens_w, h->d_lens_l, h->d_his, h->d_his_trig, h->d_his_desc, h->d_kq};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);

@@ -19,12 +19,24 @@ enum { BG_A = 0, BG_H, BG_HP, BG_RHO_G, BG_RHO_B, BG_RHO_CDM, BG_RHO_UR, BG_NCOL
 // thermodynamics columns (reference: thermodynamics_at_z, source/thermodynamics_module.cpp:114-285)
 enum { TH_XE = 0, TH_DKAPPA, TH_TAU_D, TH_DDKAPPA, TH_DDDKAPPA, TH_EXPMK, TH_G, TH_DG, TH_CB2, TH_NCOL };
 
+// non-cold species: {rho, p, pseudo_p} of species n in columns 3n..3n+2 of a table that shares the background abscissa
+enum { NCB_NCOL = 3 * CPT_MAX_NCDM };
+// momentum bins ("chains": one Boltzmann hierarchy l = 0..lmax per (species, q)) of the ncdm species, kernel argument
+struct NcdmDev {
+  int n_species, nchains, lmax;
+  int species[CPT_MAX_NCDM * CPT_MAX_Q_NCDM];
+  int first_chain[CPT_MAX_NCDM + 1];
+  double q[CPT_MAX_NCDM * CPT_MAX_Q_NCDM], w[CPT_MAX_NCDM * CPT_MAX_Q_NCDM], dlnf0[CPT_MAX_NCDM * CPT_MAX_Q_NCDM];
+  double M[CPT_MAX_NCDM], factor[CPT_MAX_NCDM];
+};
+
 struct DevTables {
   int bt_size, tt_size;
   const double* tau_table;  // [bt_size]
   const double* bg;         // [bt_size][BG_NCOL][2]
   const double* z_table;    // [tt_size] ascending z
   const double* th;         // [tt_size][TH_NCOL][2]
+  const double* ncb;        // [bt_size][NCB_NCOL][2] or null
 };
 
 struct Timer {
@@ -40,7 +52,8 @@ struct cpt_handle {
   std::string err;
   // tables
   DevTables tabs{};
-  double *d_tau_table = nullptr, *d_bg = nullptr, *d_z_table = nullptr, *d_th = nullptr;
+  double *d_tau_table = nullptr, *d_bg = nullptr, *d_z_table = nullptr, *d_th = nullptr, *d_ncb = nullptr;
+  NcdmDev ncdm{};
   // resident sources, k-major [tp][nk][ntau], left by the last perturb call or a transposed upload
   double* d_src = nullptr;
   size_t src_cap = 0;

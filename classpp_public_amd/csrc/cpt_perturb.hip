@@ -34,6 +34,8 @@ struct PtParams {
   int gauge;                   // CPT_GAUGE_NEWTONIAN / CPT_GAUGE_SYNCHRONOUS
   int l_max_g_ten, l_max_pol_g_ten, evolve_tensor_ur; double gw_ini;  // tensor modes
   int ic; double entropy_ini;  // initial condition of the mode (CPT_IC_*), isocurvature normalisation
+  int has_ncdm, nfa_method, tp_dcb; double nfa_trig, tol_ncdm_w;  // non-cold species (massive neutrinos)
+  NcdmDev nc;
   int switch_sw, switch_eisw, switch_lisw, switch_dop, switch_pol;
   double eisw_lisw_split_z, three_ceff2_ur, three_cvis2_ur;
   int tp_size, tp_t0, tp_t1, tp_t2, tp_p, tp_dm, tp_pp;
@@ -143,7 +145,8 @@ __device__ inline double ndf_erconst(int i) { return ndf_alpha(i) * ndf_G(i) + 1
 
 enum Role : int {
   R_NONE = 0, R_DELTA_G, R_THETA_G, R_SHEAR_G, R_LG /* l>=3 photon temperature */, R_POL /* l>=0 polarisation */,
-  R_DELTA_B, R_THETA_B, R_DELTA_CDM, R_DELTA_UR, R_THETA_UR, R_SHEAR_UR, R_LUR /* l>=3 ur */, R_ETA, R_THETA_CDM, R_GW, R_GWDOT
+  R_DELTA_B, R_THETA_B, R_DELTA_CDM, R_DELTA_UR, R_THETA_UR, R_SHEAR_UR, R_LUR /* l>=3 ur */, R_ETA, R_THETA_CDM, R_GW, R_GWDOT,
+  R_NCD, R_NCT /* auxiliary unknowns of the Newton system: delta rho and (rho+p) theta summed over the ncdm species */
 };
 
 #ifdef CPT_PROFILE
@@ -163,7 +166,25 @@ __device__ unsigned long long g_prof[16];
 // instantiations cost code size only.  The same holds for non-flat space (CURV): the s_l factors, k cotK(tau) and the
 // separate 1/tau coefficient cost the flat kernel 35 % when they were run-time values; in the flat instantiation they fold
 // to 1, 1/tau and nothing.
-template <int GAUGE, int CURV, int MODE>
+// NCDM = 1: scalars with non-cold species (massive neutrinos).  The block then holds 1 + NW wavefronts for ONE k-mode: wave 0
+// runs the system above, extended by two auxiliary core unknowns (the ncdm density and momentum sums that enter the
+// Einstein constraints), waves 1..NW hold the momentum-bin hierarchies Psi_l(q), l = 0..l_max_ncdm, one lane per multipole,
+// floor(64 / (l_max_ncdm+1)) bins ("chains") per wave.  All waves execute the same ndf15 control flow; norms are reduced over
+// the block through LDS, and the Newton system is solved as a bordered system (see the ncdm section below).
+constexpr int NCW_MAX = 5;   // chain waves per block (=> at most 6 waves: two per SIMD at most)
+struct NcShared {
+  double bc[4 + NCB_NCOL];     // a^2, a'/a, k cotK, 1/tau, {rho, p, pseudo_p} of every species at the published tau
+  double sums[NCW_MAX][4];     // per chain wave: partial sums of delta rho, (rho+p) theta, (rho+p) sigma
+  double metric[2];            // metric_continuity, metric_shear of the current RHS evaluation
+  double red[2][1 + NCW_MAX];  // block max, double-buffered
+  double ssum[NCW_MAX][2];     // Newton solve: weighted sums of T^-1 r over the chains
+  double z[2];                 // Newton solve: increments of (metric_continuity, metric_shear)
+  double alpha[NCW_MAX][4];    // factorisation: Schur terms of the two auxiliary rows
+  double ho[CPT_MAX_NCDM * CPT_MAX_Q_NCDM][3];   // hand-over to the fluid regime: per-chain integrals
+  int abort;
+};
+
+template <int GAUGE, int CURV, int MODE, int NCDM = 0>
 struct PT {
 // Lane map.  One lane per equation of pm.cpp:3302-3481, at a FIXED lane whatever the approximation scheme: the (at most
 // 13) densely coupled variables - densities, velocities, shears, polarisation l<=2, metric - are the CORE in lanes
@@ -175,7 +196,8 @@ struct PT {
 // structure, fixed per regime and shared by all modes, is what the linear algebra below exploits.
 // LN_ETA holds eta (synchronous gauge) or phi (Newtonian gauge, pm.cpp:3470-3478); LN_TC = theta_cdm exists in the Newtonian gauge only
 enum Lane : int { LN_DG = 0, LN_TG, LN_SG, LN_P0, LN_P1, LN_P2, LN_DB, LN_TB, LN_DC, LN_DUR, LN_TUR, LN_SUR, LN_ETA, LN_TC };
-static constexpr int NC = MODE ? 17 : ((GAUGE == CPT_GAUGE_NEWTONIAN) ? 14 : 13);
+static constexpr int NC = MODE ? 17 : ((GAUGE == CPT_GAUGE_NEWTONIAN) ? 14 : 13) + (NCDM ? 2 : 0);
+static constexpr int LN_ND = NC - 2, LN_NT = NC - 1;   // (NCDM only) auxiliary unknowns: ncdm density / momentum sums
 // Tensor modes (MODE = 1; pm.cpp:3519-3586): the same three ladders plus the gravitational wave (gw, gw').  The photon
 // source P^(2) reads the l = 4 multipoles of temperature and polarisation and the gravitational-wave source reads the
 // l = 4 multipoles of photons and ur, so the core holds every ladder up to l = 4 and the tails start at l = 5.
@@ -183,15 +205,15 @@ enum TLane : int { TL_DG = 0, TL_TG, TL_SG, TL_G3, TL_G4, TL_P0, TL_P1, TL_P2, T
 static constexpr int LFIRST = MODE ? 5 : 3;   // multipole of the first element of a tail
 
 struct Layout {
-  int tca, rsa, ufa;
+  int tca, rsa, ufa, nfa;
   int g3, gN, q3, qN, u3, uN;  // tails: lane of l=3 and length (lengths are 0 when the scheme drops the tail)
   int lmg, lmp, lmu;
   int maxlen;                  // longest tail present
 };
 
-static __device__ __forceinline__ Layout make_layout(const PtParams& P, int tca, int rsa, int ufa) {
+static __device__ __forceinline__ Layout make_layout(const PtParams& P, int tca, int rsa, int ufa, int nfa = 0) {
   Layout L;
-  L.tca = tca; L.rsa = rsa; L.ufa = ufa;
+  L.tca = tca; L.rsa = rsa; L.ufa = ufa; L.nfa = nfa;
   if (MODE) {  // tensors: photons are evolved when neither approximation is on; ur always (pm.cpp:3529-3560)
     L.ufa = 0;
     L.lmg = P.l_max_g_ten; L.lmp = P.l_max_pol_g_ten; L.lmu = P.l_max_ur;
@@ -216,6 +238,7 @@ static __device__ __forceinline__ Layout make_layout(const PtParams& P, int tca,
 // is core variable `i` evolved in this scheme?  (i wave-uniform)
 static __device__ __forceinline__ bool core_present(const PtParams& P, const Layout& L, int i) {
   if (MODE) return (i <= TL_P4) ? (!L.rsa && !L.tca) : (i <= TL_U4) ? (P.evolve_tensor_ur != 0) : true;
+  if (NCDM && i >= LN_ND) return true;
   switch (i) {
     case LN_DG: case LN_TG: return !L.rsa;
     case LN_SG: case LN_P0: case LN_P1: case LN_P2: return !L.rsa && !L.tca;
@@ -243,6 +266,8 @@ static __device__ __forceinline__ void role_of(const PtParams& P, const Layout& 
     return;
   }
   const bool g = !L.rsa, hi = !L.rsa && !L.tca, ur = P.has_ur && !L.rsa;
+  if (NCDM && i == LN_ND) { *role = R_NCD; return; }
+  if (NCDM && i == LN_NT) { *role = R_NCT; return; }
   if (i == LN_DG) { if (g) *role = R_DELTA_G; return; }
   if (i == LN_TG) { if (g) { *role = R_THETA_G; *ell = 1; } return; }
   if (i == LN_SG) { if (hi) { *role = R_SHEAR_G; *ell = 2; } return; }
@@ -326,7 +351,7 @@ static __device__ __forceinline__ double spl2(const double2 lo, const double2 hi
   return a * lo.x + b * hi.x + ((a * a * a - a) * lo.y + (b * b * b - b) * hi.y) * h2;
 }
 // a, H and dkappa at tau (what perturb_approximations and the start-time search need)
-struct AHK { double a, H, dk; };
+struct AHK { double a, H, dk, wdev; };   // wdev: max over the ncdm species of |p/rho - 1/3| (0 without ncdm)
 static __device__ __noinline__ AHK lookup_aHk(DevTables T, double n_e, double tau) {
   int inf = bsearch_up(T.tau_table, T.bt_size, tau);
   double h = T.tau_table[inf + 1] - T.tau_table[inf], b = (tau - T.tau_table[inf]) / h, a = 1. - b, h2 = h * h / 6.;
@@ -345,7 +370,14 @@ static __device__ __noinline__ AHK lookup_aHk(DevTables T, double n_e, double ta
     dk = spl2(t0[TH_DKAPPA], t0[TH_NCOL + TH_DKAPPA], az, bz, hz * hz / 6.);
   }
   AHK r;
-  r.a = av; r.H = Hv; r.dk = dk;
+  r.a = av; r.H = Hv; r.dk = dk; r.wdev = 0.;
+  if (T.ncb) {   // pm.cpp:2574-2603: every non-cold species must still be ultra-relativistic at the initial time
+    const double2* n0 = (const double2*)T.ncb + (size_t)inf * NCB_NCOL;
+    for (int n = 0; n < CPT_MAX_NCDM; n++) {
+      const double rho = spl2(n0[3 * n], n0[NCB_NCOL + 3 * n], a, b, h2), pr = spl2(n0[3 * n + 1], n0[NCB_NCOL + 3 * n + 1], a, b, h2);
+      if (rho > 0.) r.wdev = fmax(r.wdev, fabs(pr / rho - 1. / 3.));
+    }
+  }
   return r;
 }
 
@@ -365,6 +397,8 @@ struct Lookup {
   // lane c: column c of the background / thermodynamics row at tau_cached.  Values only the sampler needs (a, H',
   // e^-kappa, g, g') are extracted from these on demand instead of occupying registers through the step loop.
   double vbg, vth;
+  double vnc;                      // (NCDM) lane c: column c of the ncdm background row {rho, p, pseudo_p} x species
+  double2 nc_lo, nc_hi; double2* ncw;
   double rg, rb, rc, ru, kap, ddkappa, cb2;  // what every RHS evaluation needs (wave-uniform)
   // derived, tau-only
   double a2, aH, two_over_aH, R, inv_1pR, inv_R, tau_c, dtau_c, F, Fp, app, inv_tau, rg43, ru43;
@@ -422,8 +456,9 @@ static __device__ __forceinline__ int window_find(const double* __restrict__ x, 
   return inf;
 }
 
-static __device__ __forceinline__ void lookup_init(const PtParams& P, Lookup& Q, double2* bgw, double2* thw, int lane) {
-  Q.bgw = bgw; Q.thw = thw;
+static __device__ __forceinline__ void lookup_init(const PtParams& P, Lookup& Q, double2* bgw, double2* thw, int lane, double2* ncw = nullptr) {
+  Q.bgw = bgw; Q.thw = thw; Q.ncw = ncw; Q.vnc = 0.; Q.nc_lo = Q.nc_hi = make_double2(0., 0.);
+  if (NCDM) { double dummy; window_stage<NCB_NCOL>(P.tabs.tau_table, (const double2*)P.tabs.ncb, P.tabs.bt_size, 0, lane, &dummy, ncw); }
   Q.bg_base = 0; Q.th_base = 0; Q.bg_inf = -1; Q.th_inf = -1; Q.tau_cached = -1.;
   window_stage<BG_NCOL>(P.tabs.tau_table, (const double2*)P.tabs.bg, P.tabs.bt_size, 0, lane, &Q.bgx, bgw);
   window_stage<TH_NCOL>(P.tabs.z_table, (const double2*)P.tabs.th, P.tabs.tt_size, 0, lane, &Q.thx, thw);
@@ -448,7 +483,12 @@ static __device__ __forceinline__ void lookup(const PtParams& P, Lookup& Q, doub
   if (tau == Q.tau_cached) return;
   Q.tau_cached = tau;
   const DevTables& T = P.tabs;
+  const int base_was = Q.bg_base;
   const int inf = window_find<BG_NCOL>(T.tau_table, (const double2*)T.bg, T.bt_size, tau, lane, &Q.bgx, Q.bgw, &Q.bg_base, 8);
+  if (NCDM && Q.bg_base != base_was) {   // the ncdm columns ride in a window of their own on the same rows
+    double dummy;
+    window_stage<NCB_NCOL>(T.tau_table, (const double2*)T.ncb, T.bt_size, Q.bg_base, lane, &dummy, Q.ncw);
+  }
   if (inf != Q.bg_inf) {
     Q.bg_inf = inf;
     if (lane < BG_NCOL) {
@@ -456,11 +496,17 @@ static __device__ __forceinline__ void lookup(const PtParams& P, Lookup& Q, doub
       Q.bg_lo = r[0];
       Q.bg_hi = r[BG_NCOL];
     }
+    if (NCDM && lane < NCB_NCOL) {
+      const double2* r = Q.ncw + (inf - Q.bg_base) * NCB_NCOL + lane;
+      Q.nc_lo = r[0];
+      Q.nc_hi = r[NCB_NCOL];
+    }
   }
   {
     const double x0 = bcast(Q.bgx, inf - Q.bg_base), x1 = bcast(Q.bgx, inf - Q.bg_base + 1);
     const double h = x1 - x0, b = (tau - x0) * fast_rcp(h), a = 1. - b;
     Q.vbg = spl2(Q.bg_lo, Q.bg_hi, a, b, h * h / 6.);
+    if (NCDM) Q.vnc = spl2(Q.nc_lo, Q.nc_hi, a, b, h * h / 6.);
   }
   const double bg_a = bcast(Q.vbg, BG_A), bg_H = bcast(Q.vbg, BG_H), bg_Hp = bcast(Q.vbg, BG_HP);
   Q.rg = bcast(Q.vbg, BG_RHO_G); Q.rb = bcast(Q.vbg, BG_RHO_B); Q.rc = bcast(Q.vbg, BG_RHO_CDM); Q.ru = bcast(Q.vbg, BG_RHO_UR);
@@ -642,6 +688,11 @@ struct Metric {
   double tca_shear_g;
 };
 
+// (NCDM) what the non-cold species contribute to the Einstein equations in this RHS evaluation: delta rho, (rho+p) theta,
+// (rho+p) sigma summed over species (pm.cpp:6317-6432).  `sh` != null: publish (metric_continuity, metric_shear) for the
+// chain waves and meet them at the block barrier as soon as the metric is known.
+struct NcIn { double D, T, S; NcShared* sh; };
+
 // y of another lane (per-lane byte address): two ds_bpermute_b32, executed by every lane
 static __device__ __forceinline__ double gather(double v, int addr) {
   const int lo = __builtin_amdgcn_ds_bpermute(addr, __double2loint(v));
@@ -691,7 +742,7 @@ static __device__ __forceinline__ void store_sources_tensor(const PtParams& P, c
 // synchronous gauge, K = 0.  y: this lane's component (named components are broadcast with v_readlane).
 // Returns dy of this lane and leaves M describing the state (tau, y).
 static __device__ __forceinline__ double rhs(const PtParams& P, const Layout& L, const LaneEq& e, Lookup& Q, Metric& M, double k,
-                                      double inv_k2, double tau, double y, int lane) {
+                                      double inv_k2, double tau, double y, int lane, const NcIn& N = NcIn{0., 0., 0., nullptr}) {
   if (MODE) return rhs_tensor(P, L, e, Q, M, k, tau, y, lane);
 #ifdef CPT_PROFILE
   unsigned long long* prof = Q.prof;
@@ -722,6 +773,7 @@ static __device__ __forceinline__ double rhs(const PtParams& P, const Layout& L,
   double rps = Q.rg43 * sg;
   if (P.has_cdm) delta_rho += Q.rc * dc;
   if (P.has_ur) { delta_rho += Q.ru * dur; rpt += Q.ru43 * tur; rps += Q.ru43 * sur; }
+  if (NCDM) { delta_rho += N.D; rpt += N.T; rps += N.S; }
   // ---- Einstein equations -> the metric terms of the matter equations (pm.cpp:8049-8074):
   //      mc = metric_continuity, me = metric_euler, ms = metric_shear, msp = its derivative, mdot = eta' or phi'
   double mc, me, ms, msp, mdot;
@@ -747,6 +799,10 @@ static __device__ __forceinline__ double rhs(const PtParams& P, const Layout& L,
     const double alphap = -2. * aH * alpha + eta - 4.5 * (a2 * inv_k2) * rps;
     M.hp = hp; M.etap = etap; M.alpha = alpha; M.alphap = alphap;
     mc = 0.5 * hp; me = 0.; ms = k2 * alpha; msp = k2 * alphap; mdot = etap;
+    if (NCDM && N.sh) {   // the chain waves wait for exactly these two numbers
+      if (lane == 0) { N.sh->metric[0] = mc; N.sh->metric[1] = ms; }
+      __syncthreads();
+    }
   } else {
     // Newtonian gauge (pm.cpp:5869-5897): the LN_ETA lane holds phi; cdm has a velocity
     const double tc = bcast(y, LN_TC);
@@ -820,7 +876,8 @@ static __device__ __forceinline__ double rhs(const PtParams& P, const Layout& L,
 // perturb_sources (pm.cpp:6731-7285): the RHS has just been evaluated at (tau, y) => Q and M describe the sample.
 // dy is the dense-output derivative (only theta_b' is used, pm.cpp:6883). Lane 0 stores the tp_size values.
 static __device__ __forceinline__ void store_sources(const PtParams& P, const Layout& L, const Lookup& Q, const Metric& M, double k,
-                                              double inv_k2, double y, double dy, double tca_shear_prev, int it, int ik, int lane) {
+                                              double inv_k2, double y, double dy, double tca_shear_prev, int it, int ik, int lane,
+                                              const NcIn& N = NcIn{0., 0., 0., nullptr}) {
   if (MODE) { store_sources_tensor(P, L, Q, y, it, ik, lane); return; }
   struct { double g, dg, expmk; } th;
   th.g = bcast(Q.vth, TH_G); th.dg = bcast(Q.vth, TH_DG); th.expmk = bcast(Q.vth, TH_EXPMK);
@@ -835,7 +892,7 @@ static __device__ __forceinline__ void store_sources(const PtParams& P, const La
     else Pi = (bcast(y, LN_P0) + bcast(y, LN_P2) + 2. * Q.s2 * bcast(y, LN_SG)) / 8.;
   }
   const double eta = bcast(y, LN_ETA), tb = bcast(y, LN_TB), dtb = bcast(dy, LN_TB);
-  double delta_m = 0.;
+  double delta_m = 0., delta_cb = 0.;
   if (P.tp_dm >= 0) {  // gauge-invariant matter density contrast, pm.cpp:6573, 5979-5981
     double drm = Q.rb * bcast(y, LN_DB), rho_m = Q.rb;
     double rptm = Q.rb * tb;                       // [(rho+p) theta]_matter: cdm contributes in the Newtonian gauge (pm.cpp:6241-6243)
@@ -844,6 +901,12 @@ static __device__ __forceinline__ void store_sources(const PtParams& P, const La
       if (GAUGE == CPT_GAUGE_NEWTONIAN) rptm += Q.rc * bcast(y, LN_TC);
     }
     delta_m = (drm + 3. * aH * rptm * inv_k2) / rho_m;
+    if (NCDM) {   // pm.cpp:6309-6315, 6414-6426, 5979-5993: cdm+baryons alone, then with the non-cold species
+      delta_cb = delta_m;
+      double rho_nc = 0., p_nc = 0.;
+      for (int n = 0; n < P.nc.n_species; n++) { rho_nc += bcast(Q.vnc, 3 * n); p_nc += bcast(Q.vnc, 3 * n + 1); }
+      delta_m = (drm + N.D) / (rho_m + rho_nc) + 3. * aH * inv_k2 * (rptm + N.T) / (rho_m + rho_nc + p_nc);
+    }
   }
   int switch_isw = 1;
   if ((P.switch_eisw == 0) && (z >= P.eisw_lisw_split_z)) switch_isw = 0;
@@ -871,11 +934,12 @@ static __device__ __forceinline__ void store_sources(const PtParams& P, const La
     if (P.tp_p >= 0) P.src[P.tp_p * tstride + base] = sqrt(6.) * th.g * Pi;
     if (P.tp_pp >= 0) P.src[P.tp_pp * tstride + base] = eta + M.alphap;
     if (P.tp_dm >= 0) P.src[P.tp_dm * tstride + base] = delta_m;
+    if (NCDM && P.tp_dcb >= 0) P.src[P.tp_dcb * tstride + base] = delta_cb;   // pm.cpp:7001-7003
   }
 }
 
 // perturb_approximations (pm.cpp:5443-5670) evaluated independently by every lane at its own tau
-static __device__ __forceinline__ void approx_flags(const PtParams& P, double k, double tau, int* tca, int* rsa, int* ufa) {
+static __device__ __forceinline__ void approx_flags(const PtParams& P, double k, double tau, int* tca, int* rsa, int* ufa, int* nfa) {
   const AHK q = lookup_aHk(P.tabs, P.n_e, tau);
   const double a = q.a, H = q.H, dk = q.dk;
   const double tau_h = 1. / (H * a);
@@ -886,10 +950,11 @@ static __device__ __forceinline__ void approx_flags(const PtParams& P, double k,
   }
   *rsa = ((tau * k > P.rsa_trig) && (tau > P.tau_free_streaming) && (P.rsa_method != CPT_RSA_NONE)) ? 1 : 0;
   *ufa = (!MODE && P.has_ur && (tau * k > P.ufa_trig) && (P.ufa_method != CPT_UFA_NONE)) ? 1 : 0;   // no ur fluid for tensors
+  *nfa = (NCDM && (tau * k > P.nfa_trig) && (P.nfa_method != CPT_NCDMFA_NONE)) ? 1 : 0;             // pm.cpp:5606-5614
 }
 
 // 64-ary search for the time at which a monotone predicate flips between lo (false) and hi (true):
-// kind 0: "no longer early enough to start" (pm.cpp:2590-2635), kind 1..3: approximation ap-1 differs from `ref`
+// kind 0: "no longer early enough to start" (pm.cpp:2590-2635), kind 1..4: approximation ap-1 differs from `ref`
 static __device__ __forceinline__ double search_flip(const PtParams& P, double k, double lo, double hi, double tol_abs, double tol_rel,
                                            int kind, int ref, int lane) {
   for (int round = 0; round < 64; round++) {
@@ -899,11 +964,11 @@ static __device__ __forceinline__ double search_flip(const PtParams& P, double k
     bool pred;
     if (kind == 0) {
       const AHK q = lookup_aHk(P.tabs, P.n_e, t);
-      pred = (q.a * q.H / q.dk > P.start_small_k) || (k / q.a / q.H > P.start_large_k);
+      pred = (q.a * q.H / q.dk > P.start_small_k) || (k / q.a / q.H > P.start_large_k) || (q.wdev > P.tol_ncdm_w);
     } else {
-      int f[3];
-      approx_flags(P, k, t, &f[0], &f[1], &f[2]);
-      pred = f[kind - 1] != ref;
+      int f0, f1, f2, f3;
+      approx_flags(P, k, t, &f0, &f1, &f2, &f3);
+      pred = ((kind == 1) ? f0 : (kind == 2) ? f1 : (kind == 3) ? f2 : f3) != ref;
     }
     const unsigned long long m = __ballot(pred);
     const int j = m ? (__ffsll((long long)m) - 1) : 64;  // first lane whose sample is past the flip
@@ -912,6 +977,189 @@ static __device__ __forceinline__ double search_flip(const PtParams& P, double k
     lo = nlo; hi = nhi;
   }
   return 0.5 * (lo + hi);
+}
+
+// ---- non-cold species (NCDM = 1): the chain waves --------------------------------------------------------------------
+// Every momentum bin (species n, q) is one tridiagonal chain Psi_0..Psi_lmax (pm.cpp:8832-8879) that talks to the rest of the
+// system through two metric scalars only (metric_continuity = h'/2 into l = 0, metric_shear = k^2 alpha into l = 2) and is heard
+// by it through the three integrals of pm.cpp:6369-6395.  In the fluid regime (pm.cpp:8737-8823) the chain of the first
+// momentum bin of each species carries (delta, theta, sigma) in its l = 0..2 lanes - the same tridiagonal shape with
+// time-dependent coefficients - and the other bins idle.
+struct Ctx {
+  int wave, nw, len, cpw;      // this wave (0 = core), number of chain waves, lanes per chain, chains per wave
+  NcShared* sh;
+  int parity, abort;
+  double tau_pub;              // time at which sh->bc was last published (and read by everybody)
+  double a2, aH, kcot, inv_tau, rho, pr, pp;   // chain waves: copy of the published block (rho, p, pseudo_p of the lane's species)
+};
+struct ChainEq {
+  int l, cidx, species;
+  bool valid, first, last, holder;
+  double A, B, G, qk, q2, M2, Xmc, Xms, sw;
+};
+struct ChainCoef { double a, b, d, xmc, xms, wt; };   // dy = a y[l-1] - b y[l+1] - d y + xmc mc + xms ms;  wt: weight in its integral
+
+static __device__ __forceinline__ ChainEq make_chain_eq(const PtParams& P, const Ctx& C, int lane, double k) {
+  ChainEq c;
+  const int slot = lane / C.len;
+  c.l = lane - slot * C.len;
+  c.cidx = (C.wave - 1) * C.cpw + slot;
+  c.valid = (C.wave > 0) && (slot < C.cpw) && (c.cidx < P.nc.nchains);
+  const int ci = c.valid ? c.cidx : 0;
+  c.species = P.nc.species[ci];
+  c.first = c.valid && c.l == 0; c.last = c.valid && c.l == C.len - 1;
+  c.holder = c.valid && (ci == P.nc.first_chain[c.species]) && c.l <= 2;
+  const double q = P.nc.q[ci], dlnf0 = P.nc.dlnf0[ci], fw = P.nc.factor[c.species] * P.nc.w[ci];
+  const double k2 = k * k;
+  auto S = [&](int ll) { return CURV ? sqrt(fmax(1.0 - P.K * (ll * ll - 1.0) / k2, 0.)) : 1.0; };
+  const int l = c.l;
+  c.A = c.B = c.G = c.Xmc = c.Xms = c.sw = 0.;
+  c.qk = q * k; c.q2 = q * q; c.M2 = P.nc.M[c.species] * P.nc.M[c.species];
+  if (c.valid) {
+    if (l == C.len - 1) { c.A = 1.; c.G = 1. + l; }                                   // pm.cpp:8876
+    else if (l == 0) { c.B = 1.; c.Xmc = dlnf0 / 3.; c.sw = fw * q * q; }            // pm.cpp:8856
+    else if (l == 1) { c.A = 1. / 3.; c.B = 2. * S(2) / 3.; c.sw = k * fw * q * q * q; }   // pm.cpp:8860 (metric_euler = 0, synchronous)
+    else if (l == 2) { c.A = 2. * S(2) / 5.; c.B = 3. * S(3) / 5.; c.Xms = -S(2) * 2. / 15. * dlnf0; c.sw = 2. / 3. * fw * q * q * q * q; }   // pm.cpp:8865
+    else { c.A = l * S(l) / (2. * l + 1.); c.B = (l + 1.) * S(l + 1) / (2. * l + 1.); }     // pm.cpp:8870
+  }
+  return c;
+}
+
+// coefficients of this lane's equation at the published time (also the chain's Jacobian: the equations are linear)
+static __device__ __forceinline__ ChainCoef chain_coef(const PtParams& P, const Layout& L, const ChainEq& c, const Ctx& C, double k) {
+  ChainCoef o;
+  if (!L.nfa) {
+    const double eps = sqrt(c.q2 + C.a2 * c.M2), inv_eps = fast_rcp(eps), f = c.qk * inv_eps, inv_a4 = fast_rcp(C.a2 * C.a2);
+    o.a = f * c.A; o.b = f * c.B; o.d = c.G * C.kcot; o.xmc = c.Xmc; o.xms = c.Xms;
+    const int l = opaque(c.l);
+    o.wt = inv_a4 * c.sw * ((l == 0) ? eps : (l == 2) ? inv_eps : 1.);   // pm.cpp:6384-6393 (a_today = 1)
+  } else {   // pm.cpp:8737-8823 on the holder lanes, identity elsewhere
+    const double rho = C.rho, pr = C.pr, w = pr * fast_rcp(rho), pp_over_p = C.pp * fast_rcp(pr), inv_1pw = fast_rcp(1. + w);
+    const double ca2 = w / 3. * inv_1pw * (5. - pp_over_p), ceff2 = ca2;
+    const double cvis2 = (P.nfa_method == CPT_NCDMFA_HU) ? w : 3. * w * ca2;
+    const double s2 = CURV ? sqrt(fmax(1.0 - 3. * P.K / (k * k), 0.)) : 1.;
+    o.a = o.b = o.d = o.xmc = o.xms = o.wt = 0.;
+    const int l = opaque(c.l);
+    if (c.holder) {
+      if (l == 0) { o.b = 1. + w; o.d = 3. * C.aH * (ceff2 - w); o.xmc = -(1. + w); o.wt = rho; }
+      else if (l == 1) { o.a = ceff2 * inv_1pw * k * k; o.b = k * k; o.d = C.aH * (1. - 3. * ca2); o.wt = rho + pr; }
+      else {
+        o.a = 8. / 3. * cvis2 * inv_1pw * s2; o.wt = rho + pr;
+        if (P.nfa_method == CPT_NCDMFA_HU) { o.d = 3. * C.aH * ca2 / w; o.xms = o.a; }
+        else {
+          o.d = 3. * (C.aH * (2. / 3. - ca2 - pp_over_p / 3.) + C.inv_tau);
+          if (P.nfa_method == CPT_NCDMFA_MB) o.xms = o.a; else o.xmc = o.a;   // ncdmfa_CLASS: metric_ufa_class = h'/2 (pm.cpp:8062)
+        }
+      }
+    }
+  }
+  return o;
+}
+
+// sum over the chains of this wave of the lanes with multipole l (wave-uniform result)
+static __device__ __forceinline__ double chain_sum(double v, int l, const Ctx& C) {
+  double s = 0.;
+  for (int c = 0; c < C.cpw; c++) s += bcast(v, c * C.len + l);
+  return s;
+}
+
+// make the tables' row at tau known to every wave: wave 0 looks it up and publishes, the chain waves copy what they need
+static __device__ __forceinline__ void sync_tau(const PtParams& P, Lookup& Q, Ctx& C, const ChainEq& ce, double tau, int lane) {
+  if (tau == C.tau_pub) return;
+  C.tau_pub = tau;
+  if (C.wave == 0) {
+    lookup(P, Q, tau, lane);
+    const int i = opaque(lane);
+    const double vn = shfl_all(Q.vnc, (lane - 4) & 63);   // (own statement: every lane must execute the cross-lane read)
+    const double v = (i == 0) ? Q.a2 : (i == 1) ? Q.aH : (i == 2) ? Q.kcot : (i == 3) ? Q.inv_tau : vn;
+    if (lane < 4 + NCB_NCOL) C.sh->bc[lane] = v;
+  }
+  __syncthreads();
+  if (C.wave > 0) {
+    const double* bc = C.sh->bc;
+    C.a2 = bc[0]; C.aH = bc[1]; C.kcot = bc[2]; C.inv_tau = bc[3];
+    C.rho = bc[4 + 3 * ce.species]; C.pr = bc[5 + 3 * ce.species]; C.pp = bc[6 + 3 * ce.species];
+  }
+}
+
+// RHS of the whole block: returns this lane's dy.  N (wave 0) receives the ncdm integrals of this evaluation.
+static __device__ __forceinline__ double rhs_all(const PtParams& P, const Layout& L, const LaneEq& e, const ChainEq& ce, Lookup& Q, Metric& M,
+                                                 Ctx& C, NcIn& N, double k, double inv_k2, double tau, double y, int lane) {
+  if (!NCDM) return rhs(P, L, e, Q, M, k, inv_k2, tau, y, lane);
+  sync_tau(P, Q, C, ce, tau, lane);
+  if (C.wave == 0) {
+    __syncthreads();                         // (B) the chain waves have written their partial integrals
+    double D = 0., T = 0., S = 0.;
+    for (int w = 0; w < C.nw; w++) { D += C.sh->sums[w][0]; T += C.sh->sums[w][1]; S += C.sh->sums[w][2]; }
+    N.D = D; N.T = T; N.S = S; N.sh = C.sh;
+    return rhs(P, L, e, Q, M, k, inv_k2, tau, y, lane, N);   // (C) inside, right after the Einstein equations
+  }
+  const ChainCoef cc = chain_coef(P, L, ce, C, k);
+  {
+    const double v = cc.wt * y;
+    const double D = chain_sum(v, 0, C), T = chain_sum(v, 1, C), S = chain_sum(v, 2, C);
+    if (lane == 0) { double* o = C.sh->sums[C.wave - 1]; o[0] = D; o[1] = T; o[2] = S; }
+  }
+  const double ym = lane_below(y), yp = lane_above(y);
+#ifdef CPT_DEBUG_NCDM
+  if (L.nfa && ce.holder && C.wave == 1 && !(y == y)) printf("nan y in rhs l=%d tau=%g\n", ce.l, tau);
+  if (L.nfa && ce.holder && C.wave == 1 && !(cc.a == cc.a && cc.b == cc.b && cc.d == cc.d)) printf("nan coef l=%d tau=%g a=%g b=%g d=%g rho=%g p=%g pp=%g\n", ce.l, tau, cc.a, cc.b, cc.d, C.rho, C.pr, C.pp);
+#endif
+  __syncthreads();                           // (B)
+  __syncthreads();                           // (C) wave 0 has published the metric
+  const double mc = C.sh->metric[0], ms = C.sh->metric[1];
+  double dy = cc.a * ym - cc.b * yp - cc.d * y;
+  dy = fma(cc.xmc, mc, dy);
+  dy = fma(cc.xms, ms, dy);
+  return dy;
+}
+
+// max over the whole block of a non-negative per-lane quantity (the norms of ndf15); also carries the abort flag across
+static __device__ __forceinline__ double block_max(double v, Ctx& C, int lane) {
+  const double m = wave_max(v);
+  if (!NCDM) return m;
+  const int buf = C.parity;
+  C.parity ^= 1;
+  if (lane == 0) C.sh->red[buf][C.wave] = m;
+  __syncthreads();
+  double r = C.sh->red[buf][0];
+  for (int w = 1; w <= C.nw; w++) r = fmax(r, C.sh->red[buf][w]);
+  C.abort = C.sh->abort;
+  return r;
+}
+
+// factors of one wave's chains: T = I - hg J_chain, tridiagonal per chain (same continued fraction as the tails, no parent)
+struct ChainLu { double rinv, g, r, pv, sv, jw; };   // pv = T^-1 xmc, sv = T^-1 xms, jw: frozen integral weight
+static __device__ __forceinline__ double chain_solve(const ChainLu& F, const ChainEq& ce, double b, int len) {
+  double bp = b;
+  for (int s = 1; s < len; s++) bp = fma(-F.g, lane_above(bp), b);
+  const double u = bp * F.rinv;
+  const double rr = ce.first ? 0. : F.r;
+  double xt = u;
+  for (int s = 1; s < len; s++) xt = fma(-rr, lane_below(xt), u);
+  return xt;
+}
+static __device__ __forceinline__ void chain_factor(const ChainCoef& jc, const ChainEq& ce, double hg, int len, Ctx& C, int lane, ChainLu& F) {
+  const double a = ce.first ? 0. : -hg * jc.a;
+  const double c = ce.last ? 0. : hg * jc.b;
+  const double d = 1.0 + hg * jc.d;
+  double dp = d, r = 0.;
+  for (int s = 0; s < len; s++) {
+    r = a * fast_rcp(dp);
+    const double r_up = lane_above(r);
+    dp = fma(-c, r_up, d);
+  }
+  const double rinv = fast_rcp(dp);
+  F.rinv = rinv; F.r = a * rinv;
+  const double rinv_up = lane_above(rinv);
+  F.g = c * rinv_up;
+  F.jw = jc.wt;
+  F.pv = chain_solve(F, ce, jc.xmc, len);
+  F.sv = chain_solve(F, ce, jc.xms, len);
+  // Schur terms of the auxiliary rows: alpha_{D,1} = hg sum wD [T^-1 xmc]_0, ... (see factorise)
+  const double v1 = hg * F.jw * F.pv, v2 = hg * F.jw * F.sv;
+  const double a0 = chain_sum(v1, 0, C), a1 = chain_sum(v2, 0, C), a2 = chain_sum(v1, 1, C), a3 = chain_sum(v2, 1, C);
+  if (lane == 0) { double* o = C.sh->alpha[C.wave - 1]; o[0] = a0; o[1] = a1; o[2] = a2; o[3] = a3; }
 }
 
 // ---- structured linear algebra: (I - hg J) x = b -------------------------------------------------------------------
@@ -949,7 +1197,11 @@ static __device__ __forceinline__ double reg_get(const double (&a)[N], int i) {
   return v;
 }
 
-static __device__ __forceinline__ bool factorise(const LaneEq& e, const Jac& J, double hg, int maxlen, int lane, LuReg& F) {
+// (NCDM) the rows of the two auxiliary unknowns u_D, u_T (lanes LN_ND, LN_NT) read, after the chains are eliminated,
+//   u_D - alpha_D1 dmc - alpha_D2 dms = sum_chains w_D [T^-1 r]_0     with dmc = sum_j gmc_j x_j, dms = sum_j gms_j x_j
+// where gmc_j / gms_j are the responses of (metric_continuity, metric_shear) to unit core variable j (al[] = the four alphas)
+static __device__ __forceinline__ bool factorise(const LaneEq& e, const Jac& J, double hg, int maxlen, int lane, LuReg& F,
+                                                 const double* al = nullptr, double gmc = 0., double gms = 0.) {
   lane = opaque(lane);
   const int chain = opaque(e.chain);
   // ---- tails ----
@@ -975,6 +1227,11 @@ static __device__ __forceinline__ bool factorise(const LaneEq& e, const Jac& J, 
   double A[NC];
 #pragma unroll
   for (int j = 0; j < NC; j++) A[j] = ((j == lane) ? 1.0 - schur : 0.0) - hg * J.Jc[j * 64 + lane];   // J.Jc = 0 outside the core
+  if (NCDM) {
+    const double c1 = (lane == LN_ND) ? al[0] : (lane == LN_NT) ? al[2] : 0., c2 = (lane == LN_ND) ? al[1] : (lane == LN_NT) ? al[3] : 0.;
+#pragma unroll
+    for (int j = 0; j < NC; j++) A[j] -= c1 * bcast(gmc, j) + c2 * bcast(gms, j);
+  }
   int rowperm = lane;
   double rpivc = 1.;
   bool ok = true;
@@ -1055,6 +1312,50 @@ static __device__ __forceinline__ double lu_solve(const LaneEq& e, const LuReg& 
   return x;
 }
 
+
+// factorisation / solve of the whole block (NCDM): the chains are eliminated first (tridiagonal solves inside the chain waves),
+// the core with its two auxiliary unknowns second, the chains are back-substituted last
+static __device__ __forceinline__ void fact_all(const LaneEq& e, const ChainEq& ce, const Jac& J, const ChainCoef& jc, double hg, int maxlen,
+                                                int lane, Ctx& C, LuReg& F, ChainLu& CF, double gmc, double gms, bool* ok) {
+  if (!NCDM) { *ok = factorise(e, J, hg, maxlen, lane, F); return; }
+  *ok = true;
+  if (C.wave > 0) { chain_factor(jc, ce, hg, C.len, C, lane, CF); __syncthreads(); return; }
+  __syncthreads();
+  double al[4] = {0., 0., 0., 0.};
+  for (int w = 0; w < C.nw; w++)
+#pragma unroll
+    for (int i = 0; i < 4; i++) al[i] += C.sh->alpha[w][i];
+  const bool good = factorise(e, J, hg, maxlen, lane, F, al, gmc, gms);
+  if (!good && lane == 0) C.sh->abort = 1;   // every wave leaves at the next block_max
+}
+static __device__ __forceinline__ double solve_all(const LaneEq& e, const ChainEq& ce, const LuReg& F, const ChainLu& CF, double hg, int maxlen,
+                                                   double b, int lane, Ctx& C, double gmc, double gms) {
+  if (!NCDM) return lu_solve(e, F, maxlen, b, lane);
+  if (C.wave > 0) {
+    const double x = chain_solve(CF, ce, b, C.len);
+    const double v = CF.jw * x;
+    const double sD = chain_sum(v, 0, C), sT = chain_sum(v, 1, C);
+    if (lane == 0) { C.sh->ssum[C.wave - 1][0] = sD; C.sh->ssum[C.wave - 1][1] = sT; }
+    __syncthreads();
+    __syncthreads();
+    const double z1 = C.sh->z[0], z2 = C.sh->z[1];
+    return x + hg * (CF.pv * z1 + CF.sv * z2);
+  }
+  __syncthreads();
+  double sD = 0., sT = 0.;
+  for (int w = 0; w < C.nw; w++) { sD += C.sh->ssum[w][0]; sT += C.sh->ssum[w][1]; }
+  const int ln = opaque(lane);
+  const double bb = (ln == LN_ND) ? sD : (ln == LN_NT) ? sT : b;
+  const double x = lu_solve(e, F, maxlen, bb, lane);
+  const double v1 = gmc * x, v2 = gms * x;
+  double z1 = 0., z2 = 0.;
+#pragma unroll
+  for (int j = 0; j < NC; j++) { z1 += bcast(v1, j); z2 += bcast(v2, j); }
+  if (lane == 0) { C.sh->z[0] = z1; C.sh->z[1] = z2; }
+  __syncthreads();
+  return (ln == LN_ND || ln == LN_NT) ? 0. : x;
+}
+
 // adjust_stepsize (ev.cpp:907-943): dif[0..k-1] <- dif[0..k-1] * RU(r); every index static => registers only
 static __device__ __forceinline__ void adjust_stepsize(double* dif, double r, int k) {
   const double U[5][5] = {{-1, -2, -3, -4, -5}, {0, 1, 3, 6, 10}, {0, 0, -1, -4, -10}, {0, 0, 0, 1, 5}, {0, 0, 0, 0, -1}};
@@ -1099,7 +1400,7 @@ static __device__ __forceinline__ double dif_get(const double* dif, int i) {
 // evolver_ndf15 (ev.cpp:62-705) for one interval of constant approximation scheme, as ONE flat loop so that the RHS
 // is instantiated exactly twice: a "service" slot (Jacobian columns, f(t0), f(t0+tdel), J f0, sampled outputs, the
 // final evaluation) and the Newton slot.  Returns 0 / error code (1 step too small, 2 singular, 4 budget).
-static __device__ __forceinline__ int ndf15(const PtParams& P, const Layout& L, const LaneEq& e, Lookup& Q, Metric& M, double k,
+static __device__ __forceinline__ int ndf15(const PtParams& P, const Layout& L, const LaneEq& e, const ChainEq& ce, Ctx& C, Lookup& Q, Metric& M, double k,
                                      double inv_k2, int ik, double t0, double tfinal, double& y_io, Stat& st, int lane,
                                      int& budget, double* jac_lds, unsigned long long* prof) {
   PROF_DECL;
@@ -1114,8 +1415,12 @@ static __device__ __forceinline__ int ndf15(const PtParams& P, const Layout& L, 
 
   Jac J;
   J.Jc = jac_lds;
-  for (int j = 0; j < NC; j++) J.Jc[j * 64 + lane] = 0.;
+  if (!NCDM || C.wave == 0) for (int j = 0; j < NC; j++) J.Jc[j * 64 + lane] = 0.;
   J.jdiag = 0.;
+  ChainCoef jc = {0., 0., 0., 0., 0., 0.};
+  ChainLu CF = {1., 0., 0., 0., 0., 0.};
+  double gmc = 0., gms = 0.;   // wave 0: response of (metric_continuity, metric_shear) to unit core variable `lane`
+  NcIn N = {0., 0., 0., nullptr};
   LuReg F;
 #pragma unroll
   for (int j = 0; j < NC; j++) F.Ac[j] = 0.;
@@ -1160,24 +1465,37 @@ static __device__ __forceinline__ int ndf15(const PtParams& P, const Layout& L, 
       PROF_START();
       const int nreq = (batch == B_JAC) ? NC : 1;
       const double tca_keep = M.tca_shear_g;
+      if (NCDM && batch == B_JAC) sync_tau(P, Q, C, ce, t, lane);
+      if (NCDM && batch == B_JAC && C.wave > 0) jc = chain_coef(P, L, ce, C, k);   // the chains' Jacobian is their coefficient set
+      else
       for (int r = 0; r < nreq; r++) {
         double tq, yq;
         if (batch == B_JAC) {  // J e_r = f(t, e_r): exact, the system is linear; idle variables have no column
           if (!core_present(P, L, r)) continue;
-          tq = t; yq = (lane == r) ? 1.0 : 0.0;
+          tq = t; yq = (lane == r && !(NCDM && r >= LN_ND)) ? 1.0 : 0.0;
         }
         else if (batch == B_F0) { tq = t; yq = y; }
         else if (batch == B_F1) { tq = t + tdel; yq = y; }
         else if (batch == B_JF0) { tq = t; yq = f0; }                  // J f0 = f(t, f0)
         else if (batch == B_SAMPLE) { tq = tn; yq = yi; }
         else { tq = tnew; yq = ynew; }
-        const double dyq = rhs(P, L, e, Q, M, k, inv_k2, tq, yq, lane);
+        double dyq;
+        if (NCDM && batch == B_JAC) {   // wave 0 alone: unit ncdm integrals for the two auxiliary columns, no block barrier
+          const NcIn Nj = {r == LN_ND ? 1. : 0., r == LN_NT ? 1. : 0., 0., nullptr};
+          dyq = rhs(P, L, e, Q, M, k, inv_k2, tq, yq, lane, Nj);
+          if (lane == r) { gmc = 0.5 * M.hp; gms = k * k * M.alpha; }
+        } else dyq = rhs_all(P, L, e, ce, Q, M, C, N, k, inv_k2, tq, yq, lane);
         st.fevals++;
         if (batch == B_JAC) J.Jc[r * 64 + lane] = (lane < NC) ? dyq : 0.;
-        else if (batch == B_F0) f0 = dyq;
+        else if (batch == B_F0) {
+          f0 = dyq;
+#ifdef CPT_DEBUG_NCDM
+          if (!(y == y) || !(dyq == dyq)) printf("nan at F0: k=%g wave=%d lane=%d y=%g dy=%g t=%g\n", k, C.wave, lane, y, dyq, t);
+#endif
+        }
         else if (batch == B_F1) f1 = dyq;
         else if (batch == B_JF0) fnewton = dyq;  // temporarily J f0
-        else if (batch == B_SAMPLE) store_sources(P, L, Q, M, k, inv_k2, yi, ypi, tca_keep, next, ik, lane);
+        else if (batch == B_SAMPLE) { if (!NCDM || C.wave == 0) store_sources(P, L, Q, M, k, inv_k2, yi, ypi, tca_keep, next, ik, lane, N); }
       }
       if (batch == B_FINAL) { PROF_STOP(3); break; }  // ev.cpp:653-662: M, Q left at (tfinal, y) for the hand-over
       if (batch == B_JAC) {
@@ -1194,7 +1512,7 @@ static __device__ __forceinline__ int ndf15(const PtParams& P, const Layout& L, 
       } else if (batch == B_F0) {
         // first guess of h (ev.cpp:225-250)
         wt = fmax(fabs(y), threshold);
-        const double rh = wave_max(1.25 / sqrt(rtol) * fabs(f0 / wt));
+        const double rh = block_max(1.25 / sqrt(rtol) * fabs(f0 / wt), C, lane);
         absh = fmin(hmax, htspan);
         if (absh * rh > 1.0) absh = 1.0 / rh;
         absh = fmax(absh, hmin);
@@ -1210,7 +1528,7 @@ static __device__ __forceinline__ int ndf15(const PtParams& P, const Layout& L, 
       } else if (batch == B_JF0) {
         // ddfddt = J f0 + (f(t+tdel) - f0)/tdel  (ev.cpp:261-283)
         const double acc = fnewton + (f1 - f0) / tdel;
-        const double rh = wave_max(1.25 * sqrt(0.5 * fabs(acc / wt) / rtol));
+        const double rh = block_max(1.25 * sqrt(0.5 * fabs(acc / wt) / rtol), C, lane);
         absh = fmin(hmax, htspan);
         if (absh * rh > 1.0) absh = 1.0 / rh;
         absh = fmax(absh, hmin);
@@ -1252,13 +1570,13 @@ static __device__ __forceinline__ int ndf15(const PtParams& P, const Layout& L, 
         double hopt = temp > 0.1 ? absh * fast_rcp(temp) : 10 * absh;
         int kopt = kk;
         if (kk > 1) {
-          const double errkm1 = wave_max(fabs(dif_get(dif, kk - 1) * invwt)) * ndf_erconst(kk - 2);
+          const double errkm1 = block_max(fabs(dif_get(dif, kk - 1) * invwt), C, lane) * ndf_erconst(kk - 2);
           temp = 1.3 * fast_root(errkm1 * inv_rtol, kk);
           const double hkm1 = temp > 0.1 ? absh * fast_rcp(temp) : 10 * absh;
           if (hkm1 > hopt) { hopt = hkm1; kopt = kk - 1; }
         }
         if (kk < maxk) {
-          const double errkp1 = wave_max(fabs(dif_get(dif, kk + 1) * invwt)) * ndf_erconst(kk);
+          const double errkp1 = block_max(fabs(dif_get(dif, kk + 1) * invwt), C, lane) * ndf_erconst(kk);
           temp = 1.4 * fast_root(errkp1 * inv_rtol, kk + 2);
           const double hkp1 = temp > 0.1 ? absh * fast_rcp(temp) : 10 * absh;
           if (hkp1 > hopt) { hopt = hkp1; kopt = kk + 1; }
@@ -1292,7 +1610,9 @@ static __device__ __forceinline__ int ndf15(const PtParams& P, const Layout& L, 
     if (need_fact) {
       need_fact = false;
       PROF_START();
-      if (!factorise(e, J, hinvGak, maxlen, lane, F)) return 2;
+      bool fact_ok;
+      fact_all(e, ce, J, jc, hinvGak, maxlen, lane, C, F, CF, gmc, gms, &fact_ok);
+      if (!fact_ok) return 2;
       PROF_STOP(2);
       st.lus++;
       havrate = false;
@@ -1315,11 +1635,12 @@ static __device__ __forceinline__ int ndf15(const PtParams& P, const Layout& L, 
     ynew = pred;
     difkp1 = 0.;
     invwt = fast_rcp(fmax(fmax(fabs(ynew), fabs(y)), threshold));
-    const double minnrm = wave_max(100 * eps * fabs(ynew * invwt));
+    const double minnrm = block_max(100 * eps * fabs(ynew * invwt), C, lane);
+    if (NCDM && C.abort) return 2;
     bool tooslow = false;
     for (int iter = 1; iter <= maxit; iter++) {
       PROF_START();
-      fnewton = rhs(P, L, e, Q, M, k, inv_k2, tnew, ynew, lane);
+      fnewton = rhs_all(P, L, e, ce, Q, M, C, N, k, inv_k2, tnew, ynew, lane);
       PROF_STOP(0);
 #ifdef CPT_PROFILE
       t_inner += clock64() - pf_t0;
@@ -1327,13 +1648,13 @@ static __device__ __forceinline__ int ndf15(const PtParams& P, const Layout& L, 
       st.fevals++;
       const double rhsv = hinvGak * fnewton - (psi + difkp1);
       PROF_START();
-      const double del = lu_solve(e, F, maxlen, rhsv, lane);
+      const double del = solve_all(e, ce, F, CF, hinvGak, maxlen, rhsv, lane, C, gmc, gms);
       PROF_STOP(1);
 #ifdef CPT_PROFILE
       t_inner += clock64() - pf_t0;
 #endif
       st.solves++;
-      const double newnrm = wave_max(fabs(del * invwt));
+      const double newnrm = block_max(fabs(del * invwt), C, lane);
       difkp1 += del;
       ynew = pred + difkp1;
       if (newnrm <= minnrm) break;
@@ -1357,6 +1678,9 @@ static __device__ __forceinline__ int ndf15(const PtParams& P, const Layout& L, 
     if (tooslow) {  // ev.cpp:446-479
       st.failed++;
       if (!Jcurrent) { batch = B_JAC; continue; }
+#ifdef CPT_DEBUG_NCDM
+      if (absh <= hmin && lane == 0) printf("hmin(tooslow) k=%g wave=%d t=%g h=%g kk=%d flags tca%d rsa%d ufa%d nfa%d steps=%d\n", k, C.wave, t, absh, kk, L.tca, L.rsa, L.ufa, L.nfa, st.steps);
+#endif
       if (absh <= hmin) return 1;
       abshlast = absh;
       absh = fmax(0.3 * absh, hmin);
@@ -1370,16 +1694,19 @@ static __device__ __forceinline__ int ndf15(const PtParams& P, const Layout& L, 
     }
     // ------------------------------------------------------------------ error test (ev.cpp:483-532)
     PROF_START();
-    err = wave_max(fabs(difkp1 * invwt)) * ndf_erconst(kk - 1);
+    err = block_max(fabs(difkp1 * invwt), C, lane) * ndf_erconst(kk - 1);
     if (err > rtol) {
       st.failed++;
+#ifdef CPT_DEBUG_NCDM
+      if (absh <= hmin && lane == 0) printf("hmin(err) k=%g wave=%d t=%g h=%g kk=%d err=%g flags tca%d rsa%d ufa%d nfa%d steps=%d\n", k, C.wave, t, absh, kk, err, L.tca, L.rsa, L.ufa, L.nfa, st.steps);
+#endif
       if (absh <= hmin) return 1;
       abshlast = absh;
       if (nofailed) {
         nofailed = false;
         double hopt = absh * fmax(0.1, 0.833 * fast_root(rtol / err, kk + 1));
         if (kk > 1) {
-          const double errkm1 = wave_max(fabs((dif_get(dif, kk - 1) + difkp1) * invwt)) * ndf_erconst(kk - 2);
+          const double errkm1 = block_max(fabs((dif_get(dif, kk - 1) + difkp1) * invwt), C, lane) * ndf_erconst(kk - 2);
           const double hkm1 = absh * fmax(0.1, 0.769 * fast_root(rtol / errkm1, kk));
           if (hkm1 > hopt) { hopt = fmin(absh, hkm1); kk = kk - 1; }
         }
@@ -1427,6 +1754,10 @@ static __device__ __noinline__ double initial_conditions(DevTables T, int has_cd
   double rho_r = rg, rho_m = rb, rho_nu = 0.;
   if (has_cdm) rho_m += rc;
   if (has_ur) { rho_r += ru; rho_nu += ru; }
+  if (NCDM) {   // pm.cpp:4794-4799: the non-cold species count as relativistic relics at the initial time
+    const double2* n0 = (const double2*)T.ncb + (size_t)inf * NCB_NCOL;
+    for (int n = 0; n < CPT_MAX_NCDM; n++) { const double rn = spl2(n0[3 * n], n0[NCB_NCOL + 3 * n], aa, b, h2); rho_r += rn; rho_nu += rn; }
+  }
   const double fracnu = rho_nu / rho_r, fracb = rb / rho_m;
   const double om = a * rho_m / sqrt(rho_r);
   const double kt2 = k * k * tau * tau, kt3 = k * tau * kt2;
@@ -1478,7 +1809,7 @@ static __device__ __noinline__ double initial_conditions(DevTables T, int has_cd
   }
   double tbv = tg, tcdm = 0.;
   if (!has_cdm) dcdm = 0.;
-  if (!has_ur) { dur = tur = sur = l3u = 0.; }
+  if (!has_ur && !NCDM) { dur = tur = sur = l3u = 0.; }   // (NCDM: the chain lanes ask for the relic series, pm.cpp:5229-5256)
   if (gauge == CPT_GAUGE_NEWTONIAN) {  // gauge transformation of the synchronous series, pm.cpp:5095-5198
     const double H = spl2(r0[BG_H], r1[BG_H], aa, b, h2), aH = a * H, fracg = rg / rho_r, fraccdm = 1. - fracb, rmr = rho_m / rho_r;
     const double delta_tot = (fracg * dg + fracnu * dur + rmr * (fracb * db + fraccdm * dcdm)) / (1. + rmr);
@@ -1510,12 +1841,20 @@ static __device__ __noinline__ double initial_conditions(DevTables T, int has_cd
 static __device__ __forceinline__ void body_perturb(const PtParams& P) {
   __shared__ __attribute__((aligned(16))) double2 tabw[64 * (BG_NCOL + TH_NCOL)];
   __shared__ double jacw[NC * 64];
-  const int lane = threadIdx.x;
+  __shared__ __attribute__((aligned(16))) double2 ncw[NCDM ? 64 * NCB_NCOL : 1];
+  __shared__ __attribute__((aligned(8))) char ncsh_raw[NCDM ? sizeof(NcShared) : 8];
+  const int lane = threadIdx.x & 63;
   const int ik = P.order[blockIdx.x];
   const double k = P.k[ik];
   const double inv_k2 = 1.0 / (k * k);
   double2* bgw = tabw;
   double2* thw = tabw + 64 * BG_NCOL;
+  Ctx C;
+  C.wave = NCDM ? (int)(threadIdx.x >> 6) : 0; C.nw = NCDM ? (int)(blockDim.x >> 6) - 1 : 0;
+  C.len = NCDM ? P.nc.lmax + 1 : 64; C.cpw = 64 / C.len;
+  C.sh = (NcShared*)ncsh_raw; C.parity = 0; C.abort = 0; C.tau_pub = -1.;
+  C.a2 = C.aH = C.kcot = C.inv_tau = C.rho = C.pr = C.pp = 1.;
+  if (NCDM) { if (threadIdx.x == 0) C.sh->abort = 0; __syncthreads(); }
 
   Stat st = {0, 0, 0, 0, 0, 0};
   unsigned long long prof[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -1531,38 +1870,42 @@ static __device__ __forceinline__ void body_perturb(const PtParams& P) {
   {
     const double tl = P.tabs.tau_table[0];
     const AHK q = lookup_aHk(P.tabs, P.n_e, tl);
-    if ((q.a * q.H / q.dk > P.start_small_k) || (k / q.a / q.H > P.start_large_k)) status = 20;
+    if ((q.a * q.H / q.dk > P.start_small_k) || (k / q.a / q.H > P.start_large_k) || (q.wdev > P.tol_ncdm_w)) status = 20;
     tau_ini = first(search_flip(P, k, tl, P.tau_s[0], 0., P.tol_tau_approx, 0, 0, lane));
   }
   // ---- regime schedule: pm.cpp:2940-3231 ----
-  int fi0, fi1, fi2, fe0, fe1, fe2;
-  approx_flags(P, k, tau_ini, &fi0, &fi1, &fi2);
-  approx_flags(P, k, tau_end, &fe0, &fe1, &fe2);
-  fi0 = ufirst(fi0); fi1 = ufirst(fi1); fi2 = ufirst(fi2); fe0 = ufirst(fe0); fe1 = ufirst(fe1); fe2 = ufirst(fe2);
-  double sw0 = 0., sw1 = 0., sw2 = 0.;
-  int ap0 = 0, ap1 = 0, ap2 = 0, nsw = 0;
+  int fi0, fi1, fi2, fi3, fe0, fe1, fe2, fe3;
+  approx_flags(P, k, tau_ini, &fi0, &fi1, &fi2, &fi3);
+  approx_flags(P, k, tau_end, &fe0, &fe1, &fe2, &fe3);
+  fi0 = ufirst(fi0); fi1 = ufirst(fi1); fi2 = ufirst(fi2); fi3 = ufirst(fi3);
+  fe0 = ufirst(fe0); fe1 = ufirst(fe1); fe2 = ufirst(fe2); fe3 = ufirst(fe3);
+  // (unused slots stay at +huge so that the sorting network below leaves them last)
+  double sw0 = 1e300, sw1 = 1e300, sw2 = 1e300, sw3 = 1e300;
+  int ap0 = 0, ap1 = 0, ap2 = 0, ap3 = 0, nsw = 0;
 #pragma unroll 1
-  for (int ap = 0; ap < 3; ap++) {
-    const int fi = (ap == 0) ? fi0 : (ap == 1 ? fi1 : fi2), fe = (ap == 0) ? fe0 : (ap == 1 ? fe1 : fe2);
+  for (int ap = 0; ap < (NCDM ? 4 : 3); ap++) {
+    const int fi = (ap == 0) ? fi0 : (ap == 1) ? fi1 : (ap == 2) ? fi2 : fi3, fe = (ap == 0) ? fe0 : (ap == 1) ? fe1 : (ap == 2) ? fe2 : fe3;
     if (fi == fe) continue;
-    const bool fwd = (ap == 0) ? (fi == 1 && fe == 0) : (fi == 0 && fe == 1);  // tca: on->off, rsa/ufa: off->on
+    const bool fwd = (ap == 0) ? (fi == 1 && fe == 0) : (fi == 0 && fe == 1);  // tca: on->off, rsa/ufa/ncdmfa: off->on
     if (!fwd) { status = 21; continue; }
     const double tsw = first(search_flip(P, k, tau_ini, tau_end, P.tol_tau_approx, 0., ap + 1, fi, lane));
-    if (nsw == 0) { sw0 = tsw; ap0 = ap; } else if (nsw == 1) { sw1 = tsw; ap1 = ap; } else { sw2 = tsw; ap2 = ap; }
+    if (nsw == 0) { sw0 = tsw; ap0 = ap; } else if (nsw == 1) { sw1 = tsw; ap1 = ap; } else if (nsw == 2) { sw2 = tsw; ap2 = ap; } else { sw3 = tsw; ap3 = ap; }
     nsw++;
   }
-  // sort the (at most 3) switches chronologically (scalars only: no private arrays)
-  if (nsw >= 2 && sw1 < sw0) { double t = sw0; sw0 = sw1; sw1 = t; int a = ap0; ap0 = ap1; ap1 = a; }
-  if (nsw == 3) {
-    if (sw2 < sw1) { double t = sw1; sw1 = sw2; sw2 = t; int a = ap1; ap1 = ap2; ap2 = a; }
-    if (sw1 < sw0) { double t = sw0; sw0 = sw1; sw1 = t; int a = ap0; ap0 = ap1; ap1 = a; }
+  // sort the (at most 4) switches chronologically (scalars only: no private arrays)
+  {
+    auto cswap = [](double& x, double& y, int& a, int& b) { if (y < x) { const double t = x; x = y; y = t; const int u = a; a = b; b = u; } };
+    cswap(sw0, sw1, ap0, ap1); cswap(sw2, sw3, ap2, ap3); cswap(sw0, sw2, ap0, ap2); cswap(sw1, sw3, ap1, ap3); cswap(sw1, sw2, ap1, ap2);
   }
-  if ((nsw >= 2 && sw1 == sw0) || (nsw == 3 && sw2 == sw1)) status = 22;
-  if (!(fi0 == 1 && fi1 == 0 && fi2 == 0)) status = 23;  // pm.cpp:3720-3745
+  if ((nsw >= 2 && sw1 == sw0) || (nsw >= 3 && sw2 == sw1) || (nsw == 4 && sw3 == sw2)) status = 22;
+  if (!(fi0 == 1 && fi1 == 0 && fi2 == 0 && fi3 == 0)) status = 23;  // pm.cpp:3720-3745
 
   if (status == 0) {
     Lookup Q;
-    lookup_init(P, Q, bgw, thw, lane);
+    // (NCDM: the table windows belong to wave 0 alone - a chain wave staging them late would overwrite a window that wave 0
+    //  has already moved; the chain waves get what they need through sync_tau)
+    if (!NCDM || C.wave == 0) lookup_init(P, Q, bgw, thw, lane, ncw);
+    else { memset(&Q, 0, sizeof(Q)); Q.tau_cached = -1.; }
     lookup_set_mode(P, Q, k);
 #ifdef CPT_PROFILE
     Q.prof = prof;
@@ -1570,9 +1913,10 @@ static __device__ __forceinline__ void body_perturb(const PtParams& P) {
     Metric M;
     M.hp = M.etap = M.alpha = M.alphap = 0.;
     M.tca_shear_g = 0.; M.rsa_dg = M.rsa_tg = 0.;
-    int f_tca = fi0, f_rsa = fi1, f_ufa = fi2;
-    Layout L = make_layout(P, f_tca, f_rsa, f_ufa);
-    LaneEq e = make_lane_eq(P, L, lane, k);
+    int f_tca = fi0, f_rsa = fi1, f_ufa = fi2, f_nfa = fi3;
+    Layout L = make_layout(P, f_tca, f_rsa, f_ufa, f_nfa);
+    LaneEq e = make_lane_eq(P, L, NCDM && C.wave > 0 ? -1 : lane, k);   // (chain waves: an all-idle description)
+    const ChainEq ce = make_chain_eq(P, C, lane, k);
     double y;
     if (MODE) {  // tensors (pm.cpp:5386-5403): only the gravitational wave starts non-zero
       y = 0.;
@@ -1584,23 +1928,54 @@ static __device__ __forceinline__ void body_perturb(const PtParams& P) {
           if (P.K < 0.) y = (k2 + 3. * P.K >= 0.) ? y * sqrt(tanh(1.5707963267948966 * sqrt(k2 + 3. * P.K) / sqrt(-P.K))) : 0.;
         }
       }
+    } else if (NCDM && C.wave > 0) {   // pm.cpp:5229-5256: the relativistic-relic series times the momentum dependence of f0
+      const int l = ce.l;
+      const int role = (l == 0) ? R_DELTA_UR : (l == 1) ? R_THETA_UR : (l == 2) ? R_SHEAR_UR : (l == 3) ? R_LUR : R_NONE;
+      const double v = initial_conditions(P.tabs, P.has_cdm, P.has_ur, P.curvature_ini, P.K, P.ic, P.entropy_ini, GAUGE, role, 3, k, tau_ini);
+      const AHK q0 = lookup_aHk(P.tabs, P.n_e, tau_ini);
+      const int ci = ce.valid ? ce.cidx : 0;
+      const double eps = sqrt(ce.q2 + q0.a * q0.a * ce.M2), dl = P.nc.dlnf0[ci];
+      const double f = (l == 0) ? -0.25 : (l == 1) ? -eps / (3. * ce.qk) : (l == 2) ? -0.5 : -0.25;
+      y = (ce.valid && l <= 3) ? f * v * dl : 0.;
     } else
       y = initial_conditions(P.tabs, P.has_cdm, P.has_ur, P.curvature_ini, P.K, P.ic, P.entropy_ini, GAUGE, e.role, e.ell, k, tau_ini);
 #ifdef CPT_PROFILE
     prof[6] = clock64() - t_begin;  // schedule search + initial conditions
 #endif
     for (int iv = 0; iv <= nsw && status == 0; iv++) {
-      const double ta = (iv == 0) ? tau_ini : (iv == 1 ? sw0 : (iv == 2 ? sw1 : sw2));
-      const double tb = (iv == nsw) ? tau_end : (iv == 0 ? sw0 : (iv == 1 ? sw1 : sw2));
+      const double ta = (iv == 0) ? tau_ini : (iv == 1) ? sw0 : (iv == 2) ? sw1 : (iv == 3) ? sw2 : sw3;
+      const double tb = (iv == nsw) ? tau_end : (iv == 0) ? sw0 : (iv == 1) ? sw1 : (iv == 2) ? sw2 : sw3;
       if (iv > 0) {
         // hand-over to the new scheme (pm.cpp:3777-4260): every variable keeps its lane; the ones the new scheme
         // drops are zeroed, the ones it adds are seeded
         const int was_tca = L.tca;
-        const int ap = (iv == 1) ? ap0 : (iv == 2 ? ap1 : ap2);
-        if (ap == 0) f_tca ^= 1; else if (ap == 1) f_rsa ^= 1; else f_ufa ^= 1;
-        L = make_layout(P, f_tca, f_rsa, f_ufa);
-        e = make_lane_eq(P, L, lane, k);
+        const int ap = (iv == 1) ? ap0 : (iv == 2) ? ap1 : (iv == 3) ? ap2 : ap3;
+        const Layout Lold = L;
+        if (ap == 0) f_tca ^= 1; else if (ap == 1) f_rsa ^= 1; else if (ap == 2) f_ufa ^= 1; else f_nfa ^= 1;
+        L = make_layout(P, f_tca, f_rsa, f_ufa, f_nfa);
+        e = make_lane_eq(P, L, NCDM && C.wave > 0 ? -1 : lane, k);
         double yn = (e.role == R_NONE) ? 0. : y;
+        if (NCDM && C.wave > 0) yn = y;          // the momentum hierarchies ride through the photon / ur switches (pm.cpp:3968-3975 etc.)
+        if (NCDM && ap == 3) {
+          // fluid approximation switched on (pm.cpp:4479-4517): integrate every chain into its species' delta, theta, sigma.
+          // The published block still holds the background at the switch time (the final RHS evaluation of the last interval).
+          if (C.wave > 0) {
+            const ChainCoef cc = chain_coef(P, Lold, ce, C, k);
+            if (ce.valid && ce.l <= 2) C.sh->ho[ce.cidx][ce.l] = cc.wt * y;
+          }
+          __syncthreads();
+          if (C.wave > 0) {
+            yn = 0.;
+            if (ce.holder) {
+              double sum = 0.;
+              for (int c = P.nc.first_chain[ce.species]; c < P.nc.first_chain[ce.species + 1]; c++) sum += C.sh->ho[c][ce.l];
+              yn = sum / ((ce.l == 0) ? C.rho : C.rho + C.pr);
+#ifdef CPT_DEBUG_NCDM
+              printf("handover k=%g l=%d sum=%g rho=%g p=%g pp=%g a2=%g yn=%g\n", k, ce.l, sum, C.rho, C.pr, C.pp, C.a2, yn);
+#endif
+            }
+          }
+        }
         if (MODE) {  // tensors (pm.cpp:4640-4648): photons re-enter with delta_g = -4/3 gw'/kappa', pol0 = gw'/(3 kappa')
           if (was_tca && !L.tca) {
             const double gwd = bcast(y, TL_GWD);
@@ -1625,16 +2000,16 @@ static __device__ __forceinline__ void body_perturb(const PtParams& P) {
         y = yn;
       }
       n_regimes++;
-      const int rc = ndf15(P, L, e, Q, M, k, inv_k2, ik, ta, tb, y, st, lane, budget, jacw, prof);
+      const int rc = ndf15(P, L, e, ce, C, Q, M, k, inv_k2, ik, ta, tb, y, st, lane, budget, jacw, prof);
       if (rc) status = 10 + rc;
     }
   }
 #ifdef CPT_PROFILE
   prof[7] = clock64() - t_begin;
-  if (lane == 0 && blockIdx.x == 0)  // the heaviest mode = the critical path
+  if (lane == 0 && blockIdx.x == 0 && C.wave == 0)  // the heaviest mode = the critical path
     for (int i = 0; i < 16; i++) g_prof[i] = prof[i];
 #endif
-  if (lane == 0) {
+  if (lane == 0 && C.wave == 0) {
     if (P.status) P.status[ik] = status;
     if (P.stats) {
       cpt_stepstat s;
@@ -1733,6 +2108,9 @@ static __device__ __forceinline__ void body_dbg_solve(const PtParams& P, double 
 
 template <int GAUGE, int CURV, int MODE>
 __global__ void __launch_bounds__(64) k_perturb(PtParams P) { PT<GAUGE, CURV, MODE>::body_perturb(P); }
+// scalars with non-cold species: 1 + NW wavefronts per k-mode (synchronous gauge)
+template <int CURV>
+__global__ void __launch_bounds__(64 * (1 + NCW_MAX)) k_perturb_ncdm(PtParams P) { PT<CPT_GAUGE_SYNCHRONOUS, CURV, 0, 1>::body_perturb(P); }
 template <int GAUGE, int CURV, int MODE>
 __global__ void __launch_bounds__(64) k_dbg_lookup(PtParams P, const double* tau, int n, double* out) { PT<GAUGE, CURV, MODE>::body_dbg_lookup(P, tau, n, out); }
 template <int GAUGE, int CURV, int MODE>
@@ -1762,6 +2140,9 @@ void fill_params(const cpt_handle* h, PtParams& P) {
   P.rsa_trig = c.radiation_streaming_trigger_tau_over_tau_k; P.ufa_trig = c.ur_fluid_trigger_tau_over_tau_k;
   P.curvature_ini = c.curvature_ini; P.rtol = c.tol_perturb_integration; P.tol_tau_approx = c.tol_tau_approx;
   P.min_var = c.smallest_allowed_variation;
+  P.has_ncdm = c.has_ncdm; P.nfa_method = c.ncdm_fluid_approximation; P.nfa_trig = c.ncdm_fluid_trigger_tau_over_tau_k;
+  P.tol_ncdm_w = c.has_ncdm ? c.tol_ncdm_initial_w : 1e300; P.tp_dcb = c.has_ncdm ? c.index_tp_delta_cb : -1;
+  P.nc = h->ncdm;
   P.max_steps = 400000;
   P.k = nullptr; P.tau_s = nullptr; P.order = nullptr; P.nk = 0; P.ntau = 0; P.src = nullptr; P.stats = nullptr; P.status = nullptr;
 }
@@ -1817,6 +2198,13 @@ int cpt_perturb_impl(cpt_handle* h, const double* k, int nk, const double* tau, 
   CPT_HIP(h, hipMemsetAsync(h->d_src, 0, nsrc * sizeof(double), h->stream));  // pm.cpp:2767-2771 zero tail
   P.k = d_k; P.tau_s = d_tau; P.order = d_order; P.nk = nk; P.ntau = ntau; P.src = h->d_src; P.stats = d_stats; P.status = d_status;
   CPT_HIP(h, hipEventRecord(h->t_perturb.a, h->stream));
+  if (c.has_ncdm && c.mode == CPT_MODE_SCALARS) {
+    const int cpw = 64 / (c.l_max_ncdm + 1), nw = (h->ncdm.nchains + cpw - 1) / cpw;
+    if (nw > NCW_MAX)
+      return cpt_fail(h, CPT_ERR_UNSUPPORTED, "%d ncdm momentum bins need %d chain wavefronts per k-mode (at most %d)", h->ncdm.nchains, nw, NCW_MAX);
+    if (c.K != 0.) hipLaunchKernelGGL((k_perturb_ncdm<1>), dim3(nk), dim3(64 * (1 + nw)), 0, h->stream, P);
+    else hipLaunchKernelGGL((k_perturb_ncdm<0>), dim3(nk), dim3(64 * (1 + nw)), 0, h->stream, P);
+  } else
   CPT_PT_DISPATCH(c, k_perturb, dim3(nk), dim3(64), 0, h->stream, P);
   CPT_HIP(h, hipGetLastError());
   CPT_HIP(h, hipEventRecord(h->t_perturb.b, h->stream));

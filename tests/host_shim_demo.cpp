@@ -29,7 +29,7 @@ int main(int argc, char** argv) {
   in.tables.tau_table = tau.data(); in.tables.background_table = bg.data(); in.tables.d2background_dtau2_table = d2bg.data();
   in.tables.z_table = z.data(); in.tables.thermodynamics_table = th.data(); in.tables.d2thermodynamics_dz2_table = d2th.data();
   int bad_flag = argc > 3 ? atoi(argv[3]) : 0;
-  if (bad_flag == 1) in.config.has_ncdm = 1;            // must raise std::invalid_argument
+  if (bad_flag == 1) in.config.has_fld = 1;             // must raise std::invalid_argument
   if (bad_flag == 2) in.grid.k_step_transition = 0.;    // must raise std::invalid_argument (reference: class_test)
   try {
     auto pt = std::make_shared<const cpt::PerturbationsModule>(in);

@@ -48,7 +48,7 @@ def test_struct_layout_matches_header():
 def test_unsupported_physics_is_rejected_before_any_device_work():
     inp = Inputs("small")
     lib = capi.lib()
-    for field, value, code in (("sgnK", 1, capi.CPT_ERR_INVALID), ("has_ncdm", 1, capi.CPT_ERR_UNSUPPORTED),
+    for field, value, code in (("sgnK", 1, capi.CPT_ERR_INVALID), ("has_fld", 1, capi.CPT_ERR_UNSUPPORTED),
                                ("gauge", 7, capi.CPT_ERR_INVALID), ("l_max_g", 3, capi.CPT_ERR_INVALID),
                                ("tp_size", 0, capi.CPT_ERR_INVALID)):
         cfg = capi.CptConfig.from_buffer_copy(inp.config)

@@ -72,6 +72,6 @@ def test_shim_modules_small(tmp_path):
     assert np.max(np.abs(tr - ref) / scale) < 1e-3  # coarse tau sampling of `small` amplifies the source noise
     # error mapping
     rc, out = run_demo(exe, ipath, opath, flag=1)
-    assert rc == 10 and "invalid_argument" in out and "non-cold dark matter" in out
+    assert rc == 10 and "invalid_argument" in out and "dark-energy fluid" in out
     rc, out = run_demo(exe, ipath, opath, flag=2)
     assert rc == 10 and "division by zero" in out

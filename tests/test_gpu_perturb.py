@@ -88,7 +88,7 @@ def test_perturb_small_all_modes(small):
     print("\n[small] perturb kernel %.3f ms for %d modes, %d steps" % (ms, inp.nk, gs))
 
 
-@pytest.mark.parametrize("cfg", ["lcdm", "explanatory", "iso_cdi", "iso_nid", "newt"])
+@pytest.mark.parametrize("cfg", ["lcdm", "explanatory", "iso_cdi", "iso_nid", "newt", "ncdm", "ncdm3"])
 def test_perturb_full_size(cfg):
     """BASELINE configs 1-2: every k-mode integrated on the GPU; the 16 golden columns are compared with the reference."""
     from classpp_public_amd.backend import Backend
@@ -304,3 +304,50 @@ def test_tensor_sources_match_reference(tens):
     osrc, ostats, _, _ = oracle_lib.perturb(inp)
     gs, os_ = sum(s.steps for s in stats), sum(s.steps for s in ostats)
     assert abs(gs - os_) < 0.02 * os_, (gs, os_)
+
+
+# ---- massive neutrinos (BASELINE configs 3-4): 1 + NW wavefronts per k-mode, the momentum hierarchies Psi_l(q) in the chain waves,
+# bordered Newton system (pm.cpp:8725-8879, 6317-6432, 5229-5256, 4479-4517).  ncdm_small / ncdm3_small hold the reference's full
+# sources_ for one / three species of 0.06 eV at the coarse precision of `small`.
+@pytest.mark.parametrize("cfg", ["ncdm_small", "ncdm3_small"])
+def test_ncdm_sources_match_reference(cfg):
+    from classpp_public_amd.backend import Backend
+    inp = Inputs(cfg)
+    be = Backend(inp)
+    src, stats, status = be.perturb_solve()
+    assert not status.any()
+    got = src.cpu().numpy()
+    assert np.all(np.isfinite(got))
+    check_sources(inp.config, got, inp.d["pt.sources"])
+    ks = np.arange(0, inp.nk, 7)
+    _, ostats, _, _ = oracle_lib.perturb(inp, k=inp.k[ks])
+    gs, os_ = sum(stats[i].steps for i in ks), sum(s.steps for s in ostats)
+    assert abs(gs - os_) < 0.02 * os_, (gs, os_)          # same algorithm => same amount of work as the dense CPU restatement
+    assert [stats[i].n_regimes for i in ks] == [s.n_regimes for s in ostats]   # (5 = tca, ufa, ncdmfa, rsa switches)
+    assert max(s.n_regimes for s in stats) == 5
+    ms, n = be.kernel_ms(0)
+    print("\n[%s] perturb kernel %.1f ms for %d modes, %d steps" % (cfg, ms, inp.nk, sum(s.steps for s in stats)))
+    be.close()
+
+
+def test_tensor_modes_with_massive_neutrinos():
+    """tensors with three ncdm species in the massless approximation (rho_relativistic = rho_ur + 3 sum p_ncdm, pm.cpp:6640-6657;
+    start-time condition on the ncdm equation of state, pm.cpp:2574-2603): sources and chained transfer vs the reference"""
+    from classpp_public_amd.backend import Backend
+    inp = Inputs("ncdm3_tens")
+    be = Backend(inp)
+    src, stats, status = be.perturb_solve()
+    assert not status.any()
+    got = src.cpu().numpy()
+    ks = inp.d["pt.sources_k_index"]
+    ref = inp.d["pt.sources_subset"]
+    for tp in (inp.config.index_tp_t2, inp.config.index_tp_p):
+        scale = np.max(np.abs(ref[tp]), axis=0, keepdims=True)
+        assert np.max(np.abs(got[tp][:, ks] - ref[tp]) / scale) < 2e-4
+    tr = be.transfer(None).cpu().numpy()
+    ls = inp.d["tr.transfer_l_index"]
+    want = inp.d["tr.transfer_at_l"]
+    scale = np.max(np.abs(want), axis=-1, keepdims=True)
+    scale[scale == 0] = 1
+    assert np.max(np.abs(tr[:, ls, :] - want) / scale) < 2e-4
+    be.close()
