@@ -71,6 +71,15 @@ __device__ inline double dpp_keep(double v) {
   hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xf, 0xf, false);
   return __hiloint2double(hi, lo);
 }
+// DPP row_shr:n within each row of 16 lanes; lanes without a source get 0
+template <int N>
+__device__ inline double row_shr0(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x110 + N, 0xf, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x110 + N, 0xf, 0xf, false);
+  int l2 = lo, h2 = hi;
+  asm volatile("" : "+v"(l2), "+v"(h2));
+  return __hiloint2double(h2, l2);
+}
 // max over the 64 lanes of a NON-NEGATIVE quantity (an error norm).  The reduction runs in single precision, where
 // v_max_f32 takes a DPP operand directly: 4 row_shr steps + row_bcast:15 + row_bcast:31 = six VALU instructions
 // (the double-precision version needs ~35: v_max_f64 is VOP3-only, so every step is copy + 2 DPP movs + max).
@@ -137,6 +146,16 @@ __device__ inline double fast_rcp(double x) {
   r = fma(r, fma(-x, r, 1.0), r);
   return r;
 }
+// sqrt(x), x > 0: hardware v_rsq_f64 seed + two Goldschmidt refinements (no IEEE sqrt expansion on a critical path)
+__device__ inline double fast_sqrt(double x) {
+  const double r0 = __builtin_amdgcn_rsq(x);
+  double g = x * r0, h = 0.5 * r0;
+  double rr = fma(-h, g, 0.5);
+  g = fma(g, rr, g); h = fma(h, rr, h);
+  rr = fma(-h, g, 0.5);
+  g = fma(g, rr, g);
+  return g;
+}
 // NDF constants (ev.cpp:87-88, 171-174) as immediates: no private arrays, no scratch
 __device__ inline double ndf_G(int i) { return i == 0 ? 1.0 : i == 1 ? 1.5 : i == 2 ? 11.0 / 6.0 : i == 3 ? 25.0 / 12.0 : 137.0 / 60.0; }
 __device__ inline double ndf_alpha(int i) { return i == 0 ? -37.0 / 200 : i == 1 ? -1.0 / 9.0 : i == 2 ? -8.23e-2 : i == 3 ? -4.15e-2 : 0.; }
@@ -197,6 +216,7 @@ struct PT {
 // LN_ETA holds eta (synchronous gauge) or phi (Newtonian gauge, pm.cpp:3470-3478); LN_TC = theta_cdm exists in the Newtonian gauge only
 enum Lane : int { LN_DG = 0, LN_TG, LN_SG, LN_P0, LN_P1, LN_P2, LN_DB, LN_TB, LN_DC, LN_DUR, LN_TUR, LN_SUR, LN_ETA, LN_TC };
 static constexpr int NC = MODE ? 17 : ((GAUGE == CPT_GAUGE_NEWTONIAN) ? 14 : 13) + (NCDM ? 2 : 0);
+static_assert(!NCDM || NC <= 16, "the core must fit one DPP row");
 static constexpr int LN_ND = NC - 2, LN_NT = NC - 1;   // (NCDM only) auxiliary unknowns: ncdm density / momentum sums
 // Tensor modes (MODE = 1; pm.cpp:3519-3586): the same three ladders plus the gravitational wave (gw, gw').  The photon
 // source P^(2) reads the l = 4 multipoles of temperature and polarisation and the gravitational-wave source reads the
@@ -691,7 +711,7 @@ struct Metric {
 // (NCDM) what the non-cold species contribute to the Einstein equations in this RHS evaluation: delta rho, (rho+p) theta,
 // (rho+p) sigma summed over species (pm.cpp:6317-6432).  `sh` != null: publish (metric_continuity, metric_shear) for the
 // chain waves and meet them at the block barrier as soon as the metric is known.
-struct NcIn { double D, T, S; NcShared* sh; };
+struct NcIn { double D, T, S; NcShared* sh; int nw; };
 
 // y of another lane (per-lane byte address): two ds_bpermute_b32, executed by every lane
 static __device__ __forceinline__ double gather(double v, int addr) {
@@ -742,7 +762,7 @@ static __device__ __forceinline__ void store_sources_tensor(const PtParams& P, c
 // synchronous gauge, K = 0.  y: this lane's component (named components are broadcast with v_readlane).
 // Returns dy of this lane and leaves M describing the state (tau, y).
 static __device__ __forceinline__ double rhs(const PtParams& P, const Layout& L, const LaneEq& e, Lookup& Q, Metric& M, double k,
-                                      double inv_k2, double tau, double y, int lane, const NcIn& N = NcIn{0., 0., 0., nullptr}) {
+                                      double inv_k2, double tau, double y, int lane, NcIn* Np = nullptr) {
   if (MODE) return rhs_tensor(P, L, e, Q, M, k, tau, y, lane);
 #ifdef CPT_PROFILE
   unsigned long long* prof = Q.prof;
@@ -773,7 +793,22 @@ static __device__ __forceinline__ double rhs(const PtParams& P, const Layout& L,
   double rps = Q.rg43 * sg;
   if (P.has_cdm) delta_rho += Q.rc * dc;
   if (P.has_ur) { delta_rho += Q.ru * dur; rpt += Q.ru43 * tur; rps += Q.ru43 * sur; }
-  if (NCDM) { delta_rho += N.D; rpt += N.T; rps += N.S; }
+  if (NCDM) {
+    NcIn& N = *Np;
+    if (N.sh) {   // (B) the chain waves have written their partial integrals (they worked while this wave fetched its neighbours)
+#ifdef CPT_PROFILE
+      const unsigned long long t_b0 = clock64();
+#endif
+      __syncthreads();
+#ifdef CPT_PROFILE
+      Q.prof[9] += clock64() - t_b0;
+#endif
+      double D = 0., T = 0., S = 0.;
+      for (int w = 0; w < N.nw; w++) { D += N.sh->sums[w][0]; T += N.sh->sums[w][1]; S += N.sh->sums[w][2]; }
+      N.D = D; N.T = T; N.S = S;
+    }
+    delta_rho += N.D; rpt += N.T; rps += N.S;
+  }
   // ---- Einstein equations -> the metric terms of the matter equations (pm.cpp:8049-8074):
   //      mc = metric_continuity, me = metric_euler, ms = metric_shear, msp = its derivative, mdot = eta' or phi'
   double mc, me, ms, msp, mdot;
@@ -799,8 +834,8 @@ static __device__ __forceinline__ double rhs(const PtParams& P, const Layout& L,
     const double alphap = -2. * aH * alpha + eta - 4.5 * (a2 * inv_k2) * rps;
     M.hp = hp; M.etap = etap; M.alpha = alpha; M.alphap = alphap;
     mc = 0.5 * hp; me = 0.; ms = k2 * alpha; msp = k2 * alphap; mdot = etap;
-    if (NCDM && N.sh) {   // the chain waves wait for exactly these two numbers
-      if (lane == 0) { N.sh->metric[0] = mc; N.sh->metric[1] = ms; }
+    if (NCDM && Np->sh) {   // (C) the chain waves wait for exactly these two numbers
+      if (lane == 0) { Np->sh->metric[0] = mc; Np->sh->metric[1] = ms; }
       __syncthreads();
     }
   } else {
@@ -877,7 +912,7 @@ static __device__ __forceinline__ double rhs(const PtParams& P, const Layout& L,
 // dy is the dense-output derivative (only theta_b' is used, pm.cpp:6883). Lane 0 stores the tp_size values.
 static __device__ __forceinline__ void store_sources(const PtParams& P, const Layout& L, const Lookup& Q, const Metric& M, double k,
                                               double inv_k2, double y, double dy, double tca_shear_prev, int it, int ik, int lane,
-                                              const NcIn& N = NcIn{0., 0., 0., nullptr}) {
+                                              const NcIn& N = NcIn{0., 0., 0., nullptr, 0}) {
   if (MODE) { store_sources_tensor(P, L, Q, y, it, ik, lane); return; }
   struct { double g, dg, expmk; } th;
   th.g = bcast(Q.vth, TH_G); th.dg = bcast(Q.vth, TH_DG); th.expmk = bcast(Q.vth, TH_EXPMK);
@@ -991,6 +1026,7 @@ struct Ctx {
   int parity, abort;
   double tau_pub;              // time at which sh->bc was last published (and read by everybody)
   double a2, aH, kcot, inv_tau, rho, pr, pp;   // chain waves: copy of the published block (rho, p, pseudo_p of the lane's species)
+  double ca, cb, cd, cxmc, cxms, cwt;          // chain waves: this lane's coefficients at tau_pub (they depend on tau only)
 };
 struct ChainEq {
   int l, cidx, species;
@@ -1029,7 +1065,7 @@ static __device__ __forceinline__ ChainEq make_chain_eq(const PtParams& P, const
 static __device__ __forceinline__ ChainCoef chain_coef(const PtParams& P, const Layout& L, const ChainEq& c, const Ctx& C, double k) {
   ChainCoef o;
   if (!L.nfa) {
-    const double eps = sqrt(c.q2 + C.a2 * c.M2), inv_eps = fast_rcp(eps), f = c.qk * inv_eps, inv_a4 = fast_rcp(C.a2 * C.a2);
+    const double eps = fast_sqrt(c.q2 + C.a2 * c.M2), inv_eps = fast_rcp(eps), f = c.qk * inv_eps, inv_a4 = fast_rcp(C.a2 * C.a2);
     o.a = f * c.A; o.b = f * c.B; o.d = c.G * C.kcot; o.xmc = c.Xmc; o.xms = c.Xms;
     const int l = opaque(c.l);
     o.wt = inv_a4 * c.sw * ((l == 0) ? eps : (l == 2) ? inv_eps : 1.);   // pm.cpp:6384-6393 (a_today = 1)
@@ -1064,37 +1100,52 @@ static __device__ __forceinline__ double chain_sum(double v, int l, const Ctx& C
 }
 
 // make the tables' row at tau known to every wave: wave 0 looks it up and publishes, the chain waves copy what they need
-static __device__ __forceinline__ void sync_tau(const PtParams& P, Lookup& Q, Ctx& C, const ChainEq& ce, double tau, int lane) {
+// (ROLE: 0 = the core wave, 1 = a chain wave.  The integrator is instantiated once per role, so that neither role carries the
+//  other's state in registers through the step loop; both instantiations execute the same sequence of block barriers.)
+template <int ROLE>
+static __device__ __forceinline__ void sync_tau(const PtParams& P, const Layout& L, Lookup& Q, Ctx& C, const ChainEq& ce, double k, double tau, int lane) {
   if (tau == C.tau_pub) return;
   C.tau_pub = tau;
-  if (C.wave == 0) {
+  if (ROLE == 0) {
+#ifdef CPT_PROFILE
+    const unsigned long long t_l0 = clock64();
+#endif
     lookup(P, Q, tau, lane);
+#ifdef CPT_PROFILE
+    Q.prof[8] += clock64() - t_l0;
+#endif
     const int i = opaque(lane);
     const double vn = shfl_all(Q.vnc, (lane - 4) & 63);   // (own statement: every lane must execute the cross-lane read)
     const double v = (i == 0) ? Q.a2 : (i == 1) ? Q.aH : (i == 2) ? Q.kcot : (i == 3) ? Q.inv_tau : vn;
     if (lane < 4 + NCB_NCOL) C.sh->bc[lane] = v;
   }
   __syncthreads();
-  if (C.wave > 0) {
+  if (ROLE == 1) {
     const double* bc = C.sh->bc;
     C.a2 = bc[0]; C.aH = bc[1]; C.kcot = bc[2]; C.inv_tau = bc[3];
     C.rho = bc[4 + 3 * ce.species]; C.pr = bc[5 + 3 * ce.species]; C.pp = bc[6 + 3 * ce.species];
+    const ChainCoef cc = chain_coef(P, L, ce, C, k);
+    C.ca = cc.a; C.cb = cc.b; C.cd = cc.d; C.cxmc = cc.xmc; C.cxms = cc.xms; C.cwt = cc.wt;
   }
 }
 
 // RHS of the whole block: returns this lane's dy.  N (wave 0) receives the ncdm integrals of this evaluation.
+template <int ROLE>
 static __device__ __forceinline__ double rhs_all(const PtParams& P, const Layout& L, const LaneEq& e, const ChainEq& ce, Lookup& Q, Metric& M,
                                                  Ctx& C, NcIn& N, double k, double inv_k2, double tau, double y, int lane) {
   if (!NCDM) return rhs(P, L, e, Q, M, k, inv_k2, tau, y, lane);
-  sync_tau(P, Q, C, ce, tau, lane);
-  if (C.wave == 0) {
-    __syncthreads();                         // (B) the chain waves have written their partial integrals
-    double D = 0., T = 0., S = 0.;
-    for (int w = 0; w < C.nw; w++) { D += C.sh->sums[w][0]; T += C.sh->sums[w][1]; S += C.sh->sums[w][2]; }
-    N.D = D; N.T = T; N.S = S; N.sh = C.sh;
-    return rhs(P, L, e, Q, M, k, inv_k2, tau, y, lane, N);   // (C) inside, right after the Einstein equations
+#ifdef CPT_PROFILE
+  const unsigned long long t_sync0 = clock64();
+#endif
+  sync_tau<ROLE>(P, L, Q, C, ce, k, tau, lane);
+#ifdef CPT_PROFILE
+  if (ROLE == 0) Q.prof[15] += clock64() - t_sync0;
+#endif
+  if (ROLE == 0) {
+    N.sh = C.sh; N.nw = C.nw;
+    return rhs(P, L, e, Q, M, k, inv_k2, tau, y, lane, &N);   // barriers (B) and (C) inside
   }
-  const ChainCoef cc = chain_coef(P, L, ce, C, k);
+  const ChainCoef cc = {C.ca, C.cb, C.cd, C.cxmc, C.cxms, C.cwt};
   {
     const double v = cc.wt * y;
     const double D = chain_sum(v, 0, C), T = chain_sum(v, 1, C), S = chain_sum(v, 2, C);
@@ -1315,11 +1366,12 @@ static __device__ __forceinline__ double lu_solve(const LaneEq& e, const LuReg& 
 
 // factorisation / solve of the whole block (NCDM): the chains are eliminated first (tridiagonal solves inside the chain waves),
 // the core with its two auxiliary unknowns second, the chains are back-substituted last
+template <int ROLE>
 static __device__ __forceinline__ void fact_all(const LaneEq& e, const ChainEq& ce, const Jac& J, const ChainCoef& jc, double hg, int maxlen,
                                                 int lane, Ctx& C, LuReg& F, ChainLu& CF, double gmc, double gms, bool* ok) {
   if (!NCDM) { *ok = factorise(e, J, hg, maxlen, lane, F); return; }
   *ok = true;
-  if (C.wave > 0) { chain_factor(jc, ce, hg, C.len, C, lane, CF); __syncthreads(); return; }
+  if (ROLE == 1) { chain_factor(jc, ce, hg, maxlen, C, lane, CF); __syncthreads(); return; }   // (chain waves: maxlen = sweeps of their chains)
   __syncthreads();
   double al[4] = {0., 0., 0., 0.};
   for (int w = 0; w < C.nw; w++)
@@ -1328,11 +1380,12 @@ static __device__ __forceinline__ void fact_all(const LaneEq& e, const ChainEq& 
   const bool good = factorise(e, J, hg, maxlen, lane, F, al, gmc, gms);
   if (!good && lane == 0) C.sh->abort = 1;   // every wave leaves at the next block_max
 }
+template <int ROLE>
 static __device__ __forceinline__ double solve_all(const LaneEq& e, const ChainEq& ce, const LuReg& F, const ChainLu& CF, double hg, int maxlen,
                                                    double b, int lane, Ctx& C, double gmc, double gms) {
   if (!NCDM) return lu_solve(e, F, maxlen, b, lane);
-  if (C.wave > 0) {
-    const double x = chain_solve(CF, ce, b, C.len);
+  if (ROLE == 1) {
+    const double x = chain_solve(CF, ce, b, maxlen);
     const double v = CF.jw * x;
     const double sD = chain_sum(v, 0, C), sT = chain_sum(v, 1, C);
     if (lane == 0) { C.sh->ssum[C.wave - 1][0] = sD; C.sh->ssum[C.wave - 1][1] = sT; }
@@ -1347,10 +1400,13 @@ static __device__ __forceinline__ double solve_all(const LaneEq& e, const ChainE
   const int ln = opaque(lane);
   const double bb = (ln == LN_ND) ? sD : (ln == LN_NT) ? sT : b;
   const double x = lu_solve(e, F, maxlen, bb, lane);
-  const double v1 = gmc * x, v2 = gms * x;
-  double z1 = 0., z2 = 0.;
-#pragma unroll
-  for (int j = 0; j < NC; j++) { z1 += bcast(v1, j); z2 += bcast(v2, j); }
+  // the core lives in row 0 of the wave (NC <= 16, gmc = gms = 0 beyond it): four row_shr steps leave the sums in lane 15
+  double v1 = gmc * x, v2 = gms * x;
+  v1 += row_shr0<1>(v1); v2 += row_shr0<1>(v2);
+  v1 += row_shr0<2>(v1); v2 += row_shr0<2>(v2);
+  v1 += row_shr0<4>(v1); v2 += row_shr0<4>(v2);
+  v1 += row_shr0<8>(v1); v2 += row_shr0<8>(v2);
+  const double z1 = bcast(v1, 15), z2 = bcast(v2, 15);
   if (lane == 0) { C.sh->z[0] = z1; C.sh->z[1] = z2; }
   __syncthreads();
   return (ln == LN_ND || ln == LN_NT) ? 0. : x;
@@ -1400,6 +1456,7 @@ static __device__ __forceinline__ double dif_get(const double* dif, int i) {
 // evolver_ndf15 (ev.cpp:62-705) for one interval of constant approximation scheme, as ONE flat loop so that the RHS
 // is instantiated exactly twice: a "service" slot (Jacobian columns, f(t0), f(t0+tdel), J f0, sampled outputs, the
 // final evaluation) and the Newton slot.  Returns 0 / error code (1 step too small, 2 singular, 4 budget).
+template <int ROLE>
 static __device__ __forceinline__ int ndf15(const PtParams& P, const Layout& L, const LaneEq& e, const ChainEq& ce, Ctx& C, Lookup& Q, Metric& M, double k,
                                      double inv_k2, int ik, double t0, double tfinal, double& y_io, Stat& st, int lane,
                                      int& budget, double* jac_lds, unsigned long long* prof) {
@@ -1410,17 +1467,17 @@ static __device__ __forceinline__ int ndf15(const PtParams& P, const Layout& L, 
   const double* ts = P.tau_s;
   const int tres = P.ntau;
   const double htspan = fabs(tfinal - t0), hmax = (tfinal - t0) / 10.0;
-  const int maxlen = L.maxlen;
+  const int maxlen = (ROLE == 1) ? (L.nfa ? 3 : C.len) : L.maxlen;   // sweeps of the tails / of the chains
   enum { B_NONE = 0, B_JAC, B_F0, B_F1, B_JF0, B_SAMPLE, B_FINAL };
 
   Jac J;
   J.Jc = jac_lds;
-  if (!NCDM || C.wave == 0) for (int j = 0; j < NC; j++) J.Jc[j * 64 + lane] = 0.;
+  if (ROLE == 0) for (int j = 0; j < NC; j++) J.Jc[j * 64 + lane] = 0.;
   J.jdiag = 0.;
   ChainCoef jc = {0., 0., 0., 0., 0., 0.};
   ChainLu CF = {1., 0., 0., 0., 0., 0.};
   double gmc = 0., gms = 0.;   // wave 0: response of (metric_continuity, metric_shear) to unit core variable `lane`
-  NcIn N = {0., 0., 0., nullptr};
+  NcIn N = {0., 0., 0., nullptr, 0};
   LuReg F;
 #pragma unroll
   for (int j = 0; j < NC; j++) F.Ac[j] = 0.;
@@ -1465,8 +1522,8 @@ static __device__ __forceinline__ int ndf15(const PtParams& P, const Layout& L, 
       PROF_START();
       const int nreq = (batch == B_JAC) ? NC : 1;
       const double tca_keep = M.tca_shear_g;
-      if (NCDM && batch == B_JAC) sync_tau(P, Q, C, ce, t, lane);
-      if (NCDM && batch == B_JAC && C.wave > 0) jc = chain_coef(P, L, ce, C, k);   // the chains' Jacobian is their coefficient set
+      if (NCDM && batch == B_JAC) sync_tau<ROLE>(P, L, Q, C, ce, k, t, lane);
+      if (ROLE == 1 && batch == B_JAC) jc = ChainCoef{C.ca, C.cb, C.cd, C.cxmc, C.cxms, C.cwt};   // the chains' Jacobian is their coefficient set
       else
       for (int r = 0; r < nreq; r++) {
         double tq, yq;
@@ -1480,11 +1537,11 @@ static __device__ __forceinline__ int ndf15(const PtParams& P, const Layout& L, 
         else if (batch == B_SAMPLE) { tq = tn; yq = yi; }
         else { tq = tnew; yq = ynew; }
         double dyq;
-        if (NCDM && batch == B_JAC) {   // wave 0 alone: unit ncdm integrals for the two auxiliary columns, no block barrier
-          const NcIn Nj = {r == LN_ND ? 1. : 0., r == LN_NT ? 1. : 0., 0., nullptr};
-          dyq = rhs(P, L, e, Q, M, k, inv_k2, tq, yq, lane, Nj);
+        if (NCDM && ROLE == 0 && batch == B_JAC) {   // wave 0 alone: unit ncdm integrals for the two auxiliary columns, no block barrier
+          NcIn Nj = {r == LN_ND ? 1. : 0., r == LN_NT ? 1. : 0., 0., nullptr, 0};
+          dyq = rhs(P, L, e, Q, M, k, inv_k2, tq, yq, lane, &Nj);
           if (lane == r) { gmc = 0.5 * M.hp; gms = k * k * M.alpha; }
-        } else dyq = rhs_all(P, L, e, ce, Q, M, C, N, k, inv_k2, tq, yq, lane);
+        } else dyq = rhs_all<ROLE>(P, L, e, ce, Q, M, C, N, k, inv_k2, tq, yq, lane);
         st.fevals++;
         if (batch == B_JAC) J.Jc[r * 64 + lane] = (lane < NC) ? dyq : 0.;
         else if (batch == B_F0) {
@@ -1495,12 +1552,12 @@ static __device__ __forceinline__ int ndf15(const PtParams& P, const Layout& L, 
         }
         else if (batch == B_F1) f1 = dyq;
         else if (batch == B_JF0) fnewton = dyq;  // temporarily J f0
-        else if (batch == B_SAMPLE) { if (!NCDM || C.wave == 0) store_sources(P, L, Q, M, k, inv_k2, yi, ypi, tca_keep, next, ik, lane, N); }
+        else if (batch == B_SAMPLE) { if (ROLE == 0) store_sources(P, L, Q, M, k, inv_k2, yi, ypi, tca_keep, next, ik, lane, N); }
       }
       if (batch == B_FINAL) { PROF_STOP(3); break; }  // ev.cpp:653-662: M, Q left at (tfinal, y) for the hand-over
       if (batch == B_JAC) {
         // the tails' diagonal is analytic: freeze kappa' and 1/tau at the time of this Jacobian
-        J.jdiag = -(e.D * Q.kap + e.G * Q.kcot + (CURV ? e.Gt * Q.inv_tau : 0.));
+        if (ROLE == 0) J.jdiag = -(e.D * Q.kap + e.G * Q.kcot + (CURV ? e.Gt * Q.inv_tau : 0.));
         st.jacs++;
         M.tca_shear_g = tca_keep;
         Jcurrent = true;
@@ -1611,7 +1668,7 @@ static __device__ __forceinline__ int ndf15(const PtParams& P, const Layout& L, 
       need_fact = false;
       PROF_START();
       bool fact_ok;
-      fact_all(e, ce, J, jc, hinvGak, maxlen, lane, C, F, CF, gmc, gms, &fact_ok);
+      fact_all<ROLE>(e, ce, J, jc, hinvGak, maxlen, lane, C, F, CF, gmc, gms, &fact_ok);
       if (!fact_ok) return 2;
       PROF_STOP(2);
       st.lus++;
@@ -1640,7 +1697,7 @@ static __device__ __forceinline__ int ndf15(const PtParams& P, const Layout& L, 
     bool tooslow = false;
     for (int iter = 1; iter <= maxit; iter++) {
       PROF_START();
-      fnewton = rhs_all(P, L, e, ce, Q, M, C, N, k, inv_k2, tnew, ynew, lane);
+      fnewton = rhs_all<ROLE>(P, L, e, ce, Q, M, C, N, k, inv_k2, tnew, ynew, lane);
       PROF_STOP(0);
 #ifdef CPT_PROFILE
       t_inner += clock64() - pf_t0;
@@ -1648,7 +1705,7 @@ static __device__ __forceinline__ int ndf15(const PtParams& P, const Layout& L, 
       st.fevals++;
       const double rhsv = hinvGak * fnewton - (psi + difkp1);
       PROF_START();
-      const double del = solve_all(e, ce, F, CF, hinvGak, maxlen, rhsv, lane, C, gmc, gms);
+      const double del = solve_all<ROLE>(e, ce, F, CF, hinvGak, maxlen, rhsv, lane, C, gmc, gms);
       PROF_STOP(1);
 #ifdef CPT_PROFILE
       t_inner += clock64() - pf_t0;
@@ -1837,6 +1894,130 @@ static __device__ __noinline__ double initial_conditions(DevTables T, int has_cd
   }
 }
 
+// the integration of one mode over its intervals of constant approximation scheme, for one role (see sync_tau): the core wave
+// and the chain waves run separate instantiations, so neither carries the other's state
+struct Sched { double tau_ini, tau_end, sw0, sw1, sw2, sw3; int nsw, ap0, ap1, ap2, ap3, fi0, fi1, fi2, fi3; };
+template <int ROLE>
+static __device__ __forceinline__ int run_intervals(const PtParams& P, Ctx& C, const Sched& sc, double k, double inv_k2, int ik, int lane,
+                                                    double2* bgw, double2* thw, double2* ncw, double* jacw, Stat& st, int& n_regimes,
+                                                    int& budget, unsigned long long* prof
+#ifdef CPT_PROFILE
+                                                    , unsigned long long t_begin
+#endif
+                                                    ) {
+  int status = 0;
+  const double tau_ini = sc.tau_ini, tau_end = sc.tau_end, sw0 = sc.sw0, sw1 = sc.sw1, sw2 = sc.sw2, sw3 = sc.sw3;
+  const int nsw = sc.nsw, ap0 = sc.ap0, ap1 = sc.ap1, ap2 = sc.ap2, ap3 = sc.ap3, fi0 = sc.fi0, fi1 = sc.fi1, fi2 = sc.fi2, fi3 = sc.fi3;
+  {
+    Lookup Q;
+    // (NCDM: the table windows belong to wave 0 alone - a chain wave staging them late would overwrite a window that wave 0
+    //  has already moved; the chain waves get what they need through sync_tau)
+    if (ROLE == 0) lookup_init(P, Q, bgw, thw, lane, ncw);
+    else {   // (never read by a chain wave; plain stores keep the struct in registers)
+      Q.bgw = bgw; Q.thw = thw; Q.ncw = ncw; Q.tau_cached = -1.; Q.bg_base = Q.th_base = 0; Q.bg_inf = Q.th_inf = -1;
+      Q.bgx = Q.thx = Q.vbg = Q.vth = Q.vnc = 0.; Q.zmax = Q.xe_last = Q.taud_last = 0.;
+      Q.bg_lo = Q.bg_hi = Q.th_lo = Q.th_hi = Q.nc_lo = Q.nc_hi = make_double2(0., 0.);
+    }
+    lookup_set_mode(P, Q, k);
+#ifdef CPT_PROFILE
+    Q.prof = prof;
+#endif
+    Metric M;
+    M.hp = M.etap = M.alpha = M.alphap = 0.;
+    M.tca_shear_g = 0.; M.rsa_dg = M.rsa_tg = 0.;
+    int f_tca = fi0, f_rsa = fi1, f_ufa = fi2, f_nfa = fi3;
+    Layout L = make_layout(P, f_tca, f_rsa, f_ufa, f_nfa);
+    LaneEq e = make_lane_eq(P, L, ROLE == 1 ? -1 : lane, k);   // (chain waves: an all-idle description)
+    const ChainEq ce = make_chain_eq(P, C, lane, k);
+    double y;
+    if (MODE) {  // tensors (pm.cpp:5386-5403): only the gravitational wave starts non-zero
+      y = 0.;
+      if (e.role == R_GW) {
+        const double k2 = k * k;
+        y = P.gw_ini / 2.449489742783178;
+        if (CURV) {
+          y *= sqrt(k2 * (k2 - P.K) / (k2 + 3. * P.K) / (k2 + 2. * P.K));
+          if (P.K < 0.) y = (k2 + 3. * P.K >= 0.) ? y * sqrt(tanh(1.5707963267948966 * sqrt(k2 + 3. * P.K) / sqrt(-P.K))) : 0.;
+        }
+      }
+    } else if (ROLE == 1) {   // pm.cpp:5229-5256: the relativistic-relic series times the momentum dependence of f0
+      const int l = ce.l;
+      const int role = (l == 0) ? R_DELTA_UR : (l == 1) ? R_THETA_UR : (l == 2) ? R_SHEAR_UR : (l == 3) ? R_LUR : R_NONE;
+      const double v = initial_conditions(P.tabs, P.has_cdm, P.has_ur, P.curvature_ini, P.K, P.ic, P.entropy_ini, GAUGE, role, 3, k, tau_ini);
+      const AHK q0 = lookup_aHk(P.tabs, P.n_e, tau_ini);
+      const int ci = ce.valid ? ce.cidx : 0;
+      const double eps = sqrt(ce.q2 + q0.a * q0.a * ce.M2), dl = P.nc.dlnf0[ci];
+      const double f = (l == 0) ? -0.25 : (l == 1) ? -eps / (3. * ce.qk) : (l == 2) ? -0.5 : -0.25;
+      y = (ce.valid && l <= 3) ? f * v * dl : 0.;
+    } else
+      y = initial_conditions(P.tabs, P.has_cdm, P.has_ur, P.curvature_ini, P.K, P.ic, P.entropy_ini, GAUGE, e.role, e.ell, k, tau_ini);
+#ifdef CPT_PROFILE
+    prof[6] = clock64() - t_begin;  // schedule search + initial conditions
+#endif
+    for (int iv = 0; iv <= nsw && status == 0; iv++) {
+      const double ta = (iv == 0) ? tau_ini : (iv == 1) ? sw0 : (iv == 2) ? sw1 : (iv == 3) ? sw2 : sw3;
+      const double tb = (iv == nsw) ? tau_end : (iv == 0) ? sw0 : (iv == 1) ? sw1 : (iv == 2) ? sw2 : sw3;
+      if (iv > 0) {
+        // hand-over to the new scheme (pm.cpp:3777-4260): every variable keeps its lane; the ones the new scheme
+        // drops are zeroed, the ones it adds are seeded
+        const int was_tca = L.tca;
+        const int ap = (iv == 1) ? ap0 : (iv == 2) ? ap1 : (iv == 3) ? ap2 : ap3;
+        if (ap == 0) f_tca ^= 1; else if (ap == 1) f_rsa ^= 1; else if (ap == 2) f_ufa ^= 1; else f_nfa ^= 1;
+        L = make_layout(P, f_tca, f_rsa, f_ufa, f_nfa);
+        e = make_lane_eq(P, L, ROLE == 1 ? -1 : lane, k);
+        double yn = (e.role == R_NONE) ? 0. : y;
+        if (ROLE == 1) yn = y;          // the momentum hierarchies ride through the photon / ur switches (pm.cpp:3968-3975 etc.)
+        if (NCDM && ap == 3) {
+          // fluid approximation switched on (pm.cpp:4479-4517): integrate every chain into its species' delta, theta, sigma.
+          // The published block still holds the background at the switch time (the final RHS evaluation of the last interval).
+          if (ROLE == 1) {
+            if (ce.valid && ce.l <= 2) C.sh->ho[ce.cidx][ce.l] = C.cwt * y;   // (coefficients of the old scheme at the switch time)
+          }
+          __syncthreads();
+          if (ROLE == 1) {
+            yn = 0.;
+            if (ce.holder) {
+              double sum = 0.;
+              for (int c = P.nc.first_chain[ce.species]; c < P.nc.first_chain[ce.species + 1]; c++) sum += C.sh->ho[c][ce.l];
+              yn = sum / ((ce.l == 0) ? C.rho : C.rho + C.pr);
+#ifdef CPT_DEBUG_NCDM
+              printf("handover k=%g l=%d sum=%g rho=%g p=%g pp=%g a2=%g yn=%g\n", k, ce.l, sum, C.rho, C.pr, C.pp, C.a2, yn);
+#endif
+            }
+          }
+        }
+        if (MODE) {  // tensors (pm.cpp:4640-4648): photons re-enter with delta_g = -4/3 gw'/kappa', pol0 = gw'/(3 kappa')
+          if (was_tca && !L.tca) {
+            const double gwd = bcast(y, TL_GWD);
+            if (e.role == R_DELTA_G) yn = -4. / 3. * gwd * Q.tau_c;
+            else if (e.role == R_POL && e.ell == 0) yn = 1. / 3. * gwd * Q.tau_c;
+            else if (lane <= TL_P4 || e.chain == 1 || e.chain == 2) yn = 0.;
+          }
+        } else
+        if (was_tca && !L.tca) {  // tight coupling switched off: seed shear, l=3 and polarisation (pm.cpp:3893-3916)
+          const double sh = M.tca_shear_g, kod = k * Q.tau_c;
+          if (e.role == R_SHEAR_G) yn = sh;
+          const double s3 = CURV ? sqrt(fmax(1. - 8. * P.K / (k * k), 0.)) : 1.;
+          if (e.role == R_LG) yn = (e.ell == 3) ? 6. / 7. * kod * s3 * sh : 0.;
+          if (e.role == R_POL) {
+            if (e.ell == 0) yn = 2.5 * sh;
+            else if (e.ell == 1) yn = kod * (5. - 2. * Q.s2) / 6. * sh;
+            else if (e.ell == 2) yn = 0.5 * sh;
+            else if (e.ell == 3) yn = kod * 3. * s3 / 14. * sh;
+            else yn = 0.;
+          }
+        }
+        y = yn;
+        C.tau_pub = -1.;   // (the chain coefficients cached for this time belong to the old scheme)
+      }
+      n_regimes++;
+      const int rc = ndf15<ROLE>(P, L, e, ce, C, Q, M, k, inv_k2, ik, ta, tb, y, st, lane, budget, jacw, prof);
+      if (rc) status = 10 + rc;
+    }
+  }
+  return status;
+}
+
 // ---- the kernel: perturb_solve (pm.cpp:2463-2787) for one mode per wavefront ---------------------
 static __device__ __forceinline__ void body_perturb(const PtParams& P) {
   __shared__ __attribute__((aligned(16))) double2 tabw[64 * (BG_NCOL + TH_NCOL)];
@@ -1901,108 +2082,15 @@ static __device__ __forceinline__ void body_perturb(const PtParams& P) {
   if (!(fi0 == 1 && fi1 == 0 && fi2 == 0 && fi3 == 0)) status = 23;  // pm.cpp:3720-3745
 
   if (status == 0) {
-    Lookup Q;
-    // (NCDM: the table windows belong to wave 0 alone - a chain wave staging them late would overwrite a window that wave 0
-    //  has already moved; the chain waves get what they need through sync_tau)
-    if (!NCDM || C.wave == 0) lookup_init(P, Q, bgw, thw, lane, ncw);
-    else { memset(&Q, 0, sizeof(Q)); Q.tau_cached = -1.; }
-    lookup_set_mode(P, Q, k);
+    const Sched sc = {tau_ini, tau_end, sw0, sw1, sw2, sw3, nsw, ap0, ap1, ap2, ap3, fi0, fi1, fi2, fi3};
 #ifdef CPT_PROFILE
-    Q.prof = prof;
+#define CPT_RUN_ARGS P, C, sc, k, inv_k2, ik, lane, bgw, thw, ncw, jacw, st, n_regimes, budget, prof, t_begin
+#else
+#define CPT_RUN_ARGS P, C, sc, k, inv_k2, ik, lane, bgw, thw, ncw, jacw, st, n_regimes, budget, prof
 #endif
-    Metric M;
-    M.hp = M.etap = M.alpha = M.alphap = 0.;
-    M.tca_shear_g = 0.; M.rsa_dg = M.rsa_tg = 0.;
-    int f_tca = fi0, f_rsa = fi1, f_ufa = fi2, f_nfa = fi3;
-    Layout L = make_layout(P, f_tca, f_rsa, f_ufa, f_nfa);
-    LaneEq e = make_lane_eq(P, L, NCDM && C.wave > 0 ? -1 : lane, k);   // (chain waves: an all-idle description)
-    const ChainEq ce = make_chain_eq(P, C, lane, k);
-    double y;
-    if (MODE) {  // tensors (pm.cpp:5386-5403): only the gravitational wave starts non-zero
-      y = 0.;
-      if (e.role == R_GW) {
-        const double k2 = k * k;
-        y = P.gw_ini / 2.449489742783178;
-        if (CURV) {
-          y *= sqrt(k2 * (k2 - P.K) / (k2 + 3. * P.K) / (k2 + 2. * P.K));
-          if (P.K < 0.) y = (k2 + 3. * P.K >= 0.) ? y * sqrt(tanh(1.5707963267948966 * sqrt(k2 + 3. * P.K) / sqrt(-P.K))) : 0.;
-        }
-      }
-    } else if (NCDM && C.wave > 0) {   // pm.cpp:5229-5256: the relativistic-relic series times the momentum dependence of f0
-      const int l = ce.l;
-      const int role = (l == 0) ? R_DELTA_UR : (l == 1) ? R_THETA_UR : (l == 2) ? R_SHEAR_UR : (l == 3) ? R_LUR : R_NONE;
-      const double v = initial_conditions(P.tabs, P.has_cdm, P.has_ur, P.curvature_ini, P.K, P.ic, P.entropy_ini, GAUGE, role, 3, k, tau_ini);
-      const AHK q0 = lookup_aHk(P.tabs, P.n_e, tau_ini);
-      const int ci = ce.valid ? ce.cidx : 0;
-      const double eps = sqrt(ce.q2 + q0.a * q0.a * ce.M2), dl = P.nc.dlnf0[ci];
-      const double f = (l == 0) ? -0.25 : (l == 1) ? -eps / (3. * ce.qk) : (l == 2) ? -0.5 : -0.25;
-      y = (ce.valid && l <= 3) ? f * v * dl : 0.;
-    } else
-      y = initial_conditions(P.tabs, P.has_cdm, P.has_ur, P.curvature_ini, P.K, P.ic, P.entropy_ini, GAUGE, e.role, e.ell, k, tau_ini);
-#ifdef CPT_PROFILE
-    prof[6] = clock64() - t_begin;  // schedule search + initial conditions
-#endif
-    for (int iv = 0; iv <= nsw && status == 0; iv++) {
-      const double ta = (iv == 0) ? tau_ini : (iv == 1) ? sw0 : (iv == 2) ? sw1 : (iv == 3) ? sw2 : sw3;
-      const double tb = (iv == nsw) ? tau_end : (iv == 0) ? sw0 : (iv == 1) ? sw1 : (iv == 2) ? sw2 : sw3;
-      if (iv > 0) {
-        // hand-over to the new scheme (pm.cpp:3777-4260): every variable keeps its lane; the ones the new scheme
-        // drops are zeroed, the ones it adds are seeded
-        const int was_tca = L.tca;
-        const int ap = (iv == 1) ? ap0 : (iv == 2) ? ap1 : (iv == 3) ? ap2 : ap3;
-        const Layout Lold = L;
-        if (ap == 0) f_tca ^= 1; else if (ap == 1) f_rsa ^= 1; else if (ap == 2) f_ufa ^= 1; else f_nfa ^= 1;
-        L = make_layout(P, f_tca, f_rsa, f_ufa, f_nfa);
-        e = make_lane_eq(P, L, NCDM && C.wave > 0 ? -1 : lane, k);
-        double yn = (e.role == R_NONE) ? 0. : y;
-        if (NCDM && C.wave > 0) yn = y;          // the momentum hierarchies ride through the photon / ur switches (pm.cpp:3968-3975 etc.)
-        if (NCDM && ap == 3) {
-          // fluid approximation switched on (pm.cpp:4479-4517): integrate every chain into its species' delta, theta, sigma.
-          // The published block still holds the background at the switch time (the final RHS evaluation of the last interval).
-          if (C.wave > 0) {
-            const ChainCoef cc = chain_coef(P, Lold, ce, C, k);
-            if (ce.valid && ce.l <= 2) C.sh->ho[ce.cidx][ce.l] = cc.wt * y;
-          }
-          __syncthreads();
-          if (C.wave > 0) {
-            yn = 0.;
-            if (ce.holder) {
-              double sum = 0.;
-              for (int c = P.nc.first_chain[ce.species]; c < P.nc.first_chain[ce.species + 1]; c++) sum += C.sh->ho[c][ce.l];
-              yn = sum / ((ce.l == 0) ? C.rho : C.rho + C.pr);
-#ifdef CPT_DEBUG_NCDM
-              printf("handover k=%g l=%d sum=%g rho=%g p=%g pp=%g a2=%g yn=%g\n", k, ce.l, sum, C.rho, C.pr, C.pp, C.a2, yn);
-#endif
-            }
-          }
-        }
-        if (MODE) {  // tensors (pm.cpp:4640-4648): photons re-enter with delta_g = -4/3 gw'/kappa', pol0 = gw'/(3 kappa')
-          if (was_tca && !L.tca) {
-            const double gwd = bcast(y, TL_GWD);
-            if (e.role == R_DELTA_G) yn = -4. / 3. * gwd * Q.tau_c;
-            else if (e.role == R_POL && e.ell == 0) yn = 1. / 3. * gwd * Q.tau_c;
-            else if (lane <= TL_P4 || e.chain == 1 || e.chain == 2) yn = 0.;
-          }
-        } else
-        if (was_tca && !L.tca) {  // tight coupling switched off: seed shear, l=3 and polarisation (pm.cpp:3893-3916)
-          const double sh = M.tca_shear_g, kod = k * Q.tau_c;
-          if (e.role == R_SHEAR_G) yn = sh;
-          const double s3 = CURV ? sqrt(fmax(1. - 8. * P.K / (k * k), 0.)) : 1.;
-          if (e.role == R_LG) yn = (e.ell == 3) ? 6. / 7. * kod * s3 * sh : 0.;
-          if (e.role == R_POL) {
-            if (e.ell == 0) yn = 2.5 * sh;
-            else if (e.ell == 1) yn = kod * (5. - 2. * Q.s2) / 6. * sh;
-            else if (e.ell == 2) yn = 0.5 * sh;
-            else if (e.ell == 3) yn = kod * 3. * s3 / 14. * sh;
-            else yn = 0.;
-          }
-        }
-        y = yn;
-      }
-      n_regimes++;
-      const int rc = ndf15(P, L, e, ce, C, Q, M, k, inv_k2, ik, ta, tb, y, st, lane, budget, jacw, prof);
-      if (rc) status = 10 + rc;
-    }
+    if constexpr (NCDM != 0) { if (C.wave > 0) status = run_intervals<1>(CPT_RUN_ARGS); else status = run_intervals<0>(CPT_RUN_ARGS); }
+    else status = run_intervals<0>(CPT_RUN_ARGS);
+#undef CPT_RUN_ARGS
   }
 #ifdef CPT_PROFILE
   prof[7] = clock64() - t_begin;
@@ -2109,8 +2197,10 @@ static __device__ __forceinline__ void body_dbg_solve(const PtParams& P, double 
 template <int GAUGE, int CURV, int MODE>
 __global__ void __launch_bounds__(64) k_perturb(PtParams P) { PT<GAUGE, CURV, MODE>::body_perturb(P); }
 // scalars with non-cold species: 1 + NW wavefronts per k-mode (synchronous gauge)
-template <int CURV>
-__global__ void __launch_bounds__(64 * (1 + NCW_MAX)) k_perturb_ncdm(PtParams P) { PT<CPT_GAUGE_SYNCHRONOUS, CURV, 0, 1>::body_perturb(P); }
+// (two register budgets: up to 3 chain waves every wave has a SIMD - and its whole register file - to itself; beyond that two
+//  waves share a SIMD and the kernel is compiled for half the registers)
+template <int CURV, int NW>
+__global__ void __launch_bounds__(64 * (1 + NW)) k_perturb_ncdm(PtParams P) { PT<CPT_GAUGE_SYNCHRONOUS, CURV, 0, 1>::body_perturb(P); }
 template <int GAUGE, int CURV, int MODE>
 __global__ void __launch_bounds__(64) k_dbg_lookup(PtParams P, const double* tau, int n, double* out) { PT<GAUGE, CURV, MODE>::body_dbg_lookup(P, tau, n, out); }
 template <int GAUGE, int CURV, int MODE>
@@ -2202,8 +2292,13 @@ int cpt_perturb_impl(cpt_handle* h, const double* k, int nk, const double* tau, 
     const int cpw = 64 / (c.l_max_ncdm + 1), nw = (h->ncdm.nchains + cpw - 1) / cpw;
     if (nw > NCW_MAX)
       return cpt_fail(h, CPT_ERR_UNSUPPORTED, "%d ncdm momentum bins need %d chain wavefronts per k-mode (at most %d)", h->ncdm.nchains, nw, NCW_MAX);
-    if (c.K != 0.) hipLaunchKernelGGL((k_perturb_ncdm<1>), dim3(nk), dim3(64 * (1 + nw)), 0, h->stream, P);
-    else hipLaunchKernelGGL((k_perturb_ncdm<0>), dim3(nk), dim3(64 * (1 + nw)), 0, h->stream, P);
+    if (c.K != 0.) {
+      if (nw <= 3) hipLaunchKernelGGL((k_perturb_ncdm<1, 3>), dim3(nk), dim3(64 * (1 + nw)), 0, h->stream, P);
+      else hipLaunchKernelGGL((k_perturb_ncdm<1, NCW_MAX>), dim3(nk), dim3(64 * (1 + nw)), 0, h->stream, P);
+    } else {
+      if (nw <= 3) hipLaunchKernelGGL((k_perturb_ncdm<0, 3>), dim3(nk), dim3(64 * (1 + nw)), 0, h->stream, P);
+      else hipLaunchKernelGGL((k_perturb_ncdm<0, NCW_MAX>), dim3(nk), dim3(64 * (1 + nw)), 0, h->stream, P);
+    }
   } else
   CPT_PT_DISPATCH(c, k_perturb, dim3(nk), dim3(64), 0, h->stream, P);
   CPT_HIP(h, hipGetLastError());
