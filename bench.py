@@ -58,11 +58,14 @@ def cpu_baseline(cfg_name, nk):
             "sample": "every 4th k-mode of %s.ini (%d modes) through oracle/restate (dense-LU scalar port)" % (cfg_name, ks.size)}
 
 
-def pmc_traffic(kernel):
+def pmc_traffic(kernel, config):
     """HBM bytes per launch of `kernel` from the rocprofv3 --pmc passes committed under profiles/ (FETCH_SIZE and
-    WRITE_SIZE are collected in separate runs of this same command; FETCH_SIZE doubled per MI355X_MICROARCH.md)."""
+    WRITE_SIZE are collected in separate runs of this same command, tools/profile_bench.sh <tag> <config>; FETCH_SIZE doubled
+    per MI355X_MICROARCH.md).  profiles/<tag>_pmc_traffic.json is the lcdm.ini run, profiles/<tag>_<config>_pmc_traffic.json another config's."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
+    import re
+    pat = r"r\d+[a-z]?_pmc_traffic\.json$" if config == "lcdm" else r"r\d+[a-z]?_%s_pmc_traffic\.json$" % re.escape(config)
+    files = sorted(f for f in glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")) if re.search(pat, os.path.basename(f)))
     if not files:
         return None
     try:
@@ -153,6 +156,12 @@ def main():
     nk_local = len(stats)
 
     if rank == 0:
+        cfg = inp.config
+        cosmology = ("flat" if cfg.K == 0 else "closed" if cfg.K > 0 else "open") + " LCDM " + ("tensors" if cfg.mode == 1 else "scalars")
+        if cfg.has_ncdm:
+            cosmology += " + %d massive neutrino species (%d wavefronts per k-mode)" % (cfg.N_ncdm, 1 + -(-sum(
+                inp.tables.q_size_ncdm[n] for n in range(cfg.N_ncdm)) // (64 // (cfg.l_max_ncdm + 1))) if cfg.mode == 0 else 1)
+        pt_kernel = "k_perturb_ncdm" if (cfg.has_ncdm and cfg.mode == 0) else "k_perturb"
         ms_step = dt / args.steps * 1e3
         k_ms = float(np.mean(kms))
         t_ms = float(np.mean(tms))
@@ -170,9 +179,9 @@ def main():
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
-            "config": {"workload": "%s.ini: flat LCDM scalars tCl+pCl%s, default precision; %d k-modes x %d tau samples, "
+            "config": {"workload": "%s.ini: %s tCl+pCl%s, default precision; %d k-modes x %d tau samples, "
                                    "%d q x %d l x %d transfer types%s" % (
-                                       args.config, "+mPk" if inp.config.index_tp_delta_m >= 0 else "+lCl", nk_total, inp.ntau,
+                                       args.config, cosmology, "+mPk" if inp.config.index_tp_delta_m >= 0 else "+lCl", nk_total, inp.ntau,
                                        inp.q.size, inp.l.size, inp.config.tt_size,
                                        ("; lensed C_l" if has_lensing else "") +
                                        ("" if world == 1 else "; k grid densified %dx and sharded round-robin" % world)),
@@ -183,9 +192,9 @@ def main():
             "perturb_kmodes_per_s_kernel": nk_local * world / (k_ms * 1e-3),
             "ode_work": {"fevals": fevals, "steps": steps_tot, "max_steps_per_mode": steps_max,
                          "us_per_step_critical_path": k_ms * 1e3 / steps_max},
-            "roofline": {"kernel": "k_perturb", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "roofline": {"kernel": pt_kernel, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": pmc_traffic("k_perturb") if (world == 1 and args.config == "lcdm") else None,
+                         "traffic": pmc_traffic(pt_kernel, args.config) if world == 1 else None,
                          "note": "algorithmic bytes = fevals x 800 B + source output; the kernel is bound by the serial "
                                  "dependency chain of the longest k-mode (SURVEY S8d), not by HBM",
                          "los_kernel": {"achieved": fused * 72 / (t_ms * 1e-3) / 1e9, "unit": "GB/s", "peak": HBM_PEAK_GBS,

@@ -3,6 +3,7 @@ import csv
 import glob
 import json
 import os
+import re
 import shutil
 import sys
 
@@ -27,7 +28,8 @@ def counter_mean(sub, counter):
     for row in csv.DictReader(open(f)):
         if row.get("Counter_Name") != counter:
             continue
-        name = row["Kernel_Name"].split("(")[0].split("::")[-1]
+        m = re.search(r"\b(k_\w+)", row["Kernel_Name"])   # (templated kernels: "void (anonymous namespace)::k_perturb<1, 0, 0>(...)")
+        name = m.group(1) if m else row["Kernel_Name"]
         acc.setdefault(name, []).append(float(row["Counter_Value"]))
     return {k: sum(v) / len(v) for k, v in acc.items()}
 
@@ -41,7 +43,7 @@ for k in sorted(set(fetch) | set(write)):
     kernels[k] = {"fetch_kb_mean": fk, "write_kb_mean": wk, "hbm_bytes_raw": (fk + wk) * 1024.0,
                   "hbm_bytes_fetch_x2": (2.0 * fk + wk) * 1024.0}
 json.dump({"command": "rocprofv3 --pmc {FETCH_SIZE|WRITE_SIZE} --kernel-trace --output-format csv -- python3 bench.py --steps 2 "
-                      "--warmup 1 --no-cpu-baseline (separate passes, lcdm.ini; tools/profile_bench.sh)",
+                      "--warmup 1 --no-cpu-baseline (separate passes; tools/profile_bench.sh <tag> <config>)",
            "unit": "bytes per launch (counter value is KB; FETCH_SIZE x2 per MI355X_MICROARCH.md gfx950 correction for wide "
                    "coalesced reads; narrow/uniform reads are uncalibrated so both are given)",
            "kernels": kernels}, open(prefix + "_pmc_traffic.json", "w"), indent=1)
