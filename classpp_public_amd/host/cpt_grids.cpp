@@ -1,5 +1,5 @@
 // Host-side sampling grids (include/cpt_host.h): exact restatements of the grid builders of the reference's
-// PerturbationsModule / TransferModule constructors, flat space, scalar modes.
+// PerturbationsModule / TransferModule constructors: scalars or tensors (one mode per handle), flat / open / closed space.
 #include <algorithm>
 #include <cmath>
 #include <cstdarg>
@@ -67,21 +67,25 @@ extern "C" {
 
 const char* cpt_host_error(void) { return g_err.c_str(); }
 
-// pm.cpp:1628-1868, scalar mode, flat space
+// pm.cpp:1628-1868 (scalars), :2007-2105 (tensors: the same linear grid up to k_max_cmb, no P(k) extension)
 int cpt_host_k_list(const cpt_config* c, const cpt_grid_params* g, double* k_out, int cap, int* k_size, int* k_size_cl,
                     int* k_size_cmb) {
-  if (c->sgnK != 0) return fail("cpt_host_k_list: only flat space");
   if (g->k_step_transition == 0.) return fail("stop to avoid division by zero (k_step_transition)");
   if (g->rs_rec == 0.) return fail("stop to avoid division by zero (rs_rec)");
-  const double k_min = g->k_min_tau0 / c->tau0;
+  const bool tens = c->mode == CPT_MODE_TENSORS;
+  // first value (pm.cpp:1677-1691, 2011-2025): K > 0 starts from q = sqrt(k^2 + (1+m) K) = 3 sqrt(K), m = 0 / 2 for scalars / tensors
+  double k_min;
+  if (c->sgnK == 0) k_min = g->k_min_tau0 / c->tau0;
+  else if (c->sgnK == -1) k_min = sqrt(-c->K + pow(g->k_min_tau0 / c->tau0 / c->angular_rescaling, 2));
+  else k_min = sqrt(((tens ? 6. : 8.) - 1.e-4) * c->K);
   const double k_rec = 2. * PI / g->rs_rec;
   double k_max_cmb = k_min, k_max_cl = k_min, k_max = k_min;
   if (g->has_cls) {
-    k_max_cmb = g->k_max_tau0_over_l_max * g->l_scalar_max / c->tau0 / c->angular_rescaling;
+    k_max_cmb = g->k_max_tau0_over_l_max * (tens ? g->l_tensor_max : g->l_scalar_max) / c->tau0 / c->angular_rescaling;
     k_max_cl = k_max_cmb;
     k_max = k_max_cmb;
   }
-  if (g->has_pk_matter) k_max = std::max(k_max, g->k_max_for_pk);
+  if (g->has_pk_matter && !tens) k_max = std::max(k_max, g->k_max_for_pk);
   if (k_max < k_min) return fail("buggy definition of k_min and/or k_max");
   std::vector<double> ks;
   double k = k_min;
@@ -96,6 +100,12 @@ int cpt_host_k_list(const cpt_config* c, const cpt_grid_params* g, double* k_out
     ks.push_back(k);
   }
   *k_size_cmb = (int)ks.size();
+  if (tens) {   // pm.cpp:2096-2098
+    *k_size_cl = *k_size = *k_size_cmb;
+    if (*k_size > cap) return fail("k array too small: need %d", *k_size);
+    std::copy(ks.begin(), ks.end(), k_out);
+    return CPT_OK;
+  }
   auto logstep = [&](double kk) {
     return kk * pow(10., 1. / (g->k_per_decade_for_pk + (g->k_per_decade_for_bao - g->k_per_decade_for_pk) *
                                                               (1. - tanh(pow((log(kk) - log(g->k_bao_center * k_rec)) / log(g->k_bao_width), 4)))));
@@ -159,7 +169,7 @@ int cpt_host_tau_sampling(const cpt_config* c, const cpt_tables* t, const cpt_gr
 
 // tm.cpp:694-790
 int cpt_host_l_list(const cpt_config* c, const cpt_grid_params* g, int* l_out, int cap, int* l_size) {
-  const int l_max = g->l_scalar_max;
+  const int l_max = (c->mode == CPT_MODE_TENSORS) ? g->l_tensor_max : g->l_scalar_max;   // one mode per handle (tm.cpp:712-736)
   const double ar = c->angular_rescaling;
   std::vector<int> l;
   l.push_back(2);
@@ -177,18 +187,41 @@ int cpt_host_l_list(const cpt_config* c, const cpt_grid_params* g, int* l_out, i
   return CPT_OK;
 }
 
-// tm.cpp:884-1096, sgnK == 0
+// tm.cpp:884-1096: flat / open (one formula), closed (integer nu = q / sqrt(K) below hyper_flat_approximation_nu, then a
+// gradual return to the flat step); k_min / k_max_cl: first and last k of the mode's C_l range
 int cpt_host_q_list(const cpt_config* c, const cpt_grid_params* g, double k_min, double k_max_cl, double* q_out, int cap,
                     int* q_size) {
-  if (c->sgnK != 0) return fail("cpt_host_q_list: only flat space");
   const double q_period = 2. * PI / (c->tau0 - c->tau_rec) * c->angular_rescaling;  // tm.cpp:189
-  const double q_min = k_min, q_max = k_max_cl;
+  const double K = c->K, m1 = (c->mode == CPT_MODE_TENSORS) ? 3. : 1.;   // 1 + m
+  double q_min, q_max;
+  if (c->sgnK == 0) { q_min = k_min; q_max = k_max_cl; }
+  else if (c->sgnK == -1) { q_min = sqrt(k_min * k_min + K); q_max = std::min(sqrt(k_max_cl * k_max_cl + K), sqrt(k_max_cl * k_max_cl + m1 * K)); }
+  else { q_min = 3. * sqrt(K); q_max = k_max_cl; }
   const double q_logstep_spline = g->q_logstep_spline / pow(c->angular_rescaling, g->q_logstep_open);
+  const double q_logstep_trapzd = g->q_logstep_trapzd;
   std::vector<double> q;
   q.push_back(q_min);
+  int nu = 3, last_index = 0;
+  double last_step = 0.;
   while (q.back() < q_max) {
-    double last = q.back();
-    q.push_back(last + q_period * g->q_linstep * last / (last + g->q_linstep / q_logstep_spline));
+    const double last = q.back();
+    const int index_q = (int)q.size();
+    double qn;
+    if (c->sgnK <= 0) qn = last + q_period * g->q_linstep * last / (last + g->q_linstep / q_logstep_spline);
+    else if (nu < (int)c->hyper_flat_approximation_nu) {
+      qn = last + q_period * g->q_linstep * last / (last + g->q_linstep / q_logstep_trapzd);
+      const int nu_proposed = (int)(qn / sqrt(K));
+      nu = (nu_proposed <= nu + 1) ? nu + 1 : nu_proposed;
+      qn = nu * sqrt(K);
+      last_step = qn - last;
+      last_index = index_q + 1;
+    } else {
+      const double q_step = q_period * g->q_linstep * last / (last + g->q_linstep / q_logstep_spline);
+      if (index_q - last_index < (int)g->q_numstep_transition)
+        qn = last + (1 - (double)(index_q - last_index) / g->q_numstep_transition) * last_step + (double)(index_q - last_index) / g->q_numstep_transition * q_step;
+      else qn = last + q_step;
+    }
+    q.push_back(qn);
     if (q.size() > 10000000) return fail("buggy q-list definition");
   }
   if (q.back() > q_max) q.pop_back();

@@ -21,6 +21,7 @@ class CptGridParams(C.Structure):
         ("k_max_for_pk", _d), ("rs_rec", _d), ("tau_ini_thermo", _d),
         ("start_sources_at_tau_c_over_tau_h", _d), ("perturb_sampling_stepsize", _d),
         ("l_linstep", _d), ("l_logstep", _d), ("q_linstep", _d), ("q_logstep_spline", _d), ("q_logstep_open", _d),
+        ("l_tensor_max", _i), ("q_logstep_trapzd", _d), ("q_numstep_transition", _d),
     ]
 
 
@@ -59,6 +60,9 @@ def grid_params(inp):
     g.k_max_for_pk = float(d["ppt.k_max_for_pk"][0])
     g.rs_rec = float(t["th.rs_rec"][0])
     g.tau_ini_thermo = float(t["th.tau_ini"][0])
+    # tensors: l_max of the mode (older fixtures do not dump ppt.l_tensor_max: the l list ends exactly at it)
+    g.l_tensor_max = int(d["ppt.l_tensor_max"][0]) if "ppt.l_tensor_max" in d else (int(inp.l[-1]) if inp.config.mode == 1 and inp.has_cls else 0)
+    g.q_logstep_trapzd = float(d["ppr.q_logstep_trapzd"].reshape(-1)[0]); g.q_numstep_transition = float(d["ppr.q_numstep_transition"].reshape(-1)[0])
     return g
 
 

@@ -2,10 +2,10 @@
  * the reference's module constructors build before entering the parallel loops.  They are cheap (< 1 ms), run once
  * per cosmology and must be reproduced EXACTLY, because every downstream spline is defined on them (SURVEY S8a rows
  * A2, A3, B1):
- *   cpt_host_k_list        PerturbationsModule::perturb_get_k_list               pm.cpp:1628-1868 (scalars)
+ *   cpt_host_k_list        PerturbationsModule::perturb_get_k_list               pm.cpp:1628-1868 (scalars), :2007-2105 (tensors); flat, open, closed
  *   cpt_host_tau_sampling  PerturbationsModule::perturb_timesampling_for_sources pm.cpp:1247-1533
  *   cpt_host_l_list        TransferModule::transfer_get_l_list                   tm.cpp:694-790
- *   cpt_host_q_list        TransferModule::transfer_get_q_list (+ _k_list)       tm.cpp:884-1096 (flat: k = q)
+ *   cpt_host_q_list        TransferModule::transfer_get_q_list (+ _k_list)       tm.cpp:884-1096 (flat, open, closed)
  * Built into classpp_public_amd/host/libcpt_host.so (g++, no HIP).  The C++ shim classes that mirror the reference's
  * PerturbationsModule / TransferModule data contract on top of libcpt.so are declared in include/cpt_modules.hpp.
  */
@@ -29,6 +29,9 @@ typedef struct cpt_grid_params {
   double start_sources_at_tau_c_over_tau_h, perturb_sampling_stepsize;
   /* l, q grids */
   double l_linstep, l_logstep, q_linstep, q_logstep_spline, q_logstep_open;
+  /* appended: tensors (one mode per handle) and closed space */
+  int l_tensor_max;
+  double q_logstep_trapzd, q_numstep_transition;
 } cpt_grid_params;
 
 /* Every function returns CPT_OK or CPT_ERR_INVALID (message via cpt_host_error()); *_size are outputs; `cap` is the

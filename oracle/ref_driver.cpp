@@ -154,7 +154,7 @@ static int do_dump(const char* ini, const char* outpath) {
   put_i("ppt.has_cl_cmb_polarization", ppt->has_cl_cmb_polarization);
   put_i("ppt.has_cl_cmb_lensing_potential", ppt->has_cl_cmb_lensing_potential);
   put_i("ppt.has_pk_matter", ppt->has_pk_matter);
-  put_i("ppt.l_scalar_max", ppt->l_scalar_max); put_d("ppt.k_max_for_pk", ppt->k_max_for_pk);
+  put_i("ppt.l_scalar_max", ppt->l_scalar_max); put_i("ppt.l_tensor_max", ppt->l_tensor_max); put_d("ppt.k_max_for_pk", ppt->k_max_for_pk);
   put_d("ppt.z_max_pk", ppt->z_max_pk);
   put_i("ppt.switch_sw", ppt->switch_sw); put_i("ppt.switch_eisw", ppt->switch_eisw); put_i("ppt.switch_lisw", ppt->switch_lisw);
   put_i("ppt.switch_dop", ppt->switch_dop); put_i("ppt.switch_pol", ppt->switch_pol);
