@@ -4,6 +4,7 @@
 
 #include <hip/hip_runtime_api.h>
 
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -32,6 +33,7 @@ PerturbationsModule::PerturbationsModule(const Inputs& in) {
   tp_size_ = xalloc<int>(1); tp_size_[0] = c.tp_size;
   index_tp_t0_ = c.index_tp_t0; index_tp_t1_ = c.index_tp_t1; index_tp_t2_ = c.index_tp_t2; index_tp_p_ = c.index_tp_p;
   index_tp_delta_m_ = c.index_tp_delta_m; index_tp_phi_plus_psi_ = c.index_tp_phi_plus_psi;
+  index_tp_delta_cb_ = c.has_ncdm ? c.index_tp_delta_cb : -1;
   has_source_t_ = c.index_tp_t0 >= 0; has_source_p_ = c.index_tp_p >= 0; has_source_delta_m_ = c.index_tp_delta_m >= 0;
   has_source_phi_plus_psi_ = c.index_tp_phi_plus_psi >= 0;
   // ---- perturb_get_k_list (pm.cpp:1628-2238) ----
@@ -104,7 +106,7 @@ TransferModule::TransferModule(const Inputs& in, std::shared_ptr<const Perturbat
   // ---- transfer_indices_of_transfers (tm.cpp:402-540) ----
   tt_size_ = xalloc<int>(1); tt_size_[0] = c.tt_size;
   index_tt_t0_ = c.index_tt_t0; index_tt_t1_ = c.index_tt_t1; index_tt_t2_ = c.index_tt_t2; index_tt_e_ = c.index_tt_e;
-  index_tt_lcmb_ = c.index_tt_lcmb;
+  index_tt_lcmb_ = c.index_tt_lcmb; index_tt_b_ = c.index_tt_b;
   std::vector<double> tmp(1 << 22);
   std::vector<int> itmp(1 << 16);
   int nl = 0;
@@ -123,8 +125,16 @@ TransferModule::TransferModule(const Inputs& in, std::shared_ptr<const Perturbat
   memcpy(q_, tmp.data(), sizeof(double) * q_size_);
   k_ = xalloc<double*>(1);
   k_[0] = xalloc<double>(q_size_);
-  memcpy(k_[0], q_, sizeof(double) * q_size_);  // flat space: k = q (tm.cpp:1106-1167)
+  // transfer_get_k_list (tm.cpp:1106-1167): k^2 = q^2 - K (1 + m), m = 0 / 2 for scalars / tensors; flat space: k = q
+  const double Km = c.K * (c.mode == CPT_MODE_TENSORS ? 3. : 1.);
+  for (int i = 0; i < q_size_; i++) k_[0][i] = (c.sgnK == 0) ? q_[i] : sqrt(q_[i] * q_[i] - Km);
+  // first wavenumber treated with the flat rescaling approximation (tm.cpp:1078-1090)
   index_q_flat_approximation_ = 0;
+  if (c.sgnK != 0) {
+    const double q_approximation = c.hyper_flat_approximation_nu * sqrt(c.sgnK * c.K);
+    for (index_q_flat_approximation_ = 0; index_q_flat_approximation_ < q_size_ - 1; index_q_flat_approximation_++)
+      if (q_[index_q_flat_approximation_] > q_approximation) break;
+  }
   // ---- the q loop (tm.cpp:287-318) on the GPU, from the sources left resident in HBM by the perturbation stage ----
   const size_t ntr = (size_t)c.tt_size * nl * q_size_;
   double* d_tr = nullptr;

@@ -33,7 +33,7 @@ class PerturbationsModule {
   int index_ic_ad_ = 0;
   int* ic_size_ = nullptr;
   int index_tp_t0_ = -1, index_tp_t1_ = -1, index_tp_t2_ = -1, index_tp_p_ = -1, index_tp_delta_m_ = -1,
-      index_tp_phi_plus_psi_ = -1;
+      index_tp_phi_plus_psi_ = -1, index_tp_delta_cb_ = -1;   // (delta_cb: requested with delta_m when ncdm is present, pm.cpp:996)
   int* tp_size_ = nullptr;
   short has_source_t_ = 0, has_source_p_ = 0, has_source_delta_m_ = 0, has_source_phi_plus_psi_ = 0;
   double*** sources_ = nullptr;  // sources_[md][ic*tp_size+tp][index_tau*k_size+index_k]
@@ -65,7 +65,7 @@ class TransferModule {
   TransferModule(const TransferModule&) = delete;
 
   // ---- data contract of source/transfer_module.h ----
-  int index_tt_t0_ = -1, index_tt_t1_ = -1, index_tt_t2_ = -1, index_tt_e_ = -1, index_tt_lcmb_ = -1;
+  int index_tt_t0_ = -1, index_tt_t1_ = -1, index_tt_t2_ = -1, index_tt_e_ = -1, index_tt_lcmb_ = -1, index_tt_b_ = -1;
   int* tt_size_ = nullptr;
   int l_size_max_ = 0;
   int** l_size_tt_ = nullptr;

@@ -25,6 +25,15 @@ int main(int argc, char** argv) {
       th((size_t)t.tt_size * t.th_size), d2th(th.size());
   rd(f, tau.data(), tau.size() * 8); rd(f, bg.data(), bg.size() * 8); rd(f, d2bg.data(), d2bg.size() * 8);
   rd(f, z.data(), z.size() * 8); rd(f, th.data(), th.size() * 8); rd(f, d2th.data(), d2th.size() * 8);
+  // non-cold species: momentum grids q, w, dlnf0/dlnq of every species follow the tables
+  std::vector<std::vector<double>> ncq(CPT_MAX_NCDM), ncw(CPT_MAX_NCDM), ncd(CPT_MAX_NCDM);
+  if (in.config.has_ncdm)
+    for (int n = 0; n < in.config.N_ncdm; n++) {
+      const int nq = t.q_size_ncdm[n];
+      ncq[n].resize(nq); ncw[n].resize(nq); ncd[n].resize(nq);
+      rd(f, ncq[n].data(), nq * 8); rd(f, ncw[n].data(), nq * 8); rd(f, ncd[n].data(), nq * 8);
+      in.tables.q_ncdm[n] = ncq[n].data(); in.tables.w_ncdm[n] = ncw[n].data(); in.tables.dlnf0_dlnq_ncdm[n] = ncd[n].data();
+    }
   fclose(f);
   in.tables.tau_table = tau.data(); in.tables.background_table = bg.data(); in.tables.d2background_dtau2_table = d2bg.data();
   in.tables.z_table = z.data(); in.tables.thermodynamics_table = th.data(); in.tables.d2thermodynamics_dz2_table = d2th.data();

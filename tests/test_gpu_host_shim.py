@@ -36,6 +36,10 @@ def write_inputs(inp, path):
         for key in ("bg.tau_table", "bg.background_table", "bg.d2background_dtau2_table", "th.z_table",
                     "th.thermodynamics_table", "th.d2thermodynamics_dz2_table"):
             f.write(np.ascontiguousarray(t[key], dtype=np.float64).tobytes())
+        if inp.config.has_ncdm:
+            for n in range(inp.config.N_ncdm):
+                for key in ("ncdm.q_%d", "ncdm.w_%d", "ncdm.dlnf0_dlnq_%d"):
+                    f.write(np.ascontiguousarray(t[key % n], dtype=np.float64).tobytes())
 
 
 def run_demo(exe, inp_path, out_path, flag=0):
@@ -47,8 +51,11 @@ def run_demo(exe, inp_path, out_path, flag=0):
     return p.returncode, p.stdout + p.stderr
 
 
-def test_shim_modules_small(tmp_path):
-    inp = Inputs("small")
+@pytest.mark.parametrize("cfg", ["small", "curved", "tens", "ncdm_small"])
+def test_shim_modules(tmp_path, cfg):
+    """the reference's module data contract through the C++ shim: flat scalars, closed space (k(q), integer-nu q list,
+    index_q_flat_approximation_), tensors, massive neutrinos"""
+    inp = Inputs(cfg)
     exe = build_demo(str(tmp_path))
     ipath, opath = str(tmp_path / "in.bin"), str(tmp_path / "out.bin")
     write_inputs(inp, ipath)
@@ -70,6 +77,8 @@ def test_shim_modules_small(tmp_path):
     scale = np.max(np.abs(ref), axis=-1, keepdims=True)
     scale[scale == 0] = 1
     assert np.max(np.abs(tr - ref) / scale) < 1e-3  # coarse tau sampling of `small` amplifies the source noise
+    if cfg != "small":
+        return
     # error mapping
     rc, out = run_demo(exe, ipath, opath, flag=1)
     assert rc == 10 and "invalid_argument" in out and "dark-energy fluid" in out
