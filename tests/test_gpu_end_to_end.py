@@ -79,3 +79,41 @@ def test_cl_quadrature_weights_match_sequential_spline(cfg):
         if idx >= 0:
             assert np.max(np.abs(got[:, idx] / want[:, idx] - 1)) < 1e-9
     be.close()
+
+
+def test_sharded_pieces_on_the_gpu_match_the_single_rank_result():
+    """The multi-GPU step (classpp_public_amd/sharded.py; its exchanges are covered on CPU by tests/test_sharded_gloo.py) asks the HIP
+    backend for k subsets r::N of a densified grid and for multipole subsets r::N.  Here the two ranks' pieces are computed one after
+    the other on the one GPU, assembled by hand, and compared with the single-rank result: sources bit for bit (k-modes are
+    independent units), transfer functions to round-off (multipoles are independent units)."""
+    from classpp_public_amd.backend import Backend
+    from classpp_public_amd.sharded import GpuCompute, densify_k, shard_indices
+    inp = Inputs("small")
+    be = Backend(inp)
+    comp = GpuCompute(be)
+    world = 2
+    k_all = densify_k(inp.k, world)
+    k_size_cl = (inp.k_size_cl - 1) * world + 1
+    assert k_all.size == (inp.nk - 1) * world + 1 and k_all[k_size_cl - 1] == inp.k[inp.k_size_cl - 1]
+    full_one = comp.perturb(k_all).clone()
+    tr_one = comp.transfer(full_one, k_all, inp.l, k_size_cl).clone()
+    full = torch.empty_like(full_one)
+    for r in range(world):
+        idx = shard_indices(k_all.size, r, world)
+        full[:, :, torch.as_tensor(idx, device=full.device)] = comp.perturb(k_all[idx])
+    assert torch.equal(full, full_one)
+    tr = torch.empty_like(tr_one)
+    for r in range(world):
+        idx = shard_indices(inp.l.size, r, world)
+        tr[:, torch.as_tensor(idx, device=tr.device), :] = comp.transfer(full, k_all, inp.l[idx], k_size_cl)
+    scale = tr_one.abs().amax(dim=-1, keepdim=True).clamp_min(1e-300)
+    err = float(((tr - tr_one).abs() / scale).max())
+    print("\n[sharded pieces] transfer: max deviation from the single-rank table %.1e of the row maximum" % err)
+    assert err < 1e-10   # (the Bessel table of a multipole subset is recurred down from another l_max: round-off only, 1.5e-12 measured)
+    # and the densified grid reproduces the C_l of the original one to the interpolation accuracy of the k-spline
+    cl_dense = be.cl(tr).cpu().numpy()
+    be.perturb_solve(want_sources=False)
+    cl = be.cl(be.transfer(None)).cpu().numpy()
+    sp = inp.spectra
+    assert np.max(np.abs(cl_dense[:, sp.index_ct_tt] / cl[:, sp.index_ct_tt] - 1)) < 2e-3
+    be.close()
