@@ -21,6 +21,20 @@ int fail(const char* fmt, ...) {
   return CPT_ERR_INVALID;
 }
 const double PI = 3.1415926535897932384626433832795e0;
+}  // namespace
+namespace cpt_host {
+// error reporting shared with the other host translation units (cpt_cosmo.cpp)
+int fail_msg(int code, const char* fmt, ...) {
+  char buf[2048];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  g_err = buf;
+  return code;
+}
+}  // namespace cpt_host
+namespace {
 
 // spline row lookup on the ORIGINAL tables (tools/arrays.c:1565-1628 bisection; the closeby walk of :2173-2225 finds
 // the same bracket)

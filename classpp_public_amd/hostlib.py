@@ -25,6 +25,31 @@ class CptGridParams(C.Structure):
     ]
 
 
+class CptCosmoParams(C.Structure):
+    """struct cpt_cosmo_params (include/cpt_host.h)"""
+    _fields_ = [
+        ("H0", _d), ("T_cmb", _d), ("Omega0_g", _d), ("Omega0_b", _d), ("Omega0_cdm", _d), ("Omega0_ur", _d),
+        ("Omega0_lambda", _d), ("Omega0_k", _d), ("K", _d), ("sgnK", _i), ("a_today", _d),
+        ("has_cdm", _i), ("has_ur", _i), ("has_lambda", _i), ("has_ncdm", _i), ("has_fld", _i), ("has_scf", _i),
+        ("has_dcdm", _i), ("has_dr", _i), ("has_idr", _i), ("has_idm_dr", _i),
+        ("a_ini_over_a_today_default", _d), ("back_integration_stepsize", _d), ("tol_initial_Omega_r", _d),
+        ("smallest_allowed_variation", _d),
+    ]
+
+
+_pdd = C.POINTER(_d)
+
+
+class CptBackground(C.Structure):
+    """struct cpt_background (include/cpt_host.h): arrays owned by the library (cpt_host_background_free)"""
+    _fields_ = [("bt_size", _i), ("bg_size", _i), ("tau_table", _pdd), ("z_table", _pdd), ("d2tau_dz2_table", _pdd),
+                ("background_table", _pdd), ("d2background_dtau2_table", _pdd)] + \
+               [("index_bg_" + n, _i) for n in ("a", "H", "H_prime", "rho_g", "rho_b", "rho_cdm", "rho_lambda", "rho_ur", "rho_tot",
+                                                "p_tot", "p_tot_prime", "Omega_r", "rho_crit", "Omega_m", "conf_distance",
+                                                "ang_distance", "lum_distance", "time", "rs", "D", "f")] + \
+               [(n, _d) for n in ("conformal_age", "age", "Neff", "Omega0_m", "Omega0_r", "Omega0_de")]
+
+
 _lib = None
 
 
@@ -41,6 +66,12 @@ def lib():
         L.cpt_host_l_list.argtypes = [pc, pg, pi, _i, pi]
         L.cpt_host_q_list.argtypes = [pc, pg, _d, _d, pd, _i, pi]
         L.cpt_host_error.restype = C.c_char_p
+        L.cpt_host_cosmo_defaults.argtypes = [C.POINTER(CptCosmoParams)]
+        L.cpt_host_cosmo_defaults.restype = None
+        L.cpt_host_background.argtypes = [C.POINTER(CptCosmoParams), C.POINTER(CptBackground)]
+        L.cpt_host_background_free.argtypes = [C.POINTER(CptBackground)]
+        L.cpt_host_background_free.restype = None
+        L.cpt_host_background_tau_of_z.argtypes = [C.POINTER(CptBackground), _d, _pdd]
         _lib = L
     return _lib
 
@@ -104,3 +135,36 @@ def q_list(inp, k_min, k_max_cl, g=None):
     _check(lib().cpt_host_q_list(C.byref(inp.config), C.byref(g), float(k_min), float(k_max_cl),
                                  out.ctypes.data_as(C.POINTER(_d)), out.size, C.byref(n)))
     return out[: n.value].copy()
+
+
+def cosmo_params(inp):
+    """cpt_cosmo_params of a named configuration (struct background of the reference, dumped as pba.* by oracle/ref_driver.cpp)"""
+    d = inp.d
+    p = CptCosmoParams()
+    lib().cpt_host_cosmo_defaults(C.byref(p))
+    for f in ("H0", "T_cmb", "Omega0_g", "Omega0_b", "Omega0_cdm", "Omega0_ur", "Omega0_lambda", "Omega0_k", "K", "a_today"):
+        setattr(p, f, float(d["pba." + f][0]))
+    p.sgnK = int(d["pba.sgnK"][0])
+    for f in ("has_cdm", "has_ur", "has_lambda", "has_ncdm", "has_fld"):
+        setattr(p, f, int(d["pba." + f][0]))
+    return p
+
+
+def background(inp, p=None):
+    """-> dict of numpy arrays / scalars keyed like the reference's table dump (bg.*)"""
+    p = p or cosmo_params(inp)
+    bg = CptBackground()
+    _check(lib().cpt_host_background(C.byref(p), C.byref(bg)))
+    n, m = bg.bt_size, bg.bg_size
+    out = {"bg.bt_size": n, "bg.bg_size": m,
+           "bg.tau_table": np.ctypeslib.as_array(bg.tau_table, (n,)).copy(), "bg.z_table": np.ctypeslib.as_array(bg.z_table, (n,)).copy(),
+           "bg.d2tau_dz2_table": np.ctypeslib.as_array(bg.d2tau_dz2_table, (n,)).copy(),
+           "bg.background_table": np.ctypeslib.as_array(bg.background_table, (n, m)).copy(),
+           "bg.d2background_dtau2_table": np.ctypeslib.as_array(bg.d2background_dtau2_table, (n, m)).copy()}
+    for name, _ in CptBackground._fields_:
+        if name.startswith("index_bg_"):
+            out["bg." + name] = getattr(bg, name)
+    for name in ("conformal_age", "age", "Neff", "Omega0_m", "Omega0_r", "Omega0_de"):
+        out["bg." + name] = getattr(bg, name)
+    lib().cpt_host_background_free(C.byref(bg))
+    return out

@@ -45,6 +45,43 @@ int cpt_host_q_list(const cpt_config* cfg, const cpt_grid_params* g, double k_mi
                     int* q_size);
 const char* cpt_host_error(void);
 
+/* ---- the tables the hot path consumes, computed on the host instead of being handed over ----------------
+ * Background (BackgroundModule::background_solve_evolver, source/background_module.cpp:1326-1520 with background_functions
+ * :263-610, background_initial_conditions :1521-1690, background_derivs :1934-2064, :2272-2344): flat / curved LambdaCDM with
+ * massless neutrinos (non-cold species, fluids, scalar fields, decaying species: CPT_ERR_UNSUPPORTED).  The table has the
+ * reference's layout for that content (21 columns; index map returned), so it can be handed to cpt_create unchanged.  */
+typedef struct cpt_cosmo_params {
+  /* struct background (source/background.h) */
+  double H0;                        /* [1/Mpc] */
+  double T_cmb, Omega0_g, Omega0_b, Omega0_cdm, Omega0_ur, Omega0_lambda, Omega0_k;
+  double K; int sgnK;               /* K = -Omega0_k (a_today H0)^2 */
+  double a_today;
+  int has_cdm, has_ur, has_lambda, has_ncdm, has_fld, has_scf, has_dcdm, has_dr, has_idr, has_idm_dr;
+  /* precision (include/precisions.h:12-38) */
+  double a_ini_over_a_today_default, back_integration_stepsize, tol_initial_Omega_r, smallest_allowed_variation;
+} cpt_cosmo_params;
+
+typedef struct cpt_background {
+  int bt_size, bg_size;
+  double* tau_table;                /* [bt_size]            all arrays owned by this struct: cpt_host_background_free */
+  double* z_table;                  /* [bt_size]  */
+  double* d2tau_dz2_table;          /* [bt_size]  */
+  double* background_table;         /* [bt_size][bg_size] */
+  double* d2background_dtau2_table; /* [bt_size][bg_size] */
+  int index_bg_a, index_bg_H, index_bg_H_prime, index_bg_rho_g, index_bg_rho_b, index_bg_rho_cdm, index_bg_rho_lambda,
+      index_bg_rho_ur, index_bg_rho_tot, index_bg_p_tot, index_bg_p_tot_prime, index_bg_Omega_r, index_bg_rho_crit,
+      index_bg_Omega_m, index_bg_conf_distance, index_bg_ang_distance, index_bg_lum_distance, index_bg_time, index_bg_rs,
+      index_bg_D, index_bg_f;
+  double conformal_age, age, Neff, Omega0_m, Omega0_r, Omega0_de;
+} cpt_background;
+
+/* fills the precision members of `p` with the reference's defaults */
+void cpt_host_cosmo_defaults(cpt_cosmo_params* p);
+int cpt_host_background(const cpt_cosmo_params* p, cpt_background* out);
+void cpt_host_background_free(cpt_background* bg);
+/* conformal time at redshift z by spline interpolation in the table (BackgroundModule::background_tau_of_z, :211-255) */
+int cpt_host_background_tau_of_z(const cpt_background* bg, double z, double* tau);
+
 #ifdef __cplusplus
 }
 #endif
