@@ -168,3 +168,71 @@ def background(inp, p=None):
         out["bg." + name] = getattr(bg, name)
     lib().cpt_host_background_free(C.byref(bg))
     return out
+
+
+class CptThermoParams(C.Structure):
+    """struct cpt_thermo_params (include/cpt_host.h)"""
+    _fields_ = [("YHe", _d), ("reio_parametrization", _i), ("reio_from_tau", _i), ("z_reio", _d), ("tau_reio", _d),
+                ("reionization_exponent", _d), ("reionization_width", _d), ("helium_fullreio_redshift", _d), ("helium_fullreio_width", _d),
+                ("recfast_z_initial", _d), ("recfast_Nz0", _i), ("tol_thermo_integration", _d),
+                ("recfast_Heswitch", _i), ("recfast_fudge_He", _d), ("recfast_Hswitch", _i)] + \
+               [(n, _d) for n in ("recfast_fudge_H", "recfast_delta_fudge_H", "recfast_AGauss1", "recfast_AGauss2", "recfast_zGauss1",
+                                  "recfast_zGauss2", "recfast_wGauss1", "recfast_wGauss2", "recfast_z_He_1", "recfast_delta_z_He_1",
+                                  "recfast_z_He_2", "recfast_delta_z_He_2", "recfast_z_He_3", "recfast_delta_z_He_3",
+                                  "recfast_x_He0_trigger", "recfast_x_He0_trigger2", "recfast_x_He0_trigger_delta", "recfast_x_H0_trigger",
+                                  "recfast_x_H0_trigger2", "recfast_x_H0_trigger_delta", "recfast_H_frac",
+                                  "reionization_z_start_max", "reionization_sampling", "reionization_optical_depth_tol",
+                                  "reionization_start_factor")] + \
+               [("thermo_rate_smoothing_radius", _i), ("radiation_streaming_trigger_tau_c_over_tau", _d),
+                ("neglect_CMB_sources_below_visibility", _d)]
+
+
+_TH_COLS = ("xe", "dkappa", "tau_d", "ddkappa", "dddkappa", "exp_m_kappa", "g", "dg", "ddg", "Tb", "wb", "cb2", "rate")
+_TH_SCALARS = ("tau_ini", "YHe", "n_e", "z_rec", "tau_rec", "rs_rec", "ra_rec", "angular_rescaling", "tau_free_streaming", "tau_cut",
+               "z_reionization", "tau_reionization", "z_star", "z_d")
+
+
+class CptThermo(C.Structure):
+    """struct cpt_thermo (include/cpt_host.h)"""
+    _fields_ = [("tt_size", _i), ("th_size", _i), ("z_table", _pdd), ("thermodynamics_table", _pdd), ("d2thermodynamics_dz2_table", _pdd)] + \
+               [("index_th_" + n, _i) for n in _TH_COLS] + [(n, _d) for n in _TH_SCALARS]
+
+
+def thermo_params(inp):
+    d, t = inp.d, inp.t
+    p = CptThermoParams()
+    L = lib()
+    L.cpt_host_thermo_defaults.argtypes = [C.POINTER(CptThermoParams)]
+    L.cpt_host_thermo_defaults.restype = None
+    L.cpt_host_thermo_defaults(C.byref(p))
+    p.YHe = float(t["th.YHe"][0])
+    p.reio_parametrization = int(d["pth.reio_parametrization"][0])
+    p.reio_from_tau = 0
+    p.z_reio = float(t["th.z_reionization"][0])
+    return p
+
+
+def thermodynamics(inp, cp=None, tp=None):
+    """host background + thermodynamics -> dict keyed like the reference's table dump (bg.*, th.*)"""
+    L = lib()
+    cp = cp or cosmo_params(inp)
+    tp = tp or thermo_params(inp)
+    bg = CptBackground()
+    _check(L.cpt_host_background(C.byref(cp), C.byref(bg)))
+    th = CptThermo()
+    L.cpt_host_thermodynamics.argtypes = [C.POINTER(CptCosmoParams), C.POINTER(CptThermoParams), C.POINTER(CptBackground), C.POINTER(CptThermo)]
+    L.cpt_host_thermo_free.argtypes = [C.POINTER(CptThermo)]
+    L.cpt_host_thermo_free.restype = None
+    rc = L.cpt_host_thermodynamics(C.byref(cp), C.byref(tp), C.byref(bg), C.byref(th))
+    L.cpt_host_background_free(C.byref(bg))
+    _check(rc)
+    n, m = th.tt_size, th.th_size
+    out = {"th.tt_size": n, "th.th_size": m, "th.z_table": np.ctypeslib.as_array(th.z_table, (n,)).copy(),
+           "th.thermodynamics_table": np.ctypeslib.as_array(th.thermodynamics_table, (n, m)).copy(),
+           "th.d2thermodynamics_dz2_table": np.ctypeslib.as_array(th.d2thermodynamics_dz2_table, (n, m)).copy()}
+    for c in _TH_COLS:
+        out["th.index_th_" + c] = getattr(th, "index_th_" + c)
+    for s in _TH_SCALARS:
+        out["th." + s] = getattr(th, s)
+    L.cpt_host_thermo_free(C.byref(th))
+    return out

@@ -82,6 +82,46 @@ void cpt_host_background_free(cpt_background* bg);
 /* conformal time at redshift z by spline interpolation in the table (BackgroundModule::background_tau_of_z, :211-255) */
 int cpt_host_background_tau_of_z(const cpt_background* bg, double z, double* tau);
 
+/* Thermodynamics (ThermodynamicsModule::thermodynamics_init, source/thermodynamics_module.cpp:293-1297): RECFAST 1.5 recombination
+ * (:3335-3975, adaptive Cash-Karp integration tools/dei_rkck.c), reionization none / CAMB-like tanh with z_reio or tau_reio given
+ * (:1893-1950, 2159-2320, 2668-2990), merged table and every derived column the hot path reads (first to third derivative of kappa,
+ * exp(-kappa), the visibility g with its first two derivatives, tau_d, T_b, w_b, c_b^2, rate) with their spline second derivatives
+ * in z, and the scalars z_rec, tau_rec, r_s(rec), r_a(rec), angular_rescaling, tau_free_streaming, tau_cut.  HyRec, energy
+ * injection, the other reionization schemes and interacting dark matter are CPT_ERR_UNSUPPORTED.  The table has the reference's
+ * 13-column layout. */
+enum { CPT_REIO_NONE = 0, CPT_REIO_CAMB = 1 };
+typedef struct cpt_thermo_params {
+  double YHe;                        /* primordial helium fraction (the BBN table look-up stays outside) */
+  int reio_parametrization;          /* CPT_REIO_NONE / CPT_REIO_CAMB */
+  int reio_from_tau;                 /* 0: z_reio given, 1: tau_reio given (bisection on the optical depth, :2222-2318) */
+  double z_reio, tau_reio;
+  double reionization_exponent, reionization_width, helium_fullreio_redshift, helium_fullreio_width;
+  /* precision (include/precisions.h:60-160, 257-300) */
+  double recfast_z_initial; int recfast_Nz0; double tol_thermo_integration;
+  int recfast_Heswitch; double recfast_fudge_He; int recfast_Hswitch; double recfast_fudge_H, recfast_delta_fudge_H, recfast_AGauss1,
+      recfast_AGauss2, recfast_zGauss1, recfast_zGauss2, recfast_wGauss1, recfast_wGauss2, recfast_z_He_1, recfast_delta_z_He_1,
+      recfast_z_He_2, recfast_delta_z_He_2, recfast_z_He_3, recfast_delta_z_He_3, recfast_x_He0_trigger, recfast_x_He0_trigger2,
+      recfast_x_He0_trigger_delta, recfast_x_H0_trigger, recfast_x_H0_trigger2, recfast_x_H0_trigger_delta, recfast_H_frac;
+  double reionization_z_start_max, reionization_sampling, reionization_optical_depth_tol, reionization_start_factor;
+  int thermo_rate_smoothing_radius;
+  double radiation_streaming_trigger_tau_c_over_tau, neglect_CMB_sources_below_visibility;
+} cpt_thermo_params;
+
+typedef struct cpt_thermo {
+  int tt_size, th_size;
+  double* z_table;                     /* [tt_size] ascending z          arrays owned: cpt_host_thermo_free */
+  double* thermodynamics_table;        /* [tt_size][th_size] */
+  double* d2thermodynamics_dz2_table;  /* [tt_size][th_size] */
+  int index_th_xe, index_th_dkappa, index_th_tau_d, index_th_ddkappa, index_th_dddkappa, index_th_exp_m_kappa, index_th_g,
+      index_th_dg, index_th_ddg, index_th_Tb, index_th_wb, index_th_cb2, index_th_rate;
+  double tau_ini, YHe, n_e, z_rec, tau_rec, rs_rec, ra_rec, angular_rescaling, tau_free_streaming, tau_cut, z_reionization,
+      tau_reionization, z_star, z_d;
+} cpt_thermo;
+
+void cpt_host_thermo_defaults(cpt_thermo_params* p);
+int cpt_host_thermodynamics(const cpt_cosmo_params* cp, const cpt_thermo_params* tp, const cpt_background* bg, cpt_thermo* out);
+void cpt_host_thermo_free(cpt_thermo* th);
+
 #ifdef __cplusplus
 }
 #endif

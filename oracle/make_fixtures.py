@@ -108,6 +108,17 @@ def main():
             np.savez_compressed(os.path.join(GOLD, cfg + ".npz"), **out)
             print(cfg, {k: v.shape for k, v in out.items() if v.size > 1000})
             continue
+        if cfg == "lcdm_taureio":
+            # reionization given by its optical depth (bisection of th.cpp:2222-2318): only the thermodynamics outcome is kept
+            # (scalars + every 40th row of the table), the cosmology is that of lcdm.ini
+            keep = {k: v for k, v in tables.items() if k.startswith("th.") and v.size == 1}
+            keep["th.row_index"] = np.arange(0, tables["th.z_table"].size, 40).astype(np.int32)
+            keep["th.z_table_rows"] = tables["th.z_table"][keep["th.row_index"]]
+            keep["th.thermodynamics_table_rows"] = tables["th.thermodynamics_table"][keep["th.row_index"]]
+            keep["pth.tau_reio"] = np.array([0.0925])
+            np.savez_compressed(os.path.join(GOLD, cfg + ".npz"), **keep)
+            print(cfg, {k: v.shape for k, v in keep.items() if v.size > 10})
+            continue
         if cfg.startswith("ncdm"):
             # massive neutrinos (BASELINE configs 3, 4): one table file per cosmology (1 species / 3 species)
             tname = "tables_ncdm3.npz" if cfg.startswith("ncdm3") else "tables_ncdm1.npz"

@@ -32,3 +32,57 @@ def test_background_rejects_what_it_does_not_know():
     p.a_ini_over_a_today_default = 1e-3   # not radiation dominated (the reference's class_test, background_module.cpp:1654)
     with pytest.raises(ValueError, match="not close enough to 1"):
         hostlib.background(inp, p)
+
+
+@pytest.mark.parametrize("cfg", ["lcdm", "curved", "open"])
+def test_thermodynamics_table_bit_exact(cfg):
+    """RECFAST 1.5 (Cash-Karp steps between the 20000 redshift nodes, smoothed Saha / full-equation switches), CAMB-like
+    reionization sampled adaptively, baryon temperature, merged table, kappa and visibility columns through the reference's
+    spline integrate / derive routines, smoothed rate, second derivatives in z, and every scalar the hot path reads."""
+    inp = Inputs(cfg)
+    t = inp.t
+    th = hostlib.thermodynamics(inp)
+    assert th["th.tt_size"] == int(t["th.tt_size"][0]) and th["th.th_size"] == int(t["th.th_size"][0])
+    for key in ("th.z_table", "th.thermodynamics_table", "th.d2thermodynamics_dz2_table"):
+        assert np.array_equal(th[key], t[key]), key
+    for key in ("tau_ini", "YHe", "n_e", "z_rec", "tau_rec", "rs_rec", "ra_rec", "angular_rescaling", "tau_free_streaming", "tau_cut",
+                "z_reionization"):
+        assert th["th." + key] == float(t["th." + key][0]), key
+    for key in t.keys():
+        if key.startswith("th.index_th_"):
+            assert th[key] == int(t[key][0]), key
+
+
+def test_reionization_from_optical_depth():
+    """tau_reio given instead of z_reio: the bisection of th.cpp:2222-2318 (fixture lcdm_taureio = lcdm.ini with tau_reio = 0.0925)"""
+    inp = Inputs("lcdm")
+    ref = dict(np.load(__import__("os").path.join(__import__("os").path.dirname(__file__), "golden", "lcdm_taureio.npz")))
+    tp = hostlib.thermo_params(inp)
+    tp.reio_from_tau = 1
+    tp.tau_reio = float(ref["pth.tau_reio"][0])
+    tp.z_reio = 0.
+    th = hostlib.thermodynamics(inp, tp=tp)
+    assert th["th.z_reionization"] == float(ref["th.z_reionization"][0])
+    assert th["th.tt_size"] == int(ref["th.tt_size"][0])
+    rows = ref["th.row_index"]
+    assert np.array_equal(th["th.z_table"][rows], ref["th.z_table_rows"])
+    assert np.array_equal(th["th.thermodynamics_table"][rows], ref["th.thermodynamics_table_rows"])
+    for key in ("tau_rec", "rs_rec", "tau_free_streaming", "tau_cut"):
+        assert th["th." + key] == float(ref["th." + key][0]), key
+    assert abs(th["th.tau_reionization"] - tp.tau_reio) < 1e-4 * tp.tau_reio    # reionization_optical_depth_tol
+
+
+def test_thermodynamics_errors():
+    inp = Inputs("lcdm")
+    tp = hostlib.thermo_params(inp)
+    tp.YHe = 0.7
+    with pytest.raises(ValueError, match="out of bounds"):
+        hostlib.thermodynamics(inp, tp=tp)
+    tp = hostlib.thermo_params(inp)
+    tp.reio_parametrization = 2   # reio_bins_tanh
+    with pytest.raises(ValueError, match="none and camb only"):
+        hostlib.thermodynamics(inp, tp=tp)
+    tp = hostlib.thermo_params(inp)
+    tp.z_reio = 60.               # would start above reionization_z_start_max
+    with pytest.raises(ValueError, match="reionization_z_start_max"):
+        hostlib.thermodynamics(inp, tp=tp)
