@@ -82,6 +82,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", default="lcdm")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--from-parameters", action="store_true",
+                    help="compute the spline tables and grids on the host from the cosmological parameters (classpp_public_amd/pipeline.py) "
+                         "instead of loading them from tests/golden; the host stage is timed and reported as stage_ms.host_tables")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -98,7 +101,13 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
-    inp = Inputs(args.config)
+    t_host0 = time.perf_counter()
+    if args.from_parameters:
+        from classpp_public_amd.pipeline import ParameterInputs
+        inp = ParameterInputs(args.config)
+    else:
+        inp = Inputs(args.config)
+    host_tables_ms = (time.perf_counter() - t_host0) * 1e3 if args.from_parameters else None
     be = Backend(inp, device)
     comp = GpuCompute(be)
     k_all = densify_k(inp.k, world)
@@ -185,9 +194,11 @@ def main():
                                        inp.q.size, inp.l.size, inp.config.tt_size,
                                        ("; lensed C_l" if has_lensing else "") +
                                        ("" if world == 1 else "; k grid densified %dx and sharded round-robin" % world)),
-                       "inputs": "background/thermodynamics spline tables and grids from tests/golden (dumped from the reference)",
+                       "inputs": ("background/thermodynamics spline tables and grids computed by libcpt_host.so from the cosmological parameters"
+                                  if args.from_parameters else
+                                  "background/thermodynamics spline tables and grids from tests/golden (dumped from the reference)"),
                        "parallelism": "k-sharded x%d, l-sharded transfer, 2 RCCL exchanges" % world if world > 1 else "1 GPU"},
-            "stage_ms": {"perturb_kernel": k_ms, "los_kernel": t_ms, "step_wall": ms_step},
+            "stage_ms": {"perturb_kernel": k_ms, "los_kernel": t_ms, "step_wall": ms_step, "host_tables": host_tables_ms},
             "cl_wall_ms": ms_step,
             "perturb_kmodes_per_s_kernel": nk_local * world / (k_ms * 1e-3),
             "ode_work": {"fevals": fevals, "steps": steps_tot, "max_steps_per_mode": steps_max,

@@ -92,7 +92,10 @@ def grid_params(inp):
     g.rs_rec = float(t["th.rs_rec"][0])
     g.tau_ini_thermo = float(t["th.tau_ini"][0])
     # tensors: l_max of the mode (older fixtures do not dump ppt.l_tensor_max: the l list ends exactly at it)
-    g.l_tensor_max = int(d["ppt.l_tensor_max"][0]) if "ppt.l_tensor_max" in d else (int(inp.l[-1]) if inp.config.mode == 1 and inp.has_cls else 0)
+    if getattr(inp, "l_tensor_max", None) is not None:
+        g.l_tensor_max = int(inp.l_tensor_max)
+    else:
+        g.l_tensor_max = int(d["ppt.l_tensor_max"][0]) if "ppt.l_tensor_max" in d else (int(inp.l[-1]) if inp.config.mode == 1 and inp.has_cls else 0)
     g.q_logstep_trapzd = float(d["ppr.q_logstep_trapzd"].reshape(-1)[0]); g.q_numstep_transition = float(d["ppr.q_numstep_transition"].reshape(-1)[0])
     return g
 

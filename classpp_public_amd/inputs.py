@@ -2,9 +2,9 @@
 
 The backend's inputs (background / thermodynamics spline tables, k / tau / q / l grids, precision and physics
 parameters) are deterministic functions of an .ini, produced in the reference by modules that sit UPSTREAM of the
-hot path (InputModule, BackgroundModule, ThermodynamicsModule; SURVEY.md S2 marks them out of scope).  Until the
-backend has its own background + RECFAST they come from the committed fixtures tests/golden/*.npz,
-which were dumped from the unmodified reference by oracle/make_fixtures.py.
+hot path (InputModule, BackgroundModule, ThermodynamicsModule).  Two sources: the committed fixtures tests/golden/*.npz
+dumped from the unmodified reference by oracle/make_fixtures.py (every configuration), or - for LambdaCDM with massless
+neutrinos - the backend's own host-side background + RECFAST + grid builders (classpp_public_amd/pipeline.py).
 """
 import ctypes as C
 import os
@@ -24,12 +24,17 @@ def _s(d, key):
 class Inputs:
     """config + tables + grids for one configuration (`small`, `lcdm`, `explanatory`)."""
 
-    def __init__(self, name, golden_dir=GOLDEN):
+    def __init__(self, name, golden_dir=GOLDEN, tables=None):
+        """tables: dict keyed like the reference's table dump (bg.*, th.*) to use instead of the committed table fixture,
+        e.g. the output of the host background / thermodynamics modules (classpp_public_amd/pipeline.py)"""
         self.name = name
         self.d = dict(np.load(os.path.join(golden_dir, name + ".npz")))
         tname = "tables_%s.npz" % ("curved" if (name.startswith("curved") or name == "tens_curved") else
                                   "ncdm3" if name.startswith("ncdm3") else "ncdm1" if name.startswith("ncdm") else name)   # (open.ini has its own: tables_open.npz)
-        self.t = dict(np.load(os.path.join(golden_dir, tname if os.path.exists(os.path.join(golden_dir, tname)) else "tables_lcdm.npz")))
+        if tables is not None:
+            self.t = {k: np.atleast_1d(np.asarray(v)) for k, v in tables.items()}
+        else:
+            self.t = dict(np.load(os.path.join(golden_dir, tname if os.path.exists(os.path.join(golden_dir, tname)) else "tables_lcdm.npz")))
         d, t = self.d, self.t
         c = CptConfig()
         c.H0 = _s(d, "pba.H0"); c.K = _s(d, "pba.K"); c.sgnK = int(_s(d, "pba.sgnK"))

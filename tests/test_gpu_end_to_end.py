@@ -117,3 +117,23 @@ def test_sharded_pieces_on_the_gpu_match_the_single_rank_result():
     sp = inp.spectra
     assert np.max(np.abs(cl_dense[:, sp.index_ct_tt] / cl[:, sp.index_ct_tt] - 1)) < 2e-3
     be.close()
+
+
+@pytest.mark.parametrize("cfg", ["lcdm", "curved_full"])
+def test_from_parameters_to_cl(cfg):
+    """SURVEY S8f-1 closed: nothing but parameters goes in (classpp_public_amd/pipeline.py) - the background and thermodynamics tables
+    and the four grids are computed by libcpt_host.so, everything else on the GPU - and the reference's C_l (and P(k)) come out."""
+    from classpp_public_amd.backend import Backend
+    from classpp_public_amd.pipeline import ParameterInputs
+    inp = ParameterInputs(cfg)
+    d = inp.d
+    be = Backend(inp)
+    be.perturb_solve(want_sources=False)
+    cl = be.cl(be.transfer(None)).cpu().numpy()
+    ref, sp = d["sp.cl_table"], inp.spectra
+    for idx in (sp.index_ct_tt, sp.index_ct_ee, sp.index_ct_pp):
+        if idx >= 0:
+            assert np.max(np.abs(cl[:, idx] / ref[:, idx] - 1)) < 1e-4
+    if inp.config.index_tp_delta_m >= 0:
+        assert np.max(np.abs(be.pk_linear().cpu().numpy() / d["nl.pk_lin_z0"] - 1)) < 1e-4
+    be.close()

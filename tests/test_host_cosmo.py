@@ -86,3 +86,16 @@ def test_thermodynamics_errors():
     tp.z_reio = 60.               # would start above reionization_z_start_max
     with pytest.raises(ValueError, match="reionization_z_start_max"):
         hostlib.thermodynamics(inp, tp=tp)
+
+
+@pytest.mark.parametrize("cfg", ["small", "lcdm", "curved", "open", "tens", "tens_curved"])
+def test_parameter_inputs_reproduce_the_fixture_inputs(cfg):
+    """classpp_public_amd/pipeline.py: tables and grids computed on the host from parameters alone == what the reference handed over"""
+    from classpp_public_amd.pipeline import ParameterInputs
+    a, b = ParameterInputs(cfg), Inputs(cfg)
+    for key in ("bg.tau_table", "bg.background_table", "bg.d2background_dtau2_table", "th.z_table", "th.thermodynamics_table",
+                "th.d2thermodynamics_dz2_table"):
+        assert np.array_equal(a.t[key], b.t[key]), key
+    assert np.array_equal(a.k, b.k) and a.k_size_cl == b.k_size_cl and np.array_equal(a.tau, b.tau)
+    assert np.array_equal(a.l, b.l) and np.array_equal(a.q, b.q)
+    assert bytes(a.config) == bytes(b.config)
