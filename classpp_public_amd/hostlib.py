@@ -141,7 +141,7 @@ def q_list(inp, k_min, k_max_cl, g=None):
 
 
 def cosmo_params(inp):
-    """cpt_cosmo_params of a named configuration (struct background of the reference, dumped as pba.* by oracle/ref_driver.cpp)"""
+    """cpt_cosmo_params of a named configuration (struct background of the reference, the pba.* entries of the configuration)"""
     d = inp.d
     p = CptCosmoParams()
     lib().cpt_host_cosmo_defaults(C.byref(p))
