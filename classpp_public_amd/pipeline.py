@@ -26,13 +26,42 @@ def read_ini(path):
     return out
 
 
-class ParameterInputs(Inputs):
-    """Inputs whose spline tables and sampling grids are computed on the host from the cosmological parameters."""
+def density_parameters(h, omega_b, omega_cdm, Omega_k=0.0, N_ur=3.046, T_cmb=2.7255):
+    """The budget equation of the reference's input module for LambdaCDM + massless neutrinos (source/input_module.cpp:593-603, 702,
+    786, 1191 and the closure Omega_Lambda = 1 - Omega_k - sum): -> dict of the struct background entries the host modules read."""
+    c, G, k_B, h_P, Mpc = 2.99792458e8, 6.67428e-11, 1.3806504e-23, 6.62606896e-34, 3.085677581282e22
+    sigma_B = 2. * np.pi ** 5 * k_B ** 4 / 15. / h_P ** 3 / c ** 2
+    H0 = h * 1.e5 / c
+    Omega0_g = (4. * sigma_B / c * T_cmb ** 4) / (3. * c * c * 1.e10 * h * h / Mpc / Mpc / 8. / np.pi / G)
+    Omega0_ur = N_ur * 7. / 8. * (4. / 11.) ** (4. / 3.) * Omega0_g
+    Omega0_b, Omega0_cdm = omega_b / h / h, omega_cdm / h / h
+    Omega0_lambda = 1. - Omega_k - Omega0_g - Omega0_ur - Omega0_b - Omega0_cdm
+    K = -Omega_k * H0 ** 2
+    return {"H0": H0, "h": h, "T_cmb": T_cmb, "Omega0_g": Omega0_g, "Omega0_ur": Omega0_ur, "Omega0_b": Omega0_b, "Omega0_cdm": Omega0_cdm,
+            "Omega0_lambda": Omega0_lambda, "Omega0_k": Omega_k, "K": K, "sgnK": 0 if K == 0 else (1 if K > 0 else -1)}
 
-    def __init__(self, name, golden_dir=GOLDEN):
+
+class ParameterInputs(Inputs):
+    """Inputs whose spline tables and sampling grids are computed on the host from the cosmological parameters.
+
+    `name` selects the precision / output settings of a committed configuration; `cosmology` (a dict for density_parameters),
+    `YHe`, `z_reio` / `tau_reio` and `A_s`, `n_s` replace its cosmological parameters - any LambdaCDM + massless-neutrino
+    cosmology runs, not just the fixtures' ones."""
+
+    def __init__(self, name, golden_dir=GOLDEN, cosmology=None, YHe=None, z_reio=None, tau_reio=None, A_s=None, n_s=None):
         self.name = name
         self.d = dict(np.load(os.path.join(golden_dir, name + ".npz")))
         ini = read_ini(os.path.join(golden_dir, name + ".ini"))
+        if cosmology is not None:
+            for k, v in density_parameters(**cosmology).items():
+                self.d["pba." + k] = np.array([v], dtype=np.int32 if k == "sgnK" else np.float64)
+            self.d["pba.has_curvature"] = np.array([int(self.d["pba.sgnK"][0] != 0)], dtype=np.int32)
+        if YHe is not None:
+            ini["YHe"] = repr(YHe)
+        if z_reio is not None:
+            ini.pop("tau_reio", None); ini["z_reio"] = repr(z_reio)
+        if tau_reio is not None:
+            ini.pop("z_reio", None); ini["tau_reio"] = repr(tau_reio)
         cp = hostlib.cosmo_params(self)                       # struct background values (pba.* of the dump)
         tp = hostlib.CptThermoParams()
         hostlib.lib().cpt_host_thermo_defaults.argtypes = [hostlib.C.POINTER(hostlib.CptThermoParams)]
@@ -49,6 +78,10 @@ class ParameterInputs(Inputs):
         tables.update(hostlib.thermodynamics(self, cp, tp))
         super().__init__(name, golden_dir, tables=tables)
         self.l_tensor_max = int(ini["l_max_tensors"]) if "l_max_tensors" in ini else None
+        if A_s is not None:
+            self.spectra.A_s = A_s
+        if n_s is not None:
+            self.spectra.n_s = n_s
         # the sampling grids, rebuilt from the tables just computed (never read from the fixture)
         self.k, self.k_size_cl, _ = hostlib.k_list(self)
         self.tau = hostlib.tau_sampling(self)

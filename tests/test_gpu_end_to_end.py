@@ -137,3 +137,39 @@ def test_from_parameters_to_cl(cfg):
     if inp.config.index_tp_delta_m >= 0:
         assert np.max(np.abs(be.pk_linear().cpu().numpy() / d["nl.pk_lin_z0"] - 1)) < 1e-4
     be.close()
+
+
+@pytest.mark.parametrize("cosmo", [dict(h=0.72, omega_b=0.0235, omega_cdm=0.11, N_ur=3.3),
+                                   dict(h=0.60, omega_b=0.0200, omega_cdm=0.14),
+                                   dict(h=0.70, omega_b=0.0224, omega_cdm=0.12, Omega_k=-0.02),
+                                   dict(h=0.66, omega_b=0.0215, omega_cdm=0.125, Omega_k=0.03)])
+def test_other_cosmologies_gpu_vs_oracle(cosmo):
+    """Away from the fixtures' cosmologies: parameters -> host tables and grids (classpp_public_amd/pipeline.py) -> GPU, against the
+    CPU restatement (oracle) run on the same tables and grids, stage by stage (sources, C_l, P(k)); precision settings of `small`."""
+    from classpp_public_amd.backend import Backend
+    from classpp_public_amd.pipeline import ParameterInputs
+    inp = ParameterInputs("small", cosmology=cosmo, YHe=0.25, z_reio=8.5, n_s=0.95)
+    be = Backend(inp)
+    src, stats, status = be.perturb_solve()
+    assert not status.any()
+    cl = be.cl(be.transfer(None)).cpu().numpy()
+    pk = be.pk_linear().cpu().numpy()
+    osrc, ostats, ostatus, rc = oracle_lib.perturb(inp)
+    assert rc == 0
+    # two valid step sequences: the tolerances of check_sources, with the matter / potential columns at the level by which the
+    # reference itself moves them when its rtol is halved (3e-5, DESIGN.md S4) instead of the 1e-5 the fixtures happen to meet
+    got, c = src.cpu().numpy(), inp.config
+    for tp, tol in ((c.index_tp_t0, 3e-3), (c.index_tp_t1, 3e-3), (c.index_tp_t2, 2e-4), (c.index_tp_p, 2e-4),
+                    (c.index_tp_delta_m, 5e-5), (c.index_tp_phi_plus_psi, 5e-5)):
+        scale = np.max(np.abs(osrc[tp]), axis=0, keepdims=True)
+        scale[scale == 0] = 1
+        assert np.max(np.abs(got[tp] - osrc[tp]) / scale) < tol, (tp, np.max(np.abs(got[tp] - osrc[tp]) / scale))
+    gs, os_ = sum(s.steps for s in stats), sum(s.steps for s in ostats)
+    assert abs(gs - os_) < 0.02 * os_
+    ocl = oracle_lib.cl_table(inp, oracle_lib.transfer(inp, osrc)[0])
+    opk = oracle_lib.pk_linear(inp, osrc[inp.config.index_tp_delta_m, -1, :])
+    sp = inp.spectra
+    for idx in (sp.index_ct_tt, sp.index_ct_ee, sp.index_ct_pp):
+        assert np.max(np.abs(cl[:, idx] / ocl[:, idx] - 1)) < 3e-4
+    assert np.max(np.abs(pk / opk - 1)) < 3e-4
+    be.close()
