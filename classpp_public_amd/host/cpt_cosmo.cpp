@@ -71,6 +71,7 @@ const double GYR_OVER_MPC = 3.06601394e2;
 enum { BG_a = 0, BG_H, BG_H_prime, BG_rho_g, BG_rho_b, BG_rho_cdm, BG_rho_lambda, BG_rho_ur };   // (cdm / lambda / ur columns exist when present)
 
 struct BgLayout {
+  int number_ncdm1, rho_ncdm1, p_ncdm1, pseudo_p_ncdm1;
   int a, H, Hp, rho_g, rho_b, rho_cdm, rho_lambda, rho_ur, rho_tot, p_tot, p_tot_prime, Omega_r, rho_crit, Omega_m, conf_distance,
       ang_distance, lum_distance, time, rs, D, f, size;
 };
@@ -78,12 +79,31 @@ BgLayout make_bg_layout(const cpt_cosmo_params& p) {   // background_indices, :8
   BgLayout L;
   int i = 0;
   L.a = i++; L.H = i++; L.Hp = i++; L.rho_g = i++; L.rho_b = i++;
-  L.rho_cdm = p.has_cdm ? i++ : -1; L.rho_lambda = p.has_lambda ? i++ : -1; L.rho_ur = p.has_ur ? i++ : -1;
+  L.rho_cdm = p.has_cdm ? i++ : -1;
+  L.number_ncdm1 = L.rho_ncdm1 = L.p_ncdm1 = L.pseudo_p_ncdm1 = -1;
+  if (p.has_ncdm) { L.number_ncdm1 = i; i += p.N_ncdm; L.rho_ncdm1 = i; i += p.N_ncdm; L.p_ncdm1 = i; i += p.N_ncdm; L.pseudo_p_ncdm1 = i; i += p.N_ncdm; }
+  L.rho_lambda = p.has_lambda ? i++ : -1; L.rho_ur = p.has_ur ? i++ : -1;
   L.rho_tot = i++; L.p_tot = i++; L.p_tot_prime = i++; L.Omega_r = i++;
   L.rho_crit = i++; L.Omega_m = i++; L.conf_distance = i++; L.ang_distance = i++; L.lum_distance = i++; L.time = i++; L.rs = i++;
   L.D = i++; L.f = i++;
   L.size = i;
   return L;
+}
+
+// NonColdDarkMatter::background_ncdm_momenta_mass (tools/non_cold_dark_matter.cpp:805-846): number, density, pressure and
+// pseudo-pressure of species n at redshift z from the background momentum sampling
+void ncdm_momenta(const cpt_cosmo_params& p, int n, double z, double* num, double* rho, double* pr, double* pseudo_p) {
+  const double factor2 = p.factor_ncdm[n] * pow(1 + z, 4), M = p.M_ncdm[n];
+  double sn = 0., srho = 0., sp = 0., spp = 0.;
+  for (int iq = 0; iq < p.q_size_ncdm_bg[n]; iq++) {
+    const double q2 = p.q_ncdm_bg[n][iq] * p.q_ncdm_bg[n][iq], w = p.w_ncdm_bg[n][iq];
+    const double epsilon = sqrt(q2 + M * M / (1. + z) / (1. + z));
+    sn += q2 * w;
+    srho += q2 * epsilon * w;
+    sp += q2 * q2 / 3. / epsilon * w;
+    spp += pow(q2 / epsilon, 3) / 3.0 * w;
+  }
+  *num = sn * (factor2 / (1. + z)); *rho = srho * factor2; *pr = sp * factor2; *pseudo_p = spp * factor2;
 }
 
 // background_functions, :263-610: everything that depends on a alone
@@ -97,6 +117,16 @@ int bg_functions(const cpt_cosmo_params& p, const BgLayout& L, double a, bool lo
   v[L.rho_b] = p.Omega0_b * H02 / pow(a_rel, 3);
   rho_tot += v[L.rho_b]; rho_m += v[L.rho_b];
   if (p.has_cdm) { v[L.rho_cdm] = p.Omega0_cdm * H02 / pow(a_rel, 3); rho_tot += v[L.rho_cdm]; rho_m += v[L.rho_cdm]; }
+  if (p.has_ncdm)   // :389-420
+    for (int n = 0; n < p.N_ncdm; n++) {
+      double num, rho, pr, pp;
+      ncdm_momenta(p, n, 1. / a_rel - 1., &num, &rho, &pr, &pp);
+      v[L.number_ncdm1 + n] = num; v[L.rho_ncdm1 + n] = rho; v[L.p_ncdm1 + n] = pr; v[L.pseudo_p_ncdm1 + n] = pp;
+      rho_tot += rho; p_tot += pr;
+      dp_dloga += (pp - 5 * pr);
+      rho_r += 3. * pr;
+      rho_m += rho - 3. * pr;
+    }
   if (p.has_lambda) { v[L.rho_lambda] = p.Omega0_lambda * H02; rho_tot += v[L.rho_lambda]; p_tot -= v[L.rho_lambda]; }
   if (p.has_ur) {
     v[L.rho_ur] = p.Omega0_ur * H02 / pow(a_rel, 4);
@@ -121,6 +151,7 @@ extern "C" {
 void cpt_host_cosmo_defaults(cpt_cosmo_params* p) {
   p->a_ini_over_a_today_default = 1.e-14; p->back_integration_stepsize = 7.e-3; p->tol_initial_Omega_r = 1.e-4;
   p->smallest_allowed_variation = 2.220446049250313e-16;   // DBL_EPSILON (source/input_module.cpp:3481)
+  p->tol_ncdm_initial_w = 1.e-3;
 }
 
 void cpt_host_background_free(cpt_background* bg) {
@@ -133,13 +164,33 @@ int cpt_host_background(const cpt_cosmo_params* pp, cpt_background* out) {
   if (!pp || !out) return fail_msg(CPT_ERR_INVALID, "null argument");
   const cpt_cosmo_params& p = *pp;
   memset(out, 0, sizeof(*out));
-  if (p.has_ncdm || p.has_fld || p.has_scf || p.has_dcdm || p.has_dr || p.has_idr || p.has_idm_dr)
-    return fail_msg(CPT_ERR_UNSUPPORTED, "host background: only photons, baryons, cdm, massless neutrinos, Lambda and curvature");
+  if (p.has_fld || p.has_scf || p.has_dcdm || p.has_dr || p.has_idr || p.has_idm_dr)
+    return fail_msg(CPT_ERR_UNSUPPORTED, "host background: only photons, baryons, cdm, massless and massive neutrinos, Lambda and curvature");
+  if (p.has_ncdm) {
+    if (p.N_ncdm < 1 || p.N_ncdm > CPT_MAX_NCDM) return fail_msg(CPT_ERR_UNSUPPORTED, "host background: between 1 and %d non-cold species", CPT_MAX_NCDM);
+    for (int n = 0; n < p.N_ncdm; n++)
+      if (p.q_size_ncdm_bg[n] < 1 || !p.q_ncdm_bg[n] || !p.w_ncdm_bg[n])
+        return fail_msg(CPT_ERR_INVALID, "host background: the momentum sampling of ncdm species %d is missing", n);
+  }
   if (p.a_today <= 0) return fail_msg(CPT_ERR_INVALID, "input a_today = %e instead of strictly positive", p.a_today);
   const BgLayout L = make_bg_layout(p);
   std::vector<double> v(L.size, 0.);
   // ---- background_initial_conditions, :1521-1690 ----
-  const double a_ini = p.a_ini_over_a_today_default * p.a_today;
+  double a_ini = p.a_ini_over_a_today_default * p.a_today;
+  if (p.has_ncdm) {   // NonColdDarkMatter::GetIni (tools/non_cold_dark_matter.cpp:1080-1106): start early enough for every species to be relativistic
+    int counter;
+    for (counter = 0; counter < 10000; counter++) {
+      bool early = true;
+      for (int n = 0; n < p.N_ncdm; n++) {
+        double num, rho, pr, pp;
+        ncdm_momenta(p, n, p.a_today / a_ini - 1.0, &num, &rho, &pr, &pp);
+        if (fabs(pr / rho - 1. / 3.) > p.tol_ncdm_initial_w) early = false;
+      }
+      if (early) break;
+      a_ini *= 0.1;
+    }
+    if (counter == 10000) return fail_msg(CPT_ERR_RUNTIME, "Search for initial scale factor a such that all ncdm species are relativistic failed.");
+  }
   int rc = bg_functions(p, L, a_ini, false, v.data());
   if (rc) return rc;
   if (fabs(v[L.Omega_r] - 1.) > p.tol_initial_Omega_r)
@@ -220,6 +271,7 @@ int cpt_host_background(const cpt_cosmo_params* pp, cpt_background* out) {
   out->index_bg_rho_cdm = L.rho_cdm; out->index_bg_rho_lambda = L.rho_lambda; out->index_bg_rho_ur = L.rho_ur; out->index_bg_rho_tot = L.rho_tot;
   out->index_bg_p_tot = L.p_tot; out->index_bg_p_tot_prime = L.p_tot_prime; out->index_bg_Omega_r = L.Omega_r; out->index_bg_rho_crit = L.rho_crit;
   out->index_bg_Omega_m = L.Omega_m; out->index_bg_conf_distance = L.conf_distance; out->index_bg_ang_distance = L.ang_distance;
+  out->index_bg_number_ncdm1 = L.number_ncdm1; out->index_bg_rho_ncdm1 = L.rho_ncdm1; out->index_bg_p_ncdm1 = L.p_ncdm1; out->index_bg_pseudo_p_ncdm1 = L.pseudo_p_ncdm1;
   out->index_bg_lum_distance = L.lum_distance; out->index_bg_time = L.time; out->index_bg_rs = L.rs; out->index_bg_D = L.D; out->index_bg_f = L.f;
   return CPT_OK;
 }

@@ -34,6 +34,8 @@ class CptCosmoParams(C.Structure):
         ("has_dcdm", _i), ("has_dr", _i), ("has_idr", _i), ("has_idm_dr", _i),
         ("a_ini_over_a_today_default", _d), ("back_integration_stepsize", _d), ("tol_initial_Omega_r", _d),
         ("smallest_allowed_variation", _d),
+        ("N_ncdm", _i), ("q_size_ncdm_bg", _i * 3), ("q_ncdm_bg", C.POINTER(_d) * 3), ("w_ncdm_bg", C.POINTER(_d) * 3),
+        ("M_ncdm", _d * 3), ("factor_ncdm", _d * 3), ("tol_ncdm_initial_w", _d),
     ]
 
 
@@ -46,7 +48,8 @@ class CptBackground(C.Structure):
                 ("background_table", _pdd), ("d2background_dtau2_table", _pdd)] + \
                [("index_bg_" + n, _i) for n in ("a", "H", "H_prime", "rho_g", "rho_b", "rho_cdm", "rho_lambda", "rho_ur", "rho_tot",
                                                 "p_tot", "p_tot_prime", "Omega_r", "rho_crit", "Omega_m", "conf_distance",
-                                                "ang_distance", "lum_distance", "time", "rs", "D", "f")] + \
+                                                "ang_distance", "lum_distance", "time", "rs", "D", "f",
+                                                "number_ncdm1", "rho_ncdm1", "p_ncdm1", "pseudo_p_ncdm1")] + \
                [(n, _d) for n in ("conformal_age", "age", "Neff", "Omega0_m", "Omega0_r", "Omega0_de")]
 
 
@@ -140,7 +143,7 @@ def q_list(inp, k_min, k_max_cl, g=None):
     return out[: n.value].copy()
 
 
-def cosmo_params(inp):
+def cosmo_params(inp, ncdm=None):
     """cpt_cosmo_params of a named configuration (struct background of the reference, the pba.* entries of the configuration)"""
     d = inp.d
     p = CptCosmoParams()
@@ -150,6 +153,16 @@ def cosmo_params(inp):
     p.sgnK = int(d["pba.sgnK"][0])
     for f in ("has_cdm", "has_ur", "has_lambda", "has_ncdm", "has_fld"):
         setattr(p, f, int(d["pba." + f][0]))
+    if p.has_ncdm:   # momentum sampling, mass and normalisation of every non-cold species (inputs: ncdm.* entries)
+        nt = ncdm if ncdm is not None else inp.t
+        p.N_ncdm = int(d["pba.N_ncdm"][0])
+        p._keep = []
+        for n in range(p.N_ncdm):
+            q = np.ascontiguousarray(nt["ncdm.q_bg_%d" % n], dtype=np.float64); w = np.ascontiguousarray(nt["ncdm.w_bg_%d" % n], dtype=np.float64)
+            p._keep += [q, w]
+            p.q_size_ncdm_bg[n] = q.size
+            p.q_ncdm_bg[n] = q.ctypes.data_as(C.POINTER(_d)); p.w_ncdm_bg[n] = w.ctypes.data_as(C.POINTER(_d))
+            p.M_ncdm[n] = float(nt["ncdm.M"][n]); p.factor_ncdm[n] = float(nt["ncdm.factor"][n])
     return p
 
 

@@ -62,7 +62,14 @@ class ParameterInputs(Inputs):
             ini.pop("tau_reio", None); ini["z_reio"] = repr(z_reio)
         if tau_reio is not None:
             ini.pop("z_reio", None); ini["tau_reio"] = repr(tau_reio)
-        cp = hostlib.cosmo_params(self)                       # struct background values (pba.* of the dump)
+        ncdm = None
+        if int(self.d["pba.has_ncdm"][0]):
+            # non-cold species: their momentum samplings, masses and normalisations are inputs (the ncdm.* entries; the adaptive
+            # quadrature and the mass <-> density solve of the reference's ncdm module stay outside)
+            tname = "tables_ncdm3.npz" if name.startswith("ncdm3") else "tables_ncdm1.npz"
+            full = np.load(os.path.join(golden_dir, tname))
+            ncdm = {k: full[k] for k in full.files if k.startswith("ncdm.")}
+        cp = hostlib.cosmo_params(self, ncdm=ncdm)            # struct background values (pba.* of the dump)
         tp = hostlib.CptThermoParams()
         hostlib.lib().cpt_host_thermo_defaults.argtypes = [hostlib.C.POINTER(hostlib.CptThermoParams)]
         hostlib.lib().cpt_host_thermo_defaults.restype = None
@@ -76,6 +83,8 @@ class ParameterInputs(Inputs):
         tables = {}
         tables.update(hostlib.background(self, cp))
         tables.update(hostlib.thermodynamics(self, cp, tp))
+        if ncdm is not None:
+            tables.update(ncdm)
         super().__init__(name, golden_dir, tables=tables)
         self.l_tensor_max = int(ini["l_max_tensors"]) if "l_max_tensors" in ini else None
         if A_s is not None:

@@ -48,8 +48,8 @@ const char* cpt_host_error(void);
 /* ---- the tables the hot path consumes, computed on the host instead of being handed over ----------------
  * Background (BackgroundModule::background_solve_evolver, source/background_module.cpp:1326-1520 with background_functions
  * :263-610, background_initial_conditions :1521-1690, background_derivs :1934-2064, :2272-2344): flat / curved LambdaCDM with
- * massless neutrinos (non-cold species, fluids, scalar fields, decaying species: CPT_ERR_UNSUPPORTED).  The table has the
- * reference's layout for that content (21 columns; index map returned), so it can be handed to cpt_create unchanged.  */
+ * massless neutrinos and non-cold species given their momentum sampling (fluids, scalar fields, decaying species:
+ * CPT_ERR_UNSUPPORTED).  The table has the reference's layout for that content (21 + 4 N_ncdm columns; index map returned), so it can be handed to cpt_create unchanged.  */
 typedef struct cpt_cosmo_params {
   /* struct background (source/background.h) */
   double H0;                        /* [1/Mpc] */
@@ -59,6 +59,15 @@ typedef struct cpt_cosmo_params {
   int has_cdm, has_ur, has_lambda, has_ncdm, has_fld, has_scf, has_dcdm, has_dr, has_idr, has_idm_dr;
   /* precision (include/precisions.h:12-38) */
   double a_ini_over_a_today_default, back_integration_stepsize, tol_initial_Omega_r, smallest_allowed_variation;
+  /* non-cold species (has_ncdm): what NonColdDarkMatter holds after its own initialisation - the mass in units of the
+   * temperature, the normalisation factor and the BACKGROUND momentum sampling q_ncdm_bg_, w_ncdm_bg_ (tools/non_cold_dark_matter.h:
+   * 70-79, 120-122; the adaptive quadrature that chooses the nodes stays outside).  Host pointers, read during the call only. */
+  int N_ncdm;
+  int q_size_ncdm_bg[CPT_MAX_NCDM];
+  const double* q_ncdm_bg[CPT_MAX_NCDM];
+  const double* w_ncdm_bg[CPT_MAX_NCDM];
+  double M_ncdm[CPT_MAX_NCDM], factor_ncdm[CPT_MAX_NCDM];
+  double tol_ncdm_initial_w;
 } cpt_cosmo_params;
 
 typedef struct cpt_background {
@@ -72,6 +81,7 @@ typedef struct cpt_background {
       index_bg_rho_ur, index_bg_rho_tot, index_bg_p_tot, index_bg_p_tot_prime, index_bg_Omega_r, index_bg_rho_crit,
       index_bg_Omega_m, index_bg_conf_distance, index_bg_ang_distance, index_bg_lum_distance, index_bg_time, index_bg_rs,
       index_bg_D, index_bg_f;
+  int index_bg_number_ncdm1, index_bg_rho_ncdm1, index_bg_p_ncdm1, index_bg_pseudo_p_ncdm1;   /* -1 without ncdm; species contiguous */
   double conformal_age, age, Neff, Omega0_m, Omega0_r, Omega0_de;
 } cpt_background;
 

@@ -195,6 +195,9 @@ static int do_dump(const char* ini, const char* outpath) {
       snprintf(nm, sizeof nm, "ncdm.q_%d", n); put_f8(nm, nc.q_ncdm_[n], {nc.q_size_ncdm_[n]});
       snprintf(nm, sizeof nm, "ncdm.w_%d", n); put_f8(nm, nc.w_ncdm_[n], {nc.q_size_ncdm_[n]});
       snprintf(nm, sizeof nm, "ncdm.dlnf0_dlnq_%d", n); put_f8(nm, nc.dlnf0_dlnq_ncdm_[n], {nc.q_size_ncdm_[n]});
+      // the background's own (finer) momentum sampling, input of the host background module (tools/non_cold_dark_matter.h:120-122)
+      snprintf(nm, sizeof nm, "ncdm.q_bg_%d", n); put_f8(nm, nc.q_ncdm_bg_[n], {nc.q_size_ncdm_bg_[n]});
+      snprintf(nm, sizeof nm, "ncdm.w_bg_%d", n); put_f8(nm, nc.w_ncdm_bg_[n], {nc.q_size_ncdm_bg_[n]});
     }
     put_f8("ncdm.M", M.data(), {nc.N_ncdm_}); put_f8("ncdm.factor", fac.data(), {nc.N_ncdm_});
   }

@@ -119,7 +119,7 @@ def test_sharded_pieces_on_the_gpu_match_the_single_rank_result():
     be.close()
 
 
-@pytest.mark.parametrize("cfg", ["lcdm", "curved_full"])
+@pytest.mark.parametrize("cfg", ["lcdm", "curved_full", "ncdm"])
 def test_from_parameters_to_cl(cfg):
     """SURVEY S8f-1 closed: nothing but parameters goes in (classpp_public_amd/pipeline.py) - the background and thermodynamics tables
     and the four grids are computed by libcpt_host.so, everything else on the GPU - and the reference's C_l (and P(k)) come out."""
