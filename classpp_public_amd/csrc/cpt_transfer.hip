@@ -195,8 +195,24 @@ __global__ void __launch_bounds__(64) k_source_spline(const double* __restrict__
   d[0] = u;
   double ym = y0, yc = y1;
   double xm = x0, xc = x1;
-#pragma unroll 4
-  for (int i = 1; i < n - 1; i++) {
+  // The recurrence in u is sequential, the loads are not: fetch a block of rows first (one HBM round trip per block instead
+  // of one per k), then run the arithmetic on registers.  46 waves cannot hide the latency by occupancy.
+  constexpr int BLK = 16;
+  int i = 1;
+  for (; i + BLK <= n - 1; i += BLK) {
+    double yb[BLK], xb[BLK], sb[BLK], pb[BLK];
+#pragma unroll
+    for (int j = 0; j < BLK; j++) { yb[j] = y[(size_t)(i + 1 + j) * st]; xb[j] = x[i + 1 + j]; sb[j] = sg[i + j]; pb[j] = pp[i + j]; }
+#pragma unroll
+    for (int j = 0; j < BLK; j++) {
+      const double yn = yb[j], xn = xb[j];
+      const double ui = (yn - yc) / (xn - xc) - (yc - ym) / (xc - xm);
+      u = (6.0 * ui / (xn - xm) - sb[j] * u) / pb[j];
+      d[(size_t)(i + j) * st] = u;
+      ym = yc; yc = yn; xm = xc; xc = xn;
+    }
+  }
+  for (; i < n - 1; i++) {
     double yn = y[(size_t)(i + 1) * st];
     double xn = x[i + 1];
     double ui = (yn - yc) / (xn - xc) - (yc - ym) / (xc - xm);
@@ -210,8 +226,18 @@ __global__ void __launch_bounds__(64) k_source_spline(const double* __restrict__
   double un = (3. / (xc - xm)) * (dy_last - (yc - ym) / (xc - xm));
   double ddn = (un - 0.5 * u) / (0.5 * cc[n - 2] + 1.0);
   d[(size_t)(n - 1) * st] = ddn;
-#pragma unroll 4
-  for (int i = n - 2; i >= 0; i--) {
+  i = n - 2;
+  for (; i - BLK + 1 >= 0; i -= BLK) {
+    double ub[BLK], cb[BLK];
+#pragma unroll
+    for (int j = 0; j < BLK; j++) { ub[j] = d[(size_t)(i - j) * st]; cb[j] = cc[i - j]; }
+#pragma unroll
+    for (int j = 0; j < BLK; j++) {
+      ddn = cb[j] * ddn + ub[j];
+      d[(size_t)(i - j) * st] = ddn;
+    }
+  }
+  for (; i >= 0; i--) {
     ddn = cc[i] * ddn + d[(size_t)i * st];
     d[(size_t)i * st] = ddn;
   }
