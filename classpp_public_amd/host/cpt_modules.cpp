@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <string>
 #include <vector>
 
 namespace cpt {
@@ -24,6 +25,42 @@ T* xalloc(size_t n) {
   throw std::runtime_error(msg);
 }
 }  // namespace
+
+HostTables::HostTables(const cpt_cosmo_params& cosmo, const cpt_thermo_params& th) {
+  int rc = cpt_host_background(&cosmo, &background);
+  if (rc) raise(rc, cpt_host_error());
+  rc = cpt_host_thermodynamics(&cosmo, &th, &background, &thermo);
+  if (rc) {
+    const std::string msg = cpt_host_error();
+    cpt_host_background_free(&background);
+    raise(rc, msg.c_str());
+  }
+}
+
+HostTables::~HostTables() {
+  cpt_host_thermo_free(&thermo);
+  cpt_host_background_free(&background);
+}
+
+void HostTables::fill(Inputs& in) const {
+  cpt_tables& t = in.tables;
+  const cpt_background& b = background;
+  const cpt_thermo& h = thermo;
+  t.bt_size = b.bt_size; t.bg_size = b.bg_size; t.tau_table = b.tau_table; t.background_table = b.background_table;
+  t.d2background_dtau2_table = b.d2background_dtau2_table;
+  t.index_bg_a = b.index_bg_a; t.index_bg_H = b.index_bg_H; t.index_bg_H_prime = b.index_bg_H_prime; t.index_bg_rho_g = b.index_bg_rho_g;
+  t.index_bg_rho_b = b.index_bg_rho_b; t.index_bg_rho_cdm = b.index_bg_rho_cdm; t.index_bg_rho_ur = b.index_bg_rho_ur;
+  t.index_bg_rho_ncdm1 = b.index_bg_rho_ncdm1; t.index_bg_p_ncdm1 = b.index_bg_p_ncdm1; t.index_bg_pseudo_p_ncdm1 = b.index_bg_pseudo_p_ncdm1;
+  t.tt_size = h.tt_size; t.th_size = h.th_size; t.z_table = h.z_table; t.thermodynamics_table = h.thermodynamics_table;
+  t.d2thermodynamics_dz2_table = h.d2thermodynamics_dz2_table;
+  t.index_th_xe = h.index_th_xe; t.index_th_dkappa = h.index_th_dkappa; t.index_th_tau_d = h.index_th_tau_d; t.index_th_ddkappa = h.index_th_ddkappa;
+  t.index_th_dddkappa = h.index_th_dddkappa; t.index_th_exp_m_kappa = h.index_th_exp_m_kappa; t.index_th_g = h.index_th_g; t.index_th_dg = h.index_th_dg;
+  t.index_th_cb2 = h.index_th_cb2; t.index_th_rate = h.index_th_rate;
+  cpt_config& c = in.config;
+  c.YHe = h.YHe; c.n_e = h.n_e; c.tau0 = b.conformal_age; c.tau_rec = h.tau_rec; c.tau_free_streaming = h.tau_free_streaming;
+  c.tau_cut = h.tau_cut; c.angular_rescaling = h.angular_rescaling;
+  in.grid.rs_rec = h.rs_rec; in.grid.tau_ini_thermo = h.tau_ini;
+}
 
 PerturbationsModule::PerturbationsModule(const Inputs& in) {
   error_message_[0] = '\n';

@@ -22,6 +22,19 @@ struct Inputs {
   cpt_grid_params grid;
 };
 
+// Background + thermodynamics tables computed on the host (include/cpt_host.h) instead of taken from the
+// reference's BackgroundModule / ThermodynamicsModule: owns the tables, fills the table part of an Inputs and the scalars of
+// cpt_config / cpt_grid_params that derive from them.  Throws like the modules (std::invalid_argument / std::runtime_error).
+class HostTables {
+ public:
+  HostTables(const cpt_cosmo_params& cosmo, const cpt_thermo_params& thermo);
+  ~HostTables();
+  HostTables(const HostTables&) = delete;
+  void fill(Inputs& in) const;   // in.tables (pointers into this object: keep it alive), in.config.{tau0,...}, in.grid.{rs_rec,...}
+  cpt_background background{};
+  cpt_thermo thermo{};
+};
+
 class PerturbationsModule {
  public:
   explicit PerturbationsModule(const Inputs& in);

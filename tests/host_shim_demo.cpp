@@ -3,6 +3,7 @@
 // getters would (source/cosmology.cpp:30-35, 68-73), and writes the public tables back for comparison.
 #include <cstdio>
 #include <cstdlib>
+#include <algorithm>
 #include <memory>
 #include <vector>
 
@@ -38,6 +39,19 @@ int main(int argc, char** argv) {
   in.tables.tau_table = tau.data(); in.tables.background_table = bg.data(); in.tables.d2background_dtau2_table = d2bg.data();
   in.tables.z_table = z.data(); in.tables.thermodynamics_table = th.data(); in.tables.d2thermodynamics_dz2_table = d2th.data();
   int bad_flag = argc > 3 ? atoi(argv[3]) : 0;
+  // flag 3: ignore the tables that came with the dump and recompute them on the host from the cosmological parameters
+  // (cpt::HostTables); the parameter structs follow the arrays in the file
+  std::unique_ptr<cpt::HostTables> host_tables;
+  if (bad_flag == 3) {
+    cpt_cosmo_params cosmo; cpt_thermo_params thermo;
+    FILE* g = fopen(argv[1], "rb");
+    fseek(g, -(long)(sizeof(cosmo) + sizeof(thermo)), SEEK_END);
+    rd(g, &cosmo, sizeof(cosmo)); rd(g, &thermo, sizeof(thermo));
+    fclose(g);
+    std::fill(tau.begin(), tau.end(), 0.); std::fill(bg.begin(), bg.end(), 0.); std::fill(th.begin(), th.end(), 0.);   // (prove they are not used)
+    host_tables = std::make_unique<cpt::HostTables>(cosmo, thermo);
+    host_tables->fill(in);
+  }
   if (bad_flag == 1) in.config.has_fld = 1;             // must raise std::invalid_argument
   if (bad_flag == 2) in.grid.k_step_transition = 0.;    // must raise std::invalid_argument (reference: class_test)
   try {

@@ -40,6 +40,8 @@ def write_inputs(inp, path):
             for n in range(inp.config.N_ncdm):
                 for key in ("ncdm.q_%d", "ncdm.w_%d", "ncdm.dlnf0_dlnq_%d"):
                     f.write(np.ascontiguousarray(t[key % n], dtype=np.float64).tobytes())
+        if not inp.config.has_ncdm:   # cosmological parameters for the from-parameters mode of the demo (flag 3)
+            f.write(bytes(hostlib.cosmo_params(inp))); f.write(bytes(hostlib.thermo_params(inp)))
 
 
 def run_demo(exe, inp_path, out_path, flag=0):
@@ -77,6 +79,13 @@ def test_shim_modules(tmp_path, cfg):
     scale = np.max(np.abs(ref), axis=-1, keepdims=True)
     scale[scale == 0] = 1
     assert np.max(np.abs(tr - ref) / scale) < 1e-3  # coarse tau sampling of `small` amplifies the source noise
+    if not inp.config.has_ncdm:
+        # the same through cpt::HostTables: background and thermodynamics recomputed on the host from parameters (bit-identical
+        # tables => bit-identical outputs)
+        opath2 = str(tmp_path / "out2.bin")
+        rc, out = run_demo(exe, ipath, opath2, flag=3)
+        assert rc == 0, out
+        assert open(opath2, "rb").read() == open(opath, "rb").read()
     if cfg != "small":
         return
     # error mapping
