@@ -168,6 +168,9 @@ enum Role : int {
   R_NCD, R_NCT /* auxiliary unknowns of the Newton system: delta rho and (rho+p) theta summed over the ncdm species */
 };
 
+#ifdef CPT_COUNT_RESTAGE
+__device__ unsigned long long g_restage[4];   // diagnostic: window slides (thermo, background), bsearch fallbacks, lookups
+#endif
 #ifdef CPT_PROFILE
 __device__ unsigned long long g_prof[16];
 #define PROF_DECL unsigned long long pf_t0 = 0
@@ -203,8 +206,20 @@ struct NcShared {
   int abort;
 };
 
+// (NCDM = 0) The block holds TWO wavefronts per k-mode: wave 0 integrates, wave 1 is the SAMPLER.  Evaluating a source
+// sample costs a table look-up at the sample time, one RHS evaluation and the source algebra (~7 000 cycles, 9 % of the
+// critical path) and drags the integrator's table windows back in time; none of it feeds back into the integration.  Wave 0
+// therefore only interpolates (y, y') at the sample time from its backward differences and posts them; the sampler, with
+// table windows of its own that walk monotonically through the sample times, does the rest concurrently.
+struct SampleMsg {
+  double yi[64], ypi[64];   // dense output at the sample time, one entry per lane
+  double tca_keep;          // tight-coupling shear left by the evolver's last RHS call (pm.cpp:6810)
+  int it, flags, done;      // sample index; approximation scheme (tca | rsa<<1 | ufa<<2); done: the mode is finished
+};
+
 template <int GAUGE, int CURV, int MODE, int NCDM = 0>
 struct PT {
+static constexpr bool SAMPLER = (NCDM == 0);
 // Lane map.  One lane per equation of pm.cpp:3302-3481, at a FIXED lane whatever the approximation scheme: the (at most
 // 13) densely coupled variables - densities, velocities, shears, polarisation l<=2, metric - are the CORE in lanes
 // 0..12, followed by the three free-streaming hierarchy tails (photon temperature l>=3, polarisation l>=3, ur l>=3)
@@ -459,6 +474,9 @@ static __device__ __forceinline__ int window_find(const double* __restrict__ x, 
     if (nb < 0) nb = 0;
     *base = nb;
     window_stage<NCOL>(x, rows, n, nb, lane, xw, w);
+#ifdef CPT_COUNT_RESTAGE
+    if (blockIdx.x == 0 && lane == 0) g_restage[NCOL == TH_NCOL ? 0 : 1]++;
+#endif
     lo = bcast(*xw, 0); hi = bcast(*xw, 63);
     if (!(v >= lo && v < hi) && !(nb == 0 && v < lo) && !(nb == n - 64 && v >= hi)) {
       const int inf = bsearch_up(x, n, v);  // uniform
@@ -467,6 +485,9 @@ static __device__ __forceinline__ int window_find(const double* __restrict__ x, 
       if (nb < 0) nb = 0;
       *base = nb;
       window_stage<NCOL>(x, rows, n, nb, lane, xw, w);
+#ifdef CPT_COUNT_RESTAGE
+      if (blockIdx.x == 0 && lane == 0) g_restage[2]++;
+#endif
     }
   }
   const unsigned long long m = __ballot(*xw <= v);
@@ -502,7 +523,16 @@ static __device__ __forceinline__ void lookup_set_mode(const PtParams& P, Lookup
 static __device__ __forceinline__ void lookup(const PtParams& P, Lookup& Q, double tau, int lane) {
   if (tau == Q.tau_cached) return;
   Q.tau_cached = tau;
+#ifdef CPT_COUNT_RESTAGE
+  if (blockIdx.x == 0 && lane == 0) g_restage[3]++;
+#endif
   const DevTables& T = P.tabs;
+#ifdef CPT_PROFILE_LOOKUP
+  unsigned long long tl0 = clock64();
+#define LK_MARK(slot) { const unsigned long long tl1 = clock64(); Q.prof[slot] += tl1 - tl0; tl0 = tl1; }
+#else
+#define LK_MARK(slot)
+#endif
   const int base_was = Q.bg_base;
   const int inf = window_find<BG_NCOL>(T.tau_table, (const double2*)T.bg, T.bt_size, tau, lane, &Q.bgx, Q.bgw, &Q.bg_base, 8);
   if (NCDM && Q.bg_base != base_was) {   // the ncdm columns ride in a window of their own on the same rows
@@ -528,11 +558,13 @@ static __device__ __forceinline__ void lookup(const PtParams& P, Lookup& Q, doub
     Q.vbg = spl2(Q.bg_lo, Q.bg_hi, a, b, h * h / 6.);
     if (NCDM) Q.vnc = spl2(Q.nc_lo, Q.nc_hi, a, b, h * h / 6.);
   }
+  LK_MARK(12)   // background: window, rows, spline
   const double bg_a = bcast(Q.vbg, BG_A), bg_H = bcast(Q.vbg, BG_H), bg_Hp = bcast(Q.vbg, BG_HP);
   Q.rg = bcast(Q.vbg, BG_RHO_G); Q.rb = bcast(Q.vbg, BG_RHO_B); Q.rc = bcast(Q.vbg, BG_RHO_CDM); Q.ru = bcast(Q.vbg, BG_RHO_UR);
   const double inv_a = fast_rcp(bg_a);
   const double z = inv_a - 1.;
   const double zmax = Q.zmax;
+  LK_MARK(13)   // background broadcasts
   if (z >= zmax) {  // analytic extrapolation, th.cpp:128-219
     const double x0 = Q.xe_last, inv_1pz = fast_rcp(1. + z);
     const double dk = (1. + z) * (1. + z) * P.n_e * x0 * SIGMA_T * MPC_OVER_M;
@@ -560,6 +592,7 @@ static __device__ __forceinline__ void lookup(const PtParams& P, Lookup& Q, doub
     Q.vth = spl2(Q.th_lo, Q.th_hi, a, b, h * h / 6.);
     Q.kap = bcast(Q.vth, TH_DKAPPA); Q.ddkappa = bcast(Q.vth, TH_DDKAPPA); Q.cb2 = bcast(Q.vth, TH_CB2);
   }
+  LK_MARK(14)   // thermodynamics: window, rows, spline, broadcasts
   // tau-only derived quantities (shared by every RHS evaluation at this tau); reciprocals by v_rcp_f64 + Newton
   Q.a2 = bg_a * bg_a;
   Q.aH = bg_a * bg_H;
@@ -580,6 +613,7 @@ static __device__ __forceinline__ void lookup(const PtParams& P, Lookup& Q, doub
     const double sq = sqrt(fabs(P.K));
     Q.kcot = (P.K < 0.) ? sq / tanh(sq * tau) : sq / tan(sq * tau);
   }
+  LK_MARK(15)   // derived quantities
 }
 
 // ---- physics ------------------------------------------------------------------------------------
@@ -1027,6 +1061,7 @@ struct Ctx {
   double tau_pub;              // time at which sh->bc was last published (and read by everybody)
   double a2, aH, kcot, inv_tau, rho, pr, pp;   // chain waves: copy of the published block (rho, p, pseudo_p of the lane's species)
   double ca, cb, cd, cxmc, cxms, cwt;          // chain waves: this lane's coefficients at tau_pub (they depend on tau only)
+  SampleMsg* msg; int pending;                 // (SAMPLER) hand-over slot and whether the sampler still owns it
 };
 struct ChainEq {
   int l, cidx, species;
@@ -1524,6 +1559,14 @@ static __device__ __forceinline__ int ndf15(const PtParams& P, const Layout& L, 
       const double tca_keep = M.tca_shear_g;
       if (NCDM && batch == B_JAC) sync_tau<ROLE>(P, L, Q, C, ce, k, t, lane);
       if (ROLE == 1 && batch == B_JAC) jc = ChainCoef{C.ca, C.cb, C.cd, C.cxmc, C.cxms, C.cwt};   // the chains' Jacobian is their coefficient set
+      else if (SAMPLER && batch == B_SAMPLE) {   // hand the sample to the sampler wave
+        if (C.pending) __syncthreads();          // (C) it has consumed the previous one
+        C.msg->yi[lane] = yi; C.msg->ypi[lane] = ypi;
+        if (lane == 0) { C.msg->tca_keep = tca_keep; C.msg->it = next; C.msg->flags = L.tca | (L.rsa << 1) | (L.ufa << 2); C.msg->done = 0; }
+        __syncthreads();                         // (R)
+        C.pending = 1;
+        st.fevals++;                             // (the evaluation is counted where the reference makes it)
+      }
       else
       for (int r = 0; r < nreq; r++) {
         double tq, yq;
@@ -1644,7 +1687,9 @@ static __device__ __forceinline__ int ndf15(const PtParams& P, const Layout& L, 
       y = ynew;
       Jcurrent = false;
       new_step = true;
+#ifndef CPT_PROFILE_LOOKUP
       PROF_STOP(12);
+#endif
     }
     // ------------------------------------------------------------------ start of a step (ev.cpp:299-334)
     if (new_step) {
@@ -1662,7 +1707,9 @@ static __device__ __forceinline__ int ndf15(const PtParams& P, const Layout& L, 
         need_fact = true;
       }
       nofailed = true;
+#ifndef CPT_PROFILE_LOOKUP
       PROF_STOP(13);
+#endif
     }
     if (need_fact) {
       need_fact = false;
@@ -1791,7 +1838,9 @@ static __device__ __forceinline__ int ndf15(const PtParams& P, const Layout& L, 
     }
     if ((next < tres) && (tnew - ts[next] >= 0.0)) { batch = B_SAMPLE; prepare_sample(); }
     else post_step = true;
+#ifndef CPT_PROFILE_LOOKUP
     PROF_STOP(14);
+#endif
   }
   y_io = ynew;
   return 0;
@@ -2018,12 +2067,46 @@ static __device__ __forceinline__ int run_intervals(const PtParams& P, Ctx& C, c
   return status;
 }
 
+// the sampler wave (SAMPLER): perturb_sources (pm.cpp:6731-7285) for every sample the integrator posts
+static __device__ __forceinline__ void run_sampler(const PtParams& P, Ctx& C, double k, double inv_k2, int ik, int lane, double2* bgw, double2* thw) {
+  Lookup Q;
+  lookup_init(P, Q, bgw, thw, lane);
+  lookup_set_mode(P, Q, k);
+#ifdef CPT_PROFILE
+  unsigned long long sprof[16];
+  Q.prof = sprof;
+#endif
+  Metric M;
+  M.hp = M.etap = M.alpha = M.alphap = 0.; M.psi = M.phip = 0.;
+  M.tca_shear_g = 0.; M.rsa_dg = M.rsa_tg = 0.;
+  int flags = -1;
+  Layout L = make_layout(P, 1, 0, 0);
+  LaneEq e = make_lane_eq(P, L, lane, k);
+  for (;;) {
+    __syncthreads();                           // (R) a message is ready
+    if (C.msg->done) break;
+    const int f = C.msg->flags, it = C.msg->it;
+    const double yi = C.msg->yi[lane], ypi = C.msg->ypi[lane], tca_keep = C.msg->tca_keep;
+    if (f != flags) {                          // the integrator entered another approximation scheme
+      flags = f;
+      L = make_layout(P, f & 1, (f >> 1) & 1, (f >> 2) & 1);
+      e = make_lane_eq(P, L, lane, k);
+    }
+    const double tn = P.tau_s[it];
+    (void)rhs(P, L, e, Q, M, k, inv_k2, tn, yi, lane);   // leaves Q and M describing (tn, yi)
+    store_sources(P, L, Q, M, k, inv_k2, yi, ypi, tca_keep, it, ik, lane);
+    __syncthreads();                           // (C) the slot is free again
+  }
+}
+
 // ---- the kernel: perturb_solve (pm.cpp:2463-2787) for one mode per wavefront ---------------------
 static __device__ __forceinline__ void body_perturb(const PtParams& P) {
   __shared__ __attribute__((aligned(16))) double2 tabw[64 * (BG_NCOL + TH_NCOL)];
   __shared__ double jacw[NC * 64];
   __shared__ __attribute__((aligned(16))) double2 ncw[NCDM ? 64 * NCB_NCOL : 1];
   __shared__ __attribute__((aligned(8))) char ncsh_raw[NCDM ? sizeof(NcShared) : 8];
+  __shared__ __attribute__((aligned(16))) double2 tabw2[SAMPLER ? 64 * (BG_NCOL + TH_NCOL) : 1];   // the sampler's table windows
+  __shared__ SampleMsg smsg[SAMPLER ? 1 : 1];
   const int lane = threadIdx.x & 63;
   const int ik = P.order[blockIdx.x];
   const double k = P.k[ik];
@@ -2031,7 +2114,8 @@ static __device__ __forceinline__ void body_perturb(const PtParams& P) {
   double2* bgw = tabw;
   double2* thw = tabw + 64 * BG_NCOL;
   Ctx C;
-  C.wave = NCDM ? (int)(threadIdx.x >> 6) : 0; C.nw = NCDM ? (int)(blockDim.x >> 6) - 1 : 0;
+  C.wave = (int)(threadIdx.x >> 6); C.nw = NCDM ? (int)(blockDim.x >> 6) - 1 : 0;
+  C.msg = smsg; C.pending = 0;
   C.len = NCDM ? P.nc.lmax + 1 : 64; C.cpw = 64 / C.len;
   C.sh = (NcShared*)ncsh_raw; C.parity = 0; C.abort = 0; C.tau_pub = -1.;
   C.a2 = C.aH = C.kcot = C.inv_tau = C.rho = C.pr = C.pp = 1.;
@@ -2089,8 +2173,15 @@ static __device__ __forceinline__ void body_perturb(const PtParams& P) {
 #define CPT_RUN_ARGS P, C, sc, k, inv_k2, ik, lane, bgw, thw, ncw, jacw, st, n_regimes, budget, prof
 #endif
     if constexpr (NCDM != 0) { if (C.wave > 0) status = run_intervals<1>(CPT_RUN_ARGS); else status = run_intervals<0>(CPT_RUN_ARGS); }
-    else status = run_intervals<0>(CPT_RUN_ARGS);
+    else { if (C.wave == 0) status = run_intervals<0>(CPT_RUN_ARGS); }
 #undef CPT_RUN_ARGS
+  }
+  if (SAMPLER) {   // every path of wave 0 ends here: release the sampler (which loops on the barrier whatever happened above)
+    if (C.wave == 0) {
+      if (C.pending) __syncthreads();          // (C) of the last sample
+      if (lane == 0) C.msg->done = 1;
+      __syncthreads();                         // (R)
+    } else run_sampler(P, C, k, inv_k2, ik, lane, tabw2, tabw2 + 64 * BG_NCOL);
   }
 #ifdef CPT_PROFILE
   prof[7] = clock64() - t_begin;
@@ -2195,7 +2286,7 @@ static __device__ __forceinline__ void body_dbg_solve(const PtParams& P, double 
 };  // struct PT<GAUGE>
 
 template <int GAUGE, int CURV, int MODE>
-__global__ void __launch_bounds__(64) k_perturb(PtParams P) { PT<GAUGE, CURV, MODE>::body_perturb(P); }
+__global__ void __launch_bounds__(128) k_perturb(PtParams P) { PT<GAUGE, CURV, MODE>::body_perturb(P); }   // integrator wave + sampler wave
 // scalars with non-cold species: 1 + NW wavefronts per k-mode (synchronous gauge)
 // (two register budgets: up to 3 chain waves every wave has a SIMD - and its whole register file - to itself; beyond that two
 //  waves share a SIMD and the kernel is compiled for half the registers)
@@ -2300,7 +2391,7 @@ int cpt_perturb_impl(cpt_handle* h, const double* k, int nk, const double* tau, 
       else hipLaunchKernelGGL((k_perturb_ncdm<0, NCW_MAX>), dim3(nk), dim3(64 * (1 + nw)), 0, h->stream, P);
     }
   } else
-  CPT_PT_DISPATCH(c, k_perturb, dim3(nk), dim3(64), 0, h->stream, P);
+  CPT_PT_DISPATCH(c, k_perturb, dim3(nk), dim3(128), 0, h->stream, P);
   CPT_HIP(h, hipGetLastError());
   CPT_HIP(h, hipEventRecord(h->t_perturb.b, h->stream));
   h->src_nk = nk; h->src_ntau = ntau;
@@ -2335,6 +2426,11 @@ int cpt_perturb_impl(cpt_handle* h, const double* k, int nk, const double* tau, 
 // cycles spent by the heaviest mode of the last perturb launch: rhs(Newton), lu_solve, factorise, jacobian, sampling,
 // adjust_stepsize, schedule, total.  Zeros unless built with -DCPT_PROFILE (diagnostic builds only, tools/prof_run.py).
 extern "C" int cpt_dbg_profile(unsigned long long* out) {
+#ifdef CPT_COUNT_RESTAGE
+  unsigned long long r[4];
+  if (hipMemcpyFromSymbol(r, HIP_SYMBOL(g_restage), sizeof(r)) == hipSuccess)
+    fprintf(stderr, "[restage] thermo slides %llu  background slides %llu  bsearch fallbacks %llu  lookups %llu (block 0, cumulative)\n", r[0], r[1], r[2], r[3]);
+#endif
 #ifdef CPT_PROFILE
   return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_prof), 16 * sizeof(unsigned long long)) == hipSuccess ? 0 : 3;
 #else
