@@ -82,6 +82,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", default="lcdm")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="torch.distributed backend: nccl (= RCCL over xGMI, one GPU per rank; the measured configuration) or gloo "
+                         "(rehearsal of the multi-process path on a box with fewer GPUs than ranks: ranks share GPUs, the two "
+                         "exchanges are staged through host memory; not a performance number)")
     ap.add_argument("--from-parameters", action="store_true",
                     help="compute the spline tables and grids on the host from the cosmological parameters (classpp_public_amd/pipeline.py) "
                          "instead of loading them from tests/golden; the host stage is timed and reported as stage_ms.host_tables")
@@ -94,12 +98,18 @@ def main():
         raise SystemExit("--gpus %d needs torch.distributed.run with %d ranks (WORLD_SIZE=%d)" % (args.gpus, args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the cpt backend has no CPU fallback")
+    if args.backend == "gloo":
+        local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
+    xdev = torch.device("cpu") if args.backend == "gloo" else None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if args.backend == "gloo":
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
     t_host0 = time.perf_counter()
     if args.from_parameters:
@@ -133,7 +143,7 @@ def main():
                 cl = be.lensed_cl(cl, *lens_args)
             pk = be.pk_linear() if has_pk else None
             return cl, pk
-        out, _ = sharded_step(comp, k_all, inp.l, rank, world, device, k_size_cl)
+        out, _ = sharded_step(comp, k_all, inp.l, rank, world, device, k_size_cl, exchange_device=xdev)
         if rank == 0:
             return be.cl(out), None
         return None, None
@@ -150,7 +160,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        t = torch.tensor([dt], dtype=torch.float64, device=device if xdev is None else xdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
@@ -197,7 +207,7 @@ def main():
                        "inputs": ("background/thermodynamics spline tables and grids computed by libcpt_host.so from the cosmological parameters"
                                   if args.from_parameters else
                                   "background/thermodynamics spline tables and grids from tests/golden (dumped from the reference)"),
-                       "parallelism": "k-sharded x%d, l-sharded transfer, 2 RCCL exchanges" % world if world > 1 else "1 GPU"},
+                       "parallelism": ("k-sharded x%d, l-sharded transfer, 2 %s exchanges" % (world, "RCCL" if args.backend == "nccl" else "gloo (REHEARSAL: ranks share GPUs)")) if world > 1 else "1 GPU"},
             "stage_ms": {"perturb_kernel": k_ms, "los_kernel": t_ms, "step_wall": ms_step, "host_tables": host_tables_ms},
             "cl_wall_ms": ms_step,
             "perturb_kmodes_per_s_kernel": nk_local * world / (k_ms * 1e-3),

@@ -37,14 +37,41 @@ def densify_k(k, factor):
     return np.ascontiguousarray(out, dtype=np.float64)
 
 
-def sharded_step(compute, k_all, l_all, rank, world, device, k_size_cl=None):
+class _Plan:
+    """index tensors and exchange buffers of one (nk, nl, world, shapes) geometry, built once and reused by every step"""
+
+    def __init__(self, nk, nl, rank, world, device):
+        self.key = (nk, nl, rank, world, str(device))
+        self.k_idx = [torch.as_tensor(shard_indices(nk, r, world), device=device) for r in range(world)]
+        self.l_idx = [torch.as_tensor(shard_indices(nl, r, world), device=device) for r in range(world)]
+        self.bufs = {}
+
+    def buf(self, name, shape, device, count=1):
+        b = self.bufs.get(name)
+        if b is None or b[0].shape != tuple(shape):
+            b = [torch.zeros(shape, dtype=torch.float64, device=device) for _ in range(count)]
+            self.bufs[name] = b
+        return b
+
+
+_plan = None
+
+
+def sharded_step(compute, k_all, l_all, rank, world, device, k_size_cl=None, exchange_device=None):
     """One pass of the hot path over `world` ranks.
 
     compute.perturb(k_subset) -> torch f64 [tp][ntau][len(k_subset)] on `device`
     compute.transfer(sources_full, k_all, l_subset, k_size_cl) -> torch f64 [tt][len(l_subset)][nq] on `device`
     Returns the full transfer table [tt][nl][nq] on rank 0 (None elsewhere) and the full sources.
+    exchange_device: where the collectives run (default: `device`, i.e. RCCL on GPU tensors; torch.device("cpu") stages the two
+    exchanges through host memory - the gloo rehearsal of bench.py --backend gloo on a box with fewer GPUs than ranks).
     """
+    global _plan
+    xdev = device if exchange_device is None else exchange_device
     nk, nl = len(k_all), len(l_all)
+    if _plan is None or _plan.key != (nk, nl, rank, world, str(device)):
+        _plan = _Plan(nk, nl, rank, world, device)
+    plan = _plan
     my_k = shard_indices(nk, rank, world)
     local = compute.perturb(k_all[my_k])
     ntp, ntau = local.shape[0], local.shape[1]
@@ -53,14 +80,14 @@ def sharded_step(compute, k_all, l_all, rank, world, device, k_size_cl=None):
     else:
         # ---- exchange 1: all_gather (pad to the largest shard so that every block has the same shape) ----
         nmax = (nk + world - 1) // world
-        buf = torch.zeros((ntp, ntau, nmax), dtype=torch.float64, device=device)
+        buf = plan.buf("src_send", (ntp, ntau, nmax), xdev)[0]
         buf[:, :, : my_k.size] = local
-        blocks = [torch.empty_like(buf) for _ in range(world)]
+        blocks = plan.buf("src_recv", (ntp, ntau, nmax), xdev, world)
         dist.all_gather(blocks, buf)
-        full = torch.empty((ntp, ntau, nk), dtype=torch.float64, device=device)
+        full = plan.buf("src_full", (ntp, ntau, nk), device)[0]
         for r in range(world):
-            idx = shard_indices(nk, r, world)
-            full[:, :, torch.as_tensor(idx, device=device)] = blocks[r][:, :, : idx.size]
+            idx = plan.k_idx[r]
+            full.index_copy_(2, idx, blocks[r][:, :, : idx.numel()].to(device))
     my_l = shard_indices(nl, rank, world)
     tr_local = compute.transfer(full, k_all, l_all[my_l], nk if k_size_cl is None else k_size_cl)
     if world == 1:
@@ -68,15 +95,15 @@ def sharded_step(compute, k_all, l_all, rank, world, device, k_size_cl=None):
     # ---- exchange 2: gather on rank 0 ----
     ntt, nq = tr_local.shape[0], tr_local.shape[2]
     lmax = (nl + world - 1) // world
-    buf = torch.zeros((ntt, lmax, nq), dtype=torch.float64, device=device)
+    buf = plan.buf("tr_send", (ntt, lmax, nq), xdev)[0]
     buf[:, : my_l.size, :] = tr_local
     if rank == 0:
-        blocks = [torch.empty_like(buf) for _ in range(world)]
+        blocks = plan.buf("tr_recv", (ntt, lmax, nq), xdev, world)
         dist.gather(buf, blocks, dst=0)
-        out = torch.empty((ntt, nl, nq), dtype=torch.float64, device=device)
+        out = plan.buf("tr_full", (ntt, nl, nq), device)[0]
         for r in range(world):
-            idx = shard_indices(nl, r, world)
-            out[:, torch.as_tensor(idx, device=device), :] = blocks[r][:, : idx.size, :]
+            idx = plan.l_idx[r]
+            out.index_copy_(1, idx, blocks[r][:, : idx.numel(), :].to(device))
         return out, full
     dist.gather(buf, None, dst=0)
     return None, full
