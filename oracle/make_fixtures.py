@@ -108,6 +108,15 @@ def main():
             np.savez_compressed(os.path.join(GOLD, cfg + ".npz"), **out)
             print(cfg, {k: v.shape for k, v in out.items() if v.size > 1000})
             continue
+        if cfg == "ncdm3_st":
+            # BASELINE config 4 as the reference runs it: scalars + tensors in one run.  Only the totals at every integer l are kept
+            # (unlensed and lensed); the per-mode inputs and outputs are those of ncdm3 (scalars) and ncdm3_tens (tensors).
+            keep = {k: v for k, v in d.items() if k.startswith(("sp.cl_", "le.cl_")) and k not in ("sp.cl_table", "le.cl_lens")}
+            for k in ("sp.l_max_tot", "le.l_lensed_max"):
+                keep[k] = d[k]
+            np.savez_compressed(os.path.join(GOLD, cfg + ".npz"), **keep)
+            print(cfg, {k: v.shape for k, v in keep.items() if v.size > 10})
+            continue
         if cfg == "lcdm_taureio":
             # reionization given by its optical depth (bisection of th.cpp:2222-2318): only the thermodynamics outcome is kept
             # (scalars + every 40th row of the table), the cosmology is that of lcdm.ini

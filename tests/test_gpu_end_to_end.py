@@ -173,3 +173,51 @@ def test_other_cosmologies_gpu_vs_oracle(cosmo):
         assert np.max(np.abs(cl[:, idx] / ocl[:, idx] - 1)) < 3e-4
     assert np.max(np.abs(pk / opk - 1)) < 3e-4
     be.close()
+
+
+def test_config4_scalars_plus_tensors_with_three_massive_neutrinos():
+    """BASELINE configs[3] as the reference runs it (`modes = s,t`, three 0.06 eV species, lensing): one handle per mode on the
+    GPU (scalars: 6 wavefronts per k-mode; tensors: massless approximation), the per-mode C_l splined to every integer l and
+    summed, against the reference's total spectra (fixture ncdm3_st: totals only); then the lensed total."""
+    from classpp_public_amd.backend import Backend
+    ref = dict(np.load(__import__("os").path.join(__import__("os").path.dirname(__file__), "golden", "ncdm3_st.npz")))
+    lmax = int(ref["sp.l_max_tot"][0])
+    tot = {}
+    tables = {}
+    for cfg in ("ncdm3", "ncdm3_tens"):
+        inp = Inputs(cfg)
+        be = Backend(inp)
+        be.perturb_solve(want_sources=False)
+        cl = be.cl(be.transfer(None))
+        full = oracle_lib.cl_at_integer_l(inp, cl.cpu().numpy(), int(inp.l[-1]))   # (host post-processing: spline in l)
+        sp = inp.spectra
+        for name in ("tt", "ee", "te", "bb", "pp", "tp", "ep"):
+            idx = getattr(sp, "index_ct_" + name)
+            if idx >= 0:
+                acc = tot.setdefault(name, np.zeros(lmax + 1))
+                acc[: full.shape[1]] += full[idx]
+        tables[cfg] = (inp, be, cl, full)
+    for name in ("tt", "ee", "bb", "pp"):
+        want = ref["sp.cl_" + name]
+        sel = slice(2, lmax + 1) if name != "bb" else slice(2, int(tables["ncdm3_tens"][0].l[-1]) + 1)   # (unlensed BB is tensors only)
+        # BB: in the s,t run the tensor types live on the scalar multipole grid (tm.cpp:838-860), here on the grid of a tensors-only
+        # run; the two spline interpolations in l of the same smooth spectrum differ by up to 8e-3 near the end of the tensor range
+        assert np.max(np.abs(tot[name][sel] / want[sel] - 1)) < (1e-4 if name != "bb" else 1e-2), name
+    want = ref["sp.cl_te"]
+    assert np.max(np.abs(tot["te"][2:] - want[2:])) < 1e-4 * np.max(np.abs(want))
+    # lensed total: the summed spectra on the scalar multipole grid through the lensing kernels
+    inp, be, cl, _ = tables["ncdm3"]
+    d, sp = inp.d, inp.spectra
+    summed = cl.clone()
+    ls = torch.as_tensor(inp.l.astype(np.int64), device=summed.device)
+    for name in ("tt", "ee", "te", "bb"):
+        idx = getattr(sp, "index_ct_" + name)
+        summed[:, idx] = torch.as_tensor(tot[name][inp.l], device=summed.device)
+    got = be.lensed_cl(summed, int(d["le.l_unlensed_max"][0]), int(d["le.delta_l_max"][0])).cpu().numpy()
+    le_l = d["le.l"].astype(int)
+    sel = le_l <= int(ref["le.l_lensed_max"][0])
+    for name in ("tt", "ee", "bb"):
+        want = ref["le.cl_" + name][le_l[sel]]
+        assert np.max(np.abs(got[sel, getattr(sp, "index_ct_" + name)] / want - 1)) < (2e-4 if name != "bb" else 1e-2), name
+    for _, be_, _, _ in tables.values():
+        be_.close()
