@@ -351,3 +351,22 @@ def test_tensor_modes_with_massive_neutrinos():
     scale[scale == 0] = 1
     assert np.max(np.abs(tr[:, ls, :] - want) / scale) < 2e-4
     be.close()
+
+
+def test_perturb_error_paths(small):
+    """what the reference reports through class_test / ErrorMsg, through the C ABI: invalid arguments before any launch
+    (CPT_ERR_INVALID -> CptInputError), failures inside the kernel per mode (CPT_ERR_RUNTIME -> CptError with the mode's k)"""
+    from classpp_public_amd.backend import CptError, CptInputError
+    inp, be = small
+    with pytest.raises(CptInputError, match="division by zero"):
+        be.perturb_solve(k=np.array([1e-3, 0.0]))                       # pm.cpp:2524
+    with pytest.raises(CptInputError, match="strictly increasing"):
+        be.perturb_solve(tau=np.array([100., 90., 200.]))
+    with pytest.raises(CptInputError, match="exceeds the conformal age"):
+        be.perturb_solve(tau=np.array([100., 2. * inp.config.tau0]))
+    # a wavenumber so large that even the first line of the background table is too late to start it (pm.cpp:2562-2573)
+    with pytest.raises(CptError, match="too late for this k"):
+        be.perturb_solve(k=np.array([1e-3, 1e9]))
+    # the backend stays usable after a failed call
+    src, stats, status = be.perturb_solve(k=inp.k[::20])
+    assert not status.any() and np.all(np.isfinite(src.cpu().numpy()))
