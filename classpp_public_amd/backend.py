@@ -124,6 +124,13 @@ class Backend:
         self._check(self.lib.cpt_pk_linear(self.h, C.byref(self.inp.spectra), _dptr(k), k.size, C.c_void_p(out.data_ptr())))
         return out
 
+    def sigma(self, R, k=None, k_per_decade=80.0):
+        """sigma(R [Mpc]) of the linear matter field at z = 0 (cpt_sigma); sigma8 = sigma(8 / h)"""
+        k = np.ascontiguousarray(self.inp.k if k is None else k, dtype=np.float64)
+        out = C.c_double()
+        self._check(self.lib.cpt_sigma(self.h, C.byref(self.inp.spectra), _dptr(k), k.size, float(R), float(k_per_decade), C.byref(out)))
+        return out.value
+
     def get_sources(self, ntau, nk):
         out = torch.empty((self.inp.config.tp_size, ntau, nk), dtype=torch.float64, device=self.device)
         self._check(self.lib.cpt_get_sources(self.h, C.c_void_p(out.data_ptr())))

@@ -271,6 +271,12 @@ int cpt_cl_batch(cpt_handle* h, const cpt_spectra_params* sp, const double* tran
   return cpt_cl_impl(h, sp, transfer_dev, q, nq, nl, cl_dev);
 }
 
+int cpt_sigma(cpt_handle* h, const cpt_spectra_params* sp, const double* k, int nk, double R, double k_per_decade, double* sigma) {
+  if (!h) return CPT_ERR_INVALID;
+  if (!sp || !k || !sigma || nk < 3 || !(R >= 0.) || !(k_per_decade > 0.)) return cpt_fail(h, CPT_ERR_INVALID, "bad arguments to cpt_sigma");
+  return cpt_sigma_impl(h, sp, k, nk, R, k_per_decade, sigma);
+}
+
 int cpt_pk_linear(cpt_handle* h, const cpt_spectra_params* sp, const double* k, int nk, double* pk_dev) {
   if (!h) return CPT_ERR_INVALID;
   h->err.clear();

@@ -181,6 +181,77 @@ int cpt_cl_impl(cpt_handle* h, const cpt_spectra_params* sp, const double* trans
   return CPT_OK;
 }
 
+// sigma(R) = sqrt( 1/(2 pi^2) int dk k^2 P(k) W^2(kR) ): NonlinearModule::nonlinear_sigmas_at_z + nonlinear_sigmas
+// (source/nonlinear_module.cpp:926-963, 2041-2180): ln P splined in ln k (estimated end derivatives), integrand sampled
+// at k_per_decade points per decade, integrated over t = 1/(1+k) with the spline rule.
+static void spline_est_deriv(const double* x, const double* y, int n, double* dd) {   // tools/arrays.c:967-1092 / 261-353, EST_DERIV, one column
+  std::vector<double> u(n - 1);
+  const double dy_first = ((x[2] - x[0]) * (x[2] - x[0]) * (y[1] - y[0]) - (x[1] - x[0]) * (x[1] - x[0]) * (y[2] - y[0])) / ((x[2] - x[0]) * (x[1] - x[0]) * (x[2] - x[1]));
+  dd[0] = -0.5;
+  u[0] = (3. / (x[1] - x[0])) * ((y[1] - y[0]) / (x[1] - x[0]) - dy_first);
+  for (int i = 1; i < n - 1; i++) {
+    const double sig = (x[i] - x[i - 1]) / (x[i + 1] - x[i - 1]);
+    const double p = sig * dd[i - 1] + 2.0;
+    dd[i] = (sig - 1.0) / p;
+    u[i] = (y[i + 1] - y[i]) / (x[i + 1] - x[i]) - (y[i] - y[i - 1]) / (x[i] - x[i - 1]);
+    u[i] = (6.0 * u[i] / (x[i + 1] - x[i - 1]) - sig * u[i - 1]) / p;
+  }
+  const double dy_last = ((x[n - 3] - x[n - 1]) * (x[n - 3] - x[n - 1]) * (y[n - 2] - y[n - 1]) - (x[n - 2] - x[n - 1]) * (x[n - 2] - x[n - 1]) * (y[n - 3] - y[n - 1])) /
+                         ((x[n - 3] - x[n - 1]) * (x[n - 2] - x[n - 1]) * (x[n - 3] - x[n - 2]));
+  const double qn = 0.5, un = (3. / (x[n - 1] - x[n - 2])) * (dy_last - (y[n - 1] - y[n - 2]) / (x[n - 1] - x[n - 2]));
+  dd[n - 1] = (un - qn * u[n - 2]) / (qn * dd[n - 2] + 1.0);
+  for (int k = n - 2; k >= 0; k--) dd[k] = dd[k] * dd[k + 1] + u[k];
+}
+static double sigma_of_R(const double* kk, const double* pk, int nk, double R, double k_per_decade) {
+  const double PI = 3.1415926535897932384626433832795e0;
+  std::vector<double> lnk(nk), lnpk(nk), dd(nk);
+  for (int i = 0; i < nk; i++) { lnk[i] = log(kk[i]); lnpk[i] = log(pk[i]); }
+  spline_est_deriv(lnk.data(), lnpk.data(), nk, dd.data());
+  const int n = (int)(log(kk[nk - 1] / kk[0]) / log(10.) * k_per_decade) + 1;
+  std::vector<double> xs(n), ys(n), d2(n);
+  int last = 0;
+  for (int i = 0; i < n; i++) {
+    double k = kk[0] * pow(10., i / k_per_decade), p;
+    if (i == 0) p = exp(lnpk[0]);
+    else {   // array_interpolate_spline at ln k
+      const double v = log(k);
+      int inf = 0, sup = nk - 1;
+      while (sup - inf > 1) { const int mid = (int)(0.5 * (inf + sup)); if (v < lnk[mid]) sup = mid; else inf = mid; }
+      last = inf;
+      const double h = lnk[sup] - lnk[inf], b = (v - lnk[inf]) / h, a = 1 - b;
+      p = exp(a * lnpk[inf] + b * lnpk[sup] + ((a * a * a - a) * dd[inf] + (b * b * b - b) * dd[sup]) * h * h / 6.);
+    }
+    const double t = 1. / (1. + k);
+    if (i == (n - 1)) k *= 0.9999999;
+    const double x = k * R;
+    const double W = (x < 0.01) ? 1. - x * x / 10. : 3. / x / x / x * (sin(x) - x * cos(x));
+    xs[n - 1 - i] = t;
+    ys[n - 1 - i] = k * k * k * p * W * W / (t * (1. - t));
+  }
+  (void)last;
+  spline_est_deriv(xs.data(), ys.data(), n, d2.data());
+  double res = 0.;
+  for (int i = 0; i < n - 1; i++) {
+    const double h = xs[i + 1] - xs[i];
+    res += (ys[i] + ys[i + 1]) * h / 2. + (d2[i] + d2[i + 1]) * h * h * h / 24.;
+  }
+  return sqrt(res / (2. * PI * PI));
+}
+
+// host post-processing of the linear P(k): the device result is copied back (nk doubles) and integrated on the host
+int cpt_sigma_impl(cpt_handle* h, const cpt_spectra_params* sp, const double* k, int nk, double R, double k_per_decade, double* sigma) {
+  double* d_pk = nullptr;
+  CPT_HIP(h, hipMalloc((void**)&d_pk, nk * sizeof(double)));
+  int rc = cpt_pk_impl(h, sp, k, nk, d_pk);
+  std::vector<double> pk(nk);
+  if (!rc && hipMemcpy(pk.data(), d_pk, nk * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) rc = cpt_fail(h, CPT_ERR_NO_DEVICE, "hipMemcpy of P(k) failed");
+  (void)hipFree(d_pk);
+  if (rc) return rc;
+  for (int i = 0; i < nk; i++) if (!(pk[i] > 0.)) return cpt_fail(h, CPT_ERR_RUNTIME, "P(k) is not positive at k[%d]", i);
+  *sigma = sigma_of_R(k, pk.data(), nk, R, k_per_decade);
+  return CPT_OK;
+}
+
 int cpt_pk_impl(cpt_handle* h, const cpt_spectra_params* sp, const double* k, int nk, double* pk_dev) {
   const cpt_config& c = h->cfg;
   if (c.index_tp_delta_m < 0) return cpt_fail(h, CPT_ERR_INVALID, "P(k) requested but delta_m was not among the source types");

@@ -229,6 +229,10 @@ int cpt_cl_batch(cpt_handle* h, const cpt_spectra_params* sp, const double* tran
 /* linear matter power spectrum today P(k) = 2 pi^2/k^3 delta_m(k,tau0)^2 P_R(k) from the sources resident in the handle
  * (NonlinearModule::nonlinear_pk_linear, source/nonlinear_module.cpp:1886-2040); pk_dev device [nk]               */
 int cpt_pk_linear(cpt_handle* h, const cpt_spectra_params* sp, const double* k, int nk, double* pk_dev);
+/* sigma(R): rms of the linear density field in spheres of radius R [Mpc] at z = 0, e.g. sigma8 = sigma(8/h)
+ * (NonlinearModule::nonlinear_sigmas_at_z / nonlinear_sigmas, source/nonlinear_module.cpp:926-963, 2041-2180;
+ * k_per_decade: ppr->sigma_k_per_decade, default 80).  Needs resident sources with delta_m like cpt_pk_linear. */
+int cpt_sigma(cpt_handle* h, const cpt_spectra_params* sp, const double* k, int nk, double R, double k_per_decade, double* sigma);
 
 /* ---- CMB lensing of the C_l's (LensingModule::lensing_init, source/lensing_module.cpp:149-854) ----
  * precision parameters of include/precisions.h:492-495 plus SpectraModule::l_max_tot_ */

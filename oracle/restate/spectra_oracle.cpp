@@ -100,6 +100,67 @@ int orc_cl_at_integer_l(const int* l, int nl, int ct_size, const double* cl, int
   return 0;
 }
 
+// sigma(R) = sqrt( 1/(2 pi^2) int dk k^2 P(k) W^2(kR) ): NonlinearModule::nonlinear_sigmas_at_z + nonlinear_sigmas
+// (source/nonlinear_module.cpp:926-963, 2041-2180): ln P splined in ln k (estimated end derivatives), integrand sampled
+// at k_per_decade points per decade, integrated over t = 1/(1+k) with the spline rule.
+static void sigma_spline(const double* x, const double* y, int n, double* dd) {   // tools/arrays.c:967-1092 / 261-353, EST_DERIV, one column
+  std::vector<double> u(n - 1);
+  const double dy_first = ((x[2] - x[0]) * (x[2] - x[0]) * (y[1] - y[0]) - (x[1] - x[0]) * (x[1] - x[0]) * (y[2] - y[0])) / ((x[2] - x[0]) * (x[1] - x[0]) * (x[2] - x[1]));
+  dd[0] = -0.5;
+  u[0] = (3. / (x[1] - x[0])) * ((y[1] - y[0]) / (x[1] - x[0]) - dy_first);
+  for (int i = 1; i < n - 1; i++) {
+    const double sig = (x[i] - x[i - 1]) / (x[i + 1] - x[i - 1]);
+    const double p = sig * dd[i - 1] + 2.0;
+    dd[i] = (sig - 1.0) / p;
+    u[i] = (y[i + 1] - y[i]) / (x[i + 1] - x[i]) - (y[i] - y[i - 1]) / (x[i] - x[i - 1]);
+    u[i] = (6.0 * u[i] / (x[i + 1] - x[i - 1]) - sig * u[i - 1]) / p;
+  }
+  const double dy_last = ((x[n - 3] - x[n - 1]) * (x[n - 3] - x[n - 1]) * (y[n - 2] - y[n - 1]) - (x[n - 2] - x[n - 1]) * (x[n - 2] - x[n - 1]) * (y[n - 3] - y[n - 1])) /
+                         ((x[n - 3] - x[n - 1]) * (x[n - 2] - x[n - 1]) * (x[n - 3] - x[n - 2]));
+  const double qn = 0.5, un = (3. / (x[n - 1] - x[n - 2])) * (dy_last - (y[n - 1] - y[n - 2]) / (x[n - 1] - x[n - 2]));
+  dd[n - 1] = (un - qn * u[n - 2]) / (qn * dd[n - 2] + 1.0);
+  for (int k = n - 2; k >= 0; k--) dd[k] = dd[k] * dd[k + 1] + u[k];
+}
+static double sigma_func(const double* kk, const double* pk, int nk, double R, double k_per_decade) {
+  const double PI = 3.1415926535897932384626433832795e0;
+  std::vector<double> lnk(nk), lnpk(nk), dd(nk);
+  for (int i = 0; i < nk; i++) { lnk[i] = log(kk[i]); lnpk[i] = log(pk[i]); }
+  sigma_spline(lnk.data(), lnpk.data(), nk, dd.data());
+  const int n = (int)(log(kk[nk - 1] / kk[0]) / log(10.) * k_per_decade) + 1;
+  std::vector<double> xs(n), ys(n), d2(n);
+  int last = 0;
+  for (int i = 0; i < n; i++) {
+    double k = kk[0] * pow(10., i / k_per_decade), p;
+    if (i == 0) p = exp(lnpk[0]);
+    else {   // array_interpolate_spline at ln k
+      const double v = log(k);
+      int inf = 0, sup = nk - 1;
+      while (sup - inf > 1) { const int mid = (int)(0.5 * (inf + sup)); if (v < lnk[mid]) sup = mid; else inf = mid; }
+      last = inf;
+      const double h = lnk[sup] - lnk[inf], b = (v - lnk[inf]) / h, a = 1 - b;
+      p = exp(a * lnpk[inf] + b * lnpk[sup] + ((a * a * a - a) * dd[inf] + (b * b * b - b) * dd[sup]) * h * h / 6.);
+    }
+    const double t = 1. / (1. + k);
+    if (i == (n - 1)) k *= 0.9999999;
+    const double x = k * R;
+    const double W = (x < 0.01) ? 1. - x * x / 10. : 3. / x / x / x * (sin(x) - x * cos(x));
+    xs[n - 1 - i] = t;
+    ys[n - 1 - i] = k * k * k * p * W * W / (t * (1. - t));
+  }
+  (void)last;
+  sigma_spline(xs.data(), ys.data(), n, d2.data());
+  double res = 0.;
+  for (int i = 0; i < n - 1; i++) {
+    const double h = xs[i + 1] - xs[i];
+    res += (ys[i] + ys[i + 1]) * h / 2. + (d2[i] + d2[i + 1]) * h * h * h / 24.;
+  }
+  return sqrt(res / (2. * PI * PI));
+}
+int orc_sigma(const double* k, const double* pk, int nk, double R, double k_per_decade, double* sigma) {
+  *sigma = sigma_func(k, pk, nk, R, k_per_decade);
+  return 0;
+}
+
 int orc_pk(const cpt_spectra_params* s, const double* k, int nk, const double* delta_m_today, double* pk) {
   const double PI = 3.1415926535897932384626433832795e0;
   for (int i = 0; i < nk; i++) pk[i] = 2. * PI * PI / (k[i] * k[i] * k[i]) * delta_m_today[i] * delta_m_today[i] * primordial(*s, k[i]);

@@ -181,3 +181,13 @@ def lensing(inp, cl, l_unlensed_max, delta_l_max=500, accurate=0, num_mu_minus_l
     assert L.orc_lensing(C.byref(inp.spectra), iptr(l), l.size, dptr(cl), l_unlensed_max, delta_l_max, accurate,
                          num_mu_minus_lmax, tol_gl, dptr(out)) == 0
     return out
+
+
+def sigma(k, pk, R, k_per_decade=80.0):
+    """sigma(R) from a tabulated linear P(k) (oracle/restate/spectra_oracle.cpp: orc_sigma)"""
+    L = lib()
+    L.orc_sigma.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int, C.c_double, C.c_double, C.POINTER(C.c_double)]
+    out = C.c_double()
+    k = np.ascontiguousarray(k, dtype=np.float64); pk = np.ascontiguousarray(pk, dtype=np.float64)
+    assert L.orc_sigma(dptr(k), dptr(pk), k.size, float(R), float(k_per_decade), C.byref(out)) == 0
+    return out.value

@@ -52,6 +52,9 @@ def test_cl_and_pk_match_reference(cfg):
         err = np.max(np.abs(pk / d["nl.pk_lin_z0"] - 1))
         worst["pk"] = err
         assert err < tol, err
+        s8 = be.sigma(8. / float(d["pba.h"][0]))   # host post-processing of the device P(k) (cpt_sigma)
+        worst["sigma8"] = abs(s8 / float(d["nl.sigma8"][0]) - 1)
+        assert worst["sigma8"] < tol, (s8, float(d["nl.sigma8"][0]))
     print("\n[%s] max errors vs reference: %s" % (cfg, ", ".join("%s %.1e" % kv for kv in worst.items())))
     be.close()
 

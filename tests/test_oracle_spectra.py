@@ -38,3 +38,13 @@ def test_pk_from_reference_delta_m():
     # the reference tabulates ln P on the same k grid (nonlinear_module.cpp:1886-2040): exp(log()) round trip only
     assert np.allclose(d["nl.k"], inp.k, rtol=1e-14)
     assert np.max(np.abs(pk / d["nl.pk_lin_z0"] - 1)) < 1e-12
+
+
+@pytest.mark.parametrize("cfg", ["lcdm", "small", "ncdm"])
+def test_sigma8_matches_reference(cfg):
+    """sigma(8 Mpc/h) from the reference's own linear P(k) (nonlinear_module.cpp:926-963, 2041-2180) == its sigma8_"""
+    inp = Inputs(cfg)
+    d = inp.d
+    h = float(d["pba.h"][0])
+    got = oracle_lib.sigma(d["nl.k"], d["nl.pk_lin_z0"], 8. / h)
+    assert abs(got / float(d["nl.sigma8"][0]) - 1) < 1e-12
