@@ -35,7 +35,7 @@ def density_parameters(h, omega_b, omega_cdm, Omega_k=0.0, N_ur=3.046, T_cmb=2.7
     Omega0_g = (4. * sigma_B / c * T_cmb ** 4) / (3. * c * c * 1.e10 * h * h / Mpc / Mpc / 8. / np.pi / G)
     Omega0_ur = N_ur * 7. / 8. * (4. / 11.) ** (4. / 3.) * Omega0_g
     Omega0_b, Omega0_cdm = omega_b / h / h, omega_cdm / h / h
-    Omega0_lambda = 1. - Omega_k - Omega0_g - Omega0_ur - Omega0_b - Omega0_cdm
+    Omega0_lambda = 1. - Omega_k - (((Omega0_g + Omega0_b) + Omega0_ur) + Omega0_cdm)   # same accumulation order (Omega_tot, :725-874, 1238)
     K = -Omega_k * H0 ** 2
     return {"H0": H0, "h": h, "T_cmb": T_cmb, "Omega0_g": Omega0_g, "Omega0_ur": Omega0_ur, "Omega0_b": Omega0_b, "Omega0_cdm": Omega0_cdm,
             "Omega0_lambda": Omega0_lambda, "Omega0_k": Omega_k, "K": K, "sgnK": 0 if K == 0 else (1 if K > 0 else -1)}
@@ -48,10 +48,13 @@ class ParameterInputs(Inputs):
     `YHe`, `z_reio` / `tau_reio` and `A_s`, `n_s` replace its cosmological parameters - any LambdaCDM + massless-neutrino
     cosmology runs, not just the fixtures' ones."""
 
-    def __init__(self, name, golden_dir=GOLDEN, cosmology=None, YHe=None, z_reio=None, tau_reio=None, A_s=None, n_s=None):
+    def __init__(self, name, golden_dir=GOLDEN, cosmology=None, YHe=None, z_reio=None, tau_reio=None, A_s=None, n_s=None, params=None, ini=None):
+        """params / ini: the parameter entries and the (YHe, z_reio | tau_reio, l_max_tensors) strings given directly (classy.py)
+        instead of the committed <name>.npz / <name>.ini"""
         self.name = name
-        self.d = dict(np.load(os.path.join(golden_dir, name + ".npz")))
-        ini = read_ini(os.path.join(golden_dir, name + ".ini"))
+        self.d = dict(params) if params is not None else dict(np.load(os.path.join(golden_dir, name + ".npz")))
+        ini = dict(ini) if ini is not None else read_ini(os.path.join(golden_dir, name + ".ini"))
+        self._params_given = params is not None
         if cosmology is not None:
             for k, v in density_parameters(**cosmology).items():
                 self.d["pba." + k] = np.array([v], dtype=np.int32 if k == "sgnK" else np.float64)
@@ -85,7 +88,7 @@ class ParameterInputs(Inputs):
         tables.update(hostlib.thermodynamics(self, cp, tp))
         if ncdm is not None:
             tables.update(ncdm)
-        super().__init__(name, golden_dir, tables=tables)
+        super().__init__(name, golden_dir, tables=tables, params=self.d if self._params_given else None)
         self.l_tensor_max = int(ini["l_max_tensors"]) if "l_max_tensors" in ini else None
         if A_s is not None:
             self.spectra.A_s = A_s
