@@ -117,6 +117,18 @@ def main():
             np.savez_compressed(os.path.join(GOLD, cfg + ".npz"), **keep)
             print(cfg, {k: v.shape for k, v in keep.items() if v.size > 10})
             continue
+        if cfg.startswith("sc_"):
+            # classy-level scenarios (tests/test_classy.py): what a user of the reference's Python wrapper reads, nothing else
+            keep = {k: v for k, v in d.items() if k.startswith(("sp.cl_", "le.cl_")) and k not in ("sp.cl_table", "le.cl_lens")}
+            for k in ("sp.l_max_tot", "le.l_lensed_max", "nl.pk_lin_z0", "nl.sigma8", "pt.k", "pba.h"):
+                if k in d:
+                    keep[k] = d[k]
+            for k in ("th.z_reionization", "th.tau_reionization", "th.z_rec", "th.rs_rec", "th.ra_rec", "bg.age", "bg.conformal_age", "bg.Neff", "bg.Omega0_m"):
+                if k in tables:
+                    keep[k] = np.atleast_1d(tables[k])
+            np.savez_compressed(os.path.join(GOLD, cfg + ".npz"), **keep)
+            print(cfg, {k: v.shape for k, v in keep.items() if v.size > 10})
+            continue
         if cfg == "lcdm_taureio":
             # reionization given by its optical depth (bisection of th.cpp:2222-2318): only the thermodynamics outcome is kept
             # (scalars + every 40th row of the table), the cosmology is that of lcdm.ini
