@@ -88,7 +88,7 @@ def test_perturb_small_all_modes(small):
     print("\n[small] perturb kernel %.3f ms for %d modes, %d steps" % (ms, inp.nk, gs))
 
 
-@pytest.mark.parametrize("cfg", ["lcdm", "explanatory", "iso_cdi", "iso_nid", "newt", "ncdm", "ncdm3"])
+@pytest.mark.parametrize("cfg", ["lcdm", "explanatory", "iso_cdi", "iso_nid", "newt", "ncdm", "ncdm3", "ncdm_k3000"])
 def test_perturb_full_size(cfg):
     """BASELINE configs 1-2: every k-mode integrated on the GPU; the 16 golden columns are compared with the reference."""
     from classpp_public_amd.backend import Backend

@@ -90,7 +90,7 @@ def test_thermodynamics_errors():
         hostlib.thermodynamics(inp, tp=tp)
 
 
-@pytest.mark.parametrize("cfg", ["small", "lcdm", "curved", "open", "tens", "tens_curved", "ncdm_small", "ncdm", "ncdm3", "ncdm3_tens"])
+@pytest.mark.parametrize("cfg", ["small", "lcdm", "curved", "open", "tens", "tens_curved", "ncdm_small", "ncdm", "ncdm3", "ncdm3_tens", "ncdm_k3000"])
 def test_parameter_inputs_reproduce_the_fixture_inputs(cfg):
     """classpp_public_amd/pipeline.py: tables and grids computed on the host from parameters alone == what the reference handed over"""
     from classpp_public_amd.pipeline import ParameterInputs

@@ -8,7 +8,7 @@ from classpp_public_amd.inputs import Inputs
 
 
 @pytest.mark.parametrize("cfg", ["small", "lcdm", "explanatory", "newt", "iso_cdi", "tens", "curved", "open", "curved_full", "tens_curved",
-                                 "ncdm_small", "ncdm", "ncdm3", "ncdm3_tens"])
+                                 "ncdm_small", "ncdm", "ncdm3", "ncdm3_tens", "ncdm_k3000"])
 def test_grids_bit_exact(cfg):
     """scalars and tensors (pm.cpp:2007-2105: linear grid only, l_tensor_max), flat / open / closed space (k_min of pm.cpp:1677-1691,
     integer-nu q grid of tm.cpp:1003-1040), massive neutrinos (same builders, other cosmology)"""
