@@ -2383,11 +2383,18 @@ int cpt_perturb_impl(cpt_handle* h, const double* k, int nk, const double* tau, 
     const int cpw = 64 / (c.l_max_ncdm + 1), nw = (h->ncdm.nchains + cpw - 1) / cpw;
     if (nw > NCW_MAX)
       return cpt_fail(h, CPT_ERR_UNSUPPORTED, "%d ncdm momentum bins need %d chain wavefronts per k-mode (at most %d)", h->ncdm.nchains, nw, NCW_MAX);
+    // register budget: a launch with more k-modes than one per CU can hold at a time (3 - 4 wavefronts x 512 registers fill a CU)
+    // is throughput-bound, and two workgroups per CU at 256 registers finish sooner than one at 512; few modes (a k-shard of
+    // an 8-GPU run, the default samplings) are latency-bound and keep the whole register file.  CPT_NCDM_WAVES_PER_SIMD = 1 | 2 overrides.
+    int n_cu = 256;
+    hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, h->device);
+    bool half_regs = nw > 3 || nk > 3 * n_cu;
+    if (const char* e = getenv("CPT_NCDM_WAVES_PER_SIMD")) half_regs = nw > 3 || atoi(e) >= 2;
     if (c.K != 0.) {
-      if (nw <= 3) hipLaunchKernelGGL((k_perturb_ncdm<1, 3>), dim3(nk), dim3(64 * (1 + nw)), 0, h->stream, P);
+      if (!half_regs) hipLaunchKernelGGL((k_perturb_ncdm<1, 3>), dim3(nk), dim3(64 * (1 + nw)), 0, h->stream, P);
       else hipLaunchKernelGGL((k_perturb_ncdm<1, NCW_MAX>), dim3(nk), dim3(64 * (1 + nw)), 0, h->stream, P);
     } else {
-      if (nw <= 3) hipLaunchKernelGGL((k_perturb_ncdm<0, 3>), dim3(nk), dim3(64 * (1 + nw)), 0, h->stream, P);
+      if (!half_regs) hipLaunchKernelGGL((k_perturb_ncdm<0, 3>), dim3(nk), dim3(64 * (1 + nw)), 0, h->stream, P);
       else hipLaunchKernelGGL((k_perturb_ncdm<0, NCW_MAX>), dim3(nk), dim3(64 * (1 + nw)), 0, h->stream, P);
     }
   } else
