@@ -90,12 +90,16 @@ def build_parameters(pars, mode):
 
     # ---- background budget (input_module.cpp:593-603, 702, 786, 1191)
     h = num("h", 0.67556) if "H0" not in pars else num("H0", 67.556) / 100.
-    omega_b = num("omega_b", 0.022032) if "Omega_b" not in pars else num("Omega_b", 0.) * h * h
-    omega_cdm = num("omega_cdm", 0.12038) if "Omega_cdm" not in pars else num("Omega_cdm", 0.) * h * h
     N_ur = num("N_ur", 3.046) if "N_eff" not in pars else num("N_eff", 3.046)
-    if h <= 0 or omega_b <= 0 or omega_cdm < 0 or N_ur < 0:
+    gauge = str(pars.get("gauge", "synchronous")).strip().lower()
+    if gauge not in ("synchronous", "newtonian"):
+        raise CosmoSevereError("gauge: synchronous or newtonian")
+    opt = lambda key: num(key, 0.) if key in pars else None
+    dens = density_parameters(h, opt("omega_b"), opt("omega_cdm"), num("Omega_k", 0.), N_ur, num("T_cmb", 2.7255),
+                              Omega_b=opt("Omega_b"), Omega_cdm=opt("Omega_cdm"), gauge_synchronous=(gauge == "synchronous"))
+    omega_b = dens["Omega0_b"] * h * h
+    if h <= 0 or dens["Omega0_b"] <= 0 or dens["Omega0_cdm"] < 0 or N_ur < 0:
         raise CosmoSevereError("h and omega_b must be positive, omega_cdm and N_ur non-negative")
-    dens = density_parameters(h, omega_b, omega_cdm, num("Omega_k", 0.), N_ur, num("T_cmb", 2.7255))
     d = {}
     for k, v in dens.items():
         d["pba." + k] = _arr(v, integer=(k == "sgnK"))
@@ -114,7 +118,7 @@ def build_parameters(pars, mode):
     ini = {}
     if "YHe" in pars and str(pars["YHe"]).strip().upper() != "BBN":
         ini["YHe"] = repr(num("YHe", 0.))
-    elif omega_b == 0.022032 and N_ur == 3.046:
+    elif abs(omega_b / 0.022032 - 1.) < 1e-12 and N_ur == 3.046:
         ini["YHe"] = "0.2452539925130077"   # what the reference's BBN interpolation returns at its default (omega_b, N_ur)
     else:
         raise CosmoSevereError("YHe = BBN needs the reference's BBN table, which is not part of this package: give YHe as a number")
@@ -136,9 +140,6 @@ def build_parameters(pars, mode):
     tens = mode == "t"
     if tens and not (has_t or has_p):
         raise CosmoSevereError("tensor modes need tCl or pCl in output")
-    gauge = str(pars.get("gauge", "synchronous")).strip().lower()
-    if gauge not in ("synchronous", "newtonian"):
-        raise CosmoSevereError("gauge: synchronous or newtonian")
     ppr_delta_l_max = int(num("delta_l_max", 500))
     d["ppt.gauge"] = _arr(1 if gauge == "synchronous" else 0, True)
     d["ppt.has_scalars"] = _arr(int(not tens), True); d["ppt.has_tensors"] = _arr(int(tens), True)

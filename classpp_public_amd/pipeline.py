@@ -26,7 +26,7 @@ def read_ini(path):
     return out
 
 
-def density_parameters(h, omega_b, omega_cdm, Omega_k=0.0, N_ur=3.046, T_cmb=2.7255):
+def density_parameters(h, omega_b=None, omega_cdm=None, Omega_k=0.0, N_ur=3.046, T_cmb=2.7255, Omega_b=None, Omega_cdm=None, gauge_synchronous=True):
     """The budget equation of the reference's input module for LambdaCDM + massless neutrinos (source/input_module.cpp:593-603, 702,
     786, 1191 and the closure Omega_Lambda = 1 - Omega_k - sum): -> dict of the struct background entries the host modules read."""
     c, G, k_B, h_P, Mpc = 2.99792458e8, 6.67428e-11, 1.3806504e-23, 6.62606896e-34, 3.085677581282e22
@@ -34,7 +34,12 @@ def density_parameters(h, omega_b, omega_cdm, Omega_k=0.0, N_ur=3.046, T_cmb=2.7
     H0 = h * 1.e5 / c
     Omega0_g = (4. * sigma_B / c * T_cmb ** 4) / (3. * c * c * 1.e10 * h * h / Mpc / Mpc / 8. / np.pi / G)
     Omega0_ur = N_ur * 7. / 8. * (4. / 11.) ** (4. / 3.) * Omega0_g
-    Omega0_b, Omega0_cdm = omega_b / h / h, omega_cdm / h / h
+    # baryons / cdm: Omega or omega as given; when neither is, the default *Omega0* stays (0.022032 / 0.12038 over the default h squared,
+    # :3191-3192, whatever h is), and a vanishing cdm density is raised to Omega0_cdm_min_synchronous in the synchronous gauge (:872)
+    Omega0_b = Omega_b if Omega_b is not None else (omega_b / h / h if omega_b is not None else 0.022032 / (0.67556 * 0.67556))
+    Omega0_cdm = Omega_cdm if Omega_cdm is not None else (omega_cdm / h / h if omega_cdm is not None else 0.12038 / (0.67556 * 0.67556))
+    if gauge_synchronous and Omega0_cdm == 0.:
+        Omega0_cdm = 1.e-10
     Omega0_lambda = 1. - Omega_k - (((Omega0_g + Omega0_b) + Omega0_ur) + Omega0_cdm)   # same accumulation order (Omega_tot, :725-874, 1238)
     K = -Omega_k * H0 ** 2
     return {"H0": H0, "h": h, "T_cmb": T_cmb, "Omega0_g": Omega0_g, "Omega0_ur": Omega0_ur, "Omega0_b": Omega0_b, "Omega0_cdm": Omega0_cdm,
