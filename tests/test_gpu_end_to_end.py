@@ -84,17 +84,17 @@ def test_cl_quadrature_weights_match_sequential_spline(cfg):
     be.close()
 
 
-def test_sharded_pieces_on_the_gpu_match_the_single_rank_result():
-    """The multi-GPU step (classpp_public_amd/sharded.py; its exchanges are covered on CPU by tests/test_sharded_gloo.py) asks the HIP
+@pytest.mark.parametrize("cfg,world", [("small", 2), ("small", 8), ("lcdm", 8)])
+def test_sharded_pieces_on_the_gpu_match_the_single_rank_result(cfg, world):
+    """(lcdm, 8 = the shapes of the driver's 8-GPU scaling run: 4 529 k-modes, 13 multipoles per rank.)  The multi-GPU step (classpp_public_amd/sharded.py; its exchanges are covered on CPU by tests/test_sharded_gloo.py) asks the HIP
     backend for k subsets r::N of a densified grid and for multipole subsets r::N.  Here the two ranks' pieces are computed one after
     the other on the one GPU, assembled by hand, and compared with the single-rank result: sources bit for bit (k-modes are
     independent units), transfer functions to round-off (multipoles are independent units)."""
     from classpp_public_amd.backend import Backend
     from classpp_public_amd.sharded import GpuCompute, densify_k, shard_indices
-    inp = Inputs("small")
+    inp = Inputs(cfg)
     be = Backend(inp)
     comp = GpuCompute(be)
-    world = 2
     k_all = densify_k(inp.k, world)
     k_size_cl = (inp.k_size_cl - 1) * world + 1
     assert k_all.size == (inp.nk - 1) * world + 1 and k_all[k_size_cl - 1] == inp.k[inp.k_size_cl - 1]
