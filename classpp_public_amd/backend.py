@@ -52,6 +52,12 @@ class Backend:
         except Exception:
             pass
 
+    def _fence(self):
+        """The library runs on its own non-blocking HIP stream (cpt_api.hip) and returns with that stream drained.  Device buffers
+        handed to it may still be in flight on torch's side (an RCCL all_gather and the index_copy_ that assembles the full sources,
+        a freshly recycled block of the caching allocator): drain torch's current stream before every entry point."""
+        torch.cuda.current_stream(self.device).synchronize()
+
     def _check(self, rc):
         if rc != capi.CPT_OK:
             msg = self.lib.cpt_last_error(self.h).decode()
@@ -70,6 +76,7 @@ class Backend:
             ptr = C.c_void_p(out.data_ptr())
         stats = (CptStepstat * nk)()
         status = np.zeros(nk, dtype=np.int32)
+        self._fence()
         rc = self.lib.cpt_perturb_solve_batch(self.h, _dptr(k), nk, _dptr(tau), ntau, ptr, stats, _iptr(status))
         self._check(rc)
         return out, stats, status
@@ -89,6 +96,7 @@ class Backend:
             assert tuple(sources.shape) == (self.inp.config.tp_size, tau.size, k.size), sources.shape
             sp = C.c_void_p(sources.data_ptr())
         out = torch.empty((self.inp.config.tt_size, l.size, q.size), dtype=torch.float64, device=self.device)
+        self._fence()
         rc = self.lib.cpt_transfer_batch(self.h, sp, _dptr(k), k.size, k_size_cl, _dptr(tau), tau.size, _dptr(q), q.size,
                                          _iptr(l), l.size, C.c_void_p(out.data_ptr()))
         self._check(rc)
@@ -100,6 +108,7 @@ class Backend:
         q = np.ascontiguousarray(self.inp.q if q is None else q, dtype=np.float64)
         nl = transfer.shape[1]
         out = torch.empty((nl, self.inp.spectra.ct_size), dtype=torch.float64, device=self.device)
+        self._fence()
         self._check(self.lib.cpt_cl_batch(self.h, C.byref(self.inp.spectra), C.c_void_p(transfer.data_ptr()), _dptr(q), q.size, nl,
                                           C.c_void_p(out.data_ptr())))
         return out
@@ -114,6 +123,7 @@ class Backend:
         if n < 1:
             raise CptInputError("cpt_lensing_l_size failed")
         out = torch.empty((n, self.inp.spectra.ct_size), dtype=torch.float64, device=self.device)
+        self._fence()
         self._check(self.lib.cpt_lensing_batch(self.h, C.byref(self.inp.spectra), C.byref(lp), lptr, l.size, C.c_void_p(cl.data_ptr()),
                                                C.c_void_p(out.data_ptr())))
         return out
@@ -121,6 +131,7 @@ class Backend:
     def pk_linear(self, k=None):
         k = np.ascontiguousarray(self.inp.k if k is None else k, dtype=np.float64)
         out = torch.empty(k.size, dtype=torch.float64, device=self.device)
+        self._fence()
         self._check(self.lib.cpt_pk_linear(self.h, C.byref(self.inp.spectra), _dptr(k), k.size, C.c_void_p(out.data_ptr())))
         return out
 
@@ -128,11 +139,13 @@ class Backend:
         """sigma(R [Mpc]) of the linear matter field at z = 0 (cpt_sigma); sigma8 = sigma(8 / h)"""
         k = np.ascontiguousarray(self.inp.k if k is None else k, dtype=np.float64)
         out = C.c_double()
+        self._fence()
         self._check(self.lib.cpt_sigma(self.h, C.byref(self.inp.spectra), _dptr(k), k.size, float(R), float(k_per_decade), C.byref(out)))
         return out.value
 
     def get_sources(self, ntau, nk):
         out = torch.empty((self.inp.config.tp_size, ntau, nk), dtype=torch.float64, device=self.device)
+        self._fence()
         self._check(self.lib.cpt_get_sources(self.h, C.c_void_p(out.data_ptr())))
         return out
 

@@ -18,6 +18,10 @@
  *     ownership of caller memory.
  *   - a handle is bound to the HIP device current at cpt_create(); calls on one handle must be serialised by the
  *     caller (the reference's module constructors are single-caller too, source/cosmology.cpp:16-86).
+ *   - streams: every handle owns one non-blocking HIP stream; each entry point enqueues there and returns with that stream
+ *     drained, so outputs are complete on return.  Device INPUT buffers must be complete before the call: a caller that
+ *     produced them on another stream (an RCCL collective, a framework's stream) synchronises that stream first
+ *     (classpp_public_amd/backend.py::Backend._fence does exactly that for torch).
  *   - there is NO CPU fallback: without a usable HIP device every compute entry point fails with CPT_ERR_NO_DEVICE.
  */
 #ifndef CPT_H
