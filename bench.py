@@ -144,8 +144,12 @@ def main():
             pk = be.pk_linear() if has_pk else None
             return cl, pk
         out, _ = sharded_step(comp, k_all, inp.l, rank, world, device, k_size_cl, exchange_device=xdev)
-        if rank == 0:
-            return be.cl(out), None
+        if rank == 0:   # the same closing steps as on one GPU: C_l (+ lensing), P(k) from the gathered sources now resident in the handle
+            cl = be.cl(out)
+            if has_lensing:
+                cl = be.lensed_cl(cl, *lens_args)
+            pk = be.pk_linear(k=k_all) if has_pk else None
+            return cl, pk
         return None, None
 
     for _ in range(args.warmup):
