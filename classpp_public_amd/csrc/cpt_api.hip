@@ -244,7 +244,7 @@ int cpt_perturb_solve_batch(cpt_handle* h, const double* k, int nk, const double
                             double* sources_dev, cpt_stepstat* stats, int* status) {
   if (!h) return CPT_ERR_INVALID;
   h->err.clear();
-  if (!k || !tau_sampling || nk < 1 || ntau < 2) return cpt_fail(h, CPT_ERR_INVALID, "bad k / tau_sampling arguments");
+  if (!k || !tau_sampling || nk < 1 || ntau < 2) return cpt_fail(h, CPT_ERR_INVALID, "bad k / tau_sampling arguments: at least one k-mode and two sampling times (the last one ends the integration)");
   return cpt_perturb_impl(h, k, nk, tau_sampling, ntau, sources_dev, stats, status);
 }
 

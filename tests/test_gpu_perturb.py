@@ -370,3 +370,50 @@ def test_perturb_error_paths(small):
     # the backend stays usable after a failed call
     src, stats, status = be.perturb_solve(k=inp.k[::20])
     assert not status.any() and np.all(np.isfinite(src.cpu().numpy()))
+
+
+def test_perturb_ragged_and_empty_inputs(small):
+    """one k-mode, one sample time, an empty batch: the shapes at the edges of the batched entry point"""
+    from classpp_public_amd.backend import CptInputError
+    inp, be = small
+    full, _, _ = be.perturb_solve()
+    full = full.cpu().numpy()
+    one, stats, status = be.perturb_solve(k=inp.k[7:8])
+    assert one.shape == (inp.config.tp_size, inp.tau.size, 1) and not status.any()
+    assert np.array_equal(one.cpu().numpy()[:, :, 0], full[:, :, 7])          # k-modes are independent units: bit for bit
+    last, _, status = be.perturb_solve(k=inp.k[::9], tau=inp.tau[-2:])
+    assert last.shape == (inp.config.tp_size, 2, inp.k[::9].size) and not status.any()
+    ref = full[:, -2:, ::9]
+    assert np.max(np.abs(last.cpu().numpy() - ref)) <= 1e-4 * np.max(np.abs(ref))   # (other start of the sampling, same integration)
+    with pytest.raises(CptInputError, match="at least"):
+        be.perturb_solve(k=np.zeros(0))
+    with pytest.raises(CptInputError, match="at least"):
+        be.perturb_solve(tau=inp.tau[-1:])
+    src, _, status = be.perturb_solve(k=inp.k[:3])                               # still usable
+    assert not status.any()
+
+
+def test_perturb_is_linear_in_the_initial_amplitude_at_full_size():
+    """size-independent property at BASELINE's full size: the system is linear, so doubling the primordial curvature doubles every
+    source function - up to the step control, which is not scale-free (absolute floor 1e-15 of the error weights, ev.cpp:367-374:
+    the high multipoles start below it), i.e. within the band two valid step sequences differ by (check_sources)"""
+    from classpp_public_amd.backend import Backend
+    inp = Inputs("lcdm")
+    be = Backend(inp)
+    s1, st1, status = be.perturb_solve()
+    assert not status.any()
+    s1 = s1.cpu().numpy()
+    be.close()
+    inp2 = Inputs("lcdm")
+    inp2.config.curvature_ini = 2.0 * inp.config.curvature_ini
+    be2 = Backend(inp2)
+    s2, st2, status = be2.perturb_solve()
+    assert not status.any()
+    s2 = s2.cpu().numpy()
+    be2.close()
+    n1, n2 = sum(s.steps for s in st1), sum(s.steps for s in st2)
+    assert abs(n1 - n2) < 0.02 * n1
+    c = inp.config
+    for tp, tol in ((c.index_tp_t0, 1e-2), (c.index_tp_t1, 1e-2), (c.index_tp_t2, 5e-4), (c.index_tp_p, 5e-4), (c.index_tp_delta_m, 3e-5)):
+        scale = np.max(np.abs(s1[tp]), axis=0, keepdims=True)
+        assert np.max(np.abs(0.5 * s2[tp] - s1[tp]) / scale) < tol, tp   # (t0: 5.5e-3 measured = two step sequences of the same tolerance)
