@@ -128,19 +128,20 @@ class Backend:
                                                C.c_void_p(out.data_ptr())))
         return out
 
-    def pk_linear(self, k=None):
+    def pk_linear(self, k=None, cb=False):
+        """linear P(k) today of total matter, or of baryons + cold dark matter (cb=True, with non-cold species)"""
         k = np.ascontiguousarray(self.inp.k if k is None else k, dtype=np.float64)
         out = torch.empty(k.size, dtype=torch.float64, device=self.device)
         self._fence()
-        self._check(self.lib.cpt_pk_linear(self.h, C.byref(self.inp.spectra), _dptr(k), k.size, C.c_void_p(out.data_ptr())))
+        self._check((self.lib.cpt_pk_cb_linear if cb else self.lib.cpt_pk_linear)(self.h, C.byref(self.inp.spectra), _dptr(k), k.size, C.c_void_p(out.data_ptr())))
         return out
 
-    def sigma(self, R, k=None, k_per_decade=80.0):
+    def sigma(self, R, k=None, k_per_decade=80.0, cb=False):
         """sigma(R [Mpc]) of the linear matter field at z = 0 (cpt_sigma); sigma8 = sigma(8 / h)"""
         k = np.ascontiguousarray(self.inp.k if k is None else k, dtype=np.float64)
         out = C.c_double()
         self._fence()
-        self._check(self.lib.cpt_sigma(self.h, C.byref(self.inp.spectra), _dptr(k), k.size, float(R), float(k_per_decade), C.byref(out)))
+        self._check((self.lib.cpt_sigma_cb if cb else self.lib.cpt_sigma)(self.h, C.byref(self.inp.spectra), _dptr(k), k.size, float(R), float(k_per_decade), C.byref(out)))
         return out.value
 
     def get_sources(self, ntau, nk):

@@ -274,14 +274,27 @@ int cpt_cl_batch(cpt_handle* h, const cpt_spectra_params* sp, const double* tran
 int cpt_sigma(cpt_handle* h, const cpt_spectra_params* sp, const double* k, int nk, double R, double k_per_decade, double* sigma) {
   if (!h) return CPT_ERR_INVALID;
   if (!sp || !k || !sigma || nk < 3 || !(R >= 0.) || !(k_per_decade > 0.)) return cpt_fail(h, CPT_ERR_INVALID, "bad arguments to cpt_sigma");
-  return cpt_sigma_impl(h, sp, k, nk, R, k_per_decade, sigma);
+  return cpt_sigma_impl(h, sp, k, nk, R, k_per_decade, sigma, 0);
+}
+
+int cpt_sigma_cb(cpt_handle* h, const cpt_spectra_params* sp, const double* k, int nk, double R, double k_per_decade, double* sigma) {
+  if (!h) return CPT_ERR_INVALID;
+  if (!sp || !k || !sigma || nk < 3 || !(R >= 0.) || !(k_per_decade > 0.)) return cpt_fail(h, CPT_ERR_INVALID, "bad arguments to cpt_sigma_cb");
+  return cpt_sigma_impl(h, sp, k, nk, R, k_per_decade, sigma, 1);
 }
 
 int cpt_pk_linear(cpt_handle* h, const cpt_spectra_params* sp, const double* k, int nk, double* pk_dev) {
   if (!h) return CPT_ERR_INVALID;
   h->err.clear();
   if (!sp || !k || !pk_dev || nk < 1) return cpt_fail(h, CPT_ERR_INVALID, "bad arguments to cpt_pk_linear");
-  return cpt_pk_impl(h, sp, k, nk, pk_dev);
+  return cpt_pk_impl(h, sp, k, nk, pk_dev, 0);
+}
+
+int cpt_pk_cb_linear(cpt_handle* h, const cpt_spectra_params* sp, const double* k, int nk, double* pk_dev) {
+  if (!h) return CPT_ERR_INVALID;
+  h->err.clear();
+  if (!sp || !k || !pk_dev || nk < 1) return cpt_fail(h, CPT_ERR_INVALID, "bad arguments to cpt_pk_cb_linear");
+  return cpt_pk_impl(h, sp, k, nk, pk_dev, 1);
 }
 
 int cpt_lensing_l_size(const int* l, int nl, const cpt_lensing_params* lp) {

@@ -130,8 +130,8 @@ int cpt_perturb_impl(cpt_handle* h, const double* k, int nk, const double* tau_s
                      cpt_stepstat* stats, int* status);
 int cpt_cl_impl(cpt_handle* h, const cpt_spectra_params* sp, const double* transfer_dev, const double* q, int nq, int nl,
                 double* cl_dev);
-int cpt_pk_impl(cpt_handle* h, const cpt_spectra_params* sp, const double* k, int nk, double* pk_dev);
-int cpt_sigma_impl(cpt_handle* h, const cpt_spectra_params* sp, const double* k, int nk, double R, double k_per_decade, double* sigma);
+int cpt_pk_impl(cpt_handle* h, const cpt_spectra_params* sp, const double* k, int nk, double* pk_dev, int cb);
+int cpt_sigma_impl(cpt_handle* h, const cpt_spectra_params* sp, const double* k, int nk, double R, double k_per_decade, double* sigma, int cb);
 int cpt_dbg_lookup_impl(cpt_handle* h, const double* tau, int n, double* out);
 int cpt_dbg_derivs_impl(cpt_handle* h, double k, double tau, int tca_on, int rsa_on, int ufa_on, const double* y,
                         double* dy, int* neq);

@@ -239,10 +239,10 @@ static double sigma_of_R(const double* kk, const double* pk, int nk, double R, d
 }
 
 // host post-processing of the linear P(k): the device result is copied back (nk doubles) and integrated on the host
-int cpt_sigma_impl(cpt_handle* h, const cpt_spectra_params* sp, const double* k, int nk, double R, double k_per_decade, double* sigma) {
+int cpt_sigma_impl(cpt_handle* h, const cpt_spectra_params* sp, const double* k, int nk, double R, double k_per_decade, double* sigma, int cb) {
   double* d_pk = nullptr;
   CPT_HIP(h, hipMalloc((void**)&d_pk, nk * sizeof(double)));
-  int rc = cpt_pk_impl(h, sp, k, nk, d_pk);
+  int rc = cpt_pk_impl(h, sp, k, nk, d_pk, cb);
   std::vector<double> pk(nk);
   if (!rc && hipMemcpy(pk.data(), d_pk, nk * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) rc = cpt_fail(h, CPT_ERR_NO_DEVICE, "hipMemcpy of P(k) failed");
   (void)hipFree(d_pk);
@@ -252,15 +252,18 @@ int cpt_sigma_impl(cpt_handle* h, const cpt_spectra_params* sp, const double* k,
   return CPT_OK;
 }
 
-int cpt_pk_impl(cpt_handle* h, const cpt_spectra_params* sp, const double* k, int nk, double* pk_dev) {
+// cb: the baryon + cold dark matter spectrum P_cb (delta_cb source, only defined with non-cold species; nonlinear_module.cpp:1749-1760, 1952-1991)
+int cpt_pk_impl(cpt_handle* h, const cpt_spectra_params* sp, const double* k, int nk, double* pk_dev, int cb) {
   const cpt_config& c = h->cfg;
-  if (c.index_tp_delta_m < 0) return cpt_fail(h, CPT_ERR_INVALID, "P(k) requested but delta_m was not among the source types");
+  const int tp = cb ? c.index_tp_delta_cb : c.index_tp_delta_m;
+  if (cb && !c.has_ncdm) return cpt_fail(h, CPT_ERR_INVALID, "P_cb(k) is only defined with non-cold species (has_pk_cb, nonlinear_module.cpp:1749)");
+  if (tp < 0) return cpt_fail(h, CPT_ERR_INVALID, "P(k) requested but %s was not among the source types", cb ? "delta_cb" : "delta_m");
   if (!h->d_src || h->src_nk != nk) return cpt_fail(h, CPT_ERR_INVALID, "no resident sources for %d k-modes: run cpt_perturb_solve_batch first", nk);
   int rc;
   if ((rc = cpt_reserve(h, &h->d_k, &h->grid_cap_k, (size_t)4 * nk))) return rc;
   CPT_HIP(h, hipMemcpyAsync(h->d_k, k, nk * sizeof(double), hipMemcpyHostToDevice, h->stream));
   hipLaunchKernelGGL(k_pk, dim3((nk + 63) / 64), dim3(64), 0, h->stream, h->d_src, h->d_k, pk_dev, nk, h->src_ntau,
-                     c.index_tp_delta_m, sp->A_s, sp->n_s, sp->alpha_s, sp->k_pivot);
+                     tp, sp->A_s, sp->n_s, sp->alpha_s, sp->k_pivot);
   CPT_HIP(h, hipGetLastError());
   CPT_HIP(h, hipStreamSynchronize(h->stream));
   return CPT_OK;

@@ -237,6 +237,10 @@ int cpt_pk_linear(cpt_handle* h, const cpt_spectra_params* sp, const double* k, 
  * (NonlinearModule::nonlinear_sigmas_at_z / nonlinear_sigmas, source/nonlinear_module.cpp:926-963, 2041-2180;
  * k_per_decade: ppr->sigma_k_per_decade, default 80).  Needs resident sources with delta_m like cpt_pk_linear. */
 int cpt_sigma(cpt_handle* h, const cpt_spectra_params* sp, const double* k, int nk, double R, double k_per_decade, double* sigma);
+/* the same two for baryons + cold dark matter only, P_cb(k) and sigma_cb(R), from the delta_cb source: defined when non-cold species
+ * are present (NonlinearModule has_pk_cb_ / index_pk_cb_, source/nonlinear_module.cpp:1749-1760; classy pk_cb, sigma8_cb)           */
+int cpt_pk_cb_linear(cpt_handle* h, const cpt_spectra_params* sp, const double* k, int nk, double* pk_dev);
+int cpt_sigma_cb(cpt_handle* h, const cpt_spectra_params* sp, const double* k, int nk, double R, double k_per_decade, double* sigma);
 
 /* ---- CMB lensing of the C_l's (LensingModule::lensing_init, source/lensing_module.cpp:149-854) ----
  * precision parameters of include/precisions.h:492-495 plus SpectraModule::l_max_tot_ */

@@ -310,6 +310,13 @@ static int do_dump(const char* ini, const char* outpath) {
     for (int i = 0; i < nkk; i++) pk[i] = exp(lnpk[i]);
     put_f8("nl.k", kk.data(), {nkk}); put_f8("nl.pk_lin_z0", pk.data(), {nkk});
     put_d("nl.sigma8", nl->sigma8_[nl->index_pk_m_]);
+    if (nl->has_pk_cb_) {   // baryons + cold dark matter only (defined with non-cold species)
+      st = nl->nonlinear_pk_at_z(logarithmic, pk_linear, 0., nl->index_pk_cb_, lnpk.data(), lnpk_ic.data());
+      if (st != _SUCCESS_) { fprintf(stderr, "nonlinear_pk_at_z (cb) failed: %s\n", nl->error_message_); return 1; }
+      for (int i = 0; i < nkk; i++) pk[i] = exp(lnpk[i]);
+      put_f8("nl.pk_cb_lin_z0", pk.data(), {nkk});
+      put_d("nl.sigma8_cb", nl->sigma8_[nl->index_pk_cb_]);
+    }
   }
   fclose(g_out);
   return 0;

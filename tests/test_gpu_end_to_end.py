@@ -55,6 +55,15 @@ def test_cl_and_pk_match_reference(cfg):
         s8 = be.sigma(8. / float(d["pba.h"][0]))   # host post-processing of the device P(k) (cpt_sigma)
         worst["sigma8"] = abs(s8 / float(d["nl.sigma8"][0]) - 1)
         assert worst["sigma8"] < tol, (s8, float(d["nl.sigma8"][0]))
+        if "nl.pk_cb_lin_z0" in d:   # baryons + cdm only (cpt_pk_cb_linear / cpt_sigma_cb; NonlinearModule index_pk_cb_)
+            worst["pk_cb"] = np.max(np.abs(be.pk_linear(cb=True).cpu().numpy() / d["nl.pk_cb_lin_z0"] - 1))
+            worst["sigma8_cb"] = abs(be.sigma(8. / float(d["pba.h"][0]), cb=True) / float(d["nl.sigma8_cb"][0]) - 1)
+            assert worst["pk_cb"] < tol and worst["sigma8_cb"] < tol
+            assert np.max(be.pk_linear(cb=True).cpu().numpy() / pk - 1) > 5e-3        # (and it is a different spectrum: more power at high k)
+        elif not inp.config.has_ncdm:
+            from classpp_public_amd.backend import CptInputError
+            with pytest.raises(CptInputError, match="non-cold|delta_cb"):
+                be.pk_linear(cb=True)
     print("\n[%s] max errors vs reference: %s" % (cfg, ", ".join("%s %.1e" % kv for kv in worst.items())))
     be.close()
 

@@ -48,3 +48,12 @@ def test_sigma8_matches_reference(cfg):
     h = float(d["pba.h"][0])
     got = oracle_lib.sigma(d["nl.k"], d["nl.pk_lin_z0"], 8. / h)
     assert abs(got / float(d["nl.sigma8"][0]) - 1) < 1e-12
+
+
+@pytest.mark.parametrize("cfg", ["ncdm", "ncdm3"])
+def test_sigma8_cb_matches_reference(cfg):
+    """baryons + cold dark matter only (has_pk_cb with non-cold species): the same window integral on the reference's P_cb"""
+    d = Inputs(cfg).d
+    got = oracle_lib.sigma(d["nl.k"], d["nl.pk_cb_lin_z0"], 8. / float(d["pba.h"][0]))
+    assert abs(got / float(d["nl.sigma8_cb"][0]) - 1) < 1e-12
+    assert float(d["nl.sigma8_cb"][0]) > float(d["nl.sigma8"][0])     # free-streaming species cluster less than cdm + baryons
