@@ -2187,7 +2187,10 @@ static __device__ __forceinline__ void body_perturb(const PtParams& P) {
   }
 #ifdef CPT_PROFILE
   prof[7] = clock64() - t_begin;
-  if (lane == 0 && blockIdx.x == 0 && C.wave == 0)  // the heaviest mode = the critical path
+#ifndef CPT_PROFILE_WAVE
+#define CPT_PROFILE_WAVE 0   // which wavefront of the workgroup reports (1...: a chain wave of the ncdm kernel)
+#endif
+  if (lane == 0 && blockIdx.x == 0 && C.wave == CPT_PROFILE_WAVE)  // the heaviest mode = the critical path
     for (int i = 0; i < 16; i++) g_prof[i] = prof[i];
 #endif
   if (lane == 0 && C.wave == 0) {
