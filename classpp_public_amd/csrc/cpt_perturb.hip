@@ -159,8 +159,19 @@ __device__ inline double fast_sqrt(double x) {
 // NDF constants (ev.cpp:87-88, 171-174) as immediates: no private arrays, no scratch
 __device__ inline double ndf_G(int i) { return i == 0 ? 1.0 : i == 1 ? 1.5 : i == 2 ? 11.0 / 6.0 : i == 3 ? 25.0 / 12.0 : 137.0 / 60.0; }
 __device__ inline double ndf_alpha(int i) { return i == 0 ? -37.0 / 200 : i == 1 ? -1.0 / 9.0 : i == 2 ? -8.23e-2 : i == 3 ? -4.15e-2 : 0.; }
-__device__ inline double ndf_invGa(int i) { return 1.0 / (ndf_G(i) * (1.0 - ndf_alpha(i))); }
-__device__ inline double ndf_erconst(int i) { return ndf_alpha(i) * ndf_G(i) + 1.0 / (2.0 + i); }
+// (1 / (G (1 - alpha)) and alpha G + 1 / (k + 2): folded at compile time with the same IEEE arithmetic - a run-time division on every step otherwise)
+constexpr double ndf_G_c(int i) { return i == 0 ? 1.0 : i == 1 ? 1.5 : i == 2 ? 11.0 / 6.0 : i == 3 ? 25.0 / 12.0 : 137.0 / 60.0; }
+constexpr double ndf_alpha_c(int i) { return i == 0 ? -37.0 / 200 : i == 1 ? -1.0 / 9.0 : i == 2 ? -8.23e-2 : i == 3 ? -4.15e-2 : 0.; }
+constexpr double ndf_invGa_c(int i) { return 1.0 / (ndf_G_c(i) * (1.0 - ndf_alpha_c(i))); }
+constexpr double ndf_erconst_c(int i) { return ndf_alpha_c(i) * ndf_G_c(i) + 1.0 / (2.0 + i); }
+__device__ inline double ndf_invGa(int i) {
+  constexpr double c0 = ndf_invGa_c(0), c1 = ndf_invGa_c(1), c2 = ndf_invGa_c(2), c3 = ndf_invGa_c(3), c4 = ndf_invGa_c(4);
+  return i == 0 ? c0 : i == 1 ? c1 : i == 2 ? c2 : i == 3 ? c3 : c4;
+}
+__device__ inline double ndf_erconst(int i) {
+  constexpr double c0 = ndf_erconst_c(0), c1 = ndf_erconst_c(1), c2 = ndf_erconst_c(2), c3 = ndf_erconst_c(3), c4 = ndf_erconst_c(4), c5 = ndf_erconst_c(5);
+  return i == 0 ? c0 : i == 1 ? c1 : i == 2 ? c2 : i == 3 ? c3 : i == 4 ? c4 : c5;
+}
 
 enum Role : int {
   R_NONE = 0, R_DELTA_G, R_THETA_G, R_SHEAR_G, R_LG /* l>=3 photon temperature */, R_POL /* l>=0 polarisation */,
