@@ -566,8 +566,8 @@ static __device__ __forceinline__ void lookup(const PtParams& P, Lookup& Q, doub
   {
     const double x0 = bcast(Q.bgx, inf - Q.bg_base), x1 = bcast(Q.bgx, inf - Q.bg_base + 1);
     const double h = x1 - x0, b = (tau - x0) * fast_rcp(h), a = 1. - b;
-    Q.vbg = spl2(Q.bg_lo, Q.bg_hi, a, b, h * h / 6.);
-    if (NCDM) Q.vnc = spl2(Q.nc_lo, Q.nc_hi, a, b, h * h / 6.);
+    Q.vbg = spl2(Q.bg_lo, Q.bg_hi, a, b, h * h * (1.0 / 6.0));
+    if (NCDM) Q.vnc = spl2(Q.nc_lo, Q.nc_hi, a, b, h * h * (1.0 / 6.0));
   }
   LK_MARK(12)   // background: window, rows, spline
   const double bg_a = bcast(Q.vbg, BG_A), bg_H = bcast(Q.vbg, BG_H), bg_Hp = bcast(Q.vbg, BG_HP);
@@ -600,7 +600,7 @@ static __device__ __forceinline__ void lookup(const PtParams& P, Lookup& Q, doub
     }
     const double x0 = bcast(Q.thx, iz - Q.th_base), x1 = bcast(Q.thx, iz - Q.th_base + 1);
     const double h = x1 - x0, b = (z - x0) * fast_rcp(h), a = 1. - b;
-    Q.vth = spl2(Q.th_lo, Q.th_hi, a, b, h * h / 6.);
+    Q.vth = spl2(Q.th_lo, Q.th_hi, a, b, h * h * (1.0 / 6.0));
     Q.kap = bcast(Q.vth, TH_DKAPPA); Q.ddkappa = bcast(Q.vth, TH_DDKAPPA); Q.cb2 = bcast(Q.vth, TH_CB2);
   }
   LK_MARK(14)   // thermodynamics: window, rows, spline, broadcasts
@@ -1509,7 +1509,7 @@ static __device__ __forceinline__ int ndf15(const PtParams& P, const Layout& L, 
                                      double inv_k2, int ik, double t0, double tfinal, double& y_io, Stat& st, int lane,
                                      int& budget, double* jac_lds, unsigned long long* prof) {
   PROF_DECL;
-  const double eps = 1e-16, threshold = 1e-15, rtol = P.rtol;
+  const double eps = 1e-16, threshold = 1e-15, rtol = P.rtol, inv_rtol = 1.0 / rtol;
   const int maxit = 4, maxk = 5;
   // (idle lanes carry y = dy = dif = 0 and identity rows: they drop out of every norm by themselves)
   const double* ts = P.tau_s;
@@ -1678,7 +1678,6 @@ static __device__ __forceinline__ int ndf15(const PtParams& P, const Layout& L, 
       abshlast = absh;
       nconhk = min(nconhk + 1, maxk + 2);
       if (nconhk >= kk + 2) {
-        const double inv_rtol = 1.0 / rtol;  // loop invariant
         double temp = 1.2 * fast_root(err * inv_rtol, kk + 1);
         double hopt = temp > 0.1 ? absh * fast_rcp(temp) : 10 * absh;
         int kopt = kk;
@@ -1713,7 +1712,7 @@ static __device__ __forceinline__ int ndf15(const PtParams& P, const Layout& L, 
       if (fabs(absh - hmin) < 100 * eps) { if (at_hmin) absh = abshlast; at_hmin = true; } else at_hmin = false;
       h = absh;
       if (1.1 * absh >= fabs(tfinal - t)) { h = tfinal - t; absh = fabs(h); done = true; }
-      if (((fabs(absh - abshlast) / absh) > 1e-6) || (kk != klast)) {
+      if ((fabs(absh - abshlast) > 1e-6 * absh) || (kk != klast)) {   // (ev.cpp:318: |dh| / h > 1e-6, without the division)
         adjust_stepsize(dif, absh / abshlast, kk);
         hinvGak = h * ndf_invGa(kk - 1);
         nconhk = 0;
