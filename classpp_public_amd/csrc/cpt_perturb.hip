@@ -29,6 +29,7 @@ struct PtParams {
   DevTables tabs;
   // config scalars
   int has_cdm, has_ur, tca_method, rsa_method, ufa_method, l_max_g, l_max_pol_g, l_max_ur;
+  int rows;                    // scalars: every tail fits a 16-lane row of its own (lanes 16.., 32.., 48..) => log-depth tail solves
   double T_cmb, a_today, YHe, n_e, tau_free_streaming;
   double K;  // spatial curvature (pba->K); 0 in flat space
   int gauge;                   // CPT_GAUGE_NEWTONIAN / CPT_GAUGE_SYNCHRONOUS
@@ -76,6 +77,15 @@ template <int N>
 __device__ inline double row_shr0(double v) {
   const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x110 + N, 0xf, 0xf, false);
   const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x110 + N, 0xf, 0xf, false);
+  int l2 = lo, h2 = hi;
+  asm volatile("" : "+v"(l2), "+v"(h2));
+  return __hiloint2double(h2, l2);
+}
+// DPP row_shl:n: value of lane + n of the same row, 0 beyond the row
+template <int N>
+__device__ inline double row_shl0(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x100 + N, 0xf, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x100 + N, 0xf, 0xf, false);
   int l2 = lo, h2 = hi;
   asm volatile("" : "+v"(l2), "+v"(h2));
   return __hiloint2double(h2, l2);
@@ -228,7 +238,7 @@ struct SampleMsg {
   int it, flags, done;      // sample index; approximation scheme (tca | rsa<<1 | ufa<<2); done: the mode is finished
 };
 
-template <int GAUGE, int CURV, int MODE, int NCDM = 0>
+template <int GAUGE, int CURV, int MODE, int NCDM = 0, int ROWS = 0>
 struct PT {
 static constexpr bool SAMPLER = (NCDM == 0);
 // Lane map.  One lane per equation of pm.cpp:3302-3481, at a FIXED lane whatever the approximation scheme: the (at most
@@ -249,6 +259,11 @@ static constexpr int LN_ND = NC - 2, LN_NT = NC - 1;   // (NCDM only) auxiliary 
 // l = 4 multipoles of photons and ur, so the core holds every ladder up to l = 4 and the tails start at l = 5.
 enum TLane : int { TL_DG = 0, TL_TG, TL_SG, TL_G3, TL_G4, TL_P0, TL_P1, TL_P2, TL_P3, TL_P4, TL_DUR, TL_TUR, TL_SUR, TL_U3, TL_U4, TL_GW, TL_GWD };
 static constexpr int LFIRST = MODE ? 5 : 3;   // multipole of the first element of a tail
+// ROWS: scalars without non-cold species whose three tails each fit a 16-lane row (the host decides, PtParams::rows): tail of the
+// photon temperature on lanes 16.., polarisation 32.., ur 48.., and the tail solves become four-level cyclic reductions on row
+// DPP instead of 2 x maxlen dependent sweeps.  (Not for the ncdm kernels: their 256-register build cannot afford the eight
+// extra doubles per lane - three species 142 -> 165 ms - and the one-species kernel gains nothing, its critical path is elsewhere.)
+static constexpr bool PCR = (ROWS != 0) && (MODE == 0) && (NCDM == 0);
 
 struct Layout {
   int tca, rsa, ufa, nfa;
@@ -273,6 +288,7 @@ static __device__ __forceinline__ Layout make_layout(const PtParams& P, int tca,
   }
   L.lmg = P.l_max_g; L.lmp = P.l_max_pol_g; L.lmu = P.l_max_ur;
   L.g3 = NC; L.q3 = L.g3 + (P.l_max_g - 2); L.u3 = L.q3 + (P.l_max_pol_g - 2);
+  if (PCR) { L.g3 = 16; L.q3 = 32; L.u3 = 48; }   // one tail per 16-lane row: the tail solves are cyclic reductions on row DPP
   const bool hi = !rsa && !tca;
   L.gN = hi ? P.l_max_g - 2 : 0;
   L.qN = hi ? P.l_max_pol_g - 2 : 0;
@@ -1284,6 +1300,7 @@ struct LuReg {
   double g;        // tail lanes: c_l / d'_{l+1}, the downward-sweep multiplier (0 on the l_max element and on core lanes)
   double r;        // tail lanes: a_l / d'_l, the upward-sweep multiplier
   double cpar;     // core parents of a tail: coupling to the tail's l=3 element (0 elsewhere)
+  double al[4], ga[4];   // (PCR) cyclic reduction of the tails (one per row): multipliers of the neighbours at distance 1, 2, 4, 8
 };
 
 template <int N>
@@ -1297,6 +1314,25 @@ static __device__ __forceinline__ double reg_get(const double (&a)[N], int i) {
 // (NCDM) the rows of the two auxiliary unknowns u_D, u_T (lanes LN_ND, LN_NT) read, after the chains are eliminated,
 //   u_D - alpha_D1 dmc - alpha_D2 dms = sum_chains w_D [T^-1 r]_0     with dmc = sum_j gmc_j x_j, dms = sum_j gms_j x_j
 // where gmc_j / gms_j are the responses of (metric_continuity, metric_shear) to unit core variable j (al[] = the four alphas)
+// b <- the right-hand side after the four reduction levels (u = b * rinv solves T u = b on every tail at once)
+static __device__ __forceinline__ double pcr_apply(const LuReg& F, int maxlen, double b) {
+  if (maxlen > 1) b = fma(-F.al[0], row_shr0<1>(b), fma(-F.ga[0], row_shl0<1>(b), b));
+  if (maxlen > 2) b = fma(-F.al[1], row_shr0<2>(b), fma(-F.ga[1], row_shl0<2>(b), b));
+  if (maxlen > 4) b = fma(-F.al[2], row_shr0<4>(b), fma(-F.ga[2], row_shl0<4>(b), b));
+  if (maxlen > 8) b = fma(-F.al[3], row_shr0<8>(b), fma(-F.ga[3], row_shl0<8>(b), b));
+  return b;
+}
+template <int S>
+static __device__ __forceinline__ void pcr_level(double& a, double& c, double& d, double& al, double& ga) {
+  const double dm = row_shr0<S>(d), dq = row_shl0<S>(d);
+  const double am = row_shr0<S>(a), cm = row_shr0<S>(c), aq = row_shl0<S>(a), cq = row_shl0<S>(c);
+  al = (a != 0.) ? a * fast_rcp(dm) : 0.;   // (a = 0 where the neighbour does not exist: never 0 * inf)
+  ga = (c != 0.) ? c * fast_rcp(dq) : 0.;
+  d = fma(-al, cm, fma(-ga, aq, d));
+  a = -al * am;
+  c = -ga * cq;
+}
+
 static __device__ __forceinline__ bool factorise(const LaneEq& e, const Jac& J, double hg, int maxlen, int lane, LuReg& F,
                                                  const double* al = nullptr, double gmc = 0., double gms = 0.) {
   lane = opaque(lane);
@@ -1305,7 +1341,24 @@ static __device__ __forceinline__ bool factorise(const LaneEq& e, const Jac& J, 
   const double a = chain ? -hg * e.A : 0.;             // coefficient of x_{l-1} in row l
   const double c = (chain && !e.last) ? hg * e.B : 0.; // coefficient of x_{l+1}
   const double d = 1.0 - hg * J.jdiag;
-  double dp = d, r = 0.;
+  double r;
+  if (PCR) {
+    // T (tridiagonal inside each tail; the first element's a couples to the core parent and stays outside)
+    double ta = (chain && !e.first) ? a : 0., tc = c, td = chain ? d : 1.;
+#pragma unroll
+    for (int i = 0; i < 4; i++) F.al[i] = F.ga[i] = 0.;
+    if (maxlen > 1) pcr_level<1>(ta, tc, td, F.al[0], F.ga[0]);
+    if (maxlen > 2) pcr_level<2>(ta, tc, td, F.al[1], F.ga[1]);
+    if (maxlen > 4) pcr_level<4>(ta, tc, td, F.al[2], F.ga[2]);
+    if (maxlen > 8) pcr_level<8>(ta, tc, td, F.al[3], F.ga[3]);
+    const double rinv = fast_rcp(td);
+    F.rinv = chain ? rinv : 0.;
+    // v = T^-1 (a_first e_first): what a unit core parent sends into its tail
+    r = pcr_apply(F, maxlen, (chain && e.first) ? a : 0.) * F.rinv;
+    F.r = r; F.g = 0.;
+  } else {
+  double dp = d;
+  r = 0.;
   for (int s = 0; s < maxlen; s++) {
     r = a * fast_rcp(dp);
     const double r_up = lane_above(r);
@@ -1316,6 +1369,7 @@ static __device__ __forceinline__ bool factorise(const LaneEq& e, const Jac& J, 
   const double rinv_up = lane_above(rinv);
   F.rinv = chain ? rinv : 0.; F.r = chain ? r : 0.;
   F.g = c * rinv_up;
+  }
   // ---- core: A_cc = I - hg J_cc, Schur-corrected on the diagonal of the parents of the tails ----
   const double cpar = hg * e.Bpar;               // row parent, column l3:  -hg * (-B);  0 on every other lane
   F.cpar = cpar;
@@ -1376,10 +1430,14 @@ static __device__ __forceinline__ double lu_solve(const LaneEq& e, const LuReg& 
   lane = opaque(lane);
   const int chain = opaque(e.chain);
   // 1. tails, downward sweep: b'_l = b_l - (c_l / d'_{l+1}) b'_{l+1}; the l_max element is final at once
-  double bp = b;
-  for (int s = 1; s < maxlen; s++) bp = fma(-F.g, lane_above(bp), b);
-  // 2. core right-hand side: parents of the tails see b'_3 / d'_3
-  const double u = bp * F.rinv;                       // 0 on core lanes
+  double u;
+  if (PCR) u = pcr_apply(F, maxlen, chain ? b : 0.) * F.rinv;   // T^-1 b on every tail lane, 0 on core lanes
+  else {
+    double bp = b;
+    for (int s = 1; s < maxlen; s++) bp = fma(-F.g, lane_above(bp), b);
+    // 2. core right-hand side: parents of the tails see b'_3 / d'_3
+    u = bp * F.rinv;                       // 0 on core lanes
+  }
   const double t3 = gather(u, e.first_addr);          // executed by every lane
   const double bc = fma(-F.cpar, t3, b);
   // 3. core solve with the register-resident factors (idle rows / lanes >= NC are identity rows: x = b there)
@@ -1400,10 +1458,14 @@ static __device__ __forceinline__ double lu_solve(const LaneEq& e, const LuReg& 
   // 4. tails, upward sweep: x_l = b'_l / d'_l - (a_l / d'_l) x_{l-1}; the l=3 element takes x_{l-1} from its core parent
   if (maxlen > 0) {
     const double xpar = gather(x, e.parent_addr);
-    const double u0 = e.first ? fma(-F.r, xpar, u) : u;
-    const double rr = e.first ? 0. : F.r;
-    double xt = u0;
-    for (int s = 1; s < maxlen; s++) xt = fma(-rr, lane_below(xt), u0);
+    double xt;
+    if (PCR) xt = fma(-F.r, xpar, u);              // x_t = T^-1 b_t - x_parent T^-1 (a_first e_first)
+    else {
+      const double u0 = e.first ? fma(-F.r, xpar, u) : u;
+      const double rr = e.first ? 0. : F.r;
+      xt = u0;
+      for (int s = 1; s < maxlen; s++) xt = fma(-rr, lane_below(xt), u0);
+    }
     if (chain) x = xt;
   }
   return x;
@@ -2300,22 +2362,22 @@ static __device__ __forceinline__ void body_dbg_solve(const PtParams& P, double 
 
 };  // struct PT<GAUGE>
 
-template <int GAUGE, int CURV, int MODE>
-__global__ void __launch_bounds__(128) k_perturb(PtParams P) { PT<GAUGE, CURV, MODE>::body_perturb(P); }   // integrator wave + sampler wave
+template <int GAUGE, int CURV, int MODE, int ROWS>
+__global__ void __launch_bounds__(128) k_perturb(PtParams P) { PT<GAUGE, CURV, MODE, 0, ROWS>::body_perturb(P); }   // integrator wave + sampler wave
 // scalars with non-cold species: 1 + NW wavefronts per k-mode (synchronous gauge)
 // (two register budgets: up to 3 chain waves every wave has a SIMD - and its whole register file - to itself; beyond that two
 //  waves share a SIMD and the kernel is compiled for half the registers)
 template <int CURV, int NW>
 __global__ void __launch_bounds__(64 * (1 + NW)) k_perturb_ncdm(PtParams P) { PT<CPT_GAUGE_SYNCHRONOUS, CURV, 0, 1>::body_perturb(P); }
-template <int GAUGE, int CURV, int MODE>
-__global__ void __launch_bounds__(64) k_dbg_lookup(PtParams P, const double* tau, int n, double* out) { PT<GAUGE, CURV, MODE>::body_dbg_lookup(P, tau, n, out); }
-template <int GAUGE, int CURV, int MODE>
+template <int GAUGE, int CURV, int MODE, int ROWS>
+__global__ void __launch_bounds__(64) k_dbg_lookup(PtParams P, const double* tau, int n, double* out) { PT<GAUGE, CURV, MODE, 0, ROWS>::body_dbg_lookup(P, tau, n, out); }
+template <int GAUGE, int CURV, int MODE, int ROWS>
 __global__ void __launch_bounds__(64) k_dbg_derivs(PtParams P, double k, double tau, int tca, int rsa, int ufa, const double* y, double* dy, int* neq) {
-  PT<GAUGE, CURV, MODE>::body_dbg_derivs(P, k, tau, tca, rsa, ufa, y, dy, neq);
+  PT<GAUGE, CURV, MODE, 0, ROWS>::body_dbg_derivs(P, k, tau, tca, rsa, ufa, y, dy, neq);
 }
-template <int GAUGE, int CURV, int MODE>
+template <int GAUGE, int CURV, int MODE, int ROWS>
 __global__ void __launch_bounds__(64) k_dbg_solve(PtParams P, double k, double tau, int tca, int rsa, int ufa, double hg, const double* b, double* x) {
-  PT<GAUGE, CURV, MODE>::body_dbg_solve(P, k, tau, tca, rsa, ufa, hg, b, x);
+  PT<GAUGE, CURV, MODE, 0, ROWS>::body_dbg_solve(P, k, tau, tca, rsa, ufa, hg, b, x);
 }
 
 void fill_params(const cpt_handle* h, PtParams& P) {
@@ -2340,21 +2402,30 @@ void fill_params(const cpt_handle* h, PtParams& P) {
   P.tol_ncdm_w = c.has_ncdm ? c.tol_ncdm_initial_w : 1e300; P.tp_dcb = c.has_ncdm ? c.index_tp_delta_cb : -1;
   P.nc = h->ncdm;
   P.max_steps = 400000;
+  // one tail per 16-lane row when each fits (defaults: 10 / 8 / 15 lanes), else the packed lane map with sequential sweeps
+  P.rows = (c.mode == CPT_MODE_SCALARS && !c.has_ncdm && c.l_max_g - 2 <= 16 && c.l_max_pol_g - 2 <= 16 && (!c.has_ur || c.l_max_ur - 2 <= 16)) ? 1 : 0;
+  if (const char* e = getenv("CPT_TAIL_ROWS")) P.rows = P.rows && atoi(e) != 0;
   P.k = nullptr; P.tau_s = nullptr; P.order = nullptr; P.nk = 0; P.ntau = 0; P.src = nullptr; P.stats = nullptr; P.status = nullptr;
 }
 
 // the four instantiations (gauge x curvature) behind one launch expression
-#define CPT_PT_DISPATCH(cfg, KERNEL, ...)                                                                         \
+#define CPT_PT_DISPATCH(cfg, rows, KERNEL, ...)                                                                   \
   do {                                                                                                            \
-    const bool newt__ = (cfg).gauge == CPT_GAUGE_NEWTONIAN, curv__ = (cfg).K != 0.;                               \
+    const bool newt__ = (cfg).gauge == CPT_GAUGE_NEWTONIAN, curv__ = (cfg).K != 0., rows__ = (rows) != 0;         \
     if ((cfg).mode == CPT_MODE_TENSORS) { /* the tensor equations are the same in both gauges */                  \
-      if (curv__) hipLaunchKernelGGL((KERNEL<CPT_GAUGE_SYNCHRONOUS, 1, 1>), __VA_ARGS__);                         \
-      else hipLaunchKernelGGL((KERNEL<CPT_GAUGE_SYNCHRONOUS, 0, 1>), __VA_ARGS__);                                \
+      if (curv__) hipLaunchKernelGGL((KERNEL<CPT_GAUGE_SYNCHRONOUS, 1, 1, 0>), __VA_ARGS__);                      \
+      else hipLaunchKernelGGL((KERNEL<CPT_GAUGE_SYNCHRONOUS, 0, 1, 0>), __VA_ARGS__);                             \
     }                                                                                                             \
-    else if (newt__ && curv__) hipLaunchKernelGGL((KERNEL<CPT_GAUGE_NEWTONIAN, 1, 0>), __VA_ARGS__);              \
-    else if (newt__) hipLaunchKernelGGL((KERNEL<CPT_GAUGE_NEWTONIAN, 0, 0>), __VA_ARGS__);                        \
-    else if (curv__) hipLaunchKernelGGL((KERNEL<CPT_GAUGE_SYNCHRONOUS, 1, 0>), __VA_ARGS__);                      \
-    else hipLaunchKernelGGL((KERNEL<CPT_GAUGE_SYNCHRONOUS, 0, 0>), __VA_ARGS__);                                  \
+    else if (rows__) { /* every tail in a 16-lane row of its own: log-depth tail solves */                        \
+      if (newt__ && curv__) hipLaunchKernelGGL((KERNEL<CPT_GAUGE_NEWTONIAN, 1, 0, 1>), __VA_ARGS__);              \
+      else if (newt__) hipLaunchKernelGGL((KERNEL<CPT_GAUGE_NEWTONIAN, 0, 0, 1>), __VA_ARGS__);                   \
+      else if (curv__) hipLaunchKernelGGL((KERNEL<CPT_GAUGE_SYNCHRONOUS, 1, 0, 1>), __VA_ARGS__);                 \
+      else hipLaunchKernelGGL((KERNEL<CPT_GAUGE_SYNCHRONOUS, 0, 0, 1>), __VA_ARGS__);                             \
+    }                                                                                                             \
+    else if (newt__ && curv__) hipLaunchKernelGGL((KERNEL<CPT_GAUGE_NEWTONIAN, 1, 0, 0>), __VA_ARGS__);           \
+    else if (newt__) hipLaunchKernelGGL((KERNEL<CPT_GAUGE_NEWTONIAN, 0, 0, 0>), __VA_ARGS__);                     \
+    else if (curv__) hipLaunchKernelGGL((KERNEL<CPT_GAUGE_SYNCHRONOUS, 1, 0, 0>), __VA_ARGS__);                   \
+    else hipLaunchKernelGGL((KERNEL<CPT_GAUGE_SYNCHRONOUS, 0, 0, 0>), __VA_ARGS__);                               \
   } while (0)
 
 }  // namespace
@@ -2413,7 +2484,7 @@ int cpt_perturb_impl(cpt_handle* h, const double* k, int nk, const double* tau, 
       else hipLaunchKernelGGL((k_perturb_ncdm<0, NCW_MAX>), dim3(nk), dim3(64 * (1 + nw)), 0, h->stream, P);
     }
   } else
-  CPT_PT_DISPATCH(c, k_perturb, dim3(nk), dim3(128), 0, h->stream, P);
+  CPT_PT_DISPATCH(c, P.rows, k_perturb, dim3(nk), dim3(128), 0, h->stream, P);
   CPT_HIP(h, hipGetLastError());
   CPT_HIP(h, hipEventRecord(h->t_perturb.b, h->stream));
   h->src_nk = nk; h->src_ntau = ntau;
@@ -2470,7 +2541,7 @@ int cpt_dbg_lookup_impl(cpt_handle* h, const double* tau, int n, double* out) {
   CPT_HIP(h, hipMalloc((void**)&d_tau, n * sizeof(double)));
   CPT_HIP(h, hipMalloc((void**)&d_out, (size_t)n * 16 * sizeof(double)));
   CPT_HIP(h, hipMemcpy(d_tau, tau, n * sizeof(double), hipMemcpyHostToDevice));
-  CPT_PT_DISPATCH(h->cfg, k_dbg_lookup, dim3(1), dim3(64), 0, h->stream, P, d_tau, n, d_out);
+  CPT_PT_DISPATCH(h->cfg, P.rows, k_dbg_lookup, dim3(1), dim3(64), 0, h->stream, P, d_tau, n, d_out);
   CPT_HIP(h, hipGetLastError());
   CPT_HIP(h, hipStreamSynchronize(h->stream));
   CPT_HIP(h, hipMemcpy(out, d_out, (size_t)n * 16 * sizeof(double), hipMemcpyDeviceToHost));
@@ -2491,7 +2562,7 @@ int cpt_dbg_derivs_impl(cpt_handle* h, double k, double tau, int tca_on, int rsa
   CPT_HIP(h, hipMalloc((void**)&d_neq, sizeof(int)));
   CPT_HIP(h, hipMemset(d_dy, 0, 64 * sizeof(double)));
   CPT_HIP(h, hipMemcpy(d_y, y, 64 * sizeof(double), hipMemcpyHostToDevice));
-  CPT_PT_DISPATCH(h->cfg, k_dbg_derivs, dim3(1), dim3(64), 0, h->stream, P, k, tau, tca_on ? 1 : 0, rsa_on ? 1 : 0, ufa_on ? 1 : 0, d_y,
+  CPT_PT_DISPATCH(h->cfg, P.rows, k_dbg_derivs, dim3(1), dim3(64), 0, h->stream, P, k, tau, tca_on ? 1 : 0, rsa_on ? 1 : 0, ufa_on ? 1 : 0, d_y,
                   d_dy, d_neq);
   CPT_HIP(h, hipGetLastError());
   CPT_HIP(h, hipStreamSynchronize(h->stream));
@@ -2513,7 +2584,7 @@ int cpt_dbg_solve_impl(cpt_handle* h, double k, double tau, int tca_on, int rsa_
   CPT_HIP(h, hipMalloc((void**)&d_x, 64 * sizeof(double)));
   CPT_HIP(h, hipMemset(d_x, 0, 64 * sizeof(double)));
   CPT_HIP(h, hipMemcpy(d_b, b, 64 * sizeof(double), hipMemcpyHostToDevice));
-  CPT_PT_DISPATCH(h->cfg, k_dbg_solve, dim3(1), dim3(64), 0, h->stream, P, k, tau, tca_on ? 1 : 0, rsa_on ? 1 : 0, ufa_on ? 1 : 0, hg,
+  CPT_PT_DISPATCH(h->cfg, P.rows, k_dbg_solve, dim3(1), dim3(64), 0, h->stream, P, k, tau, tca_on ? 1 : 0, rsa_on ? 1 : 0, ufa_on ? 1 : 0, hg,
                   d_b, d_x);
   CPT_HIP(h, hipGetLastError());
   CPT_HIP(h, hipStreamSynchronize(h->stream));

@@ -417,3 +417,22 @@ def test_perturb_is_linear_in_the_initial_amplitude_at_full_size():
     for tp, tol in ((c.index_tp_t0, 1e-2), (c.index_tp_t1, 1e-2), (c.index_tp_t2, 5e-4), (c.index_tp_p, 5e-4), (c.index_tp_delta_m, 3e-5)):
         scale = np.max(np.abs(s1[tp]), axis=0, keepdims=True)
         assert np.max(np.abs(0.5 * s2[tp] - s1[tp]) / scale) < tol, tp   # (t0: 5.5e-3 measured = two step sequences of the same tolerance)
+
+
+def test_row_layout_and_packed_layout_agree(small, monkeypatch):
+    """Two lane maps of the same equations: every l >= 3 tail in a 16-lane row of its own with log-depth (cyclic reduction) tail
+    solves - the default whenever the tails fit - and the packed map with sequential sweeps (CPT_TAIL_ROWS=0, or hierarchies longer
+    than 16 as in tests/golden/sc_prec.ini).  Same Newton matrix, another elimination order: same sources to the band of two
+    valid step sequences, same amount of work."""
+    inp, be = small
+    rows, st_rows, status = be.perturb_solve()
+    assert not status.any()
+    monkeypatch.setenv("CPT_TAIL_ROWS", "0")
+    packed, st_packed, status = be.perturb_solve()
+    assert not status.any()
+    monkeypatch.delenv("CPT_TAIL_ROWS")
+    n1, n2 = sum(s.steps for s in st_rows), sum(s.steps for s in st_packed)
+    assert abs(n1 - n2) < 0.02 * n1
+    check_sources(inp.config, rows.cpu().numpy(), packed.cpu().numpy())
+    check_sources(inp.config, rows.cpu().numpy(), inp.d["pt.sources"])
+    check_sources(inp.config, packed.cpu().numpy(), inp.d["pt.sources"])
