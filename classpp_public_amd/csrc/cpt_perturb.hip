@@ -2473,7 +2473,7 @@ int cpt_perturb_impl(cpt_handle* h, const double* k, int nk, const double* tau, 
     // is throughput-bound, and two workgroups per CU at 256 registers finish sooner than one at 512; few modes (a k-shard of
     // an 8-GPU run, the default samplings) are latency-bound and keep the whole register file.  CPT_NCDM_WAVES_PER_SIMD = 1 | 2 overrides.
     int n_cu = 256;
-    hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, h->device);
+    (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, h->device);   // (256 stays if the query fails)
     bool half_regs = nw > 3 || nk > 3 * n_cu;
     if (const char* e = getenv("CPT_NCDM_WAVES_PER_SIMD")) half_regs = nw > 3 || atoi(e) >= 2;
     if (c.K != 0.) {
