@@ -16,6 +16,34 @@ from .capi import CptConfig, CptSpectraParams, CptTables
 GOLDEN = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
 
 
+# committed table fixture of every committed configuration (several configurations share one cosmology)
+TABLES_OF = {
+    "small": "tables_lcdm.npz", "lcdm": "tables_lcdm.npz", "explanatory": "tables_lcdm.npz", "explanatory_mpk": "tables_lcdm.npz",
+    "iso_cdi": "tables_lcdm.npz", "iso_nid": "tables_lcdm.npz", "newt": "tables_lcdm.npz", "tens": "tables_lcdm.npz",
+    "curved": "tables_curved.npz", "curved_full": "tables_curved.npz", "tens_curved": "tables_curved.npz", "open": "tables_open.npz",
+    "ncdm": "tables_ncdm1.npz", "ncdm_small": "tables_ncdm1.npz", "ncdm_k3000": "tables_ncdm1.npz",
+    "ncdm3": "tables_ncdm3.npz", "ncdm3_small": "tables_ncdm3.npz", "ncdm3_tens": "tables_ncdm3.npz",
+}
+
+
+def _check_tables_match(name, d, t):
+    """the parameters of the configuration and the table file must describe one cosmology: H0, and the densities today"""
+    bg = t["bg.background_table"]
+    last = bg[-1]
+    H0 = float(d["pba.H0"].reshape(-1)[0])
+
+    def col(f):
+        return float(last[int(t["bg.index_bg_" + f].reshape(-1)[0])])
+
+    checks = [("H0", col("H"), H0), ("Omega0_g", col("rho_g") / H0 ** 2, float(d["pba.Omega0_g"].reshape(-1)[0])),
+              ("Omega0_b", col("rho_b") / H0 ** 2, float(d["pba.Omega0_b"].reshape(-1)[0]))]
+    if int(d["pba.has_cdm"].reshape(-1)[0]):
+        checks.append(("Omega0_cdm", col("rho_cdm") / H0 ** 2, float(d["pba.Omega0_cdm"].reshape(-1)[0])))
+    for what, got, want in checks:
+        if not abs(got - want) <= 1e-6 * abs(want):
+            raise ValueError("configuration %r and its table file disagree on %s: %.10g (tables) vs %.10g (parameters)" % (name, what, got, want))
+
+
 def _s(d, key):
     v = d[key]
     return v.reshape(-1)[0]
@@ -30,12 +58,15 @@ class Inputs:
         self.name = name
         # params: the parameter / flag entries (pba.*, ppt.*, ppr.*, index maps ...) given directly instead of a committed fixture
         self.d = dict(params) if params is not None else dict(np.load(os.path.join(golden_dir, name + ".npz")))
-        tname = "tables_%s.npz" % ("curved" if (name.startswith("curved") or name == "tens_curved") else
-                                  "ncdm3" if name.startswith("ncdm3") else "ncdm1" if name.startswith("ncdm") else name)   # (open.ini has its own: tables_open.npz)
         if tables is not None:
             self.t = {k: np.atleast_1d(np.asarray(v)) for k, v in tables.items()}
         else:
-            self.t = dict(np.load(os.path.join(golden_dir, tname if os.path.exists(os.path.join(golden_dir, tname)) else "tables_lcdm.npz")))
+            tname = TABLES_OF.get(name)
+            if tname is None or not os.path.exists(os.path.join(golden_dir, tname)):
+                raise FileNotFoundError("no committed background/thermodynamics tables for configuration %r: pass tables= "
+                                        "(classpp_public_amd/pipeline.py computes them) or add it to inputs.TABLES_OF" % (name,))
+            self.t = dict(np.load(os.path.join(golden_dir, tname)))
+            _check_tables_match(name, self.d, self.t)
         d, t = self.d, self.t
         c = CptConfig()
         c.H0 = _s(d, "pba.H0"); c.K = _s(d, "pba.K"); c.sgnK = int(_s(d, "pba.sgnK"))
