@@ -4,12 +4,16 @@
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
-A "step" is one pass of the hot path for one cosmology: integrate every k-mode (hot path A) and project the sources on
-the Bessel functions for every (q,l) (hot path B).  Workload at N=1: BASELINE.json configs[1] = flat LambdaCDM scalars,
-tCl+pCl+mPk, default precision (tests/golden/lcdm.ini: 567 k-modes, 738 sampling times, 2237 q x 101 l x 4 types).
-The spline tables and grids are resident in HBM / pinned on the handle before the timed region.  At N>1 the k grid is
-densified N-fold (the ~3000-mode grid of BASELINE configs[2] has no .pre file in the reference) and sharded
-round-robin, with the two exchanges of classpp_public_amd/sharded.py: per-GPU ODE work is fixed => "weak" scaling.
+A "step" is one pass of the hot path for one cosmology: integrate every k-mode (hot path A), project the sources on the
+Bessel functions for every (q,l) (hot path B), then C_l, lensed C_l and P(k).  Workload at N=1: the configuration the
+metric is quoted on, explanatory.ini (`output = tCl,pCl,lCl`, `lensing = yes`, /root/reference/explanatory.ini:625-658)
+with mPk added: tests/golden/explanatory_mpk.ini = 603 k-modes x 738 sampling times x 6 source types,
+2655 q x 113 l x 5 transfer types, lensed C_l to l = 2500, linear P(k).  The spline tables are resident in HBM before the
+timed region.  At N>1 the default workload is BASELINE configs[2] at its quoted size - the fixed ncdm_k3000 grid (2 988
+k-modes, one massive neutrino species), k-sharded round-robin over the ranks with the two exchanges of
+classpp_public_amd/sharded.py: total work is fixed => "strong" scaling.  `--weak` instead densifies the k grid of
+--config N-fold (per-GPU ODE work fixed).  explanatory.ini itself does not shard usefully (every mode is already
+resident on one GPU, the wall time is the longest chain): for it the multi-GPU answer is "replicas only".
 
 Prints ONE JSON line (rank 0).
 """
@@ -80,7 +84,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--config", default="lcdm")
+    ap.add_argument("--config", default=None, help="fixture name under tests/golden (default: explanatory_mpk on one GPU, ncdm_k3000 on several)")
+    ap.add_argument("--weak", action="store_true", help="N > 1: densify the k grid of --config N-fold instead of sharding the fixed grid")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend: nccl (= RCCL over xGMI, one GPU per rank; the measured configuration) or gloo "
@@ -111,6 +116,8 @@ def main():
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
+    if args.config is None:
+        args.config = "explanatory_mpk" if world == 1 else "ncdm_k3000"
     t_host0 = time.perf_counter()
     if args.from_parameters:
         from classpp_public_amd.pipeline import ParameterInputs
@@ -120,8 +127,9 @@ def main():
     host_tables_ms = (time.perf_counter() - t_host0) * 1e3 if args.from_parameters else None
     be = Backend(inp, device)
     comp = GpuCompute(be)
-    k_all = densify_k(inp.k, world)
-    k_size_cl = (inp.k_size_cl - 1) * world + 1
+    weak = args.weak and world > 1
+    k_all = densify_k(inp.k, world) if weak else np.ascontiguousarray(inp.k, dtype=np.float64)
+    k_size_cl = (inp.k_size_cl - 1) * world + 1 if weak else inp.k_size_cl
     nk_total = k_all.size
 
     def barrier():
@@ -136,13 +144,9 @@ def main():
     def step():
         # tables-in -> C_l (and P(k)) out, nothing leaves HBM in between
         if world == 1:
-            be.perturb_solve(want_sources=False)      # sources stay resident, k-major, in HBM
-            tr = be.transfer(None)
-            cl = be.cl(tr)
-            if has_lensing:
-                cl = be.lensed_cl(cl, *lens_args)
-            pk = be.pk_linear() if has_pk else None
-            return cl, pk
+            # one library call (cpt_step): every stage enqueued back to back, sources and tables stay in HBM, one synchronisation
+            r = be.step(lensing=lens_args, want_pk=has_pk)
+            return (r["cl_lensed"] if has_lensing else r["cl"]), r["pk"]
         out, _ = sharded_step(comp, k_all, inp.l, rank, world, device, k_size_cl, exchange_device=xdev)
         if rank == 0:   # the same closing steps as on one GPU: C_l (+ lensing), P(k) from the gathered sources now resident in the handle
             cl = be.cl(out)
@@ -155,12 +159,13 @@ def main():
     for _ in range(args.warmup):
         step()
     barrier()
-    kms, tms, fev, stp = [], [], [], []
+    kms, tms, gms = [], [], []
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
         kms.append(be.kernel_ms(0)[0])
         tms.append(be.kernel_ms(1)[0])
+        gms.append(be.kernel_ms(3)[0])
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -170,7 +175,7 @@ def main():
 
     # work counters of the last step (identical every step: the computation is deterministic)
     if world == 1:
-        _, stats, _ = be.perturb_solve(want_sources=False)
+        stats = be.step(lensing=lens_args, want_pk=has_pk)["stats"]
     else:
         stats = comp.stats
     fevals = sum(s.fevals for s in stats)
@@ -191,28 +196,35 @@ def main():
         alg_bytes = fevals * BYTES_PER_FEVAL + inp.config.tp_size * inp.ntau * nk_local * 8
         achieved = alg_bytes / (k_ms * 1e-3) / 1e9
         ints, tsamp, fused = be.transfer_work()
+        ini = {"explanatory_mpk": "explanatory.ini + mPk"}.get(args.config, args.config + ".ini")
+        gpu_ms = float(np.mean(gms)) if world == 1 else None   # first kernel start -> last kernel end of a step, on the handle's stream
         out = {
-            "metric": "k-modes/s (perturbations) + C_l wall-time, explanatory.ini, 1/2/4/8 GPUs",
+            # BASELINE.json's metric; the configuration actually run is named in config.workload
+            "metric": "k-modes/s (perturbations) + C_l wall-time, %s, 1/2/4/8 GPUs" % ("explanatory.ini" if args.config.startswith("explanatory") else ini),
             "value": nk_total / (dt / args.steps),
             "unit": "k-modes/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_step,
             "higher_is_better": True,
-            "scaling": "weak",
-            "vs_baseline": None,
+            "scaling": None if world == 1 else ("weak" if weak else "strong"),
+            "vs_baseline": None,   # BASELINE.md holds no published number for this metric
             "dtype": "f64",
-            "data": "synthetic",
-            "config": {"workload": "%s.ini: %s tCl+pCl%s, default precision; %d k-modes x %d tau samples, "
+            "data": "deterministic functions of the .ini, not random numbers (SURVEY S8d): background/thermodynamics spline tables and "
+                    "k/tau/q/l grids of %s %s" % (ini, "computed on the host by libcpt_host.so from the cosmological parameters" if args.from_parameters
+                                                   else "dumped from the unmodified reference into tests/golden"),
+            "config": {"workload": "%s: %s tCl+pCl%s%s, default precision; %d k-modes x %d tau samples x %d source types, "
                                    "%d q x %d l x %d transfer types%s" % (
-                                       args.config, cosmology, "+mPk" if inp.config.index_tp_delta_m >= 0 else "+lCl", nk_total, inp.ntau,
+                                       ini, cosmology, "+lCl" if inp.config.index_tp_phi_plus_psi >= 0 else "",
+                                       "+mPk" if inp.config.index_tp_delta_m >= 0 else "", nk_total, inp.ntau, inp.config.tp_size,
                                        inp.q.size, inp.l.size, inp.config.tt_size,
                                        ("; lensed C_l" if has_lensing else "") +
-                                       ("" if world == 1 else "; k grid densified %dx and sharded round-robin" % world)),
-                       "inputs": ("background/thermodynamics spline tables and grids computed by libcpt_host.so from the cosmological parameters"
-                                  if args.from_parameters else
-                                  "background/thermodynamics spline tables and grids from tests/golden (dumped from the reference)"),
-                       "parallelism": ("k-sharded x%d, l-sharded transfer, 2 %s exchanges" % (world, "RCCL" if args.backend == "nccl" else "gloo (REHEARSAL: ranks share GPUs)")) if world > 1 else "1 GPU"},
-            "stage_ms": {"perturb_kernel": k_ms, "los_kernel": t_ms, "step_wall": ms_step, "host_tables": host_tables_ms},
+                                       ("" if world == 1 else ("; k grid densified %dx and sharded round-robin" % world if weak else
+                                                               "; the fixed k grid sharded round-robin over %d ranks" % world))),
+                       "parallelism": ("k-sharded x%d, l-sharded transfer, 2 %s exchanges" % (world, "RCCL" if args.backend == "nccl" else "gloo (REHEARSAL: ranks share GPUs)")) if world > 1 else "1 GPU",
+                       "multi_gpu_note": "explanatory.ini / lcdm.ini: replicas only (all k-modes are resident on one GPU; wall time = the longest mode's "
+                                         "dependency chain, SURVEY S8e); the sharded path is measured on ncdm_k3000 (BASELINE configs[2])"},
+            "stage_ms": {"perturb_kernel": k_ms, "los_kernel": t_ms, "step_wall": ms_step, "gpu_span": gpu_ms,
+                         "host_overhead": (ms_step - gpu_ms) if gpu_ms is not None else None, "host_tables": host_tables_ms},
             "cl_wall_ms": ms_step,
             "perturb_kmodes_per_s_kernel": nk_local * world / (k_ms * 1e-3),
             "ode_work": {"fevals": fevals, "steps": steps_tot, "max_steps_per_mode": steps_max,
@@ -229,6 +241,8 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(args.config, inp.nk)
+                if out["cpu_baseline"].get("value"):
+                    out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
             except Exception as e:  # the baseline is a report, never a reason to lose the measurement
                 out["cpu_baseline"] = {"value": None, "unit": "k-modes/s", "cores": 0, "kind": "port", "sample": "failed: %r" % (e,)}
         print(json.dumps(out))

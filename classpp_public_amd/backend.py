@@ -102,6 +102,53 @@ class Backend:
         self._check(rc)
         return out
 
+    # ---- the whole pass, fused: one library call, one stream synchronisation ----
+    def step(self, lensing=None, want_pk=None):
+        """k-modes -> sources -> transfer functions -> C_l (-> lensed C_l) (-> P(k)) through cpt_step.
+        lensing: None or (l_unlensed_max, delta_l_max[, accurate, num_mu_minus_lmax, tol]); want_pk: default = the configuration has delta_m.
+        -> dict(transfer, cl, cl_lensed, pk, stats, status); device tensors are owned by the backend and reused by the next step()"""
+        from .capi import CptLensingParams, CptStepIo
+        inp = self.inp
+        if want_pk is None:
+            want_pk = inp.config.index_tp_delta_m >= 0
+        key = (tuple(lensing) if lensing else None, bool(want_pk))
+        st = getattr(self, "_step_state", None)
+        if st is None or st["key"] != key:
+            k = np.ascontiguousarray(inp.k, dtype=np.float64); tau = np.ascontiguousarray(inp.tau, dtype=np.float64)
+            q = np.ascontiguousarray(inp.q, dtype=np.float64); l = np.ascontiguousarray(inp.l, dtype=np.int32)
+            dev, f64 = self.device, torch.float64
+            st = {"key": key, "k": k, "tau": tau, "q": q, "l": l,
+                  "transfer": torch.empty((inp.config.tt_size, l.size, q.size), dtype=f64, device=dev),
+                  "cl": torch.empty((l.size, inp.spectra.ct_size), dtype=f64, device=dev),
+                  "cl_lensed": None, "pk": torch.empty(k.size, dtype=f64, device=dev) if want_pk else None,
+                  "stats": (CptStepstat * k.size)(), "status": np.zeros(k.size, dtype=np.int32), "lp": None}
+            io = CptStepIo()
+            io.k = _dptr(k); io.nk = k.size; io.k_size_cl = inp.k_size_cl
+            io.tau_sampling = _dptr(tau); io.ntau = tau.size; io.q = _dptr(q); io.nq = q.size; io.l = _iptr(l); io.nl = l.size
+            io.sp = C.pointer(inp.spectra)
+            if lensing:
+                a = list(lensing) + [500, False, 70, 0.0][len(lensing) - 1:]
+                lp = CptLensingParams(int(a[0]), int(a[1]), int(bool(a[2])), int(a[3]), float(a[4]))
+                n = self.lib.cpt_lensing_l_size(_iptr(l), l.size, C.byref(lp))
+                if n < 1:
+                    raise CptInputError("cpt_lensing_l_size failed")
+                st["lp"] = lp
+                st["cl_lensed"] = torch.empty((n, inp.spectra.ct_size), dtype=f64, device=dev)
+                io.lp = C.pointer(lp)
+                io.cl_lensed_dev = st["cl_lensed"].data_ptr()
+            io.transfer_dev = st["transfer"].data_ptr(); io.cl_dev = st["cl"].data_ptr()
+            io.pk_dev = st["pk"].data_ptr() if want_pk else None
+            io.stats = st["stats"]; io.status = _iptr(st["status"])
+            st["io"] = io
+            self._step_state = st
+            self._fence()   # the fresh output tensors may be recycled blocks still in flight on torch's stream
+        self._check(self.lib.cpt_step(self.h, C.byref(st["io"])))
+        return st
+
+    def step_gpu_ms(self):
+        """milliseconds from the first to the last kernel of the last step() on the library's stream"""
+        return self.kernel_ms(3)[0]
+
     # ---- "next" rows: observables ----
     def cl(self, transfer, q=None):
         """transfer: device [tt][nl][nq] -> C_l table [nl][ct_size] on device (cpt_cl_batch)"""

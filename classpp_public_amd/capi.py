@@ -93,12 +93,20 @@ class CptLensingParams(C.Structure):
                 ("tol_gauss_legendre", _d)]
 
 
+class CptStepIo(C.Structure):
+    """struct cpt_step_io (include/cpt.h): arguments of the fused cpt_step"""
+    _fields_ = [("k", _pd), ("nk", _i), ("k_size_cl", _i), ("tau_sampling", _pd), ("ntau", _i), ("q", _pd), ("nq", _i),
+                ("l", C.POINTER(_i)), ("nl", _i), ("sp", C.POINTER(CptSpectraParams)), ("lp", C.POINTER(CptLensingParams)),
+                ("transfer_dev", C.c_void_p), ("cl_dev", C.c_void_p), ("cl_lensed_dev", C.c_void_p), ("pk_dev", C.c_void_p),
+                ("stats", C.POINTER(CptStepstat)), ("status", C.POINTER(_i))]
+
+
 # every symbol include/cpt.h declares (tests check that the built library exports all of them)
 EXPORTS = [
     "cpt_create", "cpt_destroy", "cpt_last_error", "cpt_create_error", "cpt_perturb_solve_batch",
     "cpt_transfer_batch", "cpt_get_sources", "cpt_last_kernel_ms", "cpt_last_transfer_work",
     "cpt_dbg_lookup", "cpt_dbg_derivs", "cpt_dbg_solve", "cpt_dbg_bessel", "cpt_cl_batch", "cpt_pk_linear", "cpt_sigma", "cpt_pk_cb_linear", "cpt_sigma_cb",
-    "cpt_lensing_l_size", "cpt_lensing_batch",
+    "cpt_lensing_l_size", "cpt_lensing_batch", "cpt_step",
 ]
 
 _lib = None
@@ -150,6 +158,8 @@ def lib():
     L.cpt_lensing_l_size.restype = _i
     L.cpt_lensing_batch.argtypes = [vp, C.POINTER(CptSpectraParams), C.POINTER(CptLensingParams), pi, _i, vp, vp]
     L.cpt_lensing_batch.restype = _i
+    L.cpt_step.argtypes = [vp, C.POINTER(CptStepIo)]
+    L.cpt_step.restype = _i
     L.cpt_dbg_lookup.argtypes = [vp, _pd, _i, _pd]
     L.cpt_dbg_lookup.restype = _i
     L.cpt_dbg_derivs.argtypes = [vp, _d, _d, _i, _i, _i, _pd, _pd, pi]

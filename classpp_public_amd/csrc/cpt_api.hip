@@ -18,6 +18,80 @@ int cpt_fail(cpt_handle* h, int code, const char* fmt, ...) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// A handle is bound to the device that was current at cpt_create: every entry point runs with that device current and
+// restores the caller's device on the way out (allocations and launches would otherwise land on whatever device the
+// calling thread last selected).
+struct DeviceGuard {
+  int prev = -1;
+  bool switched = false;
+  explicit DeviceGuard(const cpt_handle* h) {
+    if (h && hipGetDevice(&prev) == hipSuccess && prev != h->device) switched = (hipSetDevice(h->device) == hipSuccess);
+  }
+  ~DeviceGuard() {
+    if (switched) (void)hipSetDevice(prev);
+  }
+  DeviceGuard(const DeviceGuard&) = delete;
+  DeviceGuard& operator=(const DeviceGuard&) = delete;
+};
+
+// ---- pinned staging arena ----
+void cpt_pin_reset(cpt_handle* h) {
+  for (char* p : h->pin_retired) (void)hipHostFree(p);
+  h->pin_retired.clear();
+  h->pin_off = 0;
+}
+void* cpt_pin(cpt_handle* h, const void* src, size_t bytes) {
+  const size_t need = (bytes + 63) & ~(size_t)63;
+  if (h->pin_off + need > h->pin_cap) {
+    // outgrown: copies enqueued earlier in this call may still read the old arena, so it is only retired here and freed at the
+    // next reset
+    size_t cap = h->pin_cap ? h->pin_cap * 2 : ((size_t)1 << 20);
+    while (cap < need) cap *= 2;
+    char* p = nullptr;
+    if (hipHostMalloc((void**)&p, cap, hipHostMallocDefault) != hipSuccess) return nullptr;
+    if (h->pin) h->pin_retired.push_back(h->pin);
+    h->pin = p; h->pin_cap = cap; h->pin_off = 0;
+  }
+  char* dst = h->pin + h->pin_off;
+  h->pin_off += need;
+  if (src) memcpy(dst, src, bytes);
+  return dst;
+}
+int cpt_upload(cpt_handle* h, void* dst_dev, const void* src_host, size_t bytes) {
+  if (!bytes) return CPT_OK;
+  void* staged = cpt_pin(h, src_host, bytes);
+  if (!staged) return cpt_fail(h, CPT_ERR_NO_DEVICE, "hipHostMalloc of the staging arena failed");
+  CPT_HIP(h, hipMemcpyAsync(dst_dev, staged, bytes, hipMemcpyHostToDevice, h->stream));
+  return CPT_OK;
+}
+void cpt_timer_start(cpt_handle* h, int which) {
+  Timer& t = h->timers[which];
+  t.armed = hipEventRecord(t.a, h->stream) == hipSuccess;
+}
+void cpt_timer_stop(cpt_handle* h, int which) {
+  Timer& t = h->timers[which];
+  t.armed = t.armed && hipEventRecord(t.b, h->stream) == hipSuccess;
+}
+// drain the stream (unless a fused cpt_step is collecting several stages) and read back what the stages left pending
+int cpt_finish(cpt_handle* h) {
+  if (h->defer) return CPT_OK;
+  CPT_HIP(h, hipStreamSynchronize(h->stream));
+  for (int i = 0; i < CPT_T_N; i++) {
+    Timer& t = h->timers[i];
+    if (!t.armed) continue;
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, t.a, t.b) == hipSuccess) { t.ms = ms; t.launches = 1; }
+    t.armed = false;
+  }
+  if (h->pend_work) {
+    const unsigned long long* w = (const unsigned long long*)(h->pin_out);
+    h->work_integrals = (long long)w[0]; h->work_samples = (long long)w[1]; h->work_fused = (long long)w[2];
+    h->pend_work = false;
+  }
+  return CPT_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
 // layout transposes between the reference's [tp][tau][k] and the resident k-major [tp][k][tau]
 // (tile through LDS so that both the read and the write are coalesced)
 // ---------------------------------------------------------------------------------------------
@@ -217,42 +291,50 @@ int cpt_create(const cpt_config* cfg, const cpt_tables* t, cpt_handle** out) {
   h->tabs.th = h->d_th;
   if (hipMalloc((void**)&h->d_work, 4 * sizeof(unsigned long long)) != hipSuccess)
     return bail(cpt_fail(h, CPT_ERR_NO_DEVICE, "hipMalloc failed"));
-  for (Timer* tm : {&h->t_perturb, &h->t_transfer}) {
-    if (hipEventCreate(&tm->a) != hipSuccess || hipEventCreate(&tm->b) != hipSuccess)
+  for (Timer& tm : h->timers) {
+    if (hipEventCreate(&tm.a) != hipSuccess || hipEventCreate(&tm.b) != hipSuccess)
       return bail(cpt_fail(h, CPT_ERR_NO_DEVICE, "hipEventCreate failed"));
   }
+  // landing zone of the device -> host results (grown on demand by the perturbation stage)
+  h->pin_out_cap = (size_t)1 << 16;
+  if (hipHostMalloc((void**)&h->pin_out, h->pin_out_cap, hipHostMallocDefault) != hipSuccess)
+    return bail(cpt_fail(h, CPT_ERR_NO_DEVICE, "hipHostMalloc failed"));
   *out = h;
   return CPT_OK;
 }
 
 void cpt_destroy(cpt_handle* h) {
   if (!h) return;
+  DeviceGuard guard(h);
+  if (h->stream) (void)hipStreamSynchronize(h->stream);
   // (d_splc and d_ik are interior pointers into d_k / d_q and must not be freed)
   void* ptrs[] = {h->d_ncb, h->d_tau_table, h->d_bg, h->d_z_table, h->d_th, h->d_src, h->d_dd, h->d_u, h->d_k, h->d_tau, h->d_q,
                   h->d_l, h->d_bes, h->d_chi_min, h->d_work, h->d_pt_scratch, h->d_lens, h->d_lens_w, h->d_lens_l, h->d_his, h->d_his_trig, h->d_his_desc, h->d_kq};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
-  for (Timer* tm : {&h->t_perturb, &h->t_transfer}) {
-    if (tm->a) (void)hipEventDestroy(tm->a);
-    if (tm->b) (void)hipEventDestroy(tm->b);
+  for (Timer& tm : h->timers) {
+    if (tm.a) (void)hipEventDestroy(tm.a);
+    if (tm.b) (void)hipEventDestroy(tm.b);
   }
+  if (h->d_clw) (void)hipFree(h->d_clw);
+  if (h->d_pk_k) (void)hipFree(h->d_pk_k);
+  cpt_pin_reset(h);
+  if (h->pin) (void)hipHostFree(h->pin);
+  if (h->pin_out) (void)hipHostFree(h->pin_out);
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
 }
 
-int cpt_perturb_solve_batch(cpt_handle* h, const double* k, int nk, const double* tau_sampling, int ntau,
-                            double* sources_dev, cpt_stepstat* stats, int* status) {
-  if (!h) return CPT_ERR_INVALID;
-  h->err.clear();
-  if (!k || !tau_sampling || nk < 1 || ntau < 2) return cpt_fail(h, CPT_ERR_INVALID, "bad k / tau_sampling arguments: at least one k-mode and two sampling times (the last one ends the integration)");
-  return cpt_perturb_impl(h, k, nk, tau_sampling, ntau, sources_dev, stats, status);
-}
+// every compute entry point: the handle's device current, error cleared, staging arena recycled (the previous call has drained
+// the stream), the stages enqueue, then ONE synchronisation in cpt_finish
+#define CPT_ENTER(h)          \
+  if (!(h)) return CPT_ERR_INVALID; \
+  DeviceGuard guard__(h);     \
+  (h)->err.clear();           \
+  cpt_pin_reset(h)
 
-int cpt_transfer_batch(cpt_handle* h, const double* sources_dev, const double* k, int nk, int k_size_cl,
-                       const double* tau_sampling, int ntau, const double* q, int nq, const int* l, int nl,
-                       double* transfer_dev) {
-  if (!h) return CPT_ERR_INVALID;
-  h->err.clear();
+static int check_transfer_args(cpt_handle* h, const double* k, int nk, int k_size_cl, const double* tau_sampling, int ntau, const double* q, int nq,
+                               const int* l, int nl, const double* transfer_dev) {
   if (!k || !tau_sampling || !q || !l || !transfer_dev || nk < 3 || ntau < 3 || nq < 1 || nl < 1 || k_size_cl < 1 ||
       k_size_cl > nk)
     return cpt_fail(h, CPT_ERR_INVALID, "bad arguments to cpt_transfer_batch");
@@ -260,41 +342,64 @@ int cpt_transfer_batch(cpt_handle* h, const double* sources_dev, const double* k
   if (h->cfg.K > 0. && sqrt(h->cfg.K) * h->cfg.tau0 >= 1.5707963267948966 - h->cfg.hyper_x_min)
     return cpt_fail(h, CPT_ERR_UNSUPPORTED, "closed space with sqrt(K) tau0 >= pi/2: the folding of chi onto [0, pi/2] (ClosedModY, "
                     "hyperspherical.c:1025-1052) is not implemented");
-  return cpt_transfer_impl(h, sources_dev, k, nk, k_size_cl, tau_sampling, ntau, q, nq, l, nl, transfer_dev);
+  return CPT_OK;
+}
+
+int cpt_perturb_solve_batch(cpt_handle* h, const double* k, int nk, const double* tau_sampling, int ntau,
+                            double* sources_dev, cpt_stepstat* stats, int* status) {
+  CPT_ENTER(h);
+  if (!k || !tau_sampling || nk < 1 || ntau < 2) return cpt_fail(h, CPT_ERR_INVALID, "bad k / tau_sampling arguments: at least one k-mode and two sampling times (the last one ends the integration)");
+  int rc = cpt_perturb_impl(h, k, nk, tau_sampling, ntau, sources_dev, stats, status);
+  if (rc) { (void)hipStreamSynchronize(h->stream); h->pend_nk = 0; return rc; }
+  if ((rc = cpt_finish(h))) return rc;
+  return cpt_perturb_collect(h, k, stats, status);
+}
+
+int cpt_transfer_batch(cpt_handle* h, const double* sources_dev, const double* k, int nk, int k_size_cl,
+                       const double* tau_sampling, int ntau, const double* q, int nq, const int* l, int nl,
+                       double* transfer_dev) {
+  CPT_ENTER(h);
+  int rc = check_transfer_args(h, k, nk, k_size_cl, tau_sampling, ntau, q, nq, l, nl, transfer_dev);
+  if (rc) return rc;
+  if ((rc = cpt_transfer_impl(h, sources_dev, k, nk, k_size_cl, tau_sampling, ntau, q, nq, l, nl, transfer_dev))) { (void)hipStreamSynchronize(h->stream); return rc; }
+  return cpt_finish(h);
 }
 
 int cpt_cl_batch(cpt_handle* h, const cpt_spectra_params* sp, const double* transfer_dev, const double* q, int nq, int nl,
                  double* cl_dev) {
-  if (!h) return CPT_ERR_INVALID;
-  h->err.clear();
+  CPT_ENTER(h);
   if (!sp || !transfer_dev || !q || !cl_dev || nq < 3 || nl < 1) return cpt_fail(h, CPT_ERR_INVALID, "bad arguments to cpt_cl_batch");
-  return cpt_cl_impl(h, sp, transfer_dev, q, nq, nl, cl_dev);
+  int rc = cpt_cl_impl(h, sp, transfer_dev, q, nq, nl, cl_dev);
+  if (rc) { (void)hipStreamSynchronize(h->stream); return rc; }
+  return cpt_finish(h);
 }
 
 int cpt_sigma(cpt_handle* h, const cpt_spectra_params* sp, const double* k, int nk, double R, double k_per_decade, double* sigma) {
-  if (!h) return CPT_ERR_INVALID;
+  CPT_ENTER(h);
   if (!sp || !k || !sigma || nk < 3 || !(R >= 0.) || !(k_per_decade > 0.)) return cpt_fail(h, CPT_ERR_INVALID, "bad arguments to cpt_sigma");
   return cpt_sigma_impl(h, sp, k, nk, R, k_per_decade, sigma, 0);
 }
 
 int cpt_sigma_cb(cpt_handle* h, const cpt_spectra_params* sp, const double* k, int nk, double R, double k_per_decade, double* sigma) {
-  if (!h) return CPT_ERR_INVALID;
+  CPT_ENTER(h);
   if (!sp || !k || !sigma || nk < 3 || !(R >= 0.) || !(k_per_decade > 0.)) return cpt_fail(h, CPT_ERR_INVALID, "bad arguments to cpt_sigma_cb");
   return cpt_sigma_impl(h, sp, k, nk, R, k_per_decade, sigma, 1);
 }
 
 int cpt_pk_linear(cpt_handle* h, const cpt_spectra_params* sp, const double* k, int nk, double* pk_dev) {
-  if (!h) return CPT_ERR_INVALID;
-  h->err.clear();
+  CPT_ENTER(h);
   if (!sp || !k || !pk_dev || nk < 1) return cpt_fail(h, CPT_ERR_INVALID, "bad arguments to cpt_pk_linear");
-  return cpt_pk_impl(h, sp, k, nk, pk_dev, 0);
+  int rc = cpt_pk_impl(h, sp, k, nk, pk_dev, 0);
+  if (rc) { (void)hipStreamSynchronize(h->stream); return rc; }
+  return cpt_finish(h);
 }
 
 int cpt_pk_cb_linear(cpt_handle* h, const cpt_spectra_params* sp, const double* k, int nk, double* pk_dev) {
-  if (!h) return CPT_ERR_INVALID;
-  h->err.clear();
+  CPT_ENTER(h);
   if (!sp || !k || !pk_dev || nk < 1) return cpt_fail(h, CPT_ERR_INVALID, "bad arguments to cpt_pk_cb_linear");
-  return cpt_pk_impl(h, sp, k, nk, pk_dev, 1);
+  int rc = cpt_pk_impl(h, sp, k, nk, pk_dev, 1);
+  if (rc) { (void)hipStreamSynchronize(h->stream); return rc; }
+  return cpt_finish(h);
 }
 
 int cpt_lensing_l_size(const int* l, int nl, const cpt_lensing_params* lp) {
@@ -304,25 +409,49 @@ int cpt_lensing_l_size(const int* l, int nl, const cpt_lensing_params* lp) {
 
 int cpt_lensing_batch(cpt_handle* h, const cpt_spectra_params* sp, const cpt_lensing_params* lp, const int* l, int nl,
                       const double* cl_dev, double* cl_lensed_dev) {
-  if (!h) return CPT_ERR_INVALID;
-  h->err.clear();
+  CPT_ENTER(h);
   if (!sp || !lp || !l || !cl_dev || !cl_lensed_dev) return cpt_fail(h, CPT_ERR_INVALID, "bad arguments to cpt_lensing_batch");
-  return cpt_lensing_impl(h, sp, lp, l, nl, cl_dev, cl_lensed_dev);
+  int rc = cpt_lensing_impl(h, sp, lp, l, nl, cl_dev, cl_lensed_dev);
+  if (rc) { (void)hipStreamSynchronize(h->stream); return rc; }
+  return cpt_finish(h);
+}
+
+// One pass for one cosmology - k-modes -> sources -> transfer functions -> C_l (-> lensed C_l) (-> P(k)) - enqueued back to back
+// on the handle's stream with a single synchronisation at the end.
+int cpt_step(cpt_handle* h, const cpt_step_io* io) {
+  CPT_ENTER(h);
+  if (!io || !io->k || !io->tau_sampling || !io->q || !io->l || !io->sp || !io->transfer_dev || !io->cl_dev || io->nk < 3 || io->ntau < 3)
+    return cpt_fail(h, CPT_ERR_INVALID, "bad arguments to cpt_step");
+  if (io->lp && !io->cl_lensed_dev) return cpt_fail(h, CPT_ERR_INVALID, "cpt_step: lensing parameters without an output buffer");
+  int rc = check_transfer_args(h, io->k, io->nk, io->k_size_cl, io->tau_sampling, io->ntau, io->q, io->nq, io->l, io->nl, io->transfer_dev);
+  if (rc) return rc;
+  if (io->nq < 3) return cpt_fail(h, CPT_ERR_INVALID, "bad arguments to cpt_step");
+  h->defer = true;
+  cpt_timer_start(h, CPT_T_STEP);
+  rc = cpt_perturb_impl(h, io->k, io->nk, io->tau_sampling, io->ntau, nullptr, io->stats, io->status);
+  if (!rc) rc = cpt_transfer_impl(h, nullptr, io->k, io->nk, io->k_size_cl, io->tau_sampling, io->ntau, io->q, io->nq, io->l, io->nl, io->transfer_dev);
+  if (!rc) rc = cpt_cl_impl(h, io->sp, io->transfer_dev, io->q, io->nq, io->nl, io->cl_dev);
+  if (!rc && io->lp) rc = cpt_lensing_impl(h, io->sp, io->lp, io->l, io->nl, io->cl_dev, io->cl_lensed_dev);
+  if (!rc && io->pk_dev) rc = cpt_pk_impl(h, io->sp, io->k, io->nk, io->pk_dev, 0);
+  cpt_timer_stop(h, CPT_T_STEP);
+  h->defer = false;
+  if (rc) { (void)hipStreamSynchronize(h->stream); h->pend_nk = 0; h->pend_work = false; return rc; }
+  if ((rc = cpt_finish(h))) return rc;
+  // a k-mode whose integration failed invalidates everything computed from the sources: reported here, after the single sync
+  return cpt_perturb_collect(h, io->k, io->stats, io->status);
 }
 
 int cpt_get_sources(cpt_handle* h, double* sources_dev) {
-  if (!h) return CPT_ERR_INVALID;
-  h->err.clear();
+  CPT_ENTER(h);
   if (!h->d_src || !h->src_nk) return cpt_fail(h, CPT_ERR_INVALID, "no resident sources: run cpt_perturb_solve_batch first");
   int rc = cpt_transpose_from_kmajor(h, h->d_src, sources_dev, h->cfg.tp_size, h->src_ntau, h->src_nk);
   if (rc) return rc;
-  CPT_HIP(h, hipStreamSynchronize(h->stream));
-  return CPT_OK;
+  return cpt_finish(h);
 }
 
 int cpt_last_kernel_ms(const cpt_handle* h, int stage, double* ms, int* launches) {
-  if (!h || !ms || !launches) return CPT_ERR_INVALID;
-  const Timer& t = stage == 0 ? h->t_perturb : h->t_transfer;
+  if (!h || !ms || !launches || stage < 0 || stage >= CPT_T_N) return CPT_ERR_INVALID;
+  const Timer& t = h->timers[stage];
   *ms = t.ms;
   *launches = t.launches;
   return CPT_OK;
@@ -337,31 +466,28 @@ int cpt_last_transfer_work(const cpt_handle* h, long long* integrals, long long*
 }
 
 int cpt_dbg_lookup(cpt_handle* h, const double* tau, int n, double* out) {
-  if (!h) return CPT_ERR_INVALID;
-  h->err.clear();
+  CPT_ENTER(h);
   return cpt_dbg_lookup_impl(h, tau, n, out);
 }
 
 int cpt_dbg_derivs(cpt_handle* h, double k, double tau, int tca_on, int rsa_on, int ufa_on, const double* y, double* dy,
                    int* neq) {
-  if (!h) return CPT_ERR_INVALID;
-  h->err.clear();
+  CPT_ENTER(h);
   return cpt_dbg_derivs_impl(h, k, tau, tca_on, rsa_on, ufa_on, y, dy, neq);
 }
 
 int cpt_dbg_solve(cpt_handle* h, double k, double tau, int tca_on, int rsa_on, int ufa_on, double hg, const double* b,
                   double* x) {
-  if (!h) return CPT_ERR_INVALID;
-  h->err.clear();
+  CPT_ENTER(h);
   return cpt_dbg_solve_impl(h, k, tau, tca_on, rsa_on, ufa_on, hg, b, x);
 }
 
 int cpt_dbg_bessel(cpt_handle* h, const int* l, int nl, double xmax, int* nx, double* phi, double* dphi,
                    double* chi_at_phimin, int cap_nx) {
-  if (!h) return CPT_ERR_INVALID;
-  h->err.clear();
+  CPT_ENTER(h);
   int rc = cpt_bessel_build(h, l, nl, xmax);
   if (rc) return rc;
+  CPT_HIP(h, hipStreamSynchronize(h->stream));
   *nx = h->bes_nx;
   if (h->bes_nx > cap_nx) return cpt_fail(h, CPT_ERR_INVALID, "cap_nx=%d too small for nx=%d", cap_nx, h->bes_nx);
   std::vector<double2> tmp((size_t)nl * h->bes_nx);

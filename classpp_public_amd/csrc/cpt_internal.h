@@ -40,10 +40,13 @@ struct DevTables {
 };
 
 struct Timer {
-  hipEvent_t a = nullptr, b = nullptr;
+  hipEvent_t a = nullptr, b = nullptr;   // created once with the handle, recorded around the stage on the handle's stream
   double ms = 0;
   int launches = 0;
+  bool armed = false;                    // both events recorded since the last read-out
 };
+// timers of the last call(s): perturbation kernel, line-of-sight kernel, whole transfer stage, whole cpt_step (first to last kernel)
+enum { CPT_T_PERTURB = 0, CPT_T_LOS, CPT_T_TRANSFER, CPT_T_STEP, CPT_T_N };
 
 struct cpt_handle {
   cpt_config cfg;
@@ -94,8 +97,43 @@ struct cpt_handle {
   // perturb scratch
   void* d_pt_scratch = nullptr;
   size_t pt_scratch_cap = 0;
-  Timer t_perturb, t_transfer;
+  Timer timers[CPT_T_N];
+  // ---- host staging and geometry caches: nothing on the per-step path allocates, copies from pageable memory or syncs twice ----
+  // pinned arena: every host -> device copy of a call is staged here (the caller's arrays and the library's own prepared
+  // arrays are pageable), bump-allocated, reset when a call begins (the previous call has drained the stream)
+  char* pin = nullptr;
+  size_t pin_cap = 0, pin_off = 0;
+  std::vector<char*> pin_retired;   // arenas outgrown during the current call (still referenced by copies in flight)
+  // pinned landing zone of the per-mode status / statistics and of the transfer work counters (device -> host, read after the sync)
+  char* pin_out = nullptr;
+  size_t pin_out_cap = 0;
+  int pend_nk = 0;                  // perturbation results waiting in pin_out for cpt_perturb_collect (0 = none)
+  bool pend_work = false;           // transfer work counters waiting in pin_out
+  bool defer = false;               // inside cpt_step: stages enqueue only, one synchronisation at the end
+  // geometry of the last perturbation / transfer call (content of k, tau, q, l): identical grids are not prepared or uploaded again
+  std::vector<double> geo_pt_k, geo_pt_tau, geo_tr_k, geo_tr_tau, geo_tr_q;
+  std::vector<int> geo_tr_l;
+  int geo_tr_k_size_cl = -1;
+  bool geo_tr_valid = false, geo_pt_valid = false;
+  int geo_imin_lcmb = 0, geo_i_cut = -1, geo_index_q_flat = 0, geo_his_max_nx = 0;
+  size_t geo_n_desc = 0;
+  double* d_clw = nullptr;          // C_l quadrature weights (own buffer: d_q keeps the q grid of the cached geometry)
+  size_t clw_cap = 0;
+  std::vector<double> geo_cl_q; double geo_cl_sp[4] = {0, 0, 0, 0}; bool geo_cl_valid = false;
+  double* d_pk_k = nullptr;
+  size_t pk_k_cap = 0;
 };
+
+// stage `bytes` of host memory in the pinned arena and return the staged copy (valid until the next call on the handle begins)
+void* cpt_pin(cpt_handle* h, const void* src, size_t bytes);
+void cpt_pin_reset(cpt_handle* h);
+// enqueue an asynchronous host -> device copy of pageable host memory through the arena
+int cpt_upload(cpt_handle* h, void* dst_dev, const void* src_host, size_t bytes);
+// end of an entry point: unless inside cpt_step, drain the stream and read timers / counters / statuses back
+int cpt_finish(cpt_handle* h);
+int cpt_perturb_collect(cpt_handle* h, const double* k, cpt_stepstat* stats, int* status);
+void cpt_timer_start(cpt_handle* h, int which);
+void cpt_timer_stop(cpt_handle* h, int which);
 
 int cpt_fail(cpt_handle* h, int code, const char* fmt, ...);
 

@@ -286,6 +286,13 @@ int cpt_lensing_l_size_impl(const int* l, int nl, const cpt_lensing_params* lp) 
 int cpt_lensing_impl(cpt_handle* h, const cpt_spectra_params* sp, const cpt_lensing_params* lp, const int* l, int nl,
                      const double* cl_dev, double* cl_lensed_dev) {
   const int lmax = lp->l_unlensed_max, ct = sp->ct_size;
+  // (the kernels index the C_l table with these: an inconsistent cpt_spectra_params must not reach them)
+  if (ct < 1 || ct > 8) return cpt_fail(h, CPT_ERR_INVALID, "ct_size=%d out of range", ct);
+  {
+    const int cts[7] = {sp->index_ct_tt, sp->index_ct_ee, sp->index_ct_te, sp->index_ct_bb, sp->index_ct_pp, sp->index_ct_tp, sp->index_ct_ep};
+    for (int i = 0; i < 7; i++)
+      if (cts[i] >= ct) return cpt_fail(h, CPT_ERR_INVALID, "index_ct_* >= ct_size");
+  }
   if (sp->index_ct_pp < 0) return cpt_fail(h, CPT_ERR_INVALID, "lensing needs the lensing potential spectrum C_l^phiphi (lCl)");
   if (nl < 4) return cpt_fail(h, CPT_ERR_INVALID, "need at least 4 l values");
   for (int i = 1; i < nl; i++)
@@ -319,8 +326,8 @@ int cpt_lensing_impl(cpt_handle* h, const cpt_spectra_params* sp, const cpt_lens
     h->lens_cgl = p; p += 2 * num_mu;
     h->lens_ksi = p; p += 4 * num_mu;
     h->lens_work = p;
-    CPT_HIP(h, hipMemcpy(h->lens_mu, mu.data(), num_mu * sizeof(double), hipMemcpyHostToDevice));
-    CPT_HIP(h, hipMemcpy(h->lens_w8, w8.data(), num_mu * sizeof(double), hipMemcpyHostToDevice));
+    if ((rc = cpt_upload(h, h->lens_mu, mu.data(), num_mu * sizeof(double)))) return rc;
+    if ((rc = cpt_upload(h, h->lens_w8, w8.data(), num_mu * sizeof(double)))) return rc;
     hipLaunchKernelGGL(k_lens_fac, dim3((lmax + 256) / 256, NM), dim3(256), 0, h->stream, lmax, h->lens_fac);
     hipLaunchKernelGGL(k_lens_d, dim3((num_mu + 63) / 64, NM), dim3(64), 0, h->stream, h->lens_mu, num_mu, lmax, h->lens_fac, h->lens_d);
     CPT_HIP(h, hipGetLastError());
@@ -329,7 +336,7 @@ int cpt_lensing_impl(cpt_handle* h, const cpt_spectra_params* sp, const cpt_lens
   // work area: l grid (as int), ddcl, u, full spectra
   int rc;
   if ((rc = cpt_reserve(h, &h->d_lens_l, &h->lens_l_cap, (size_t)nl))) return rc;
-  CPT_HIP(h, hipMemcpyAsync(h->d_lens_l, l, nl * sizeof(int), hipMemcpyHostToDevice, h->stream));
+  if ((rc = cpt_upload(h, h->d_lens_l, l, nl * sizeof(int)))) return rc;
   const size_t wneed = (size_t)2 * nl * ct + (size_t)ct * (lmax + 1);
   if ((rc = cpt_reserve(h, &h->d_lens_w, &h->lens_w_cap, wneed))) return rc;
   double* dd = h->d_lens_w;
@@ -349,6 +356,5 @@ int cpt_lensing_impl(cpt_handle* h, const cpt_spectra_params* sp, const cpt_lens
   O.ct_bb = sp->index_ct_bb; O.accurate = lp->accurate_lensing;
   hipLaunchKernelGGL(k_lens_out, dim3(l_size), dim3(64), 0, h->stream, O);
   CPT_HIP(h, hipGetLastError());
-  CPT_HIP(h, hipStreamSynchronize(h->stream));
   return CPT_OK;
 }

@@ -93,11 +93,13 @@ __device__ inline double row_shl0(double v) {
 // max over the 64 lanes of a NON-NEGATIVE quantity (an error norm).  The reduction runs in single precision, where
 // v_max_f32 takes a DPP operand directly: 4 row_shr steps + row_bcast:15 + row_bcast:31 = six VALU instructions
 // (the double-precision version needs ~35: v_max_f64 is VOP3-only, so every step is copy + 2 DPP movs + max).
-// The value is rounded UP to float first, so the result is >= the exact maximum and <= (1 + 2^-23) times it - the
+// The value is rounded UP to float first (f32_up), so the result is >= the exact maximum and <= (1 + 2^-22) times it - the
 // norms only steer the step size and the Newton stopping test (ev.cpp:367-444), at rtol-level thresholds.
+// v >= 0 as a float that is >= v: round-to-nearest conversion + one ulp up (integer increment of a non-negative float, saturated
+// at +inf) - 3 instructions, where the directed-rounding conversion __double2float_ru is a 12-instruction software sequence
+__device__ inline float f32_up(double v) { return __int_as_float(min(__float_as_int((float)v) + 1, 0x7f800000)); }
 __device__ inline double wave_max(double v) {
-  float f = __double2float_ru(v);
-  int x = __float_as_int(f), t;
+  int x = __float_as_int(f32_up(v)), t;
   asm volatile(
       "s_nop 1\n\t"
       "v_max_f32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
@@ -116,6 +118,12 @@ __device__ inline double wave_max(double v) {
       : "+v"(x), "=s"(t));
   return (double)__int_as_float(t);
 }
+// A condition that is the same in every lane (all control flow of the integrator is), made PROVABLY uniform: the compiler then
+// branches on the scalar unit instead of masking EXEC and merging every variable of the two arms with v_cndmask.
+__device__ inline bool uni(bool c) { return __builtin_amdgcn_ballot_w64(c) != 0ull; }
+// max over the wave of v (>= 0) <= thr, without forming the maximum: one compare + one scalar test instead of a
+// conversion, six DPP steps with their wait states and a readlane.  A NaN lane counts as "not below".
+__device__ inline bool wave_all_le(double v, double thr) { return __builtin_amdgcn_ballot_w64(!(v <= thr)) == 0ull; }
 // Cross-lane reads must execute with EVERY lane active: a DPP / bpermute source lane that is masked off by EXEC
 // yields 0.  Never call these inside a lane-dependent branch or the lazy arm of a ?: - hoist the call into its own
 // statement.  The volatile asm additionally stops the compiler from sinking the (side-effect free) instruction into
@@ -471,20 +479,24 @@ struct Lookup {
 #endif
 };
 
-// All NCOL loads are issued before the first LDS store (one HBM/L2 round trip per restage, not NCOL of them); rows past
-// the end of the table are clamped to the last row - their abscissa is +huge, so they are never selected.
+// The window travels HBM/L2 -> LDS by LDS-DMA (global_load_lds_dwordx4: 64 lanes x 16 B = one 1 KiB column block per
+// instruction, no VGPR staging): all NCOL blocks and the abscissa load are in flight together and retire behind ONE wait.
+// (Staged through registers the compiler re-used one 4-VGPR temporary under the kernel's register pressure and waited for every
+// load before issuing the next: NCOL dependent L2 round trips per restage.)  Rows past the end of the table are clamped to the
+// last row - their abscissa is +huge, so they are never selected.
 template <int NCOL>
 static __device__ __forceinline__ void window_stage(const double* __restrict__ x, const double2* __restrict__ rows, int n, int base, int lane,
                                              double* xw, double2* w) {
   const int i = base + lane;
   const double xv = x[min(i, n - 1)];
   const size_t g0 = (size_t)base * NCOL, glast = (size_t)n * NCOL - 1;
-  double2 tmp[NCOL];
+  // (the wave's own earlier LDS reads of this window have returned: they fed registers that were consumed before this call)
 #pragma unroll
-  for (int c = 0; c < NCOL; c++) tmp[c] = rows[min(g0 + (size_t)(lane + 64 * c), glast)];
+  for (int c = 0; c < NCOL; c++)
+    __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(rows + min(g0 + (size_t)(lane + 64 * c), glast)),
+                                     (void __attribute__((address_space(3)))*)(w + 64 * c), 16, 0, 0);
   *xw = (i < n) ? xv : 1e300;
-#pragma unroll
-  for (int c = 0; c < NCOL; c++) w[lane + 64 * c] = tmp[c];
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the DMA writes have landed (and xv has arrived)
 }
 
 // returns inf with x[inf] <= v <= x[inf+1] (x ascending), re-staging the 64-row window when v leaves it.
@@ -1393,7 +1405,7 @@ static __device__ __forceinline__ bool factorise(const LaneEq& e, const Jac& J, 
     if (__ballot(mag > 1e3 * diag) != 0ull || diag == 0.) {  // rare: the diagonal is not an acceptable pivot
       const double big = wave_max(mag);
       if (big == 0.) ok = false;
-      const int p = __ffsll((long long)__ballot((double)__double2float_ru(mag) == big && big > 0.)) - 1;  // wave_max rounds up to float
+      const int p = __ffsll((long long)__ballot((double)f32_up(mag) == big && big > 0.)) - 1;  // wave_max rounds up to float
       if (p > j) {
         // exchange rows p and j (register rows of two lanes) and the row bookkeeping
 #pragma unroll
@@ -1555,12 +1567,19 @@ static __device__ __forceinline__ void adjust_stepsize(double* dif, double r, in
 struct Stat { int steps, failed, fevals, jacs, lus, solves; };
 
 
-// register selects on the backward-difference array (static indices only => no scratch)
+// element `i` of the backward-difference array; i is wave-uniform (held in an SGPR), so this is a scalar jump to one register
+// move instead of seven compare + select pairs (static indices only => no scratch)
 static __device__ __forceinline__ double dif_get(const double* dif, int i) {
-  double v = 0.;
-#pragma unroll
-  for (int j = 0; j < 7; j++) if (j == i) v = dif[j];
-  return v;
+  switch (__builtin_amdgcn_readfirstlane(i)) {
+    case 0: return dif[0];
+    case 1: return dif[1];
+    case 2: return dif[2];
+    case 3: return dif[3];
+    case 4: return dif[4];
+    case 5: return dif[5];
+    case 6: return dif[6];
+    default: return 0.;
+  }
 }
 
 // evolver_ndf15 (ev.cpp:62-705) for one interval of constant approximation scheme, as ONE flat loop so that the RHS
@@ -1596,6 +1615,9 @@ static __device__ __forceinline__ int ndf15(const PtParams& P, const Layout& L, 
   double dif[7] = {0., 0., 0., 0., 0., 0., 0.};
   int next = 0;
   while (next < tres && ts[next] < t0) next++;
+  // time of the next sample, kept in a register: the test "has this step passed a sample time" runs after every step, and a
+  // scalar load there is a trip to the scalar cache (or L2) on the critical path of the step
+  double tnext = (next < tres) ? ts[next] : 1e300;
   double t = t0, tnew = t0, h = 0., absh = 0., abshlast = 0., hmin = 16.0 * eps * fabs(t0), hinvGak = 0.;
   int kk = 1, klast = 1, nconhk = 0;
   bool Jcurrent = false, havrate = false, done = false, at_hmin = false, nofailed = true;
@@ -1603,11 +1625,19 @@ static __device__ __forceinline__ int ndf15(const PtParams& P, const Layout& L, 
   double rate = 0., oldnrm = 0., err = 0., invwt = 0., difkp1 = 0.;
   double yi = 0., ypi = 0., tn = 0.;
   int batch = B_JAC;
+  // minnrm = 100 eps max |ynew / wt| (ev.cpp:375): the maximum is 1 whenever one component has not shrunk during the step and never
+  // more, and the test it feeds only fires on corrections at round-off level; its upper bound replaces a reduction per step
+  const double minnrm = 100 * eps;
+  double thr1 = minnrm;        // first Newton iteration converged <=> max |del / wt| <= thr1 (see the Newton loop)
+  bool have_err = false;       // err holds the norm of the accepted correction (formed lazily)
+  // constants of the current order, refreshed where kk changes: 1 / (G (1 - alpha)), the error constant and rtol / error constant
+  double iga = ndf_invGa(0), erc = ndf_erconst(0), errthr = rtol * fast_rcp(ndf_erconst(0));
+  auto set_order = [&]() { iga = ndf_invGa(kk - 1); erc = ndf_erconst(kk - 1); errthr = rtol * fast_rcp(erc); };
 
   // dense output at the next sample time (ev.cpp:547-571, interp_from_dif :860-905)
   auto prepare_sample = [&]() {
-    tn = ts[next];
-    if (tnew == tn) { yi = ynew; ypi = fnewton; }
+    tn = tnext;
+    if (uni(tnew == tn)) { yi = ynew; ypi = fnewton; }
     else {
       const double inv_h = fast_rcp(h), s = (tn - tnew) * inv_h;
       double prod = 1.0, sumfrac = 0.;
@@ -1709,8 +1739,9 @@ static __device__ __forceinline__ int ndf15(const PtParams& P, const Layout& L, 
         absh = fmax(absh, hmin);
         h = absh;
         kk = 1; klast = 1; abshlast = absh;
+        set_order();
         dif[0] = h * f0;
-        hinvGak = h * ndf_invGa(kk - 1);
+        hinvGak = h * iga;
         nconhk = 0;
         need_fact = true;
         new_step = true;
@@ -1720,7 +1751,8 @@ static __device__ __forceinline__ int ndf15(const PtParams& P, const Layout& L, 
       } else {  // B_SAMPLE
         M.tca_shear_g = tca_keep;
         next++;
-        if ((next < tres) && (tnew - ts[next] >= 0.0)) {
+        tnext = (next < tres) ? ts[next] : 1e300;
+        if (uni(tnew - tnext >= 0.0)) {
           prepare_sample();  // stay in B_SAMPLE
           PROF_STOP(4);
           continue;
@@ -1740,22 +1772,24 @@ static __device__ __forceinline__ int ndf15(const PtParams& P, const Layout& L, 
       abshlast = absh;
       nconhk = min(nconhk + 1, maxk + 2);
       if (nconhk >= kk + 2) {
+        // (the norm of the accepted correction is only formed here, where its value steers the step size: one step in ~five)
+        if (!have_err) err = block_max(fabs(difkp1 * invwt), C, lane) * erc;
         double temp = 1.2 * fast_root(err * inv_rtol, kk + 1);
-        double hopt = temp > 0.1 ? absh * fast_rcp(temp) : 10 * absh;
+        double hopt = uni(temp > 0.1) ? absh * fast_rcp(temp) : 10 * absh;
         int kopt = kk;
         if (kk > 1) {
           const double errkm1 = block_max(fabs(dif_get(dif, kk - 1) * invwt), C, lane) * ndf_erconst(kk - 2);
           temp = 1.3 * fast_root(errkm1 * inv_rtol, kk);
-          const double hkm1 = temp > 0.1 ? absh * fast_rcp(temp) : 10 * absh;
-          if (hkm1 > hopt) { hopt = hkm1; kopt = kk - 1; }
+          const double hkm1 = uni(temp > 0.1) ? absh * fast_rcp(temp) : 10 * absh;
+          if (uni(hkm1 > hopt)) { hopt = hkm1; kopt = kk - 1; }
         }
         if (kk < maxk) {
           const double errkp1 = block_max(fabs(dif_get(dif, kk + 1) * invwt), C, lane) * ndf_erconst(kk);
           temp = 1.4 * fast_root(errkp1 * inv_rtol, kk + 2);
-          const double hkp1 = temp > 0.1 ? absh * fast_rcp(temp) : 10 * absh;
-          if (hkp1 > hopt) { hopt = hkp1; kopt = kk + 1; }
+          const double hkp1 = uni(temp > 0.1) ? absh * fast_rcp(temp) : 10 * absh;
+          if (uni(hkp1 > hopt)) { hopt = hkp1; kopt = kk + 1; }
         }
-        if (hopt > absh) { absh = hopt; kk = kopt; }
+        if (uni(hopt > absh)) { absh = hopt; if (kopt != kk) { kk = kopt; set_order(); } }
       }
       t = tnew;
       y = ynew;
@@ -1771,12 +1805,12 @@ static __device__ __forceinline__ int ndf15(const PtParams& P, const Layout& L, 
       PROF_START();
       hmin = P.min_var;
       absh = fmin(hmax, fmax(hmin, absh));
-      if (fabs(absh - hmin) < 100 * eps) { if (at_hmin) absh = abshlast; at_hmin = true; } else at_hmin = false;
+      if (uni(fabs(absh - hmin) < 100 * eps)) { if (at_hmin) absh = abshlast; at_hmin = true; } else at_hmin = false;
       h = absh;
-      if (1.1 * absh >= fabs(tfinal - t)) { h = tfinal - t; absh = fabs(h); done = true; }
-      if ((fabs(absh - abshlast) > 1e-6 * absh) || (kk != klast)) {   // (ev.cpp:318: |dh| / h > 1e-6, without the division)
-        adjust_stepsize(dif, absh / abshlast, kk);
-        hinvGak = h * ndf_invGa(kk - 1);
+      if (uni(1.1 * absh >= fabs(tfinal - t))) { h = tfinal - t; absh = fabs(h); done = true; }
+      if (uni(fabs(absh - abshlast) > 1e-6 * absh) || (kk != klast)) {   // (ev.cpp:318: |dh| / h > 1e-6, without the division)
+        adjust_stepsize(dif, absh * fast_rcp(abshlast), kk);
+        hinvGak = h * iga;
         nconhk = 0;
         need_fact = true;
       }
@@ -1794,28 +1828,38 @@ static __device__ __forceinline__ int ndf15(const PtParams& P, const Layout& L, 
       PROF_STOP(2);
       st.lus++;
       havrate = false;
+      thr1 = minnrm;
     }
     // ------------------------------------------------------------------ predictor + simplified Newton (ev.cpp:342-445)
 #ifdef CPT_PROFILE
     const unsigned long long t_newton0 = clock64();
     unsigned long long t_inner = 0;
 #endif
-    double psi = 0., pred = y;
-    {
-      const double iga = ndf_invGa(kk - 1);
-#pragma unroll
-      for (int j = 0; j < 5; j++)
-        if (j < kk) { psi += dif[j] * (ndf_G(j) * iga); pred += dif[j]; }
+    // psi = (1 / (G_k (1 - alpha_k))) sum_j G_j dif_j,  pred = y + sum_j dif_j over the kk differences in use: one straight-line
+    // variant per order, reached by a scalar jump
+    double psi, pred;
+    switch (__builtin_amdgcn_readfirstlane(kk)) {
+      case 1: psi = dif[0]; pred = y + dif[0]; break;
+      case 2: psi = fma(1.5, dif[1], dif[0]); pred = y + (dif[0] + dif[1]); break;
+      case 3: psi = fma(11.0 / 6.0, dif[2], fma(1.5, dif[1], dif[0])); pred = y + ((dif[0] + dif[1]) + dif[2]); break;
+      case 4: psi = fma(25.0 / 12.0, dif[3], fma(11.0 / 6.0, dif[2], fma(1.5, dif[1], dif[0]))); pred = y + ((dif[0] + dif[1]) + (dif[2] + dif[3])); break;
+      default: psi = fma(137.0 / 60.0, dif[4], fma(25.0 / 12.0, dif[3], fma(11.0 / 6.0, dif[2], fma(1.5, dif[1], dif[0]))));
+               pred = y + (((dif[0] + dif[1]) + (dif[2] + dif[3])) + dif[4]); break;
     }
+    psi *= iga;
     tnew = t + h;
     if (done) tnew = tfinal;
     h = tnew - t;
     ynew = pred;
     difkp1 = 0.;
-    invwt = fast_rcp(fmax(fmax(fabs(ynew), fabs(y)), threshold));
-    const double minnrm = block_max(100 * eps * fabs(ynew * invwt), C, lane);
+    {  // weights of the norms (ev.cpp:367-374): the seed + one Newton step (2e-15) is ample for a weight
+      const double w = fmax(fmax(fabs(ynew), fabs(y)), threshold);
+      const double r = __builtin_amdgcn_rcp(w);
+      invwt = fma(r, fma(-w, r, 1.0), r);
+    }
     if (NCDM && C.abort) return 2;
     bool tooslow = false;
+    double newnrm = 0.;
     for (int iter = 1; iter <= maxit; iter++) {
       PROF_START();
       fnewton = rhs_all<ROLE>(P, L, e, ce, Q, M, C, N, k, inv_k2, tnew, ynew, lane);
@@ -1832,21 +1876,33 @@ static __device__ __forceinline__ int ndf15(const PtParams& P, const Layout& L, 
       t_inner += clock64() - pf_t0;
 #endif
       st.solves++;
-      const double newnrm = block_max(fabs(del * invwt), C, lane);
+      const double dn = fabs(del * invwt);
       difkp1 += del;
       ynew = pred + difkp1;
-      if (newnrm <= minnrm) break;
-      else if (iter == 1) {
-        if (havrate) { const double errit = newnrm * rate * fast_rcp(1.0 - rate); if (errit <= 0.05 * rtol) break; }
-        else rate = 0.0;
-      } else if (newnrm > 0.9 * oldnrm) { tooslow = true; break; }
-      else {
+      if (iter == 1) {
+        // converged when |del| <= minnrm or, with a rate estimate, |del| rate / (1 - rate) <= 0.05 rtol: both are "max over the
+        // lanes <= thr1" with thr1 kept up to date where the rate changes, i.e. one compare + one scalar test, no reduction
+        if (NCDM) {
+          newnrm = block_max(dn, C, lane);
+          if (NCDM && C.abort) return 2;
+          if (uni(newnrm <= thr1)) break;
+        } else {
+          if (wave_all_le(dn, thr1)) break;
+          newnrm = wave_max(dn);
+        }
+        if (!havrate) rate = 0.0;
+      } else {
+        newnrm = block_max(dn, C, lane);
+        if (NCDM && C.abort) return 2;
+        if (uni(newnrm <= minnrm)) break;
+        if (uni(newnrm > 0.9 * oldnrm)) { tooslow = true; break; }
         rate = fmax(0.9 * rate, newnrm * fast_rcp(oldnrm));
         havrate = true;
-        const double errit = newnrm * rate * fast_rcp(1.0 - rate);
-        if (errit <= 0.5 * rtol) break;
+        const double q = rate * fast_rcp(1.0 - rate), errit = newnrm * q;
+        thr1 = fmax(minnrm, 0.05 * rtol * fast_rcp(q));
+        if (uni(errit <= 0.5 * rtol)) break;
         else if (iter == maxit) { tooslow = true; break; }
-        else if (0.5 * rtol < errit * fast_powi(rate, maxit - iter)) { tooslow = true; break; }
+        else if (uni(0.5 * rtol < errit * fast_powi(rate, maxit - iter))) { tooslow = true; break; }
       }
       oldnrm = newnrm;
     }
@@ -1859,58 +1915,62 @@ static __device__ __forceinline__ int ndf15(const PtParams& P, const Layout& L, 
 #ifdef CPT_DEBUG_NCDM
       if (absh <= hmin && lane == 0) printf("hmin(tooslow) k=%g wave=%d t=%g h=%g kk=%d flags tca%d rsa%d ufa%d nfa%d steps=%d\n", k, C.wave, t, absh, kk, L.tca, L.rsa, L.ufa, L.nfa, st.steps);
 #endif
-      if (absh <= hmin) return 1;
+      if (uni(absh <= hmin)) return 1;
       abshlast = absh;
       absh = fmax(0.3 * absh, hmin);
       h = absh;
       done = false;
-      adjust_stepsize(dif, absh / abshlast, kk);
-      hinvGak = h * ndf_invGa(kk - 1);
+      adjust_stepsize(dif, absh * fast_rcp(abshlast), kk);
+      hinvGak = h * iga;
       nconhk = 0;
       need_fact = true;
       continue;
     }
     // ------------------------------------------------------------------ error test (ev.cpp:483-532)
     PROF_START();
-    err = block_max(fabs(difkp1 * invwt), C, lane) * ndf_erconst(kk - 1);
-    if (err > rtol) {
+    // err = max |difkp1 / wt| * erconst > rtol  <=>  some lane has |difkp1 / wt| > rtol / erconst: a compare, not a reduction
+    bool err_ok;
+    {
+      const double dn = fabs(difkp1 * invwt);
+      if (NCDM) { err = block_max(dn, C, lane) * erc; have_err = true; err_ok = !uni(err > rtol); }
+      else { have_err = false; err_ok = wave_all_le(dn, errthr); if (!err_ok) { err = wave_max(dn) * erc; have_err = true; } }
+    }
+    if (!err_ok) {
       st.failed++;
 #ifdef CPT_DEBUG_NCDM
       if (absh <= hmin && lane == 0) printf("hmin(err) k=%g wave=%d t=%g h=%g kk=%d err=%g flags tca%d rsa%d ufa%d nfa%d steps=%d\n", k, C.wave, t, absh, kk, err, L.tca, L.rsa, L.ufa, L.nfa, st.steps);
 #endif
-      if (absh <= hmin) return 1;
+      if (uni(absh <= hmin)) return 1;
       abshlast = absh;
       if (nofailed) {
         nofailed = false;
-        double hopt = absh * fmax(0.1, 0.833 * fast_root(rtol / err, kk + 1));
+        double hopt = absh * fmax(0.1, 0.833 * fast_root(rtol * fast_rcp(err), kk + 1));
         if (kk > 1) {
           const double errkm1 = block_max(fabs((dif_get(dif, kk - 1) + difkp1) * invwt), C, lane) * ndf_erconst(kk - 2);
-          const double hkm1 = absh * fmax(0.1, 0.769 * fast_root(rtol / errkm1, kk));
-          if (hkm1 > hopt) { hopt = fmin(absh, hkm1); kk = kk - 1; }
+          const double hkm1 = absh * fmax(0.1, 0.769 * fast_root(rtol * fast_rcp(errkm1), kk));
+          if (uni(hkm1 > hopt)) { hopt = fmin(absh, hkm1); kk = kk - 1; set_order(); }
         }
         absh = fmax(hmin, hopt);
       } else absh = fmax(hmin, 0.5 * absh);
       h = absh;
-      if (absh < abshlast) done = false;
-      adjust_stepsize(dif, absh / abshlast, kk);
-      hinvGak = h * ndf_invGa(kk - 1);
+      if (uni(absh < abshlast)) done = false;
+      adjust_stepsize(dif, absh * fast_rcp(abshlast), kk);
+      hinvGak = h * iga;
       nconhk = 0;
       need_fact = true;
       continue;
     }
     // ------------------------------------------------------------------ accepted: update differences (ev.cpp:537-545)
     st.steps++;
-    {
-      const double old_k = dif_get(dif, kk);
-#pragma unroll
-      for (int j = 0; j < 7; j++) {
-        if (j == kk + 1) dif[j] = difkp1 - old_k;
-        if (j == kk) dif[j] = difkp1;
-      }
-#pragma unroll
-      for (int j = 5; j >= 1; j--) if (j <= kk) dif[j - 1] += dif[j];
+    // dif[kk+1] = difkp1 - dif[kk]; dif[kk] = difkp1; dif[j-1] += dif[j] for j = kk..1: one straight-line variant per order
+    switch (__builtin_amdgcn_readfirstlane(kk)) {
+      case 1: dif[2] = difkp1 - dif[1]; dif[1] = difkp1; dif[0] += dif[1]; break;
+      case 2: dif[3] = difkp1 - dif[2]; dif[2] = difkp1; dif[1] += dif[2]; dif[0] += dif[1]; break;
+      case 3: dif[4] = difkp1 - dif[3]; dif[3] = difkp1; dif[2] += dif[3]; dif[1] += dif[2]; dif[0] += dif[1]; break;
+      case 4: dif[5] = difkp1 - dif[4]; dif[4] = difkp1; dif[3] += dif[4]; dif[2] += dif[3]; dif[1] += dif[2]; dif[0] += dif[1]; break;
+      default: dif[6] = difkp1 - dif[5]; dif[5] = difkp1; dif[4] += dif[5]; dif[3] += dif[4]; dif[2] += dif[3]; dif[1] += dif[2]; dif[0] += dif[1]; break;
     }
-    if ((next < tres) && (tnew - ts[next] >= 0.0)) { batch = B_SAMPLE; prepare_sample(); }
+    if (uni(tnew - tnext >= 0.0)) { batch = B_SAMPLE; prepare_sample(); }
     else post_step = true;
 #ifndef CPT_PROFILE_LOOKUP
     PROF_STOP(14);
@@ -2444,11 +2504,12 @@ int cpt_perturb_impl(cpt_handle* h, const double* k, int nk, const double* tau, 
   const size_t nsrc = (size_t)ntp * nk * ntau;
   int rc;
   if ((rc = cpt_reserve(h, &h->d_src, &h->src_cap, nsrc))) return rc;
-  // scratch: k[nk] tau[ntau] | order[nk] status[nk] | stats[nk]
+  h->src_nk = h->src_ntau = 0;   // no resident sources until this launch has been checked (cpt_perturb_collect)
+  // scratch: k[nk] tau[ntau] | stats[nk] | order[nk] status[nk]
   const size_t bytes = (size_t)(nk + ntau) * sizeof(double) + (size_t)2 * nk * sizeof(int) + (size_t)nk * sizeof(cpt_stepstat) + 64;
   if (h->pt_scratch_cap < bytes) {
     if (h->d_pt_scratch) (void)hipFree(h->d_pt_scratch);
-    h->d_pt_scratch = nullptr; h->pt_scratch_cap = 0;
+    h->d_pt_scratch = nullptr; h->pt_scratch_cap = 0; h->geo_pt_valid = false;
     CPT_HIP(h, hipMalloc(&h->d_pt_scratch, bytes));
     h->pt_scratch_cap = bytes;
   }
@@ -2457,14 +2518,23 @@ int cpt_perturb_impl(cpt_handle* h, const double* k, int nk, const double* tau, 
   cpt_stepstat* d_stats = (cpt_stepstat*)(d_tau + ntau);
   int* d_order = (int*)(d_stats + nk);
   int* d_status = d_order + nk;
-  std::vector<int> order(nk);
-  for (int i = 0; i < nk; i++) order[i] = nk - 1 - i;  // largest k first: the longest chains start first (pm.cpp:685)
-  CPT_HIP(h, hipMemcpyAsync(d_k, k, nk * sizeof(double), hipMemcpyHostToDevice, h->stream));
-  CPT_HIP(h, hipMemcpyAsync(d_tau, tau, ntau * sizeof(double), hipMemcpyHostToDevice, h->stream));
-  CPT_HIP(h, hipMemcpyAsync(d_order, order.data(), nk * sizeof(int), hipMemcpyHostToDevice, h->stream));
+  // the grids travel once per geometry: a call with the k and tau of the previous one finds them (and the launch order) in HBM
+  const bool same_grids = h->geo_pt_valid && (int)h->geo_pt_k.size() == nk && (int)h->geo_pt_tau.size() == ntau &&
+                          memcmp(h->geo_pt_k.data(), k, nk * sizeof(double)) == 0 && memcmp(h->geo_pt_tau.data(), tau, ntau * sizeof(double)) == 0;
+  if (!same_grids) {
+    h->geo_pt_valid = false;
+    int* order = (int*)cpt_pin(h, nullptr, nk * sizeof(int));
+    if (!order) return cpt_fail(h, CPT_ERR_NO_DEVICE, "hipHostMalloc of the staging arena failed");
+    for (int i = 0; i < nk; i++) order[i] = nk - 1 - i;  // largest k first: the longest chains start first (pm.cpp:685)
+    if ((rc = cpt_upload(h, d_k, k, nk * sizeof(double)))) return rc;
+    if ((rc = cpt_upload(h, d_tau, tau, ntau * sizeof(double)))) return rc;
+    CPT_HIP(h, hipMemcpyAsync(d_order, order, nk * sizeof(int), hipMemcpyHostToDevice, h->stream));
+    h->geo_pt_k.assign(k, k + nk); h->geo_pt_tau.assign(tau, tau + ntau);
+    h->geo_pt_valid = true;
+  }
   CPT_HIP(h, hipMemsetAsync(h->d_src, 0, nsrc * sizeof(double), h->stream));  // pm.cpp:2767-2771 zero tail
   P.k = d_k; P.tau_s = d_tau; P.order = d_order; P.nk = nk; P.ntau = ntau; P.src = h->d_src; P.stats = d_stats; P.status = d_status;
-  CPT_HIP(h, hipEventRecord(h->t_perturb.a, h->stream));
+  cpt_timer_start(h, CPT_T_PERTURB);
   if (c.has_ncdm && c.mode == CPT_MODE_SCALARS) {
     const int cpw = 64 / (c.l_max_ncdm + 1), nw = (h->ncdm.nchains + cpw - 1) / cpw;
     if (nw > NCW_MAX)
@@ -2486,22 +2556,39 @@ int cpt_perturb_impl(cpt_handle* h, const double* k, int nk, const double* tau, 
   } else
   CPT_PT_DISPATCH(c, P.rows, k_perturb, dim3(nk), dim3(128), 0, h->stream, P);
   CPT_HIP(h, hipGetLastError());
-  CPT_HIP(h, hipEventRecord(h->t_perturb.b, h->stream));
-  h->src_nk = nk; h->src_ntau = ntau;
+  cpt_timer_stop(h, CPT_T_PERTURB);
   if (sources_dev) {
     if ((rc = cpt_transpose_from_kmajor(h, h->d_src, sources_dev, ntp, ntau, nk))) return rc;
   }
-  std::vector<int> hstatus(nk);
-  std::vector<cpt_stepstat> hstats(nk);
-  CPT_HIP(h, hipMemcpyAsync(hstatus.data(), d_status, nk * sizeof(int), hipMemcpyDeviceToHost, h->stream));
-  CPT_HIP(h, hipMemcpyAsync(hstats.data(), d_stats, nk * sizeof(cpt_stepstat), hipMemcpyDeviceToHost, h->stream));
-  CPT_HIP(h, hipStreamSynchronize(h->stream));
-  float ms = 0;
-  CPT_HIP(h, hipEventElapsedTime(&ms, h->t_perturb.a, h->t_perturb.b));
-  h->t_perturb.ms = ms;
-  h->t_perturb.launches = 1;
-  if (stats) memcpy(stats, hstats.data(), nk * sizeof(cpt_stepstat));
-  if (status) memcpy(status, hstatus.data(), nk * sizeof(int));
+  // per-mode status and work counters land in pinned host memory; they are read after the (single) synchronisation of the call
+  const size_t need_out = 64 + (size_t)nk * (sizeof(int) + sizeof(cpt_stepstat)) + 64;
+  if (h->pin_out_cap < need_out) {
+    CPT_HIP(h, hipStreamSynchronize(h->stream));
+    if (h->pin_out) (void)hipHostFree(h->pin_out);
+    h->pin_out = nullptr; h->pin_out_cap = 0;
+    CPT_HIP(h, hipHostMalloc((void**)&h->pin_out, need_out * 2, hipHostMallocDefault));
+    h->pin_out_cap = need_out * 2;
+  }
+  cpt_stepstat* hstats = (cpt_stepstat*)(h->pin_out + 64);
+  int* hstatus = (int*)(hstats + nk);
+  CPT_HIP(h, hipMemcpyAsync(hstatus, d_status, nk * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+  CPT_HIP(h, hipMemcpyAsync(hstats, d_stats, nk * sizeof(cpt_stepstat), hipMemcpyDeviceToHost, h->stream));
+  h->pend_nk = nk;
+  // (later stages of a fused cpt_step read the resident sources of THIS launch: shape known now, validity checked at the end)
+  h->src_nk = nk; h->src_ntau = ntau;
+  (void)stats; (void)status;
+  return CPT_OK;
+}
+
+// after the synchronisation: hand the per-mode results to the caller and turn a failed mode into the call's error
+int cpt_perturb_collect(cpt_handle* h, const double* k, cpt_stepstat* stats, int* status) {
+  const int nk = h->pend_nk;
+  if (!nk) return CPT_OK;
+  h->pend_nk = 0;
+  const cpt_stepstat* hstats = (const cpt_stepstat*)(h->pin_out + 64);
+  const int* hstatus = (const int*)(hstats + nk);
+  if (stats) memcpy(stats, hstats, nk * sizeof(cpt_stepstat));
+  if (status) memcpy(status, hstatus, nk * sizeof(int));
   for (int i = 0; i < nk; i++) {
     if (hstatus[i]) {
       const char* what = hstatus[i] == 11   ? "Step size too small (ev.cpp:461,492)"
@@ -2510,6 +2597,7 @@ int cpt_perturb_impl(cpt_handle* h, const double* k, int nk, const double* tau, 
                          : hstatus[i] == 20 ? "initial time of the background table is too late for this k (pm.cpp:2562-2573)"
                          : hstatus[i] >= 21 ? "approximation switching times cannot be ordered (pm.cpp:3137-3173)"
                                             : "integration failure";
+      h->src_nk = h->src_ntau = 0;   // partially integrated sources must not feed cpt_transfer_batch(NULL) / cpt_pk_linear
       return cpt_fail(h, CPT_ERR_RUNTIME, "perturb_solve failed for k=%e (mode %d): %s [status %d]", k[i], i, what, hstatus[i]);
     }
   }

@@ -151,33 +151,43 @@ int cpt_cl_impl(cpt_handle* h, const cpt_spectra_params* sp, const double* trans
     if (!(q[i] > q[i - 1])) return cpt_fail(h, CPT_ERR_INVALID, "q grid must be strictly increasing");
   if (nq < 4) return cpt_fail(h, CPT_ERR_INVALID, "need at least 4 q values for the integrand spline");
   int rc;
-  if ((rc = cpt_reserve(h, &h->d_q, &h->grid_cap_q, (size_t)4 * nq))) return rc;
-  std::vector<double> W(nq), kk(nq);
-  // integration variable k(q) = sqrt(q^2 - K(1+m)) (spectra_module.cpp:990-994); flat: k = q
-  for (int i = 0; i < nq; i++) kk[i] = (c.K == 0.) ? q[i] : sqrt(q[i] * q[i] - c.K * (tens ? 3. : 1.));
-  int index_q_spline = 0;
-  if (c.K > 0.) {  // closed: trapezoidal rule where nu is integer (below the flat-approximation index), spectra_module.cpp:1293-1316
-    const double q_approximation = c.hyper_flat_approximation_nu * sqrt(c.K);
-    for (index_q_spline = 0; index_q_spline < nq - 1; index_q_spline++)
-      if (q[index_q_spline] > q_approximation) break;
+  const double* w0 = h->d_clw;
+  if ((rc = cpt_reserve(h, &h->d_clw, &h->clw_cap, (size_t)nq))) return rc;
+  if (h->d_clw != w0) h->geo_cl_valid = false;
+  // the quadrature weights depend on the q grid and the primordial spectrum only: computed and uploaded once per (q, A_s, n_s, ...)
+  const double spk[4] = {sp->A_s, sp->n_s, sp->alpha_s, sp->k_pivot};
+  const bool hit = h->geo_cl_valid && (int)h->geo_cl_q.size() == nq && memcmp(h->geo_cl_q.data(), q, nq * sizeof(double)) == 0 &&
+                   memcmp(h->geo_cl_sp, spk, sizeof(spk)) == 0;
+  if (!hit) {
+    h->geo_cl_valid = false;
+    std::vector<double> W(nq), kk(nq);
+    // integration variable k(q) = sqrt(q^2 - K(1+m)) (spectra_module.cpp:990-994); flat: k = q
+    for (int i = 0; i < nq; i++) kk[i] = (c.K == 0.) ? q[i] : sqrt(q[i] * q[i] - c.K * (tens ? 3. : 1.));
+    int index_q_spline = 0;
+    if (c.K > 0.) {  // closed: trapezoidal rule where nu is integer (below the flat-approximation index), spectra_module.cpp:1293-1316
+      const double q_approximation = c.hyper_flat_approximation_nu * sqrt(c.K);
+      for (index_q_spline = 0; index_q_spline < nq - 1; index_q_spline++)
+        if (q[index_q_spline] > q_approximation) break;
+    }
+    spline_integration_weights(kk.data(), nq, index_q_spline, W.data());
+    if (c.K > 0.) W[0] += q[0] / kk[0] * sqrt(c.K) / 2.;   // discrete sum over nu: weight of the first point, spectra_module.cpp:1319-1321
+    const double PI = 3.1415926535897932384626433832795e0;
+    for (int i = 0; i < nq; i++) {  // primordial_module.cpp:911-925 (analytic spectrum) and the 4 pi / k of the measure
+      const double lk = log(kk[i] / sp->k_pivot);
+      W[i] *= sp->A_s * exp((sp->n_s - 1.) * lk + 0.5 * sp->alpha_s * lk * lk) * (4. * PI / kk[i]);
+    }
+    if ((rc = cpt_upload(h, h->d_clw, W.data(), (size_t)nq * sizeof(double)))) return rc;
+    h->geo_cl_q.assign(q, q + nq); memcpy(h->geo_cl_sp, spk, sizeof(spk));
+    h->geo_cl_valid = true;
   }
-  spline_integration_weights(kk.data(), nq, index_q_spline, W.data());
-  if (c.K > 0.) W[0] += q[0] / kk[0] * sqrt(c.K) / 2.;   // discrete sum over nu: weight of the first point, spectra_module.cpp:1319-1321
-  const double PI = 3.1415926535897932384626433832795e0;
-  for (int i = 0; i < nq; i++) {  // primordial_module.cpp:911-925 (analytic spectrum) and the 4 pi / k of the measure
-    const double lk = log(kk[i] / sp->k_pivot);
-    W[i] *= sp->A_s * exp((sp->n_s - 1.) * lk + 0.5 * sp->alpha_s * lk * lk) * (4. * PI / kk[i]);
-  }
-  CPT_HIP(h, hipMemcpyAsync(h->d_q, W.data(), (size_t)nq * sizeof(double), hipMemcpyHostToDevice, h->stream));
   ClParams P;
-  P.tr = transfer_dev; P.w = h->d_q; P.cl = cl_dev; P.nq = nq; P.nl = nl; P.ct_size = sp->ct_size;
+  P.tr = transfer_dev; P.w = h->d_clw; P.cl = cl_dev; P.nq = nq; P.nl = nl; P.ct_size = sp->ct_size;
   P.tt_t0 = c.index_tt_t0; P.tt_t1 = c.index_tt_t1; P.tt_t2 = c.index_tt_t2; P.tt_e = c.index_tt_e; P.tt_lcmb = c.index_tt_lcmb;
   P.tt_b = c.index_tt_b; P.tensors = (c.mode == CPT_MODE_TENSORS) ? 1 : 0;
   P.ct_tt = sp->index_ct_tt; P.ct_ee = sp->index_ct_ee; P.ct_te = sp->index_ct_te; P.ct_bb = sp->index_ct_bb;
   P.ct_pp = sp->index_ct_pp; P.ct_tp = sp->index_ct_tp; P.ct_ep = sp->index_ct_ep;
   hipLaunchKernelGGL(k_cl, dim3(nl), dim3(256), 0, h->stream, P);
   CPT_HIP(h, hipGetLastError());
-  CPT_HIP(h, hipStreamSynchronize(h->stream));  // W is a stack vector: the copy above must have completed
   return CPT_OK;
 }
 
@@ -243,6 +253,7 @@ int cpt_sigma_impl(cpt_handle* h, const cpt_spectra_params* sp, const double* k,
   double* d_pk = nullptr;
   CPT_HIP(h, hipMalloc((void**)&d_pk, nk * sizeof(double)));
   int rc = cpt_pk_impl(h, sp, k, nk, d_pk, cb);
+  if (!rc && hipStreamSynchronize(h->stream) != hipSuccess) rc = cpt_fail(h, CPT_ERR_NO_DEVICE, "hipStreamSynchronize failed");
   std::vector<double> pk(nk);
   if (!rc && hipMemcpy(pk.data(), d_pk, nk * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) rc = cpt_fail(h, CPT_ERR_NO_DEVICE, "hipMemcpy of P(k) failed");
   (void)hipFree(d_pk);
@@ -260,11 +271,10 @@ int cpt_pk_impl(cpt_handle* h, const cpt_spectra_params* sp, const double* k, in
   if (tp < 0) return cpt_fail(h, CPT_ERR_INVALID, "P(k) requested but %s was not among the source types", cb ? "delta_cb" : "delta_m");
   if (!h->d_src || h->src_nk != nk) return cpt_fail(h, CPT_ERR_INVALID, "no resident sources for %d k-modes: run cpt_perturb_solve_batch first", nk);
   int rc;
-  if ((rc = cpt_reserve(h, &h->d_k, &h->grid_cap_k, (size_t)4 * nk))) return rc;
-  CPT_HIP(h, hipMemcpyAsync(h->d_k, k, nk * sizeof(double), hipMemcpyHostToDevice, h->stream));
-  hipLaunchKernelGGL(k_pk, dim3((nk + 63) / 64), dim3(64), 0, h->stream, h->d_src, h->d_k, pk_dev, nk, h->src_ntau,
+  if ((rc = cpt_reserve(h, &h->d_pk_k, &h->pk_k_cap, (size_t)nk))) return rc;
+  if ((rc = cpt_upload(h, h->d_pk_k, k, nk * sizeof(double)))) return rc;
+  hipLaunchKernelGGL(k_pk, dim3((nk + 63) / 64), dim3(64), 0, h->stream, h->d_src, h->d_pk_k, pk_dev, nk, h->src_ntau,
                      tp, sp->A_s, sp->n_s, sp->alpha_s, sp->k_pivot);
   CPT_HIP(h, hipGetLastError());
-  CPT_HIP(h, hipStreamSynchronize(h->stream));
   return CPT_OK;
 }

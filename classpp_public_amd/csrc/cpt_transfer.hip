@@ -143,6 +143,8 @@ int cpt_bessel_build(cpt_handle* h, const int* l, int nl, double xmax) {
   if (l[0] < 0) return cpt_fail(h, CPT_ERR_INVALID, "negative l");
   bool hit = (h->bes_xmax == xmax) && ((int)h->bes_l.size() == nl) && (memcmp(h->bes_l.data(), l, nl * sizeof(int)) == 0);
   if (hit) return CPT_OK;
+  h->geo_tr_valid = false;   // the cached transfer geometry refers to the table (and l list) replaced here
+  int rc;
   const double PI = 3.1415926535897932384626433832795;
   const double xmin = c.hyper_x_min;
   int nx = (int)((xmax - xmin) * c.hyper_sampling_flat / (2 * PI));
@@ -151,18 +153,16 @@ int cpt_bessel_build(cpt_handle* h, const int* l, int nl, double xmax) {
   const int lmax = l[nl - 1];
   const double xfwd = sqrt(lmax * (lmax + 1.0));
   const int xfwdidx = (int)((xfwd - xmin) / dx);
-  int rc;
   if ((rc = cpt_reserve(h, &h->d_bes, &h->bes_cap, (size_t)nl * nx))) return rc;
   if ((rc = cpt_reserve(h, &h->d_l, &h->grid_cap_l, (size_t)nl))) return rc;
   if (h->d_chi_min) { (void)hipFree(h->d_chi_min); h->d_chi_min = nullptr; }
   CPT_HIP(h, hipMalloc((void**)&h->d_chi_min, nl * sizeof(double)));
-  CPT_HIP(h, hipMemcpyAsync(h->d_l, l, nl * sizeof(int), hipMemcpyHostToDevice, h->stream));
+  if ((rc = cpt_upload(h, h->d_l, l, nl * sizeof(int)))) return rc;
   hipLaunchKernelGGL(k_bessel, dim3((nx + 63) / 64), dim3(64), 0, h->stream, h->d_bes, h->d_l, nl, nx, xmin, dx, xfwdidx);
   CPT_HIP(h, hipGetLastError());
   hipLaunchKernelGGL(k_chi_at_phimin, dim3((nl + 63) / 64), dim3(64), 0, h->stream, h->d_chi_min, h->d_l, nl,
                      c.hyper_phi_min_abs);
   CPT_HIP(h, hipGetLastError());
-  CPT_HIP(h, hipStreamSynchronize(h->stream));  // d_l was read from pageable host memory
   h->bes_l.assign(l, l + nl);
   h->bes_xmax = xmax;
   h->bes_nx = nx;
@@ -946,15 +946,6 @@ int cpt_transfer_impl(cpt_handle* h, const double* sources_dev, const double* k,
   const cpt_config& c = h->cfg;
   const int ntp = c.tp_size;
   int rc;
-  // ---- host-side validation of everything the kernels index with (no out-of-bounds launches) ----
-  for (int i = 1; i < nk; i++)
-    if (!(k[i] > k[i - 1])) return cpt_fail(h, CPT_ERR_INVALID, "k grid must be strictly increasing");
-  for (int i = 1; i < ntau; i++)
-    if (!(tau[i] > tau[i - 1])) return cpt_fail(h, CPT_ERR_INVALID, "tau_sampling must be strictly increasing");
-  for (int i = 1; i < nq; i++)
-    if (!(q[i] > q[i - 1])) return cpt_fail(h, CPT_ERR_INVALID, "q grid must be strictly increasing");
-  if (!(q[0] > 0.) || !(k[0] > 0.)) return cpt_fail(h, CPT_ERR_INVALID, "wavenumbers must be positive");
-  if (!(tau[ntau - 1] <= c.tau0)) return cpt_fail(h, CPT_ERR_INVALID, "tau_sampling exceeds conformal age");
   const bool tens = c.mode == CPT_MODE_TENSORS;
   const int tts_s[5] = {c.index_tt_t0, c.index_tt_t1, c.index_tt_t2, c.index_tt_e, c.index_tt_lcmb};
   const int tps_s[5] = {c.index_tp_t0, c.index_tp_t1, c.index_tp_t2, c.index_tp_p, c.index_tp_phi_plus_psi};
@@ -972,7 +963,12 @@ int cpt_transfer_impl(cpt_handle* h, const double* sources_dev, const double* k,
                     ntp, nk, ntau);
   size_t lds_bytes = (size_t)(c.K != 0. ? 9 : 7) * ntau * sizeof(double) + 16;
   if (lds_bytes > 160 * 1024 - 256) return cpt_fail(h, CPT_ERR_UNSUPPORTED, "ntau=%d too large for the LDS staging (160 KB/CU)", ntau);
+  const bool closed = c.K != 0.;   // (any curved space: closed or open)
+  const int sgnK = (c.K > 0.) ? 1 : (c.K < 0. ? -1 : 0);
 
+  // ---- geometry cache: everything below that depends on the grids only (validation, spline elimination factors, bracketing
+  //      indices, Bessel / hyperspherical tables, their uploads) is done once per (k, tau, q, l) and found in HBM afterwards ----
+  const double* kbuf0 = h->d_k; const double* qbuf0 = h->d_q; const double* taubuf0 = h->d_tau;
   const size_t nsrc = (size_t)ntp * nk * ntau;
   if ((rc = cpt_reserve(h, &h->d_dd, &h->dd_cap, nsrc))) return rc;
   if ((rc = cpt_reserve(h, &h->d_k, &h->grid_cap_k, (size_t)4 * nk))) return rc;  // k + splc[3][nk]
@@ -980,95 +976,134 @@ int cpt_transfer_impl(cpt_handle* h, const double* sources_dev, const double* k,
   if ((rc = cpt_reserve(h, &h->d_q, &h->grid_cap_q, (size_t)2 * nq))) return rc;  // q + ik (as int)
   h->d_splc = h->d_k + nk;
   h->d_ik = (int*)(h->d_q + nq);
+  if (h->d_k != kbuf0 || h->d_q != qbuf0 || h->d_tau != taubuf0) h->geo_tr_valid = false;
+  const bool hit = h->geo_tr_valid && h->geo_tr_k_size_cl == k_size_cl && (int)h->geo_tr_k.size() == nk && (int)h->geo_tr_tau.size() == ntau &&
+                   (int)h->geo_tr_q.size() == nq && (int)h->geo_tr_l.size() == nl && memcmp(h->geo_tr_k.data(), k, nk * sizeof(double)) == 0 &&
+                   memcmp(h->geo_tr_tau.data(), tau, ntau * sizeof(double)) == 0 && memcmp(h->geo_tr_q.data(), q, nq * sizeof(double)) == 0 &&
+                   memcmp(h->geo_tr_l.data(), l, nl * sizeof(int)) == 0;
+  cpt_timer_start(h, CPT_T_TRANSFER);
+  if (!hit) {
+    h->geo_tr_valid = false;
+    // ---- host-side validation of everything the kernels index with (no out-of-bounds launches) ----
+    for (int i = 1; i < nk; i++)
+      if (!(k[i] > k[i - 1])) return cpt_fail(h, CPT_ERR_INVALID, "k grid must be strictly increasing");
+    for (int i = 1; i < ntau; i++)
+      if (!(tau[i] > tau[i - 1])) return cpt_fail(h, CPT_ERR_INVALID, "tau_sampling must be strictly increasing");
+    for (int i = 1; i < nq; i++)
+      if (!(q[i] > q[i - 1])) return cpt_fail(h, CPT_ERR_INVALID, "q grid must be strictly increasing");
+    if (!(q[0] > 0.) || !(k[0] > 0.)) return cpt_fail(h, CPT_ERR_INVALID, "wavenumbers must be positive");
+    if (!(tau[ntau - 1] <= c.tau0)) return cpt_fail(h, CPT_ERR_INVALID, "tau_sampling exceeds conformal age");
 
-  // ---- Bessel table (cached on (l list, xmax)); tm.cpp:246-262 ----
-  double xmax = q[nq - 1] * c.tau0;
-  if (c.K < 0.) xmax *= (l[nl - 1] / c.hyper_flat_approximation_nu) / asinh(l[nl - 1] / c.hyper_flat_approximation_nu) * 1.01;   // tm.cpp:247-249
-  if ((rc = cpt_bessel_build(h, l, nl, xmax))) return rc;
+    // ---- Bessel table (cached on (l list, xmax)); tm.cpp:246-262 ----
+    double xmax = q[nq - 1] * c.tau0;
+    if (c.K < 0.) xmax *= (l[nl - 1] / c.hyper_flat_approximation_nu) / asinh(l[nl - 1] / c.hyper_flat_approximation_nu) * 1.01;   // tm.cpp:247-249
+    if ((rc = cpt_bessel_build(h, l, nl, xmax))) return rc;
+    const double bes_xmax = c.hyper_x_min + (h->bes_nx - 1) * h->bes_dx;
+    if (c.K == 0. && q[nq - 1] > bes_xmax / (c.tau0 - tau[0]))
+      return cpt_fail(h, CPT_ERR_RUNTIME, "q_max exceeds q_max_bessel (tm.cpp:1660): Limber fallback for CMB types not implemented");
+
+    // ---- host prep: spline elimination factors of the k grid, bracketing indices ----
+    std::vector<double> hk((size_t)4 * nk);
+    memcpy(hk.data(), k, nk * sizeof(double));
+    double* cc = hk.data() + nk;
+    double* sg = cc + nk;
+    double* pp = sg + nk;
+    cc[0] = -0.5; sg[0] = 0.; pp[0] = 1.;
+    for (int i = 1; i < nk - 1; i++) {
+      sg[i] = (k[i] - k[i - 1]) / (k[i + 1] - k[i - 1]);
+      pp[i] = sg[i] * cc[i - 1] + 2.0;
+      cc[i] = (sg[i] - 1.0) / pp[i];
+    }
+    cc[nk - 1] = 0.; sg[nk - 1] = 0.; pp[nk - 1] = 1.;
+    std::vector<double> kq(nq);  // k(q) = sqrt(q^2 - K(1+m)), tm.cpp:1106-1167 (scalars: m = 0); flat: k = q
+    for (int i = 0; i < nq; i++) kq[i] = closed ? sqrt(q[i] * q[i] - c.K * (tens ? 3. : 1.)) : q[i];   // m = 2 for tensors
+    std::vector<int> ik(nq);
+    {
+      int j = 0;  // tm.cpp:1794-1802 (q ascending -> resume the scan)
+      for (int i = 0; i < nq; i++) {
+        if (!(kq[i] <= k[k_size_cl - 1])) { ik[i] = -1; continue; }
+        while ((j + 1) < nk && k[j + 1] < kq[i]) j++;
+        ik[i] = (j + 1 < nk) ? j : nk - 2;
+      }
+    }
+    // ---- closed space: one hyperspherical table per q below the flat-approximation threshold (tm.cpp:3777-3887, 1081-1088) ----
+    int index_q_flat = 0, his_max_nx = 0;
+    std::vector<HisDesc> desc;
+    size_t his_total = 0, trig_total = 0;
+    if (closed) {
+      const double sqrtK = sqrt(fabs(c.K)), PI = 3.1415926535897932384626433832795;
+      const double q_approximation = c.hyper_flat_approximation_nu * sqrtK;
+      for (index_q_flat = 0; index_q_flat < nq - 1; index_q_flat++)
+        if (q[index_q_flat] > q_approximation) break;
+      desc.resize(index_q_flat);
+      const double xmin = c.hyper_x_min, xmaxK = (sgnK == 1) ? std::min(sqrtK * c.tau0, PI / 2.0 - xmin) : sqrtK * c.tau0;
+      for (int i = 0; i < index_q_flat; i++) {
+        HisDesc& D = desc[i];
+        double nu = q[i] / sqrtK;
+        int nlq = nl;
+        if (sgnK == 1) {
+          nu = (double)(int)(q[i] / sqrtK + 0.2);
+          if (q[i] / sqrtK - nu > 1.e-6)
+            return cpt_fail(h, CPT_ERR_INVALID, "problem in q list definition in closed case for index_q=%d, nu=%e (tm.cpp:3800-3803)", i, q[i] / sqrtK);
+          while (nlq > 0 && (double)l[nlq - 1] >= nu) nlq--;
+        }
+        // open space: every l of the list (the reference's WKB/Airy l_max cut, tm.cpp:3823-3856, only drops functions that
+        // stay below hyper_phi_min_abs on the whole range)
+        const double sampling = (nu > c.hyper_nu_sampling_step) ? c.hyper_sampling_curved_high_nu : c.hyper_sampling_curved_low_nu;
+        int nx = (int)((xmaxK - xmin) * sampling / (2 * PI / nu));
+        if (nx < 2) nx = 2;
+        D.nu = nu; D.nl = nlq; D.nx = nx; D.dx = (xmaxK - xmin) / (nx - 1.0);
+        D.off = his_total; D.trig_off = trig_total;
+        D.special = 0; D.L = 0; D.xfwdidx = 0;
+        if (nlq > 0) {
+          const int lmax = l[nlq - 1];
+          D.special = (sgnK == 1 && (int)(nu + 0.2) == lmax + 1) ? 1 : 0;
+          D.L = D.special ? lmax : lmax + 1;
+          const double xfwd = (sgnK == 1) ? asin(sqrt(lmax * (lmax + 1.0)) / nu) : asinh(sqrt(lmax * (lmax + 1.0)) / nu);
+          D.xfwdidx = (int)((xfwd - xmin) / D.dx);
+          his_total += (size_t)nlq * nx;
+        }
+        trig_total += (size_t)nx;
+        his_max_nx = std::max(his_max_nx, nx);
+      }
+    }
+    int imin_lcmb = 0;
+    while (imin_lcmb < ntau && tau[imin_lcmb] <= c.tau_rec) imin_lcmb++;
+    if (tts[4] >= 0 && ntau - imin_lcmb < 3)
+      return cpt_fail(h, CPT_ERR_INVALID, "fewer than 3 sampling times after recombination for the lensing source");
+    int i_cut = -1;
+    for (int i = 0; i < ntau; i++)
+      if (c.tau0 - tau[i] >= c.tau0 - c.tau_cut) i_cut = i;
+
+    if ((rc = cpt_upload(h, h->d_k, hk.data(), hk.size() * sizeof(double)))) return rc;
+    if ((rc = cpt_upload(h, h->d_tau, tau, ntau * sizeof(double)))) return rc;
+    if ((rc = cpt_upload(h, h->d_q, q, nq * sizeof(double)))) return rc;
+    if ((rc = cpt_upload(h, h->d_ik, ik.data(), nq * sizeof(int)))) return rc;
+    if (closed) {
+      if ((rc = cpt_reserve(h, &h->d_his, &h->his_cap, his_total + 1))) return rc;
+      if ((rc = cpt_reserve(h, &h->d_his_trig, &h->his_trig_cap, trig_total + 1))) return rc;
+      if ((rc = cpt_reserve(h, &h->d_kq, &h->kq_cap, (size_t)nq))) return rc;
+      {
+        char* pdesc = (char*)h->d_his_desc;
+        size_t cap = h->his_desc_cap;
+        if ((rc = cpt_reserve(h, &pdesc, &cap, (desc.size() + 1) * sizeof(HisDesc)))) return rc;
+        h->d_his_desc = pdesc; h->his_desc_cap = cap;
+      }
+      if ((rc = cpt_upload(h, h->d_kq, kq.data(), nq * sizeof(double)))) return rc;
+      if (!desc.empty()) {
+        if ((rc = cpt_upload(h, h->d_his_desc, desc.data(), desc.size() * sizeof(HisDesc)))) return rc;
+        // the per-q hyperspherical tables depend on (q, l, K) only: built here, once per geometry
+        hipLaunchKernelGGL(k_his_curved, dim3((his_max_nx + 63) / 64, (unsigned)desc.size()), dim3(64), 0, h->stream, (const HisDesc*)h->d_his_desc,
+                           h->d_l, c.hyper_x_min, sgnK, h->d_his, h->d_his_trig);
+        CPT_HIP(h, hipGetLastError());
+      }
+    }
+    h->geo_imin_lcmb = imin_lcmb; h->geo_i_cut = i_cut; h->geo_index_q_flat = index_q_flat; h->geo_his_max_nx = his_max_nx; h->geo_n_desc = desc.size();
+    h->geo_tr_k.assign(k, k + nk); h->geo_tr_tau.assign(tau, tau + ntau); h->geo_tr_q.assign(q, q + nq); h->geo_tr_l.assign(l, l + nl);
+    h->geo_tr_k_size_cl = k_size_cl;
+    h->geo_tr_valid = true;
+  }
   const double bes_xmax = c.hyper_x_min + (h->bes_nx - 1) * h->bes_dx;
-  if (c.K == 0. && q[nq - 1] > bes_xmax / (c.tau0 - tau[0]))
-    return cpt_fail(h, CPT_ERR_RUNTIME, "q_max exceeds q_max_bessel (tm.cpp:1660): Limber fallback for CMB types not implemented");
-
-  // ---- host prep: spline elimination factors of the k grid, bracketing indices ----
-  std::vector<double> hk((size_t)4 * nk);
-  memcpy(hk.data(), k, nk * sizeof(double));
-  double* cc = hk.data() + nk;
-  double* sg = cc + nk;
-  double* pp = sg + nk;
-  cc[0] = -0.5; sg[0] = 0.; pp[0] = 1.;
-  for (int i = 1; i < nk - 1; i++) {
-    sg[i] = (k[i] - k[i - 1]) / (k[i + 1] - k[i - 1]);
-    pp[i] = sg[i] * cc[i - 1] + 2.0;
-    cc[i] = (sg[i] - 1.0) / pp[i];
-  }
-  cc[nk - 1] = 0.; sg[nk - 1] = 0.; pp[nk - 1] = 1.;
-  const bool closed = c.K != 0.;   // (any curved space: closed or open)
-  const int sgnK = (c.K > 0.) ? 1 : (c.K < 0. ? -1 : 0);
-  std::vector<double> kq(nq);  // k(q) = sqrt(q^2 - K(1+m)), tm.cpp:1106-1167 (scalars: m = 0); flat: k = q
-  for (int i = 0; i < nq; i++) kq[i] = closed ? sqrt(q[i] * q[i] - c.K * (tens ? 3. : 1.)) : q[i];   // m = 2 for tensors
-  std::vector<int> ik(nq);
-  {
-    int j = 0;  // tm.cpp:1794-1802 (q ascending -> resume the scan)
-    for (int i = 0; i < nq; i++) {
-      if (!(kq[i] <= k[k_size_cl - 1])) { ik[i] = -1; continue; }
-      while ((j + 1) < nk && k[j + 1] < kq[i]) j++;
-      ik[i] = (j + 1 < nk) ? j : nk - 2;
-    }
-  }
-  // ---- closed space: one hyperspherical table per q below the flat-approximation threshold (tm.cpp:3777-3887, 1081-1088) ----
-  int index_q_flat = 0, his_max_nx = 0;
-  std::vector<HisDesc> desc;
-  size_t his_total = 0, trig_total = 0;
-  if (closed) {
-    const double sqrtK = sqrt(fabs(c.K)), PI = 3.1415926535897932384626433832795;
-    const double q_approximation = c.hyper_flat_approximation_nu * sqrtK;
-    for (index_q_flat = 0; index_q_flat < nq - 1; index_q_flat++)
-      if (q[index_q_flat] > q_approximation) break;
-    desc.resize(index_q_flat);
-    const double xmin = c.hyper_x_min, xmax = (sgnK == 1) ? std::min(sqrtK * c.tau0, PI / 2.0 - xmin) : sqrtK * c.tau0;
-    for (int i = 0; i < index_q_flat; i++) {
-      HisDesc& D = desc[i];
-      double nu = q[i] / sqrtK;
-      int nlq = nl;
-      if (sgnK == 1) {
-        nu = (double)(int)(q[i] / sqrtK + 0.2);
-        if (q[i] / sqrtK - nu > 1.e-6)
-          return cpt_fail(h, CPT_ERR_INVALID, "problem in q list definition in closed case for index_q=%d, nu=%e (tm.cpp:3800-3803)", i, q[i] / sqrtK);
-        while (nlq > 0 && (double)l[nlq - 1] >= nu) nlq--;
-      }
-      // open space: every l of the list (the reference's WKB/Airy l_max cut, tm.cpp:3823-3856, only drops functions that
-      // stay below hyper_phi_min_abs on the whole range)
-      const double sampling = (nu > c.hyper_nu_sampling_step) ? c.hyper_sampling_curved_high_nu : c.hyper_sampling_curved_low_nu;
-      int nx = (int)((xmax - xmin) * sampling / (2 * PI / nu));
-      if (nx < 2) nx = 2;
-      D.nu = nu; D.nl = nlq; D.nx = nx; D.dx = (xmax - xmin) / (nx - 1.0);
-      D.off = his_total; D.trig_off = trig_total;
-      D.special = 0; D.L = 0; D.xfwdidx = 0;
-      if (nlq > 0) {
-        const int lmax = l[nlq - 1];
-        D.special = (sgnK == 1 && (int)(nu + 0.2) == lmax + 1) ? 1 : 0;
-        D.L = D.special ? lmax : lmax + 1;
-        const double xfwd = (sgnK == 1) ? asin(sqrt(lmax * (lmax + 1.0)) / nu) : asinh(sqrt(lmax * (lmax + 1.0)) / nu);
-        D.xfwdidx = (int)((xfwd - xmin) / D.dx);
-        his_total += (size_t)nlq * nx;
-      }
-      trig_total += (size_t)nx;
-      his_max_nx = std::max(his_max_nx, nx);
-    }
-  }
-  int imin_lcmb = 0;
-  while (imin_lcmb < ntau && tau[imin_lcmb] <= c.tau_rec) imin_lcmb++;
-  if (tts[4] >= 0 && ntau - imin_lcmb < 3)
-    return cpt_fail(h, CPT_ERR_INVALID, "fewer than 3 sampling times after recombination for the lensing source");
-  int i_cut = -1;
-  for (int i = 0; i < ntau; i++)
-    if (c.tau0 - tau[i] >= c.tau0 - c.tau_cut) i_cut = i;
-
-  CPT_HIP(h, hipEventRecord(h->t_transfer.a, h->stream));
-  CPT_HIP(h, hipMemcpyAsync(h->d_k, hk.data(), hk.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
-  CPT_HIP(h, hipMemcpyAsync(h->d_tau, tau, ntau * sizeof(double), hipMemcpyHostToDevice, h->stream));
-  CPT_HIP(h, hipMemcpyAsync(h->d_q, q, nq * sizeof(double), hipMemcpyHostToDevice, h->stream));
-  CPT_HIP(h, hipMemcpyAsync(h->d_ik, ik.data(), nq * sizeof(int), hipMemcpyHostToDevice, h->stream));
   CPT_HIP(h, hipMemsetAsync(h->d_work, 0, 3 * sizeof(unsigned long long), h->stream));
 
   if (sources_dev) {
@@ -1095,50 +1130,21 @@ int cpt_transfer_impl(cpt_handle* h, const double* sources_dev, const double* k,
   P.t0mt_cut = c.tau0 - c.tau_cut; P.late_l = c.transfer_neglect_late_source * c.angular_rescaling;
   P.l_switch_limber = c.l_switch_limber;
   P.lcmb_fac_rescale = c.lcmb_rescale; P.lcmb_tilt = c.lcmb_tilt; P.lcmb_pivot = c.lcmb_pivot;
-  P.imin_lcmb = imin_lcmb; P.i_cut = i_cut;
+  P.imin_lcmb = h->geo_imin_lcmb; P.i_cut = h->geo_i_cut;
 
-  hipEvent_t ka, kb;
-  CPT_HIP(h, hipEventCreate(&ka));
-  CPT_HIP(h, hipEventCreate(&kb));
-  CPT_HIP(h, hipEventRecord(ka, h->stream));
+  cpt_timer_start(h, CPT_T_LOS);
   if (closed) {
-    if ((rc = cpt_reserve(h, &h->d_his, &h->his_cap, his_total + 1))) return rc;
-    if ((rc = cpt_reserve(h, &h->d_his_trig, &h->his_trig_cap, trig_total + 1))) return rc;
-    if ((rc = cpt_reserve(h, &h->d_kq, &h->kq_cap, (size_t)nq))) return rc;
-    {
-      char* pdesc = (char*)h->d_his_desc;
-      size_t cap = h->his_desc_cap;
-      if ((rc = cpt_reserve(h, &pdesc, &cap, (desc.size() + 1) * sizeof(HisDesc)))) return rc;
-      h->d_his_desc = pdesc; h->his_desc_cap = cap;
-    }
-    CPT_HIP(h, hipMemcpyAsync(h->d_kq, kq.data(), nq * sizeof(double), hipMemcpyHostToDevice, h->stream));
-    if (!desc.empty()) {
-      CPT_HIP(h, hipMemcpyAsync(h->d_his_desc, desc.data(), desc.size() * sizeof(HisDesc), hipMemcpyHostToDevice, h->stream));
-      hipLaunchKernelGGL(k_his_curved, dim3((his_max_nx + 63) / 64, (unsigned)desc.size()), dim3(64), 0, h->stream, (const HisDesc*)h->d_his_desc,
-                         h->d_l, c.hyper_x_min, sgnK, h->d_his, h->d_his_trig);
-      CPT_HIP(h, hipGetLastError());
-    }
     LosClosedParams CP;
     CP.b = P; CP.kq = h->d_kq; CP.desc = (const HisDesc*)h->d_his_desc; CP.his = h->d_his; CP.trig = h->d_his_trig;
-    CP.K = c.K; CP.sqrtK = sqrt(fabs(c.K)); CP.sgnK = sgnK; CP.his_xmin = c.hyper_x_min; CP.phiminabs = c.hyper_phi_min_abs; CP.index_q_flat = index_q_flat;
+    CP.K = c.K; CP.sqrtK = sqrt(fabs(c.K)); CP.sgnK = sgnK; CP.his_xmin = c.hyper_x_min; CP.phiminabs = c.hyper_phi_min_abs; CP.index_q_flat = h->geo_index_q_flat;
     hipLaunchKernelGGL(k_los_curved, dim3(nq), dim3(256), lds_bytes, h->stream, CP);
   } else
     hipLaunchKernelGGL(k_los, dim3(nq), dim3(256), lds_bytes, h->stream, P);
   CPT_HIP(h, hipGetLastError());
-  CPT_HIP(h, hipStreamSynchronize(h->stream));   // (desc / kq live in host vectors until the copies have completed)
-  CPT_HIP(h, hipEventRecord(kb, h->stream));
-  CPT_HIP(h, hipEventRecord(h->t_transfer.b, h->stream));
-  CPT_HIP(h, hipStreamSynchronize(h->stream));
-  float ms = 0;
-  CPT_HIP(h, hipEventElapsedTime(&ms, ka, kb));
-  h->t_transfer.ms = ms;
-  h->t_transfer.launches = 1;
-  (void)hipEventDestroy(ka);
-  (void)hipEventDestroy(kb);
-  unsigned long long w[3];
-  CPT_HIP(h, hipMemcpy(w, h->d_work, sizeof(w), hipMemcpyDeviceToHost));
-  h->work_integrals = (long long)w[0];
-  h->work_samples = (long long)w[1];
-  h->work_fused = (long long)w[2];
+  cpt_timer_stop(h, CPT_T_LOS);
+  cpt_timer_stop(h, CPT_T_TRANSFER);
+  // work counters -> pinned landing zone, read by cpt_finish after the synchronisation of the call
+  CPT_HIP(h, hipMemcpyAsync(h->pin_out, h->d_work, 3 * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
+  h->pend_work = true;
   return CPT_OK;
 }

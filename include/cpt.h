@@ -16,10 +16,11 @@
  *   - all arithmetic is IEEE double ("f64"); integers only for indices and flags.
  *   - pointers named *_dev are DEVICE (HBM) pointers, all others are HOST pointers.  The library never takes
  *     ownership of caller memory.
- *   - a handle is bound to the HIP device current at cpt_create(); calls on one handle must be serialised by the
- *     caller (the reference's module constructors are single-caller too, source/cosmology.cpp:16-86).
+ *   - a handle is bound to the HIP device current at cpt_create(): every entry point makes that device current for its
+ *     duration and restores the caller's device on return.  Calls on one handle must be serialised by the caller (the
+ *     reference's module constructors are single-caller too, source/cosmology.cpp:16-86).
  *   - streams: every handle owns one non-blocking HIP stream; each entry point enqueues there and returns with that stream
- *     drained, so outputs are complete on return.  Device INPUT buffers must be complete before the call: a caller that
+ *     drained (one synchronisation per call, at its end), so outputs are complete on return.  Device INPUT buffers must be complete before the call: a caller that
  *     produced them on another stream (an RCCL collective, a framework's stream) synchronises that stream first
  *     (classpp_public_amd/backend.py::Backend._fence does exactly that for torch).
  *   - there is NO CPU fallback: without a usable HIP device every compute entry point fails with CPT_ERR_NO_DEVICE.
@@ -259,12 +260,35 @@ int cpt_lensing_l_size(const int* l, int nl, const cpt_lensing_params* lp);
 int cpt_lensing_batch(cpt_handle* h, const cpt_spectra_params* sp, const cpt_lensing_params* lp, const int* l, int nl,
                       const double* cl_dev, double* cl_lensed_dev);
 
+/* ---- one whole pass for one cosmology, fused: cpt_perturb_solve_batch -> cpt_transfer_batch (resident sources) ->
+ * cpt_cl_batch -> [cpt_lensing_batch] -> [cpt_pk_linear], enqueued back to back on the handle's stream with ONE
+ * synchronisation at the end.  This is what the reference does between the constructors of PerturbationsModule and
+ * LensingModule (source/cosmology.cpp:16-86) for the path of this backend; the separate entry points above remain for callers
+ * that need the intermediate tables on the host side in between.  Grids that did not change since the last call on the
+ * handle are not validated, prepared or uploaded again.  All pointers as in the separate entry points. */
+typedef struct cpt_step_io {
+  const double* k; int nk; int k_size_cl;          /* host */
+  const double* tau_sampling; int ntau;            /* host */
+  const double* q; int nq;                         /* host */
+  const int* l; int nl;                            /* host */
+  const cpt_spectra_params* sp;
+  const cpt_lensing_params* lp;                    /* NULL: no lensing */
+  double* transfer_dev;                            /* device [tt_size][nl][nq]                         */
+  double* cl_dev;                                  /* device [nl][ct_size]                             */
+  double* cl_lensed_dev;                           /* device [cpt_lensing_l_size][ct_size] or NULL     */
+  double* pk_dev;                                  /* device [nk] or NULL (needs the delta_m source)   */
+  cpt_stepstat* stats; int* status;                /* host [nk], may be NULL                           */
+} cpt_step_io;
+int cpt_step(cpt_handle* h, const cpt_step_io* io);
+
 /* Device-side copy of the resident sources into the reference layout [tp_size][ntau][nk] (device pointer). */
 int cpt_get_sources(cpt_handle* h, double* sources_dev);
 
 /* ---- measurement hooks (used by bench.py; they time with hipEvents on the library's own stream) ---- */
-/* milliseconds spent in the dominant kernel of the last call of each stage, and its launch count */
-int cpt_last_kernel_ms(const cpt_handle* h, int stage /*0 = perturb, 1 = transfer*/, double* ms, int* launches);
+/* milliseconds between two events recorded on the handle's stream during the last call that ran the stage, and the launch count:
+ * stage 0 = the perturbation kernel, 1 = the line-of-sight kernel, 2 = the whole transfer stage (uploads, source spline, LOS),
+ * 3 = a whole cpt_step, first to last kernel (wall time of the call minus this = host overhead) */
+int cpt_last_kernel_ms(const cpt_handle* h, int stage, double* ms, int* launches);
 /* work counters of the last transfer call: number of (q,l,type) integrals, of (q,l,type,tau) samples (the
  * reference evaluates each separately) and of fused (q,l,tau) samples (types sharing one Phi_l row) */
 int cpt_last_transfer_work(const cpt_handle* h, long long* integrals, long long* type_samples,
