@@ -72,29 +72,23 @@ __device__ inline double dpp_keep(double v) {
   hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xf, 0xf, false);
   return __hiloint2double(hi, lo);
 }
-// DPP row_shr:n within each row of 16 lanes; lanes without a source get 0
+// DPP row_shr:n within each row of 16 lanes; lanes without a source get 0 (bound_ctrl: the hardware writes the zero, no
+// register has to be cleared first)
 template <int N>
 __device__ inline double row_shr0(double v) {
-  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x110 + N, 0xf, 0xf, false);
-  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x110 + N, 0xf, 0xf, false);
-  int l2 = lo, h2 = hi;
+  int l2 = __builtin_amdgcn_mov_dpp(__double2loint(v), 0x110 + N, 0xf, 0xf, true);
+  int h2 = __builtin_amdgcn_mov_dpp(__double2hiint(v), 0x110 + N, 0xf, 0xf, true);
   asm volatile("" : "+v"(l2), "+v"(h2));
   return __hiloint2double(h2, l2);
 }
 // DPP row_shl:n: value of lane + n of the same row, 0 beyond the row
 template <int N>
 __device__ inline double row_shl0(double v) {
-  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x100 + N, 0xf, 0xf, false);
-  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x100 + N, 0xf, 0xf, false);
-  int l2 = lo, h2 = hi;
+  int l2 = __builtin_amdgcn_mov_dpp(__double2loint(v), 0x100 + N, 0xf, 0xf, true);
+  int h2 = __builtin_amdgcn_mov_dpp(__double2hiint(v), 0x100 + N, 0xf, 0xf, true);
   asm volatile("" : "+v"(l2), "+v"(h2));
   return __hiloint2double(h2, l2);
 }
-// max over the 64 lanes of a NON-NEGATIVE quantity (an error norm).  The reduction runs in single precision, where
-// v_max_f32 takes a DPP operand directly: 4 row_shr steps + row_bcast:15 + row_bcast:31 = six VALU instructions
-// (the double-precision version needs ~35: v_max_f64 is VOP3-only, so every step is copy + 2 DPP movs + max).
-// The value is rounded UP to float first (f32_up), so the result is >= the exact maximum and <= (1 + 2^-22) times it - the
-// norms only steer the step size and the Newton stopping test (ev.cpp:367-444), at rtol-level thresholds.
 // v >= 0 as a float that is >= v: round-to-nearest conversion + one ulp up (integer increment of a non-negative float, saturated
 // at +inf) - 3 instructions, where the directed-rounding conversion __double2float_ru is a 12-instruction software sequence
 __device__ inline float f32_up(double v) { return __int_as_float(min(__float_as_int((float)v) + 1, 0x7f800000)); }
@@ -235,16 +229,32 @@ struct NcShared {
   int abort;
 };
 
-// (NCDM = 0) The block holds TWO wavefronts per k-mode: wave 0 integrates, wave 1 is the SAMPLER.  Evaluating a source
-// sample costs a table look-up at the sample time, one RHS evaluation and the source algebra (~7 000 cycles, 9 % of the
-// critical path) and drags the integrator's table windows back in time; none of it feeds back into the integration.  Wave 0
-// therefore only interpolates (y, y') at the sample time from its backward differences and posts them; the sampler, with
-// table windows of its own that walk monotonically through the sample times, does the rest concurrently.
-struct SampleMsg {
-  double yi[64], ypi[64];   // dense output at the sample time, one entry per lane
-  double tca_keep;          // tight-coupling shear left by the evolver's last RHS call (pm.cpp:6810)
-  int it, flags, done;      // sample index; approximation scheme (tca | rsa<<1 | ufa<<2); done: the mode is finished
+// (NCDM = 0) The block holds TWO wavefronts per k-mode: wave 0 integrates, wave 1 is its HELPER.  Two jobs are taken off the
+// integrator's dependency chain - the one thing that sets the run time of the launch - and done concurrently on the second SIMD:
+//  * the table look-ups.  background_at_tau + thermodynamics_at_z is a chain of ~150 dependent instructions (two bracket
+//    searches, two row fetches, two splines, a dozen reciprocals) that depends on tau alone.  The integrator therefore ASKS for the
+//    row of the time it will need next - as soon as that time is known, i.e. one whole step ahead in the common case that the step
+//    size stays - and finds the answer (22 wave-uniform doubles) in LDS when it gets there.  The integrator itself owns no table
+//    windows at all.
+//  * the source samples.  Evaluating a sample costs a look-up at the sample time, one RHS evaluation and the source algebra, none
+//    of which feeds back into the integration: wave 0 only interpolates (y, y') from its backward differences and posts them in a
+//    ring of NSLOT slots, so bursts of samples inside one step do not stall it.
+// No barriers: both directions are single-producer / single-consumer counters in LDS (release / acquire at workgroup scope, LDS
+// executes a wave's operations in order).  The helper never waits for the integrator except by polling, and leaves when `done` is
+// set and the ring is drained; the integrator only waits for work the helper is certain to finish: no cycle, every wave exits.
+constexpr int MB_NSLOT = 4;      // sample ring
+constexpr int MB_NANS = 24;      // doubles of a look-up answer
+struct Mailbox {
+  double yi[MB_NSLOT][64], ypi[MB_NSLOT][64];   // dense output at the sample time, one entry per lane
+  double tca_keep[MB_NSLOT];                    // tight-coupling shear left by the evolver's last RHS call (pm.cpp:6810)
+  int it[MB_NSLOT], flags[MB_NSLOT];            // sample index; approximation scheme (tca | rsa<<1 | ufa<<2)
+  int head, tail, done;                         // samples posted (integrator) / consumed (helper); the mode is finished
+  int req_seq, ans_seq;                         // look-ups requested (integrator) / answered (helper)
+  double req_tau;
+  double ans[MB_NANS];
 };
+__device__ inline int mb_load(const int* p) { return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ inline void mb_store(int* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP); }
 
 template <int GAUGE, int CURV, int MODE, int NCDM = 0, int ROWS = 0>
 struct PT {
@@ -474,6 +484,8 @@ struct Lookup {
   double a2, aH, two_over_aH, R, inv_1pR, inv_R, tau_c, dtau_c, F, Fp, app, inv_tau, rg43, ru43;
   double zmax, xe_last, taud_last;  // last row of the thermodynamics table (analytic continuation beyond it)
   double k2s2, inv_k2s2, s2, s2sq, kcot;  // per-mode curvature factors (set_mode) and k cotK_gen(tau_cached); flat: k^2, 1/k^2, 1, 1, 1/tau
+  // (integrator wave of the two-wave kernels) the rows come from the helper wave: mailbox, number of requests posted, time of the last one
+  Mailbox* mb; int my_req; double req_tau;
 #ifdef CPT_PROFILE
   unsigned long long* prof;
 #endif
@@ -538,6 +550,7 @@ static __device__ __forceinline__ int window_find(const double* __restrict__ x, 
 
 static __device__ __forceinline__ void lookup_init(const PtParams& P, Lookup& Q, double2* bgw, double2* thw, int lane, double2* ncw = nullptr) {
   Q.bgw = bgw; Q.thw = thw; Q.ncw = ncw; Q.vnc = 0.; Q.nc_lo = Q.nc_hi = make_double2(0., 0.);
+  Q.mb = nullptr; Q.my_req = 0; Q.req_tau = -1.;
   if (NCDM) { double dummy; window_stage<NCB_NCOL>(P.tabs.tau_table, (const double2*)P.tabs.ncb, P.tabs.bt_size, 0, lane, &dummy, ncw); }
   Q.bg_base = 0; Q.th_base = 0; Q.bg_inf = -1; Q.th_inf = -1; Q.tau_cached = -1.;
   window_stage<BG_NCOL>(P.tabs.tau_table, (const double2*)P.tabs.bg, P.tabs.bt_size, 0, lane, &Q.bgx, bgw);
@@ -653,6 +666,33 @@ static __device__ __forceinline__ void lookup(const PtParams& P, Lookup& Q, doub
     Q.kcot = (P.K < 0.) ? sq / tanh(sq * tau) : sq / tan(sq * tau);
   }
   LK_MARK(15)   // derived quantities
+}
+
+// ---- look-ups through the helper wave (see Mailbox) ----------------------------------------------------------------
+// ask for the row at tau unless that is what was asked for last (the answer may still be on its way: mb_fetch waits for it)
+static __device__ __forceinline__ void mb_request(Lookup& Q, double tau, int lane) {
+  if (uni(tau == Q.req_tau)) return;
+  Q.req_tau = tau;
+  Q.my_req++;
+  if (lane == 0) Q.mb->req_tau = tau;
+  mb_store(&Q.mb->req_seq, Q.my_req);
+}
+// Q <- the row at tau; returns false if the helper never answered (cannot happen unless the kernel is broken: the caller turns it
+// into an error status instead of spinning for ever)
+static __device__ __forceinline__ bool mb_fetch(Lookup& Q, double tau, int lane) {
+  if (uni(tau == Q.tau_cached)) return true;
+  mb_request(Q, tau, lane);
+  int spins = 0;
+  while (mb_load(&Q.mb->ans_seq) != Q.my_req) {
+    __builtin_amdgcn_s_sleep(1);
+    if (++spins > (1 << 24)) return false;
+  }
+  const double* a = Q.mb->ans;
+  Q.rg = a[0]; Q.rb = a[1]; Q.rc = a[2]; Q.ru = a[3]; Q.kap = a[4]; Q.ddkappa = a[5]; Q.cb2 = a[6]; Q.a2 = a[7];
+  Q.aH = a[8]; Q.two_over_aH = a[9]; Q.R = a[10]; Q.inv_1pR = a[11]; Q.inv_R = a[12]; Q.tau_c = a[13]; Q.dtau_c = a[14]; Q.F = a[15];
+  Q.Fp = a[16]; Q.app = a[17]; Q.inv_tau = a[18]; Q.rg43 = a[19]; Q.ru43 = a[20]; Q.kcot = a[21];
+  Q.tau_cached = tau;
+  return true;
 }
 
 // ---- physics ------------------------------------------------------------------------------------
@@ -794,9 +834,11 @@ static __device__ __forceinline__ double gather(double v, int addr) {
 }
 
 // tensor modes: gw_source (pm.cpp:6616-6660), the Einstein equation for gw'' (:6036-6040) and perturb_derivs :9045-9215
+template <bool VIA_HELPER>
 static __device__ __forceinline__ double rhs_tensor(const PtParams& P, const Layout& L, const LaneEq& e, Lookup& Q, Metric& M, double k,
                                                     double tau, double y, int lane) {
-  lookup(P, Q, tau, lane);
+  if (VIA_HELPER) { if (!mb_fetch(Q, tau, lane)) return nan(""); }
+  else lookup(P, Q, tau, lane);
   const double ym = gather(y, e.dn), yp = gather(y, e.up);
   const double SQRT6 = 2.449489742783178;
   // (lanes the scheme does not evolve read as 0)
@@ -834,15 +876,19 @@ static __device__ __forceinline__ void store_sources_tensor(const PtParams& P, c
 // perturb_rsa_delta_and_theta (pm.cpp:9530-9636) and perturb_tca_slip_and_shear (pm.cpp:9229-9516) folded in;
 // synchronous gauge, K = 0.  y: this lane's component (named components are broadcast with v_readlane).
 // Returns dy of this lane and leaves M describing the state (tau, y).
+template <bool VIA_HELPER = false>
 static __device__ __forceinline__ double rhs(const PtParams& P, const Layout& L, const LaneEq& e, Lookup& Q, Metric& M, double k,
                                       double inv_k2, double tau, double y, int lane, NcIn* Np = nullptr) {
-  if (MODE) return rhs_tensor(P, L, e, Q, M, k, tau, y, lane);
+  if (MODE) return rhs_tensor<VIA_HELPER>(P, L, e, Q, M, k, tau, y, lane);
 #ifdef CPT_PROFILE
   unsigned long long* prof = Q.prof;
   PROF_DECL;
   PROF_START();
 #endif
-  lookup(P, Q, tau, lane);
+  // (a helper that never answers - impossible unless the kernel is broken - poisons the result: the step then fails its norm
+  //  tests, shrinks to the minimal step and the mode ends with "step size too small" instead of spinning for ever)
+  if (VIA_HELPER) { if (!mb_fetch(Q, tau, lane)) return nan(""); }
+  else lookup(P, Q, tau, lane);
 #ifdef CPT_PROFILE
   PROF_STOP(8); PROF_START();
 #endif
@@ -1100,7 +1146,7 @@ struct Ctx {
   double tau_pub;              // time at which sh->bc was last published (and read by everybody)
   double a2, aH, kcot, inv_tau, rho, pr, pp;   // chain waves: copy of the published block (rho, p, pseudo_p of the lane's species)
   double ca, cb, cd, cxmc, cxms, cwt;          // chain waves: this lane's coefficients at tau_pub (they depend on tau only)
-  SampleMsg* msg; int pending;                 // (SAMPLER) hand-over slot and whether the sampler still owns it
+  Mailbox* mb; int posted, tail_seen;          // (SAMPLER) mailbox, samples posted so far, last value read of the helper's tail
 };
 struct ChainEq {
   int l, cidx, species;
@@ -1207,7 +1253,7 @@ static __device__ __forceinline__ void sync_tau(const PtParams& P, const Layout&
 template <int ROLE>
 static __device__ __forceinline__ double rhs_all(const PtParams& P, const Layout& L, const LaneEq& e, const ChainEq& ce, Lookup& Q, Metric& M,
                                                  Ctx& C, NcIn& N, double k, double inv_k2, double tau, double y, int lane) {
-  if (!NCDM) return rhs(P, L, e, Q, M, k, inv_k2, tau, y, lane);
+  if (!NCDM) return rhs<true>(P, L, e, Q, M, k, inv_k2, tau, y, lane);   // (the integrator wave of the two-wave kernels)
 #ifdef CPT_PROFILE
   const unsigned long long t_sync0 = clock64();
 #endif
@@ -1308,6 +1354,7 @@ struct LuReg {
   double Ac[NC];   // lane i < NC: row i of the core factors (L below / unit-diagonal U above the diagonal)
   double rpivc;    // lane j < nc: reciprocal of the j-th core pivot
   int rowperm;     // lane i < nc: original row now at position i (identity on tail lanes)
+  int permuted;    // (wave-uniform) some rows were exchanged: rowperm is not the identity
   double rinv;     // tail lanes: 1 / d'_l   (0 on core lanes)
   double g;        // tail lanes: c_l / d'_{l+1}, the downward-sweep multiplier (0 on the l_max element and on core lanes)
   double r;        // tail lanes: a_l / d'_l, the upward-sweep multiplier
@@ -1327,11 +1374,13 @@ static __device__ __forceinline__ double reg_get(const double (&a)[N], int i) {
 //   u_D - alpha_D1 dmc - alpha_D2 dms = sum_chains w_D [T^-1 r]_0     with dmc = sum_j gmc_j x_j, dms = sum_j gms_j x_j
 // where gmc_j / gms_j are the responses of (metric_continuity, metric_shear) to unit core variable j (al[] = the four alphas)
 // b <- the right-hand side after the four reduction levels (u = b * rinv solves T u = b on every tail at once)
-static __device__ __forceinline__ double pcr_apply(const LuReg& F, int maxlen, double b) {
-  if (maxlen > 1) b = fma(-F.al[0], row_shr0<1>(b), fma(-F.ga[0], row_shl0<1>(b), b));
-  if (maxlen > 2) b = fma(-F.al[1], row_shr0<2>(b), fma(-F.ga[1], row_shl0<2>(b), b));
-  if (maxlen > 4) b = fma(-F.al[2], row_shr0<4>(b), fma(-F.ga[2], row_shl0<4>(b), b));
-  if (maxlen > 8) b = fma(-F.al[3], row_shr0<8>(b), fma(-F.ga[3], row_shl0<8>(b), b));
+// (all four levels, whatever the tails' lengths: a level the factorisation did not need has al = ga = 0 and leaves b alone,
+//  which costs two multiply-adds where a test of maxlen costs a scalar reload, a compare and a branch per level)
+static __device__ __forceinline__ double pcr_apply(const LuReg& F, double b) {
+  b = fma(-F.al[0], row_shr0<1>(b), fma(-F.ga[0], row_shl0<1>(b), b));
+  b = fma(-F.al[1], row_shr0<2>(b), fma(-F.ga[1], row_shl0<2>(b), b));
+  b = fma(-F.al[2], row_shr0<4>(b), fma(-F.ga[2], row_shl0<4>(b), b));
+  b = fma(-F.al[3], row_shr0<8>(b), fma(-F.ga[3], row_shl0<8>(b), b));
   return b;
 }
 template <int S>
@@ -1366,7 +1415,7 @@ static __device__ __forceinline__ bool factorise(const LaneEq& e, const Jac& J, 
     const double rinv = fast_rcp(td);
     F.rinv = chain ? rinv : 0.;
     // v = T^-1 (a_first e_first): what a unit core parent sends into its tail
-    r = pcr_apply(F, maxlen, (chain && e.first) ? a : 0.) * F.rinv;
+    r = pcr_apply(F, (chain && e.first) ? a : 0.) * F.rinv;
     F.r = r; F.g = 0.;
   } else {
   double dp = d;
@@ -1395,7 +1444,7 @@ static __device__ __forceinline__ bool factorise(const LaneEq& e, const Jac& J, 
 #pragma unroll
     for (int j = 0; j < NC; j++) A[j] -= c1 * bcast(gmc, j) + c2 * bcast(gms, j);
   }
-  int rowperm = lane;
+  int rowperm = lane, permuted = 0;
   double rpivc = 1.;
   bool ok = true;
 #pragma unroll
@@ -1407,6 +1456,7 @@ static __device__ __forceinline__ bool factorise(const LaneEq& e, const Jac& J, 
       if (big == 0.) ok = false;
       const int p = __ffsll((long long)__ballot((double)f32_up(mag) == big && big > 0.)) - 1;  // wave_max rounds up to float
       if (p > j) {
+        permuted = 1;
         // exchange rows p and j (register rows of two lanes) and the row bookkeeping
 #pragma unroll
         for (int cidx = 0; cidx < NC; cidx++) {
@@ -1434,6 +1484,7 @@ static __device__ __forceinline__ bool factorise(const LaneEq& e, const Jac& J, 
   for (int j = 0; j < NC; j++) F.Ac[j] = (j > lane) ? A[j] * rpivc : A[j];
   F.rpivc = rpivc;
   F.rowperm = rowperm;
+  F.permuted = __builtin_amdgcn_readfirstlane(permuted);
   return ok;
 }
 
@@ -1443,33 +1494,48 @@ static __device__ __forceinline__ double lu_solve(const LaneEq& e, const LuReg& 
   const int chain = opaque(e.chain);
   // 1. tails, downward sweep: b'_l = b_l - (c_l / d'_{l+1}) b'_{l+1}; the l_max element is final at once
   double u;
-  if (PCR) u = pcr_apply(F, maxlen, chain ? b : 0.) * F.rinv;   // T^-1 b on every tail lane, 0 on core lanes
+  if (PCR) u = pcr_apply(F, chain ? b : 0.) * F.rinv;   // T^-1 b on every tail lane, 0 on core lanes
   else {
     double bp = b;
     for (int s = 1; s < maxlen; s++) bp = fma(-F.g, lane_above(bp), b);
     // 2. core right-hand side: parents of the tails see b'_3 / d'_3
     u = bp * F.rinv;                       // 0 on core lanes
   }
-  const double t3 = gather(u, e.first_addr);          // executed by every lane
+  double t3;
+  if (PCR) {
+    // the three parents (shear_g, pol2, shear_ur) take u from the first lane of their tail's row: three broadcasts and two selects
+    // are a shorter dependency chain than a trip through the LDS crossbar (ds_bpermute + wait), and cpar is 0 on every other lane
+    const double u1 = bcast(u, 16), u2 = bcast(u, 32), u3 = bcast(u, 48);
+    t3 = (lane == LN_SG) ? u1 : (lane == LN_P2) ? u2 : u3;
+  } else t3 = gather(u, e.first_addr);          // executed by every lane
   const double bc = fma(-F.cpar, t3, b);
   // 3. core solve with the register-resident factors (idle rows / lanes >= NC are identity rows: x = b there)
-  double x = gather(chain ? 0. : bc, F.rowperm * 4);
+  // (rows are only exchanged when a diagonal entry was not an acceptable pivot: almost never, and then the gather is skipped)
+  double x = chain ? 0. : bc;
+  if (F.permuted) x = gather(x, F.rowperm * 4);
+  // Row i keeps its L entries (columns j < i) and its U entries (j > i) in ONE register array, so each substitution step must
+  // switch the entry off on the rows it does not concern.  Clearing the HIGH word alone does that in one v_cndmask instead of
+  // two: what is left is a subnormal (|m| < 2^-1022), and m * xj then vanishes against x unless |xj / x| > 2^970.
 #pragma unroll
   for (int j = 0; j < NC; j++) {   // forward, unit lower
     const double xj = bcast(x, j);
-    const double m = (lane > j) ? F.Ac[j] : 0.;
+    const double m = __hiloint2double((lane > j) ? __double2hiint(F.Ac[j]) : 0, __double2loint(F.Ac[j]));
     x = fma(-m, xj, x);
   }
   x *= F.rpivc;   // 1 outside the core
 #pragma unroll
   for (int j = NC - 1; j >= 0; j--) {  // backward, unit upper
     const double xj = bcast(x, j);
-    const double uj = (lane < j) ? F.Ac[j] : 0.;
+    const double uj = __hiloint2double((lane < j) ? __double2hiint(F.Ac[j]) : 0, __double2loint(F.Ac[j]));
     x = fma(-uj, xj, x);
   }
   // 4. tails, upward sweep: x_l = b'_l / d'_l - (a_l / d'_l) x_{l-1}; the l=3 element takes x_{l-1} from its core parent
   if (maxlen > 0) {
-    const double xpar = gather(x, e.parent_addr);
+    double xpar;
+    if (PCR) {
+      const double x1 = bcast(x, LN_SG), x2 = bcast(x, LN_P2), x3 = bcast(x, LN_SUR);
+      xpar = (lane < 32) ? x1 : (lane < 48) ? x2 : x3;   // (core lanes of row 0 take x1: unused there, `chain` selects below)
+    } else xpar = gather(x, e.parent_addr);
     double xt;
     if (PCR) xt = fma(-F.r, xpar, u);              // x_t = T^-1 b_t - x_parent T^-1 (a_first e_first)
     else {
@@ -1610,7 +1676,9 @@ static __device__ __forceinline__ int ndf15(const PtParams& P, const Layout& L, 
   LuReg F;
 #pragma unroll
   for (int j = 0; j < NC; j++) F.Ac[j] = 0.;
-  F.rpivc = 1.; F.rowperm = lane; F.rinv = F.r = F.g = F.cpar = 0.;
+  F.rpivc = 1.; F.rowperm = lane; F.permuted = 0; F.rinv = F.r = F.g = F.cpar = 0.;
+#pragma unroll
+  for (int j = 0; j < 4; j++) F.al[j] = F.ga[j] = 0.;
   double y = y_io, ynew = y_io, f0 = 0., f1 = 0., fnewton = 0., wt = 0., tdel = 0.;
   double dif[7] = {0., 0., 0., 0., 0., 0., 0.};
   int next = 0;
@@ -1664,12 +1732,19 @@ static __device__ __forceinline__ int ndf15(const PtParams& P, const Layout& L, 
       const double tca_keep = M.tca_shear_g;
       if (NCDM && batch == B_JAC) sync_tau<ROLE>(P, L, Q, C, ce, k, t, lane);
       if (ROLE == 1 && batch == B_JAC) jc = ChainCoef{C.ca, C.cb, C.cd, C.cxmc, C.cxms, C.cwt};   // the chains' Jacobian is their coefficient set
-      else if (SAMPLER && batch == B_SAMPLE) {   // hand the sample to the sampler wave
-        if (C.pending) __syncthreads();          // (C) it has consumed the previous one
-        C.msg->yi[lane] = yi; C.msg->ypi[lane] = ypi;
-        if (lane == 0) { C.msg->tca_keep = tca_keep; C.msg->it = next; C.msg->flags = L.tca | (L.rsa << 1) | (L.ufa << 2); C.msg->done = 0; }
-        __syncthreads();                         // (R)
-        C.pending = 1;
+      else if (SAMPLER && batch == B_SAMPLE) {   // hand the sample to the helper wave: next free slot of the ring
+        if (C.posted - C.tail_seen >= MB_NSLOT) {   // ring full: wait for the helper (it is certain to consume)
+          int spins = 0;
+          while (C.posted - (C.tail_seen = mb_load(&C.mb->tail)) >= MB_NSLOT) {
+            __builtin_amdgcn_s_sleep(1);
+            if (++spins > (1 << 24)) return 5;
+          }
+        }
+        const int slot = C.posted & (MB_NSLOT - 1);
+        C.mb->yi[slot][lane] = yi; C.mb->ypi[slot][lane] = ypi;
+        if (lane == 0) { C.mb->tca_keep[slot] = tca_keep; C.mb->it[slot] = next; C.mb->flags[slot] = L.tca | (L.rsa << 1) | (L.ufa << 2); }
+        C.posted++;
+        mb_store(&C.mb->head, C.posted);
         st.fevals++;                             // (the evaluation is counted where the reference makes it)
       }
       else
@@ -1815,6 +1890,9 @@ static __device__ __forceinline__ int ndf15(const PtParams& P, const Layout& L, 
         need_fact = true;
       }
       nofailed = true;
+      // the time of this step is known: ask the helper for its table row now (a no-op when the step size did not change - the
+      // row was requested a whole step ago - and otherwise early enough to arrive behind the factorisation)
+      if (SAMPLER) mb_request(Q, done ? tfinal : t + h, lane);
 #ifndef CPT_PROFILE_LOOKUP
       PROF_STOP(13);
 #endif
@@ -1863,6 +1941,8 @@ static __device__ __forceinline__ int ndf15(const PtParams& P, const Layout& L, 
     for (int iter = 1; iter <= maxit; iter++) {
       PROF_START();
       fnewton = rhs_all<ROLE>(P, L, e, ce, Q, M, C, N, k, inv_k2, tnew, ynew, lane);
+      // the row of THIS step is in registers: speculate that the step size stays and ask for the next one (t' + h' = tnew + absh)
+      if (SAMPLER && iter == 1 && !done) mb_request(Q, tnew + absh, lane);
       PROF_STOP(0);
 #ifdef CPT_PROFILE
       t_inner += clock64() - pf_t0;
@@ -1920,6 +2000,7 @@ static __device__ __forceinline__ int ndf15(const PtParams& P, const Layout& L, 
       absh = fmax(0.3 * absh, hmin);
       h = absh;
       done = false;
+      if (SAMPLER) mb_request(Q, t + h, lane);
       adjust_stepsize(dif, absh * fast_rcp(abshlast), kk);
       hinvGak = h * iga;
       nconhk = 0;
@@ -1954,6 +2035,7 @@ static __device__ __forceinline__ int ndf15(const PtParams& P, const Layout& L, 
       } else absh = fmax(hmin, 0.5 * absh);
       h = absh;
       if (uni(absh < abshlast)) done = false;
+      if (SAMPLER) mb_request(Q, done ? tfinal : t + h, lane);
       adjust_stepsize(dif, absh * fast_rcp(abshlast), kk);
       hinvGak = h * iga;
       nconhk = 0;
@@ -2095,12 +2177,16 @@ static __device__ __forceinline__ int run_intervals(const PtParams& P, Ctx& C, c
     Lookup Q;
     // (NCDM: the table windows belong to wave 0 alone - a chain wave staging them late would overwrite a window that wave 0
     //  has already moved; the chain waves get what they need through sync_tau)
-    if (ROLE == 0) lookup_init(P, Q, bgw, thw, lane, ncw);
+    // (SAMPLER: the integrator wave owns no windows - its rows come from the helper wave through the mailbox)
+    if (ROLE == 0 && !SAMPLER) lookup_init(P, Q, bgw, thw, lane, ncw);
     else {   // (never read by a chain wave; plain stores keep the struct in registers)
       Q.bgw = bgw; Q.thw = thw; Q.ncw = ncw; Q.tau_cached = -1.; Q.bg_base = Q.th_base = 0; Q.bg_inf = Q.th_inf = -1;
       Q.bgx = Q.thx = Q.vbg = Q.vth = Q.vnc = 0.; Q.zmax = Q.xe_last = Q.taud_last = 0.;
       Q.bg_lo = Q.bg_hi = Q.th_lo = Q.th_hi = Q.nc_lo = Q.nc_hi = make_double2(0., 0.);
+      Q.rg = Q.rb = Q.rc = Q.ru = Q.kap = Q.ddkappa = Q.cb2 = Q.a2 = Q.aH = Q.two_over_aH = Q.R = Q.inv_1pR = Q.inv_R = 0.;
+      Q.tau_c = Q.dtau_c = Q.F = Q.Fp = Q.app = Q.inv_tau = Q.rg43 = Q.ru43 = Q.kcot = 0.;
     }
+    Q.mb = C.mb; Q.my_req = 0; Q.req_tau = -1.;
     lookup_set_mode(P, Q, k);
 #ifdef CPT_PROFILE
     Q.prof = prof;
@@ -2201,35 +2287,64 @@ static __device__ __forceinline__ int run_intervals(const PtParams& P, Ctx& C, c
   return status;
 }
 
-// the sampler wave (SAMPLER): perturb_sources (pm.cpp:6731-7285) for every sample the integrator posts
-static __device__ __forceinline__ void run_sampler(const PtParams& P, Ctx& C, double k, double inv_k2, int ik, int lane, double2* bgw, double2* thw) {
-  Lookup Q;
-  lookup_init(P, Q, bgw, thw, lane);
+// the helper wave (SAMPLER, see Mailbox): answers the integrator's table look-ups and evaluates perturb_sources
+// (pm.cpp:6731-7285) for every sample the integrator posts.  Two sets of table windows: the samples walk monotonically through
+// the sample times, the look-ups run one step ahead of the integration.
+static __device__ __forceinline__ void run_helper(const PtParams& P, Mailbox* mb, double k, double inv_k2, int ik, int lane, double2* bgw_s, double2* thw_s,
+                                                  double2* bgw_p, double2* thw_p) {
+  Lookup Q, Qp;
+  lookup_init(P, Q, bgw_s, thw_s, lane);
   lookup_set_mode(P, Q, k);
+  lookup_init(P, Qp, bgw_p, thw_p, lane);
+  lookup_set_mode(P, Qp, k);
 #ifdef CPT_PROFILE
   unsigned long long sprof[16];
-  Q.prof = sprof;
+  Q.prof = sprof; Qp.prof = sprof;
 #endif
   Metric M;
   M.hp = M.etap = M.alpha = M.alphap = 0.; M.psi = M.phip = 0.;
   M.tca_shear_g = 0.; M.rsa_dg = M.rsa_tg = 0.;
-  int flags = -1;
+  int flags = -1, tail = 0, answered = 0;
   Layout L = make_layout(P, 1, 0, 0);
   LaneEq e = make_lane_eq(P, L, lane, k);
   for (;;) {
-    __syncthreads();                           // (R) a message is ready
-    if (C.msg->done) break;
-    const int f = C.msg->flags, it = C.msg->it;
-    const double yi = C.msg->yi[lane], ypi = C.msg->ypi[lane], tca_keep = C.msg->tca_keep;
-    if (f != flags) {                          // the integrator entered another approximation scheme
-      flags = f;
-      L = make_layout(P, f & 1, (f >> 1) & 1, (f >> 2) & 1);
-      e = make_lane_eq(P, L, lane, k);
+    // look-ups first: the integrator may be waiting for one, a sample never holds it up while the ring has room
+    const int rq = mb_load(&mb->req_seq);
+    if (rq != answered) {
+      const double tau = mb->req_tau;            // (a request posted meanwhile is picked up on the next turn)
+      lookup(P, Qp, tau, lane);
+      if (lane == 0) {
+        double* a = mb->ans;
+        a[0] = Qp.rg; a[1] = Qp.rb; a[2] = Qp.rc; a[3] = Qp.ru; a[4] = Qp.kap; a[5] = Qp.ddkappa; a[6] = Qp.cb2; a[7] = Qp.a2;
+        a[8] = Qp.aH; a[9] = Qp.two_over_aH; a[10] = Qp.R; a[11] = Qp.inv_1pR; a[12] = Qp.inv_R; a[13] = Qp.tau_c; a[14] = Qp.dtau_c; a[15] = Qp.F;
+        a[16] = Qp.Fp; a[17] = Qp.app; a[18] = Qp.inv_tau; a[19] = Qp.rg43; a[20] = Qp.ru43; a[21] = Qp.kcot;
+      }
+      answered = rq;
+      mb_store(&mb->ans_seq, rq);
+      continue;
     }
-    const double tn = P.tau_s[it];
-    (void)rhs(P, L, e, Q, M, k, inv_k2, tn, yi, lane);   // leaves Q and M describing (tn, yi)
-    store_sources(P, L, Q, M, k, inv_k2, yi, ypi, tca_keep, it, ik, lane);
-    __syncthreads();                           // (C) the slot is free again
+    const int head = mb_load(&mb->head);
+    if (tail != head) {
+      const int slot = tail & (MB_NSLOT - 1);
+      const int f = mb->flags[slot], it = mb->it[slot];
+      const double yi = mb->yi[slot][lane], ypi = mb->ypi[slot][lane], tca_keep = mb->tca_keep[slot];
+      tail++;
+      mb_store(&mb->tail, tail);                 // (the slot's content is in registers: the integrator may refill it)
+      if (f != flags) {                          // the integrator entered another approximation scheme
+        flags = f;
+        L = make_layout(P, f & 1, (f >> 1) & 1, (f >> 2) & 1);
+        e = make_lane_eq(P, L, lane, k);
+      }
+      const double tn = P.tau_s[it];
+      (void)rhs<false>(P, L, e, Q, M, k, inv_k2, tn, yi, lane);   // leaves Q and M describing (tn, yi)
+      store_sources(P, L, Q, M, k, inv_k2, yi, ypi, tca_keep, it, ik, lane);
+      continue;
+    }
+    if (mb_load(&mb->done)) {
+      if (mb_load(&mb->head) == tail) break;     // finished and drained
+      continue;
+    }
+    __builtin_amdgcn_s_sleep(2);
   }
 }
 
@@ -2239,8 +2354,8 @@ static __device__ __forceinline__ void body_perturb(const PtParams& P) {
   __shared__ double jacw[NC * 64];
   __shared__ __attribute__((aligned(16))) double2 ncw[NCDM ? 64 * NCB_NCOL : 1];
   __shared__ __attribute__((aligned(8))) char ncsh_raw[NCDM ? sizeof(NcShared) : 8];
-  __shared__ __attribute__((aligned(16))) double2 tabw2[SAMPLER ? 64 * (BG_NCOL + TH_NCOL) : 1];   // the sampler's table windows
-  __shared__ SampleMsg smsg[SAMPLER ? 1 : 1];
+  __shared__ __attribute__((aligned(16))) double2 tabw2[SAMPLER ? 64 * (BG_NCOL + TH_NCOL) : 1];   // the helper's second set of table windows
+  __shared__ __attribute__((aligned(16))) Mailbox mbox[1];
   const int lane = threadIdx.x & 63;
   const int ik = P.order[blockIdx.x];
   const double k = P.k[ik];
@@ -2249,7 +2364,11 @@ static __device__ __forceinline__ void body_perturb(const PtParams& P) {
   double2* thw = tabw + 64 * BG_NCOL;
   Ctx C;
   C.wave = (int)(threadIdx.x >> 6); C.nw = NCDM ? (int)(blockDim.x >> 6) - 1 : 0;
-  C.msg = smsg; C.pending = 0;
+  C.mb = mbox; C.posted = 0; C.tail_seen = 0;
+  if (SAMPLER) {   // (the only barrier of the two-wave kernels: the counters are zero before either wave looks at them)
+    if (threadIdx.x == 0) { mbox->head = mbox->tail = mbox->done = mbox->req_seq = mbox->ans_seq = 0; mbox->req_tau = -1.; }
+    __syncthreads();
+  }
   C.len = NCDM ? P.nc.lmax + 1 : 64; C.cpw = 64 / C.len;
   C.sh = (NcShared*)ncsh_raw; C.parity = 0; C.abort = 0; C.tau_pub = -1.;
   C.a2 = C.aH = C.kcot = C.inv_tau = C.rho = C.pr = C.pp = 1.;
@@ -2310,12 +2429,9 @@ static __device__ __forceinline__ void body_perturb(const PtParams& P) {
     else { if (C.wave == 0) status = run_intervals<0>(CPT_RUN_ARGS); }
 #undef CPT_RUN_ARGS
   }
-  if (SAMPLER) {   // every path of wave 0 ends here: release the sampler (which loops on the barrier whatever happened above)
-    if (C.wave == 0) {
-      if (C.pending) __syncthreads();          // (C) of the last sample
-      if (lane == 0) C.msg->done = 1;
-      __syncthreads();                         // (R)
-    } else run_sampler(P, C, k, inv_k2, ik, lane, tabw2, tabw2 + 64 * BG_NCOL);
+  if (SAMPLER) {   // every path of wave 0 ends here: tell the helper (which polls `done` whatever happened above) to drain and leave
+    if (C.wave == 0) mb_store(&mbox->done, 1);
+    else run_helper(P, mbox, k, inv_k2, ik, lane, tabw2, tabw2 + 64 * BG_NCOL, bgw, thw);
   }
 #ifdef CPT_PROFILE
   prof[7] = clock64() - t_begin;
@@ -2594,6 +2710,7 @@ int cpt_perturb_collect(cpt_handle* h, const double* k, cpt_stepstat* stats, int
       const char* what = hstatus[i] == 11   ? "Step size too small (ev.cpp:461,492)"
                          : hstatus[i] == 12 ? "singular matrix in LU (ev.cpp:975)"
                          : hstatus[i] == 14 ? "step budget exhausted"
+                         : hstatus[i] == 15 ? "helper wavefront unresponsive (internal error)"
                          : hstatus[i] == 20 ? "initial time of the background table is too late for this k (pm.cpp:2562-2573)"
                          : hstatus[i] >= 21 ? "approximation switching times cannot be ordered (pm.cpp:3137-3173)"
                                             : "integration failure";
