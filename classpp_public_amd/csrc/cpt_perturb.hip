@@ -141,8 +141,9 @@ __device__ inline double lane_above(double v) {  // value of lane+1
 // ds_bpermute with a per-lane source index, pinned for the same reason
 __device__ inline double shfl_all(double v, int src) { return pin(__shfl(v, src, 64)); }
 // x^p for the step-size heuristics (ev.cpp:497-505, 580-625): single precision is ample (the result only steers h)
-__device__ inline double fast_root(double x, int n) { return (double)exp2f(log2f((float)x) * __frcp_rn((float)n)); }  // x^(1/n)
-__device__ inline double fast_powi(double x, int n) { return (double)exp2f(log2f((float)x) * (float)n); }                // x^n
+// (the bare v_log_f32 / v_exp_f32 / v_rcp_f32: the library forms add subnormal scaling and an IEEE division, ~25 instructions)
+__device__ inline double fast_root(double x, int n) { return (double)__builtin_amdgcn_exp2f(__builtin_amdgcn_logf((float)x) * __builtin_amdgcn_rcpf((float)n)); }  // x^(1/n)
+__device__ inline double fast_powi(double x, int n) { return (double)__builtin_amdgcn_exp2f(__builtin_amdgcn_logf((float)x) * (float)n); }                // x^n
 // 1/x: hardware v_rcp_f64 seed + two Newton-Raphson refinements (full double accuracy to ~1 ulp, no IEEE division
 // expansion with its denormal/scale handling on the critical path)
 // Hide a lane-dependent integer from loop-invariant code motion: without this, hipcc hoists the dozens of
@@ -2062,6 +2063,333 @@ static __device__ __forceinline__ int ndf15(const PtParams& P, const Layout& L, 
   return 0;
 }
 
+// evolver_ndf15 (ev.cpp:62-705) for the INTEGRATOR wave of the two-wave kernels (NCDM = 0), one interval of constant
+// approximation scheme.  Same algorithm and same arithmetic as ndf15<ROLE> above (which the multi-wave ncdm kernels keep: their
+// waves must walk through one barrier sequence), written as structured code: now that the table look-ups live on the helper wave
+// an inlined RHS is ~300 instructions, so the flat one-call-site loop with its state flags - every variable live everywhere, a
+// dozen register moves at every merge point - is no longer worth its price.  Returns 0 / error code (1 step too small,
+// 2 singular, 4 budget, 5 helper unresponsive).
+static __device__ __forceinline__ int ndf15s(const PtParams& P, const Layout& L, const LaneEq& e, Ctx& C, Lookup& Q, Metric& M, double k, double inv_k2,
+                                             double t0, double tfinal, double& y_io, Stat& st, int lane, int& budget, double* jac_lds,
+                                             unsigned long long* prof) {
+  PROF_DECL;
+  const double eps = 1e-16, threshold = 1e-15, rtol = P.rtol, inv_rtol = 1.0 / rtol;
+  const int maxit = 4, maxk = 5;
+  const double* ts = P.tau_s;
+  const int tres = P.ntau;
+  const double htspan = fabs(tfinal - t0), hmax = (tfinal - t0) / 10.0;
+  const int maxlen = L.maxlen;
+  const double minnrm = 100 * eps;   // (see ndf15: upper bound of 100 eps max |ynew / wt|)
+
+  Jac J;
+  J.Jc = jac_lds;
+  for (int j = 0; j < NC; j++) J.Jc[j * 64 + lane] = 0.;
+  J.jdiag = 0.;
+  LuReg F;
+#pragma unroll
+  for (int j = 0; j < NC; j++) F.Ac[j] = 0.;
+  F.rpivc = 1.; F.rowperm = lane; F.permuted = 0; F.rinv = F.r = F.g = F.cpar = 0.;
+#pragma unroll
+  for (int j = 0; j < 4; j++) F.al[j] = F.ga[j] = 0.;
+  double y = y_io;
+  double dif[7] = {0., 0., 0., 0., 0., 0., 0.};
+  // sample times: the next one and the one after it sit in registers (the second is loaded one sample ahead, so its trip to
+  // memory is never on the path of a step)
+  int next = 0;
+  while (next < tres && ts[next] < t0) next++;
+  double tnext = (next < tres) ? ts[next] : 1e300, tnext2 = (next + 1 < tres) ? ts[next + 1] : 1e300;
+
+  auto eval = [&](double tq, double yq) {
+    st.fevals++;
+    return rhs<true>(P, L, e, Q, M, k, inv_k2, tq, yq, lane);
+  };
+  // J e_r = f(t, e_r): exact, the system is linear and homogeneous; idle variables have no column; tails analytic
+  auto jacobian = [&](double tq) {
+    const double keep = M.tca_shear_g;
+    for (int r = 0; r < NC; r++) {
+      if (!core_present(P, L, r)) continue;
+      const double col = eval(tq, (lane == r) ? 1.0 : 0.0);
+      J.Jc[r * 64 + lane] = (lane < NC) ? col : 0.;
+    }
+    J.jdiag = -(e.D * Q.kap + e.G * Q.kcot + (CURV ? e.Gt * Q.inv_tau : 0.));   // frozen at the time of this Jacobian (ev.cpp keeps J fixed)
+    M.tca_shear_g = keep;
+    st.jacs++;
+  };
+
+  // ------------------------------------------------------------------ first guess of h (ev.cpp:225-283)
+  double t = t0, absh, h;
+  const double hmin0 = 16.0 * eps * fabs(t0);
+  PROF_START();
+  jacobian(t);
+  {
+    const double f0 = eval(t, y);
+    const double wt = fmax(fabs(y), threshold);
+    double rh = wave_max(1.25 / sqrt(rtol) * fabs(f0 / wt));
+    absh = fmin(hmax, htspan);
+    if (uni(absh * rh > 1.0)) absh = 1.0 / rh;
+    absh = fmax(absh, hmin0);
+    const double tdel = (t + fmin(sqrt(eps) * fmax(fabs(t), fabs(t + absh)), absh)) - t;
+    const double f1 = eval(t + tdel, y);
+    const double Jf0 = eval(t, f0);                      // J f0 = f(t, f0)
+    const double acc = Jf0 + (f1 - f0) / tdel;           // ddfddt (ev.cpp:261-283)
+    rh = wave_max(1.25 * sqrt(0.5 * fabs(acc / wt) / rtol));
+    absh = fmin(hmax, htspan);
+    if (uni(absh * rh > 1.0)) absh = 1.0 / rh;
+    absh = fmax(absh, hmin0);
+    h = absh;
+    dif[0] = h * f0;
+  }
+  PROF_STOP(3);
+  int kk = 1, klast = 1, nconhk = 0;
+  double iga = ndf_invGa(0), erc = ndf_erconst(0), errthr = rtol * fast_rcp(ndf_erconst(0));
+  auto set_order = [&]() { iga = ndf_invGa(kk - 1); erc = ndf_erconst(kk - 1); errthr = rtol * fast_rcp(erc); };
+  double abshlast = absh, hinvGak = h * iga, hmin = hmin0;
+  double rate = 0., thr1 = minnrm, err = 0.;
+  bool Jcurrent = true, havrate = false, done = false, at_hmin = false, need_fact = true;
+  double tnew = t0, ynew = y, fnewton = 0., difkp1 = 0., invwt = 0.;
+
+  for (;;) {   // ------------------------------------------------ one turn = one accepted step
+    // ---------------------------------------------------------------- start of a step (ev.cpp:299-334)
+    PROF_START();
+    hmin = P.min_var;
+    absh = fmin(hmax, fmax(hmin, absh));
+    if (uni(fabs(absh - hmin) < 100 * eps)) { if (at_hmin) absh = abshlast; at_hmin = true; } else at_hmin = false;
+    h = absh;
+    if (uni(1.1 * absh >= fabs(tfinal - t))) { h = tfinal - t; absh = fabs(h); done = true; }
+    if (uni(fabs(absh - abshlast) > 1e-6 * absh) || (kk != klast)) {   // (ev.cpp:318: |dh| / h > 1e-6, without the division)
+      adjust_stepsize(dif, absh * fast_rcp(abshlast), kk);
+      hinvGak = h * iga;
+      nconhk = 0;
+      need_fact = true;
+    }
+    // the time of this step is known: ask the helper for its table row now (a no-op when the step size did not change - the row
+    // was requested a whole step ago - and otherwise early enough to arrive behind the factorisation)
+    mb_request(Q, done ? tfinal : t + h, lane);
+    bool nofailed = true;
+    PROF_STOP(13);
+    for (;;) {   // -------------------------------------------- attempts at this step
+      if (--budget < 0) return 4;
+      if (need_fact) {
+        need_fact = false;
+        PROF_START();
+        if (!factorise(e, J, hinvGak, maxlen, lane, F)) return 2;
+        PROF_STOP(2);
+        st.lus++;
+        havrate = false;
+        thr1 = minnrm;
+      }
+      // -------------------------------------------------------------- predictor + simplified Newton (ev.cpp:342-445)
+#ifdef CPT_PROFILE
+      const unsigned long long t_newton0 = clock64();
+      unsigned long long t_inner = 0;
+#endif
+      double psi, pred;
+      switch (__builtin_amdgcn_readfirstlane(kk)) {
+        case 1: psi = dif[0]; pred = y + dif[0]; break;
+        case 2: psi = fma(1.5, dif[1], dif[0]); pred = y + (dif[0] + dif[1]); break;
+        case 3: psi = fma(11.0 / 6.0, dif[2], fma(1.5, dif[1], dif[0])); pred = y + ((dif[0] + dif[1]) + dif[2]); break;
+        case 4: psi = fma(25.0 / 12.0, dif[3], fma(11.0 / 6.0, dif[2], fma(1.5, dif[1], dif[0]))); pred = y + ((dif[0] + dif[1]) + (dif[2] + dif[3])); break;
+        default: psi = fma(137.0 / 60.0, dif[4], fma(25.0 / 12.0, dif[3], fma(11.0 / 6.0, dif[2], fma(1.5, dif[1], dif[0]))));
+                 pred = y + (((dif[0] + dif[1]) + (dif[2] + dif[3])) + dif[4]); break;
+      }
+      psi *= iga;
+      tnew = t + h;
+      if (done) tnew = tfinal;
+      h = tnew - t;
+      ynew = pred;
+      difkp1 = 0.;
+      {  // weights of the norms (ev.cpp:367-374): the seed + one Newton step (2e-15) is ample for a weight
+        const double w = fmax(fmax(fabs(ynew), fabs(y)), threshold);
+        const double r = __builtin_amdgcn_rcp(w);
+        invwt = fma(r, fma(-w, r, 1.0), r);
+      }
+      bool tooslow = false;
+      double newnrm = 0., oldnrm = 0.;
+      for (int iter = 1; iter <= maxit; iter++) {
+        PROF_START();
+        fnewton = eval(tnew, ynew);
+        // the row of THIS step is in registers: speculate that the step size stays and ask for the next one (t' + h' = tnew + absh)
+        if (iter == 1 && !done) mb_request(Q, tnew + absh, lane);
+        PROF_STOP(0);
+#ifdef CPT_PROFILE
+        t_inner += clock64() - pf_t0;
+#endif
+        const double rhsv = hinvGak * fnewton - (psi + difkp1);
+        PROF_START();
+        const double del = lu_solve(e, F, maxlen, rhsv, lane);
+        PROF_STOP(1);
+#ifdef CPT_PROFILE
+        t_inner += clock64() - pf_t0;
+#endif
+        st.solves++;
+        const double dn = fabs(del * invwt);
+        difkp1 += del;
+        ynew = pred + difkp1;
+        if (iter == 1) {   // converged <=> max |del / wt| <= thr1 (see ndf15): one compare + one scalar test, no reduction
+          if (wave_all_le(dn, thr1)) break;
+          newnrm = wave_max(dn);
+          if (!havrate) rate = 0.0;
+        } else {
+          newnrm = wave_max(dn);
+          if (uni(newnrm <= minnrm)) break;
+          if (uni(newnrm > 0.9 * oldnrm)) { tooslow = true; break; }
+          rate = fmax(0.9 * rate, newnrm * fast_rcp(oldnrm));
+          havrate = true;
+          const double q = rate * fast_rcp(1.0 - rate), errit = newnrm * q;
+          thr1 = fmax(minnrm, 0.05 * rtol * fast_rcp(q));
+          if (uni(errit <= 0.5 * rtol)) break;
+          else if (iter == maxit) { tooslow = true; break; }
+          else if (uni(0.5 * rtol < errit * fast_powi(rate, maxit - iter))) { tooslow = true; break; }
+        }
+        oldnrm = newnrm;
+      }
+#ifdef CPT_PROFILE
+      prof[5] += clock64() - t_newton0 - t_inner;  // predictor + Newton control without rhs / solve
+#endif
+      if (tooslow) {  // ev.cpp:446-479
+        st.failed++;
+        if (!Jcurrent) {
+          PROF_START();
+          jacobian(t);
+          st.fevals++;  // the reference also re-evaluates f(t,y) here (ev.cpp:451)
+          Jcurrent = true;
+          need_fact = true;
+          PROF_STOP(3);
+          continue;
+        }
+        if (uni(absh <= hmin)) return 1;
+        abshlast = absh;
+        absh = fmax(0.3 * absh, hmin);
+        h = absh;
+        done = false;
+        mb_request(Q, t + h, lane);
+        adjust_stepsize(dif, absh * fast_rcp(abshlast), kk);
+        hinvGak = h * iga;
+        nconhk = 0;
+        need_fact = true;
+        continue;
+      }
+      // -------------------------------------------------------------- error test (ev.cpp:483-532)
+      // err = max |difkp1 / wt| * erconst > rtol  <=>  some lane has |difkp1 / wt| > rtol / erconst: a compare, not a reduction
+      PROF_START();
+      const double dn = fabs(difkp1 * invwt);
+      if (wave_all_le(dn, errthr)) { PROF_STOP(14); break; }   // accepted
+      err = wave_max(dn) * erc;
+      st.failed++;
+      if (uni(absh <= hmin)) return 1;
+      abshlast = absh;
+      if (nofailed) {
+        nofailed = false;
+        double hopt = absh * fmax(0.1, 0.833 * fast_root(rtol * fast_rcp(err), kk + 1));
+        if (kk > 1) {
+          const double errkm1 = wave_max(fabs((dif_get(dif, kk - 1) + difkp1) * invwt)) * ndf_erconst(kk - 2);
+          const double hkm1 = absh * fmax(0.1, 0.769 * fast_root(rtol * fast_rcp(errkm1), kk));
+          if (uni(hkm1 > hopt)) { hopt = fmin(absh, hkm1); kk = kk - 1; set_order(); }
+        }
+        absh = fmax(hmin, hopt);
+      } else absh = fmax(hmin, 0.5 * absh);
+      h = absh;
+      if (uni(absh < abshlast)) done = false;
+      mb_request(Q, done ? tfinal : t + h, lane);
+      adjust_stepsize(dif, absh * fast_rcp(abshlast), kk);
+      hinvGak = h * iga;
+      nconhk = 0;
+      need_fact = true;
+      PROF_STOP(14);
+    }
+    // ------------------------------------------------------------------ accepted: update differences (ev.cpp:537-545)
+    st.steps++;
+    switch (__builtin_amdgcn_readfirstlane(kk)) {
+      case 1: dif[2] = difkp1 - dif[1]; dif[1] = difkp1; dif[0] += dif[1]; break;
+      case 2: dif[3] = difkp1 - dif[2]; dif[2] = difkp1; dif[1] += dif[2]; dif[0] += dif[1]; break;
+      case 3: dif[4] = difkp1 - dif[3]; dif[3] = difkp1; dif[2] += dif[3]; dif[1] += dif[2]; dif[0] += dif[1]; break;
+      case 4: dif[5] = difkp1 - dif[4]; dif[4] = difkp1; dif[3] += dif[4]; dif[2] += dif[3]; dif[1] += dif[2]; dif[0] += dif[1]; break;
+      default: dif[6] = difkp1 - dif[5]; dif[5] = difkp1; dif[4] += dif[5]; dif[3] += dif[4]; dif[2] += dif[3]; dif[1] += dif[2]; dif[0] += dif[1]; break;
+    }
+    // ------------------------------------------------------------------ dense output at the sample times this step has passed
+    // (ev.cpp:547-571, interp_from_dif :860-905), handed to the helper wave
+    if (uni(tnew - tnext >= 0.0)) {
+      PROF_START();
+      const double tca_keep = M.tca_shear_g;
+      const int flags = L.tca | (L.rsa << 1) | (L.ufa << 2);
+      const double inv_h = fast_rcp(h);
+      do {
+        double yi, ypi;
+        if (uni(tnew == tnext)) { yi = ynew; ypi = fnewton; }
+        else {
+          // y(tn) = ynew + sum_j p_j / j! dif_j, p_j = prod_{i <= j} (s + i), s = (tn - tnew) / h; the derivative takes dp_j / ds by the
+          // product rule dp_j = dp_{j-1} (s + j) + p_{j-1} (= p_j sum_i 1 / (s + i), the form of ev.cpp:885-896, without divisions)
+          const double sx = (tnext - tnew) * inv_h;
+          double pj = sx, dpj = 1.0;
+          yi = fma(pj, dif[0], ynew); ypi = dif[0];
+#pragma unroll
+          for (int j = 1; j < 5; j++) {
+            if (j < kk) {
+              const double inv_fact = (j == 1) ? 0.5 : (j == 2) ? 1.0 / 6.0 : (j == 3) ? 1.0 / 24.0 : 1.0 / 120.0;
+              dpj = fma(dpj, sx + j, pj);
+              pj *= (sx + j);
+              yi = fma(pj * inv_fact, dif[j], yi);
+              ypi = fma(dpj * inv_fact, dif[j], ypi);
+            }
+          }
+          ypi *= inv_h;
+        }
+        if (C.posted - C.tail_seen >= MB_NSLOT) {   // ring full: wait for the helper (it is certain to consume)
+          int spins = 0;
+          while (C.posted - (C.tail_seen = mb_load(&C.mb->tail)) >= MB_NSLOT) {
+            __builtin_amdgcn_s_sleep(1);
+            if (++spins > (1 << 24)) return 5;
+          }
+        }
+        const int slot = C.posted & (MB_NSLOT - 1);
+        C.mb->yi[slot][lane] = yi; C.mb->ypi[slot][lane] = ypi;
+        if (lane == 0) { C.mb->tca_keep[slot] = tca_keep; C.mb->it[slot] = next; C.mb->flags[slot] = flags; }
+        C.posted++;
+        mb_store(&C.mb->head, C.posted);
+        st.fevals++;                             // (the evaluation is counted where the reference makes it)
+        next++;
+        tnext = tnext2;
+        tnext2 = (next + 1 < tres) ? ts[next + 1] : 1e300;
+      } while (uni(tnew - tnext >= 0.0));
+      PROF_STOP(4);
+    }
+    if (done) break;
+    // ------------------------------------------------------------------ after an accepted step (ev.cpp:573-635)
+    PROF_START();
+    klast = kk;
+    abshlast = absh;
+    nconhk = min(nconhk + 1, maxk + 2);
+    if (nconhk >= kk + 2) {
+      // (the norm of the accepted correction is only formed here, where its value steers the step size: one step in ~five)
+      err = wave_max(fabs(difkp1 * invwt)) * erc;
+      double temp = 1.2 * fast_root(err * inv_rtol, kk + 1);
+      double hopt = uni(temp > 0.1) ? absh * fast_rcp(temp) : 10 * absh;
+      int kopt = kk;
+      if (kk > 1) {
+        const double errkm1 = wave_max(fabs(dif_get(dif, kk - 1) * invwt)) * ndf_erconst(kk - 2);
+        temp = 1.3 * fast_root(errkm1 * inv_rtol, kk);
+        const double hkm1 = uni(temp > 0.1) ? absh * fast_rcp(temp) : 10 * absh;
+        if (uni(hkm1 > hopt)) { hopt = hkm1; kopt = kk - 1; }
+      }
+      if (kk < maxk) {
+        const double errkp1 = wave_max(fabs(dif_get(dif, kk + 1) * invwt)) * ndf_erconst(kk);
+        temp = 1.4 * fast_root(errkp1 * inv_rtol, kk + 2);
+        const double hkp1 = uni(temp > 0.1) ? absh * fast_rcp(temp) : 10 * absh;
+        if (uni(hkp1 > hopt)) { hopt = hkp1; kopt = kk + 1; }
+      }
+      if (uni(hopt > absh)) { absh = hopt; if (kopt != kk) { kk = kopt; set_order(); } }
+    }
+    t = tnew;
+    y = ynew;
+    Jcurrent = false;
+    PROF_STOP(12);
+  }
+  // ev.cpp:653-662: one last evaluation leaves M and Q describing (tfinal, y) for the hand-over to the next scheme
+  (void)eval(tnew, ynew);
+  y_io = ynew;
+  return 0;
+}
+
 // perturb_initial_conditions (pm.cpp:4723-5408): adiabatic, synchronous gauge, flat. Returns this lane's y.
 static __device__ __noinline__ double initial_conditions(DevTables T, int has_cdm, int has_ur, double ci, double K, int ic, double ei, int gauge, int role,
                                                   int ell, double k, double tau) {
@@ -2280,7 +2608,9 @@ static __device__ __forceinline__ int run_intervals(const PtParams& P, Ctx& C, c
         C.tau_pub = -1.;   // (the chain coefficients cached for this time belong to the old scheme)
       }
       n_regimes++;
-      const int rc = ndf15<ROLE>(P, L, e, ce, C, Q, M, k, inv_k2, ik, ta, tb, y, st, lane, budget, jacw, prof);
+      int rc;
+      if constexpr (SAMPLER) rc = ndf15s(P, L, e, C, Q, M, k, inv_k2, ta, tb, y, st, lane, budget, jacw, prof);
+      else rc = ndf15<ROLE>(P, L, e, ce, C, Q, M, k, inv_k2, ik, ta, tb, y, st, lane, budget, jacw, prof);
       if (rc) status = 10 + rc;
     }
   }
