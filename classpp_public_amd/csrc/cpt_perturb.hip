@@ -1351,8 +1351,14 @@ struct Jac {
                    // Jacobian refresh writes it and only the factorisation reads it: no reason to pin 26 VGPRs
   double jdiag;    // tail lanes: J_ll = -(D kappa' + G/tau) frozen at the time of the Jacobian (ev.cpp keeps J fixed)
 };
+// The bulky part of the factors lives in LDS, not in registers: row i of the core factors (L below / unit-diagonal U above the
+// diagonal) of lane i < NC, and the cyclic-reduction multipliers of the tails.  Kept in registers they push the integrator past
+// 256 VGPRs, and every use then costs a v_accvgpr_read per dword; from LDS a ds_read_b128 brings two doubles per instruction,
+// issued ahead of their use.  Layout: pair p of lane l at fw[p * 64 + l] (conflict-free b128 accesses).
+static constexpr int FW_ACP = (NC + 1) / 2;      // pairs holding Ac[0..NC-1]
+static constexpr int FW_PAIRS = FW_ACP + 4;      // + (al, ga) of the four reduction levels
 struct LuReg {
-  double Ac[NC];   // lane i < NC: row i of the core factors (L below / unit-diagonal U above the diagonal)
+  double2* fw;     // LDS [FW_PAIRS][64]
   double rpivc;    // lane j < nc: reciprocal of the j-th core pivot
   int rowperm;     // lane i < nc: original row now at position i (identity on tail lanes)
   int permuted;    // (wave-uniform) some rows were exchanged: rowperm is not the identity
@@ -1360,7 +1366,6 @@ struct LuReg {
   double g;        // tail lanes: c_l / d'_{l+1}, the downward-sweep multiplier (0 on the l_max element and on core lanes)
   double r;        // tail lanes: a_l / d'_l, the upward-sweep multiplier
   double cpar;     // core parents of a tail: coupling to the tail's l=3 element (0 elsewhere)
-  double al[4], ga[4];   // (PCR) cyclic reduction of the tails (one per row): multipliers of the neighbours at distance 1, 2, 4, 8
 };
 
 template <int N>
@@ -1377,11 +1382,13 @@ static __device__ __forceinline__ double reg_get(const double (&a)[N], int i) {
 // b <- the right-hand side after the four reduction levels (u = b * rinv solves T u = b on every tail at once)
 // (all four levels, whatever the tails' lengths: a level the factorisation did not need has al = ga = 0 and leaves b alone,
 //  which costs two multiply-adds where a test of maxlen costs a scalar reload, a compare and a branch per level)
-static __device__ __forceinline__ double pcr_apply(const LuReg& F, double b) {
-  b = fma(-F.al[0], row_shr0<1>(b), fma(-F.ga[0], row_shl0<1>(b), b));
-  b = fma(-F.al[1], row_shr0<2>(b), fma(-F.ga[1], row_shl0<2>(b), b));
-  b = fma(-F.al[2], row_shr0<4>(b), fma(-F.ga[2], row_shl0<4>(b), b));
-  b = fma(-F.al[3], row_shr0<8>(b), fma(-F.ga[3], row_shl0<8>(b), b));
+static __device__ __forceinline__ double pcr_apply(const LuReg& F, double b, int lane) {
+  const double2 m0 = F.fw[(FW_ACP + 0) * 64 + lane], m1 = F.fw[(FW_ACP + 1) * 64 + lane], m2 = F.fw[(FW_ACP + 2) * 64 + lane],
+                m3 = F.fw[(FW_ACP + 3) * 64 + lane];   // {al, ga} of the four levels
+  b = fma(-m0.x, row_shr0<1>(b), fma(-m0.y, row_shl0<1>(b), b));
+  b = fma(-m1.x, row_shr0<2>(b), fma(-m1.y, row_shl0<2>(b), b));
+  b = fma(-m2.x, row_shr0<4>(b), fma(-m2.y, row_shl0<4>(b), b));
+  b = fma(-m3.x, row_shr0<8>(b), fma(-m3.y, row_shl0<8>(b), b));
   return b;
 }
 template <int S>
@@ -1407,16 +1414,17 @@ static __device__ __forceinline__ bool factorise(const LaneEq& e, const Jac& J, 
   if (PCR) {
     // T (tridiagonal inside each tail; the first element's a couples to the core parent and stays outside)
     double ta = (chain && !e.first) ? a : 0., tc = c, td = chain ? d : 1.;
+    double al[4] = {0., 0., 0., 0.}, ga[4] = {0., 0., 0., 0.};
+    if (maxlen > 1) pcr_level<1>(ta, tc, td, al[0], ga[0]);
+    if (maxlen > 2) pcr_level<2>(ta, tc, td, al[1], ga[1]);
+    if (maxlen > 4) pcr_level<4>(ta, tc, td, al[2], ga[2]);
+    if (maxlen > 8) pcr_level<8>(ta, tc, td, al[3], ga[3]);
 #pragma unroll
-    for (int i = 0; i < 4; i++) F.al[i] = F.ga[i] = 0.;
-    if (maxlen > 1) pcr_level<1>(ta, tc, td, F.al[0], F.ga[0]);
-    if (maxlen > 2) pcr_level<2>(ta, tc, td, F.al[1], F.ga[1]);
-    if (maxlen > 4) pcr_level<4>(ta, tc, td, F.al[2], F.ga[2]);
-    if (maxlen > 8) pcr_level<8>(ta, tc, td, F.al[3], F.ga[3]);
+    for (int i = 0; i < 4; i++) F.fw[(FW_ACP + i) * 64 + lane] = make_double2(al[i], ga[i]);
     const double rinv = fast_rcp(td);
     F.rinv = chain ? rinv : 0.;
     // v = T^-1 (a_first e_first): what a unit core parent sends into its tail
-    r = pcr_apply(F, (chain && e.first) ? a : 0.) * F.rinv;
+    r = pcr_apply(F, (chain && e.first) ? a : 0., lane) * F.rinv;
     F.r = r; F.g = 0.;
   } else {
   double dp = d;
@@ -1482,7 +1490,9 @@ static __device__ __forceinline__ bool factorise(const LaneEq& e, const Jac& J, 
   }
   // unit-diagonal U: scale the upper part of every row by its reciprocal pivot
 #pragma unroll
-  for (int j = 0; j < NC; j++) F.Ac[j] = (j > lane) ? A[j] * rpivc : A[j];
+  for (int j = 0; j < NC; j++) A[j] = (j > lane) ? A[j] * rpivc : A[j];
+#pragma unroll
+  for (int q = 0; q < FW_ACP; q++) F.fw[q * 64 + lane] = make_double2(A[2 * q], (2 * q + 1 < NC) ? A[2 * q + 1] : 0.);
   F.rpivc = rpivc;
   F.rowperm = rowperm;
   F.permuted = __builtin_amdgcn_readfirstlane(permuted);
@@ -1495,7 +1505,11 @@ static __device__ __forceinline__ double lu_solve(const LaneEq& e, const LuReg& 
   const int chain = opaque(e.chain);
   // 1. tails, downward sweep: b'_l = b_l - (c_l / d'_{l+1}) b'_{l+1}; the l_max element is final at once
   double u;
-  if (PCR) u = pcr_apply(F, chain ? b : 0.) * F.rinv;   // T^-1 b on every tail lane, 0 on core lanes
+  // the rows of the core factors: requested now, they arrive behind the tail reduction
+  double Ac[2 * FW_ACP];
+#pragma unroll
+  for (int q = 0; q < FW_ACP; q++) { const double2 v = F.fw[q * 64 + lane]; Ac[2 * q] = v.x; Ac[2 * q + 1] = v.y; }
+  if (PCR) u = pcr_apply(F, chain ? b : 0., lane) * F.rinv;   // T^-1 b on every tail lane, 0 on core lanes
   else {
     double bp = b;
     for (int s = 1; s < maxlen; s++) bp = fma(-F.g, lane_above(bp), b);
@@ -1520,14 +1534,14 @@ static __device__ __forceinline__ double lu_solve(const LaneEq& e, const LuReg& 
 #pragma unroll
   for (int j = 0; j < NC; j++) {   // forward, unit lower
     const double xj = bcast(x, j);
-    const double m = __hiloint2double((lane > j) ? __double2hiint(F.Ac[j]) : 0, __double2loint(F.Ac[j]));
+    const double m = __hiloint2double((lane > j) ? __double2hiint(Ac[j]) : 0, __double2loint(Ac[j]));
     x = fma(-m, xj, x);
   }
   x *= F.rpivc;   // 1 outside the core
 #pragma unroll
   for (int j = NC - 1; j >= 0; j--) {  // backward, unit upper
     const double xj = bcast(x, j);
-    const double uj = __hiloint2double((lane < j) ? __double2hiint(F.Ac[j]) : 0, __double2loint(F.Ac[j]));
+    const double uj = __hiloint2double((lane < j) ? __double2hiint(Ac[j]) : 0, __double2loint(Ac[j]));
     x = fma(-uj, xj, x);
   }
   // 4. tails, upward sweep: x_l = b'_l / d'_l - (a_l / d'_l) x_{l-1}; the l=3 element takes x_{l-1} from its core parent
@@ -1655,7 +1669,7 @@ static __device__ __forceinline__ double dif_get(const double* dif, int i) {
 template <int ROLE>
 static __device__ __forceinline__ int ndf15(const PtParams& P, const Layout& L, const LaneEq& e, const ChainEq& ce, Ctx& C, Lookup& Q, Metric& M, double k,
                                      double inv_k2, int ik, double t0, double tfinal, double& y_io, Stat& st, int lane,
-                                     int& budget, double* jac_lds, unsigned long long* prof) {
+                                     int& budget, double* jac_lds, double2* fw_lds, unsigned long long* prof) {
   PROF_DECL;
   const double eps = 1e-16, threshold = 1e-15, rtol = P.rtol, inv_rtol = 1.0 / rtol;
   const int maxit = 4, maxk = 5;
@@ -1675,11 +1689,8 @@ static __device__ __forceinline__ int ndf15(const PtParams& P, const Layout& L, 
   double gmc = 0., gms = 0.;   // wave 0: response of (metric_continuity, metric_shear) to unit core variable `lane`
   NcIn N = {0., 0., 0., nullptr, 0};
   LuReg F;
-#pragma unroll
-  for (int j = 0; j < NC; j++) F.Ac[j] = 0.;
+  F.fw = fw_lds;
   F.rpivc = 1.; F.rowperm = lane; F.permuted = 0; F.rinv = F.r = F.g = F.cpar = 0.;
-#pragma unroll
-  for (int j = 0; j < 4; j++) F.al[j] = F.ga[j] = 0.;
   double y = y_io, ynew = y_io, f0 = 0., f1 = 0., fnewton = 0., wt = 0., tdel = 0.;
   double dif[7] = {0., 0., 0., 0., 0., 0., 0.};
   int next = 0;
@@ -2071,7 +2082,7 @@ static __device__ __forceinline__ int ndf15(const PtParams& P, const Layout& L, 
 // 2 singular, 4 budget, 5 helper unresponsive).
 static __device__ __forceinline__ int ndf15s(const PtParams& P, const Layout& L, const LaneEq& e, Ctx& C, Lookup& Q, Metric& M, double k, double inv_k2,
                                              double t0, double tfinal, double& y_io, Stat& st, int lane, int& budget, double* jac_lds,
-                                             unsigned long long* prof) {
+                                             double2* fw_lds, unsigned long long* prof) {
   PROF_DECL;
   const double eps = 1e-16, threshold = 1e-15, rtol = P.rtol, inv_rtol = 1.0 / rtol;
   const int maxit = 4, maxk = 5;
@@ -2086,11 +2097,8 @@ static __device__ __forceinline__ int ndf15s(const PtParams& P, const Layout& L,
   for (int j = 0; j < NC; j++) J.Jc[j * 64 + lane] = 0.;
   J.jdiag = 0.;
   LuReg F;
-#pragma unroll
-  for (int j = 0; j < NC; j++) F.Ac[j] = 0.;
+  F.fw = fw_lds;
   F.rpivc = 1.; F.rowperm = lane; F.permuted = 0; F.rinv = F.r = F.g = F.cpar = 0.;
-#pragma unroll
-  for (int j = 0; j < 4; j++) F.al[j] = F.ga[j] = 0.;
   double y = y_io;
   double dif[7] = {0., 0., 0., 0., 0., 0., 0.};
   // sample times: the next one and the one after it sit in registers (the second is loaded one sample ahead, so its trip to
@@ -2492,7 +2500,7 @@ static __device__ __noinline__ double initial_conditions(DevTables T, int has_cd
 struct Sched { double tau_ini, tau_end, sw0, sw1, sw2, sw3; int nsw, ap0, ap1, ap2, ap3, fi0, fi1, fi2, fi3; };
 template <int ROLE>
 static __device__ __forceinline__ int run_intervals(const PtParams& P, Ctx& C, const Sched& sc, double k, double inv_k2, int ik, int lane,
-                                                    double2* bgw, double2* thw, double2* ncw, double* jacw, Stat& st, int& n_regimes,
+                                                    double2* bgw, double2* thw, double2* ncw, double* jacw, double2* fww, Stat& st, int& n_regimes,
                                                     int& budget, unsigned long long* prof
 #ifdef CPT_PROFILE
                                                     , unsigned long long t_begin
@@ -2609,8 +2617,8 @@ static __device__ __forceinline__ int run_intervals(const PtParams& P, Ctx& C, c
       }
       n_regimes++;
       int rc;
-      if constexpr (SAMPLER) rc = ndf15s(P, L, e, C, Q, M, k, inv_k2, ta, tb, y, st, lane, budget, jacw, prof);
-      else rc = ndf15<ROLE>(P, L, e, ce, C, Q, M, k, inv_k2, ik, ta, tb, y, st, lane, budget, jacw, prof);
+      if constexpr (SAMPLER) rc = ndf15s(P, L, e, C, Q, M, k, inv_k2, ta, tb, y, st, lane, budget, jacw, fww, prof);
+      else rc = ndf15<ROLE>(P, L, e, ce, C, Q, M, k, inv_k2, ik, ta, tb, y, st, lane, budget, jacw, fww, prof);
       if (rc) status = 10 + rc;
     }
   }
@@ -2682,6 +2690,7 @@ static __device__ __forceinline__ void run_helper(const PtParams& P, Mailbox* mb
 static __device__ __forceinline__ void body_perturb(const PtParams& P) {
   __shared__ __attribute__((aligned(16))) double2 tabw[64 * (BG_NCOL + TH_NCOL)];
   __shared__ double jacw[NC * 64];
+  __shared__ __attribute__((aligned(16))) double2 fwsh[FW_PAIRS * 64];   // the integrator / core wave's factors (LuReg)
   __shared__ __attribute__((aligned(16))) double2 ncw[NCDM ? 64 * NCB_NCOL : 1];
   __shared__ __attribute__((aligned(8))) char ncsh_raw[NCDM ? sizeof(NcShared) : 8];
   __shared__ __attribute__((aligned(16))) double2 tabw2[SAMPLER ? 64 * (BG_NCOL + TH_NCOL) : 1];   // the helper's second set of table windows
@@ -2751,9 +2760,9 @@ static __device__ __forceinline__ void body_perturb(const PtParams& P) {
   if (status == 0) {
     const Sched sc = {tau_ini, tau_end, sw0, sw1, sw2, sw3, nsw, ap0, ap1, ap2, ap3, fi0, fi1, fi2, fi3};
 #ifdef CPT_PROFILE
-#define CPT_RUN_ARGS P, C, sc, k, inv_k2, ik, lane, bgw, thw, ncw, jacw, st, n_regimes, budget, prof, t_begin
+#define CPT_RUN_ARGS P, C, sc, k, inv_k2, ik, lane, bgw, thw, ncw, jacw, fwsh, st, n_regimes, budget, prof, t_begin
 #else
-#define CPT_RUN_ARGS P, C, sc, k, inv_k2, ik, lane, bgw, thw, ncw, jacw, st, n_regimes, budget, prof
+#define CPT_RUN_ARGS P, C, sc, k, inv_k2, ik, lane, bgw, thw, ncw, jacw, fwsh, st, n_regimes, budget, prof
 #endif
     if constexpr (NCDM != 0) { if (C.wave > 0) status = run_intervals<1>(CPT_RUN_ARGS); else status = run_intervals<0>(CPT_RUN_ARGS); }
     else { if (C.wave == 0) status = run_intervals<0>(CPT_RUN_ARGS); }
@@ -2857,7 +2866,9 @@ static __device__ __forceinline__ void body_dbg_solve(const PtParams& P, double 
     J.Jc[r * 64 + lane] = (lane < NC) ? col : 0.;
   }
   J.jdiag = -(e.D * Q.kap + e.G * Q.kcot + (CURV ? e.Gt * Q.inv_tau : 0.));
+  __shared__ __attribute__((aligned(16))) double2 fwsh[FW_PAIRS * 64];
   LuReg F;
+  F.fw = fwsh;
   const bool ok = factorise(e, J, hg, L.maxlen, lane, F);
   int nref;
   const int ri = ref_index_of(P, tca, rsa, ufa, e.role, e.ell, &nref);
