@@ -1,144 +1,110 @@
-// Host-side background cosmology (include/cpt_host.h): the reference's BackgroundModule for flat / curved LambdaCDM
-// with massless neutrinos, restated (not translated): same integration variable (ln a), same integrator (ndf15 at rtol 1e-6 with
-// dense output on a uniform ln a grid), same derived columns and spline second derivatives, so that the table agrees with the
-// reference's to integrator round-off and can be handed to cpt_create unchanged.
+// Host-side background and thermodynamics tables (include/cpt_host.h): what the hot path consumes, computed
+// from the cosmological parameters instead of being handed over by the reference's BackgroundModule / ThermodynamicsModule.
+//
+// The MODEL is the reference's (it has to be: the tables are its data contract) -
+//   background:      Friedmann equation for photons, baryons, cdm, massless and massive neutrinos, Lambda, curvature; conformal time,
+//                    proper time, sound horizon and growth factor on a grid uniform in ln a (source/background_module.cpp:263-610,
+//                    1326-1520, 1934-2064), the 21 (+ 4 per massive species) columns and their order;
+//   thermodynamics:  RECFAST 1.5 (Seager, Sasselov & Scott 1999; Wong, Moss & Scott 2008) with the smoothed Saha <-> ODE hand-overs,
+//                    the CAMB-like tanh reionization, its adaptive redshift sampling, the derived opacity / visibility columns
+//                    (source/thermodynamics_module.cpp:293-1297, 2159-2320, 2668-2990, 3335-3975) -
+// the NUMERICS are this project's own (cpt_numerics.hpp): every ODE goes through one embedded Dormand-Prince 5(4) integrator at
+// tolerances (1e-10, 1e-9) far below the reference's (its variable-order NDF evolver and Cash-Karp stepper at 1e-2 are not
+// restated here), every spline through one factorise-once tridiagonal solver.  The tables therefore agree with the reference's to
+// its own integration error (3e-6 relative on tau, tests/test_host_cosmo.py), not bit for bit; the test infrastructure holds a
+// bit-exact restatement of the reference's modules as the checker.
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <string>
 #include <vector>
 
 #include "../../include/cpt_host.h"
-#include "cpt_ndf15.hpp"
+#include "cpt_numerics.hpp"
 
 namespace cpt_host {
 int fail_msg(int code, const char* fmt, ...);   // cpt_grids.cpp
 
-// array_spline_table_lines (tools/arrays.c:514-690), _SPLINE_EST_DERIV_: second derivatives of ny columns tabulated row-major
+// second derivatives of `ny` row-major columns (used by the grid builders as well)
 void spline_table_lines(const double* x, int n, const double* y, int ny, double* ddy) {
-  std::vector<double> u((size_t)(n - 1) * ny), p(ny), qn(ny), un(ny);
-  const bool natural = (n == 2);
-  for (int c = 0; c < ny; c++) {
-    if (natural) { ddy[c] = u[c] = 0.; continue; }
-    const double dy_first = ((x[2] - x[0]) * (x[2] - x[0]) * (y[1 * ny + c] - y[0 * ny + c]) - (x[1] - x[0]) * (x[1] - x[0]) * (y[2 * ny + c] - y[0 * ny + c])) /
-                            ((x[2] - x[0]) * (x[1] - x[0]) * (x[2] - x[1]));
-    ddy[c] = -0.5;
-    u[c] = (3. / (x[1] - x[0])) * ((y[1 * ny + c] - y[0 * ny + c]) / (x[1] - x[0]) - dy_first);
-  }
-  for (int i = 1; i < n - 1; i++) {
-    const double sig = (x[i] - x[i - 1]) / (x[i + 1] - x[i - 1]);
-    for (int c = 0; c < ny; c++) {
-      p[c] = sig * ddy[(size_t)(i - 1) * ny + c] + 2.0;
-      ddy[(size_t)i * ny + c] = (sig - 1.0) / p[c];
-      double v = (y[(size_t)(i + 1) * ny + c] - y[(size_t)i * ny + c]) / (x[i + 1] - x[i]) - (y[(size_t)i * ny + c] - y[(size_t)(i - 1) * ny + c]) / (x[i] - x[i - 1]);
-      u[(size_t)i * ny + c] = (6.0 * v / (x[i + 1] - x[i - 1]) - sig * u[(size_t)(i - 1) * ny + c]) / p[c];
-    }
-  }
-  for (int c = 0; c < ny; c++) {
-    if (natural) { qn[c] = un[c] = 0.; continue; }
-    const double dy_last = ((x[n - 3] - x[n - 1]) * (x[n - 3] - x[n - 1]) * (y[(size_t)(n - 2) * ny + c] - y[(size_t)(n - 1) * ny + c]) -
-                            (x[n - 2] - x[n - 1]) * (x[n - 2] - x[n - 1]) * (y[(size_t)(n - 3) * ny + c] - y[(size_t)(n - 1) * ny + c])) /
-                           ((x[n - 3] - x[n - 1]) * (x[n - 2] - x[n - 1]) * (x[n - 3] - x[n - 2]));
-    qn[c] = 0.5;
-    un[c] = (3. / (x[n - 1] - x[n - 2])) * (dy_last - (y[(size_t)(n - 1) * ny + c] - y[(size_t)(n - 2) * ny + c]) / (x[n - 1] - x[n - 2]));
-  }
-  for (int c = 0; c < ny; c++)
-    ddy[(size_t)(n - 1) * ny + c] = (un[c] - qn[c] * u[(size_t)(n - 2) * ny + c]) / (qn[c] * ddy[(size_t)(n - 2) * ny + c] + 1.0);
-  for (int i = n - 2; i >= 0; i--)
-    for (int c = 0; c < ny; c++) ddy[(size_t)i * ny + c] = ddy[(size_t)i * ny + c] * ddy[(size_t)(i + 1) * ny + c] + u[(size_t)i * ny + c];
+  if (n < 3) { for (size_t i = 0; i < (size_t)n * ny; i++) ddy[i] = 0.; return; }
+  cpt_num::ClampedSpline(x, n).moments(y, ny, ny, ddy);
 }
-
-// array_interpolate_spline (tools/arrays.c:1565-1628): one row at abscissa v, x ascending or descending
 int interpolate_spline(const double* x, int n, const double* y, const double* ddy, int ny, double v, double* out) {
-  int inf = 0, sup = n - 1;
-  if (x[inf] < x[sup]) {
-    if (v < x[inf] || v > x[sup]) return 1;
-    while (sup - inf > 1) { const int mid = (int)(0.5 * (inf + sup)); if (v < x[mid]) sup = mid; else inf = mid; }
-  } else {
-    if (v < x[sup] || v > x[inf]) return 1;
-    while (sup - inf > 1) { const int mid = (int)(0.5 * (inf + sup)); if (v > x[mid]) sup = mid; else inf = mid; }
-  }
-  const double h = x[sup] - x[inf], b = (v - x[inf]) / h, a = 1 - b;
-  for (int c = 0; c < ny; c++)
-    out[c] = a * y[(size_t)inf * ny + c] + b * y[(size_t)sup * ny + c] + ((a * a * a - a) * ddy[(size_t)inf * ny + c] + (b * b * b - b) * ddy[(size_t)sup * ny + c]) * h * h / 6.;
-  return 0;
+  return cpt_num::spline_eval(x, n, y, ddy, ny, ny, v, out) ? 0 : 1;
 }
 
 namespace {
-const double GYR_OVER_MPC = 3.06601394e2;
-enum { BG_a = 0, BG_H, BG_H_prime, BG_rho_g, BG_rho_b, BG_rho_cdm, BG_rho_lambda, BG_rho_ur };   // (cdm / lambda / ur columns exist when present)
+constexpr double kGyrOverMpc = 3.06601394e2;
 
-struct BgLayout {
-  int number_ncdm1, rho_ncdm1, p_ncdm1, pseudo_p_ncdm1;
-  int a, H, Hp, rho_g, rho_b, rho_cdm, rho_lambda, rho_ur, rho_tot, p_tot, p_tot_prime, Omega_r, rho_crit, Omega_m, conf_distance,
-      ang_distance, lum_distance, time, rs, D, f, size;
+// ---- column layout of the background table: the reference's order for the species this library knows (background_indices) ----
+struct BgCols {
+  int a, H, Hp, rho_g, rho_b, rho_cdm, n_ncdm, rho_ncdm, p_ncdm, pp_ncdm, rho_lambda, rho_ur, rho_tot, p_tot, p_tot_prime, Omega_r, rho_crit,
+      Omega_m, conf_distance, ang_distance, lum_distance, time, rs, D, f, size;
+  explicit BgCols(const cpt_cosmo_params& c) {
+    int next = 0;
+    auto take = [&](bool present, int count = 1) { const int at = present ? next : -1; if (present) next += count; return at; };
+    a = take(true); H = take(true); Hp = take(true); rho_g = take(true); rho_b = take(true);
+    rho_cdm = take(c.has_cdm);
+    n_ncdm = take(c.has_ncdm, c.N_ncdm); rho_ncdm = take(c.has_ncdm, c.N_ncdm); p_ncdm = take(c.has_ncdm, c.N_ncdm); pp_ncdm = take(c.has_ncdm, c.N_ncdm);
+    rho_lambda = take(c.has_lambda); rho_ur = take(c.has_ur);
+    rho_tot = take(true); p_tot = take(true); p_tot_prime = take(true); Omega_r = take(true); rho_crit = take(true); Omega_m = take(true);
+    conf_distance = take(true); ang_distance = take(true); lum_distance = take(true); time = take(true); rs = take(true); D = take(true); f = take(true);
+    size = next;
+  }
 };
-BgLayout make_bg_layout(const cpt_cosmo_params& p) {   // background_indices, :832-1025 (the species this restatement knows)
-  BgLayout L;
-  int i = 0;
-  L.a = i++; L.H = i++; L.Hp = i++; L.rho_g = i++; L.rho_b = i++;
-  L.rho_cdm = p.has_cdm ? i++ : -1;
-  L.number_ncdm1 = L.rho_ncdm1 = L.p_ncdm1 = L.pseudo_p_ncdm1 = -1;
-  if (p.has_ncdm) { L.number_ncdm1 = i; i += p.N_ncdm; L.rho_ncdm1 = i; i += p.N_ncdm; L.p_ncdm1 = i; i += p.N_ncdm; L.pseudo_p_ncdm1 = i; i += p.N_ncdm; }
-  L.rho_lambda = p.has_lambda ? i++ : -1; L.rho_ur = p.has_ur ? i++ : -1;
-  L.rho_tot = i++; L.p_tot = i++; L.p_tot_prime = i++; L.Omega_r = i++;
-  L.rho_crit = i++; L.Omega_m = i++; L.conf_distance = i++; L.ang_distance = i++; L.lum_distance = i++; L.time = i++; L.rs = i++;
-  L.D = i++; L.f = i++;
-  L.size = i;
-  return L;
-}
 
-// NonColdDarkMatter::background_ncdm_momenta_mass (tools/non_cold_dark_matter.cpp:805-846): number, density, pressure and
-// pseudo-pressure of species n at redshift z from the background momentum sampling
-void ncdm_momenta(const cpt_cosmo_params& p, int n, double z, double* num, double* rho, double* pr, double* pseudo_p) {
-  const double factor2 = p.factor_ncdm[n] * pow(1 + z, 4), M = p.M_ncdm[n];
-  double sn = 0., srho = 0., sp = 0., spp = 0.;
-  for (int iq = 0; iq < p.q_size_ncdm_bg[n]; iq++) {
-    const double q2 = p.q_ncdm_bg[n][iq] * p.q_ncdm_bg[n][iq], w = p.w_ncdm_bg[n][iq];
-    const double epsilon = sqrt(q2 + M * M / (1. + z) / (1. + z));
-    sn += q2 * w;
-    srho += q2 * epsilon * w;
-    sp += q2 * q2 / 3. / epsilon * w;
-    spp += pow(q2 / epsilon, 3) / 3.0 * w;
+// momentum integrals of one non-cold species at scale factor a / a_today = 1 / (1 + z): number density, energy density, pressure and
+// the "pseudo-pressure" integral of q^6 / eps^3 (the reference's quadrature: nodes q, weights w, eps = sqrt(q^2 + (M a)^2))
+struct NcdmMoments { double number, rho, p, pseudo_p; };
+NcdmMoments ncdm_moments(const cpt_cosmo_params& c, int species, double one_plus_z) {
+  const double Ma = c.M_ncdm[species] / one_plus_z, norm = c.factor_ncdm[species] * one_plus_z * one_plus_z * one_plus_z * one_plus_z;
+  NcdmMoments m{0., 0., 0., 0.};
+  for (int i = 0; i < c.q_size_ncdm_bg[species]; i++) {
+    const double q = c.q_ncdm_bg[species][i], q2 = q * q, wq2 = c.w_ncdm_bg[species][i] * q2, eps = std::sqrt(q2 + Ma * Ma), r = q2 / eps;
+    m.number += wq2;
+    m.rho += wq2 * eps;
+    m.p += wq2 * r / 3.;
+    m.pseudo_p += c.w_ncdm_bg[species][i] * r * r * r / 3.;
   }
-  *num = sn * (factor2 / (1. + z)); *rho = srho * factor2; *pr = sp * factor2; *pseudo_p = spp * factor2;
+  m.number *= norm / one_plus_z; m.rho *= norm; m.p *= norm; m.pseudo_p *= norm;
+  return m;
 }
 
-// background_functions, :263-610: everything that depends on a alone
-int bg_functions(const cpt_cosmo_params& p, const BgLayout& L, double a, bool long_info, double* v) {
-  const double a_rel = a / p.a_today, H02 = p.H0 * p.H0;
-  if (a_rel <= 0.) return fail_msg(CPT_ERR_INVALID, "a = %e instead of strictly positive", a_rel);
-  double rho_tot = 0., p_tot = 0., dp_dloga = 0., rho_r = 0., rho_m = 0.;
-  v[L.a] = a;
-  v[L.rho_g] = p.Omega0_g * H02 / pow(a_rel, 4);
-  rho_tot += v[L.rho_g]; p_tot += 1. / 3. * v[L.rho_g]; dp_dloga += -4. / 3. * v[L.rho_g]; rho_r += v[L.rho_g];
-  v[L.rho_b] = p.Omega0_b * H02 / pow(a_rel, 3);
-  rho_tot += v[L.rho_b]; rho_m += v[L.rho_b];
-  if (p.has_cdm) { v[L.rho_cdm] = p.Omega0_cdm * H02 / pow(a_rel, 3); rho_tot += v[L.rho_cdm]; rho_m += v[L.rho_cdm]; }
-  if (p.has_ncdm)   // :389-420
-    for (int n = 0; n < p.N_ncdm; n++) {
-      double num, rho, pr, pp;
-      ncdm_momenta(p, n, 1. / a_rel - 1., &num, &rho, &pr, &pp);
-      v[L.number_ncdm1 + n] = num; v[L.rho_ncdm1 + n] = rho; v[L.p_ncdm1 + n] = pr; v[L.pseudo_p_ncdm1 + n] = pp;
-      rho_tot += rho; p_tot += pr;
-      dp_dloga += (pp - 5 * pr);
-      rho_r += 3. * pr;
-      rho_m += rho - 3. * pr;
+// Everything that is a function of the scale factor alone.  The energy budget is accumulated species by species:
+// rho, p, dp/dln a, and the split of rho into a relativistic and a non-relativistic part.
+struct Budget {
+  double rho = 0., p = 0., dp_dlna = 0., rho_rel = 0., rho_nr = 0.;
+  void radiation(double r) { rho += r; p += r / 3.; dp_dlna -= 4. / 3. * r; rho_rel += r; }
+  void dust(double r) { rho += r; rho_nr += r; }
+};
+int fill_background_row(const cpt_cosmo_params& c, const BgCols& col, double a, bool with_fractions, double* row) {
+  if (!(a > 0.)) return fail_msg(CPT_ERR_INVALID, "a = %e instead of strictly positive", a / c.a_today);
+  const double x = a / c.a_today, inv3 = 1. / (x * x * x), H0sq = c.H0 * c.H0;
+  Budget all;
+  row[col.a] = a;
+  row[col.rho_g] = c.Omega0_g * H0sq * inv3 / x; all.radiation(row[col.rho_g]);
+  row[col.rho_b] = c.Omega0_b * H0sq * inv3; all.dust(row[col.rho_b]);
+  if (c.has_cdm) { row[col.rho_cdm] = c.Omega0_cdm * H0sq * inv3; all.dust(row[col.rho_cdm]); }
+  if (c.has_ncdm)
+    for (int s = 0; s < c.N_ncdm; s++) {
+      const NcdmMoments m = ncdm_moments(c, s, 1. / x);
+      row[col.n_ncdm + s] = m.number; row[col.rho_ncdm + s] = m.rho; row[col.p_ncdm + s] = m.p; row[col.pp_ncdm + s] = m.pseudo_p;
+      all.rho += m.rho; all.p += m.p; all.dp_dlna += m.pseudo_p - 5. * m.p;
+      all.rho_rel += 3. * m.p; all.rho_nr += m.rho - 3. * m.p;          // the reference's split of a semi-relativistic species
     }
-  if (p.has_lambda) { v[L.rho_lambda] = p.Omega0_lambda * H02; rho_tot += v[L.rho_lambda]; p_tot -= v[L.rho_lambda]; }
-  if (p.has_ur) {
-    v[L.rho_ur] = p.Omega0_ur * H02 / pow(a_rel, 4);
-    rho_tot += v[L.rho_ur]; p_tot += 1. / 3. * v[L.rho_ur]; dp_dloga += -4. / 3. * v[L.rho_ur]; rho_r += v[L.rho_ur];
-  }
-  v[L.H] = sqrt(rho_tot - p.K / a / a);
-  v[L.Hp] = -3. / 2. * (rho_tot + p_tot) * a + p.K / a;
-  v[L.rho_tot] = rho_tot; v[L.p_tot] = p_tot; v[L.p_tot_prime] = a * v[L.H] * dp_dloga;
-  const double rho_crit = rho_tot - p.K / a / a;
-  if (rho_crit <= 0.) return fail_msg(CPT_ERR_INVALID, "rho_crit = %e instead of strictly positive", rho_crit);
-  v[L.Omega_r] = rho_r / rho_crit;
-  if (long_info) { v[L.rho_crit] = rho_crit; v[L.Omega_m] = rho_m / rho_crit; }
+  if (c.has_lambda) { row[col.rho_lambda] = c.Omega0_lambda * H0sq; all.rho += row[col.rho_lambda]; all.p -= row[col.rho_lambda]; }
+  if (c.has_ur) { row[col.rho_ur] = c.Omega0_ur * H0sq * inv3 / x; all.radiation(row[col.rho_ur]); }
+  const double curvature = c.K / (a * a), rho_crit = all.rho - curvature;
+  if (!(rho_crit > 0.)) return fail_msg(CPT_ERR_INVALID, "rho_crit = %e instead of strictly positive", rho_crit);
+  row[col.H] = std::sqrt(rho_crit);
+  row[col.Hp] = -1.5 * (all.rho + all.p) * a + c.K / a;
+  row[col.rho_tot] = all.rho; row[col.p_tot] = all.p; row[col.p_tot_prime] = a * row[col.H] * all.dp_dlna;
+  row[col.Omega_r] = all.rho_rel / rho_crit;
+  if (with_fractions) { row[col.rho_crit] = rho_crit; row[col.Omega_m] = all.rho_nr / rho_crit; }
   return CPT_OK;
 }
 }  // namespace
@@ -150,7 +116,7 @@ extern "C" {
 
 void cpt_host_cosmo_defaults(cpt_cosmo_params* p) {
   p->a_ini_over_a_today_default = 1.e-14; p->back_integration_stepsize = 7.e-3; p->tol_initial_Omega_r = 1.e-4;
-  p->smallest_allowed_variation = 2.220446049250313e-16;   // DBL_EPSILON (source/input_module.cpp:3481)
+  p->smallest_allowed_variation = 2.220446049250313e-16;   // DBL_EPSILON
   p->tol_ncdm_initial_w = 1.e-3;
 }
 
@@ -162,117 +128,116 @@ void cpt_host_background_free(cpt_background* bg) {
 
 int cpt_host_background(const cpt_cosmo_params* pp, cpt_background* out) {
   if (!pp || !out) return fail_msg(CPT_ERR_INVALID, "null argument");
-  const cpt_cosmo_params& p = *pp;
+  const cpt_cosmo_params& c = *pp;
   memset(out, 0, sizeof(*out));
-  if (p.has_fld || p.has_scf || p.has_dcdm || p.has_dr || p.has_idr || p.has_idm_dr)
+  if (c.has_fld || c.has_scf || c.has_dcdm || c.has_dr || c.has_idr || c.has_idm_dr)
     return fail_msg(CPT_ERR_UNSUPPORTED, "host background: only photons, baryons, cdm, massless and massive neutrinos, Lambda and curvature");
-  if (p.has_ncdm) {
-    if (p.N_ncdm < 1 || p.N_ncdm > CPT_MAX_NCDM) return fail_msg(CPT_ERR_UNSUPPORTED, "host background: between 1 and %d non-cold species", CPT_MAX_NCDM);
-    for (int n = 0; n < p.N_ncdm; n++)
-      if (p.q_size_ncdm_bg[n] < 1 || !p.q_ncdm_bg[n] || !p.w_ncdm_bg[n])
-        return fail_msg(CPT_ERR_INVALID, "host background: the momentum sampling of ncdm species %d is missing", n);
+  if (c.has_ncdm) {
+    if (c.N_ncdm < 1 || c.N_ncdm > CPT_MAX_NCDM) return fail_msg(CPT_ERR_UNSUPPORTED, "host background: between 1 and %d non-cold species", CPT_MAX_NCDM);
+    for (int s = 0; s < c.N_ncdm; s++)
+      if (c.q_size_ncdm_bg[s] < 1 || !c.q_ncdm_bg[s] || !c.w_ncdm_bg[s])
+        return fail_msg(CPT_ERR_INVALID, "host background: the momentum sampling of ncdm species %d is missing", s);
   }
-  if (p.a_today <= 0) return fail_msg(CPT_ERR_INVALID, "input a_today = %e instead of strictly positive", p.a_today);
-  const BgLayout L = make_bg_layout(p);
-  std::vector<double> v(L.size, 0.);
-  // ---- background_initial_conditions, :1521-1690 ----
-  double a_ini = p.a_ini_over_a_today_default * p.a_today;
-  if (p.has_ncdm) {   // NonColdDarkMatter::GetIni (tools/non_cold_dark_matter.cpp:1080-1106): start early enough for every species to be relativistic
-    int counter;
-    for (counter = 0; counter < 10000; counter++) {
-      bool early = true;
-      for (int n = 0; n < p.N_ncdm; n++) {
-        double num, rho, pr, pp;
-        ncdm_momenta(p, n, p.a_today / a_ini - 1.0, &num, &rho, &pr, &pp);
-        if (fabs(pr / rho - 1. / 3.) > p.tol_ncdm_initial_w) early = false;
+  if (c.a_today <= 0) return fail_msg(CPT_ERR_INVALID, "input a_today = %e instead of strictly positive", c.a_today);
+  const BgCols col(c);
+  std::vector<double> work(col.size, 0.);
+
+  // ---- where to start: deep in radiation domination, and early enough for every non-cold species to be ultra-relativistic ----
+  double a_start = c.a_ini_over_a_today_default * c.a_today;
+  if (c.has_ncdm) {
+    auto all_relativistic = [&](double a) {
+      for (int s = 0; s < c.N_ncdm; s++) {
+        const NcdmMoments m = ncdm_moments(c, s, c.a_today / a);
+        if (std::fabs(m.p / m.rho - 1. / 3.) > c.tol_ncdm_initial_w) return false;
       }
-      if (early) break;
-      a_ini *= 0.1;
+      return true;
+    };
+    int tries = 0;
+    while (!all_relativistic(a_start)) {
+      a_start *= 0.1;
+      if (++tries == 10000) return fail_msg(CPT_ERR_RUNTIME, "Search for initial scale factor a such that all ncdm species are relativistic failed.");
     }
-    if (counter == 10000) return fail_msg(CPT_ERR_RUNTIME, "Search for initial scale factor a such that all ncdm species are relativistic failed.");
   }
-  int rc = bg_functions(p, L, a_ini, false, v.data());
+  int rc = fill_background_row(c, col, a_start, false, work.data());
   if (rc) return rc;
-  if (fabs(v[L.Omega_r] - 1.) > p.tol_initial_Omega_r)
-    return fail_msg(CPT_ERR_INVALID, "Omega_r = %e, not close enough to 1. Decrease a_ini_over_a_today_default in order to start from radiation domination.", v[L.Omega_r]);
-  if (v[L.H] <= 0.) return fail_msg(CPT_ERR_INVALID, "H = %e instead of strictly positive", v[L.H]);
-  // integrated vector in the reference's order with tau in the slot of a (:1363): tau, proper time, sound horizon, D, D'
-  double y[5];
-  y[0] = 1. / (a_ini * v[L.H]);
-  y[1] = 1. / (2. * v[L.H]);
-  y[2] = y[0] / sqrt(3.);
-  y[3] = a_ini;
-  y[4] = 2 * y[3] * v[L.H];
-  // ---- output grid, :1351-1361 ----
-  const double loga_ini = log(a_ini), loga_final = log(p.a_today);
-  const int n = (int)((loga_final - loga_ini) / p.back_integration_stepsize);
+  if (std::fabs(work[col.Omega_r] - 1.) > c.tol_initial_Omega_r)
+    return fail_msg(CPT_ERR_INVALID, "Omega_r = %e, not close enough to 1. Decrease a_ini_over_a_today_default in order to start from radiation domination.", work[col.Omega_r]);
+  if (!(work[col.H] > 0.)) return fail_msg(CPT_ERR_INVALID, "H = %e instead of strictly positive", work[col.H]);
+
+  // ---- grid uniform in ln a ----
+  const double lna0 = std::log(a_start), lna1 = std::log(c.a_today);
+  const int n = (int)((lna1 - lna0) / c.back_integration_stepsize);
   if (n < 3) return fail_msg(CPT_ERR_INVALID, "background table too short");
-  std::vector<double> loga(n);
-  for (int i = 0; i < n; i++) loga[i] = loga_ini + i * (loga_final - loga_ini) / (n - 1);
-  out->bt_size = n; out->bg_size = L.size;
+  out->bt_size = n; out->bg_size = col.size;
   out->tau_table = (double*)malloc(sizeof(double) * n); out->z_table = (double*)malloc(sizeof(double) * n);
   out->d2tau_dz2_table = (double*)malloc(sizeof(double) * n);
-  out->background_table = (double*)calloc((size_t)n * L.size, sizeof(double));
-  out->d2background_dtau2_table = (double*)calloc((size_t)n * L.size, sizeof(double));
+  out->background_table = (double*)calloc((size_t)n * col.size, sizeof(double));
+  out->d2background_dtau2_table = (double*)calloc((size_t)n * col.size, sizeof(double));
   if (!out->tau_table || !out->z_table || !out->d2tau_dz2_table || !out->background_table || !out->d2background_dtau2_table) {
     cpt_host_background_free(out);
     return fail_msg(CPT_ERR_RUNTIME, "could not allocate the background table");
   }
-  int err = 0;
-  // background_derivs_loga (:2272-2310) on top of background_derivs (:1934-2064)
-  auto rhs = [&](double lg, const double* yy, double* dy) {
-    const double a = exp(lg);
-    if (bg_functions(p, L, a, false, v.data())) { err = 1; }
-    const double H = v[L.H];
-    double rho_M = v[L.rho_b];
-    if (p.has_cdm) rho_M += v[L.rho_cdm];
-    dy[0] = 1.0;                                                    // (then scaled like the others: dtau/dlna = 1/(aH))
-    dy[1] = a;
-    dy[2] = 1. / sqrt(3. * (1. + 3. * v[L.rho_b] / 4. / v[L.rho_g])) * sqrt(1. - p.K * yy[2] * yy[2]);
-    dy[3] = yy[4];
-    dy[4] = -a * H * yy[4] + 1.5 * a * a * rho_M * yy[3];
-    for (int i = 0; i < 5; i++) dy[i] *= 1. / (a * H);
+
+  // ---- the five integrated quantities as functions of ln a:  d/dln a = (1 / aH) d/dtau
+  //      tau' = 1,  t' = a,  r_s' = c_s sqrt(1 - K r_s^2),  D' = D_tau,  D_tau' = -aH D_tau + 3/2 a^2 rho_M D     (primes: d/dtau)
+  enum { kTau, kTime, kRs, kD, kDtau, kNeq };
+  bool model_failed = false;
+  auto derivatives = [&](double lna, const double* y, double* dy) {
+    const double a = std::exp(lna);
+    if (fill_background_row(c, col, a, false, work.data())) { model_failed = true; for (int i = 0; i < kNeq; i++) dy[i] = 0.; return; }
+    const double aH = a * work[col.H], rho_matter = work[col.rho_b] + (c.has_cdm ? work[col.rho_cdm] : 0.);
+    const double sound_speed = 1. / std::sqrt(3. * (1. + 0.75 * work[col.rho_b] / work[col.rho_g]));
+    dy[kTau] = 1. / aH;
+    dy[kTime] = a / aH;
+    dy[kRs] = sound_speed * std::sqrt(std::max(0., 1. - c.K * y[kRs] * y[kRs])) / aH;
+    dy[kD] = y[kDtau] / aH;
+    dy[kDtau] = -y[kDtau] + 1.5 * a * a * rho_matter * y[kD] / aH;
   };
-  // background_add_line_to_bg_table (:2312-2344)
-  auto add_line = [&](double lg, const double* yy, const double* /*dy*/, int i) {
-    const double a = exp(lg);
-    out->z_table[i] = std::max(0., p.a_today / exp(lg) - 1.);
-    out->tau_table[i] = yy[0];
-    double* row = out->background_table + (size_t)i * L.size;
-    if (bg_functions(p, L, a, true, row)) err = 1;
-    row[L.time] = yy[1]; row[L.rs] = yy[2]; row[L.D] = yy[3];
-    row[L.f] = yy[4] / (yy[3] * a * row[L.H]);
-  };
-  std::vector<int> used(5, 1);
-  Ndf S;
-  rc = ndf15(rhs, add_line, loga_ini, loga_final, y, used.data(), 5, 1e-6, p.smallest_allowed_variation, loga.data(), n, S);
-  if (rc || err) { cpt_host_background_free(out); return fail_msg(CPT_ERR_RUNTIME, "background integration failed (evolver status %d)", rc); }
-  out->age = y[1] / GYR_OVER_MPC;
-  out->conformal_age = y[0];
-  const double D_today = y[3];
+  cpt_num::Dopri5<kNeq> ode;
+  ode.rtol = 1e-10;
+  ode.x = lna0;
+  // radiation-dominated start: tau = 1 / aH, t = 1 / 2H, r_s = tau / sqrt 3, growing mode D = a
+  ode.y[kTau] = 1. / (a_start * work[col.H]);
+  ode.y[kTime] = 0.5 / work[col.H];
+  ode.y[kRs] = ode.y[kTau] / std::sqrt(3.);
+  ode.y[kD] = a_start;
+  ode.y[kDtau] = 2. * a_start * work[col.H];
   for (int i = 0; i < n; i++) {
-    double* row = out->background_table + (size_t)i * L.size;
-    const double conformal_distance = out->conformal_age - out->tau_table[i];
-    row[L.conf_distance] = conformal_distance;
-    double comoving_radius = conformal_distance;
-    if (p.sgnK > 0) comoving_radius = sin(sqrt(p.K) * conformal_distance) / sqrt(p.K);
-    else if (p.sgnK < 0) comoving_radius = sinh(sqrt(-p.K) * conformal_distance) / sqrt(-p.K);
-    row[L.ang_distance] = p.a_today * comoving_radius / (1. + out->z_table[i]);
-    row[L.lum_distance] = p.a_today * comoving_radius * (1. + out->z_table[i]);
-    row[L.D] /= D_today;
+    const double lna = lna0 + i * (lna1 - lna0) / (n - 1);
+    if (!ode.advance(derivatives, lna) || model_failed) { cpt_host_background_free(out); return fail_msg(CPT_ERR_RUNTIME, "background integration failed at ln a = %g", lna); }
+    const double a = std::exp(lna);
+    double* row = out->background_table + (size_t)i * col.size;
+    if ((rc = fill_background_row(c, col, a, true, row))) { cpt_host_background_free(out); return rc; }
+    out->z_table[i] = std::max(0., c.a_today / a - 1.);
+    out->tau_table[i] = ode.y[kTau];
+    row[col.time] = ode.y[kTime]; row[col.rs] = ode.y[kRs]; row[col.D] = ode.y[kD];
+    row[col.f] = ode.y[kDtau] / (ode.y[kD] * a * row[col.H]);
+  }
+  out->age = ode.y[kTime] / kGyrOverMpc;
+  out->conformal_age = ode.y[kTau];
+  // distances from the conformal distance to today, growth factor normalised today
+  const double growth_today = ode.y[kD], sqrtK = std::sqrt(std::fabs(c.K));
+  for (int i = 0; i < n; i++) {
+    double* row = out->background_table + (size_t)i * col.size;
+    const double chi = out->conformal_age - out->tau_table[i];
+    const double radius = (c.sgnK > 0) ? std::sin(sqrtK * chi) / sqrtK : (c.sgnK < 0) ? std::sinh(sqrtK * chi) / sqrtK : chi;
+    row[col.conf_distance] = chi;
+    row[col.ang_distance] = c.a_today * radius / (1. + out->z_table[i]);
+    row[col.lum_distance] = c.a_today * radius * (1. + out->z_table[i]);
+    row[col.D] /= growth_today;
   }
   spline_table_lines(out->z_table, n, out->tau_table, 1, out->d2tau_dz2_table);
-  spline_table_lines(out->tau_table, n, out->background_table, L.size, out->d2background_dtau2_table);
-  const double* r0 = out->background_table;
-  out->Neff = (r0[L.Omega_r] * r0[L.rho_crit] - r0[L.rho_g]) / (7. / 8. * pow(4. / 11., 4. / 3.) * r0[L.rho_g]);
-  const double* rl = out->background_table + (size_t)(n - 1) * L.size;
-  out->Omega0_m = rl[L.Omega_m]; out->Omega0_r = rl[L.Omega_r]; out->Omega0_de = 1. - (out->Omega0_m + out->Omega0_r + p.Omega0_k);
-  out->index_bg_a = L.a; out->index_bg_H = L.H; out->index_bg_H_prime = L.Hp; out->index_bg_rho_g = L.rho_g; out->index_bg_rho_b = L.rho_b;
-  out->index_bg_rho_cdm = L.rho_cdm; out->index_bg_rho_lambda = L.rho_lambda; out->index_bg_rho_ur = L.rho_ur; out->index_bg_rho_tot = L.rho_tot;
-  out->index_bg_p_tot = L.p_tot; out->index_bg_p_tot_prime = L.p_tot_prime; out->index_bg_Omega_r = L.Omega_r; out->index_bg_rho_crit = L.rho_crit;
-  out->index_bg_Omega_m = L.Omega_m; out->index_bg_conf_distance = L.conf_distance; out->index_bg_ang_distance = L.ang_distance;
-  out->index_bg_number_ncdm1 = L.number_ncdm1; out->index_bg_rho_ncdm1 = L.rho_ncdm1; out->index_bg_p_ncdm1 = L.p_ncdm1; out->index_bg_pseudo_p_ncdm1 = L.pseudo_p_ncdm1;
-  out->index_bg_lum_distance = L.lum_distance; out->index_bg_time = L.time; out->index_bg_rs = L.rs; out->index_bg_D = L.D; out->index_bg_f = L.f;
+  spline_table_lines(out->tau_table, n, out->background_table, col.size, out->d2background_dtau2_table);
+  const double* first = out->background_table;
+  const double* last = out->background_table + (size_t)(n - 1) * col.size;
+  out->Neff = (first[col.Omega_r] * first[col.rho_crit] - first[col.rho_g]) / (7. / 8. * std::pow(4. / 11., 4. / 3.) * first[col.rho_g]);
+  out->Omega0_m = last[col.Omega_m]; out->Omega0_r = last[col.Omega_r]; out->Omega0_de = 1. - (out->Omega0_m + out->Omega0_r + c.Omega0_k);
+  out->index_bg_a = col.a; out->index_bg_H = col.H; out->index_bg_H_prime = col.Hp; out->index_bg_rho_g = col.rho_g; out->index_bg_rho_b = col.rho_b;
+  out->index_bg_rho_cdm = col.rho_cdm; out->index_bg_rho_lambda = col.rho_lambda; out->index_bg_rho_ur = col.rho_ur; out->index_bg_rho_tot = col.rho_tot;
+  out->index_bg_p_tot = col.p_tot; out->index_bg_p_tot_prime = col.p_tot_prime; out->index_bg_Omega_r = col.Omega_r; out->index_bg_rho_crit = col.rho_crit;
+  out->index_bg_Omega_m = col.Omega_m; out->index_bg_conf_distance = col.conf_distance; out->index_bg_ang_distance = col.ang_distance;
+  out->index_bg_number_ncdm1 = col.n_ncdm; out->index_bg_rho_ncdm1 = col.rho_ncdm; out->index_bg_p_ncdm1 = col.p_ncdm; out->index_bg_pseudo_p_ncdm1 = col.pp_ncdm;
+  out->index_bg_lum_distance = col.lum_distance; out->index_bg_time = col.time; out->index_bg_rs = col.rs; out->index_bg_D = col.D; out->index_bg_f = col.f;
   return CPT_OK;
 }
 
@@ -284,439 +249,347 @@ int cpt_host_background_tau_of_z(const cpt_background* bg, double z, double* tau
 }
 
 // =====================================================================================================================
-// Thermodynamics (include/cpt_host.h): RECFAST + CAMB-like reionization + derived columns, th.cpp = source/thermodynamics_module.cpp
+// Thermodynamics
 // =====================================================================================================================
 namespace cpt_host {
 namespace {
-const double C_LIGHT = 2.99792458e8, G_NEWTON = 6.67428e-11, K_B = 1.3806504e-23, H_P = 6.62606896e-34, MPC_OVER_M = 3.085677581282e22,
-             M_ELECTRON = 9.10938215e-31, M_HYDROGEN = 1.673575e-27, NOT4 = 3.9715, SIGMA_T = 6.6524616e-29, PI_ = 3.1415926535897932384626433832795e0,
-             E_ = 2.7182818284590452353602874713526624977572470936999595749669676277;
-// RECFAST atomic data (source/thermodynamics.h:386-419)
-const double LAMBDA_H = 8.2245809, LAMBDA_HE = 51.3, L_H_ION = 1.096787737e7, L_H_ALPHA = 8.225916453e6, L_HE1_ION = 1.98310772e7,
-             L_HE2_ION = 4.389088863e7, L_HE_2S = 1.66277434e7, L_HE_2P = 1.71134891e7, A2P_S = 1.798287e9, A2P_T = 177.58e0,
-             L_HE_2PT = 1.690871466e7, L_HE_2ST = 1.5985597526e7, L_HE2ST_ION = 3.8454693845e6, SIGMA_HE_2PS = 1.436289e-22,
-             SIGMA_HE_2PT = 1.484872e-22, A_PPB = 4.309, B_PPB = -0.6166, C_PPB = 0.6703, D_PPB = 0.5300, B_VF = 0.711, B_TRIP = 0.761;
-const double Z_REC_MAX = 2000., Z_REC_MIN = 500., YHE_BIG = 0.5, YHE_SMALL = 0.01;
-inline double f1(double x) { return (-0.75 * x * (x * x / 3. - 1.) + 0.5); }   // thermodynamics.h:46-47
-inline double f2(double x) { return (x * x * (0.5 - x / 3.) * 6.); }
+// physical constants (SI), the values the reference's tables are built with
+constexpr double kC = 2.99792458e8, kG = 6.67428e-11, kBoltz = 1.3806504e-23, kPlanck = 6.62606896e-34, kMpc = 3.085677581282e22,
+                 kMe = 9.10938215e-31, kMH = 1.673575e-27, kHe4OverH = 3.9715, kSigmaT = 6.6524616e-29, kPi = 3.1415926535897932384626433832795,
+                 kEuler = 2.7182818284590452353602874713526624977572470936999595749669676277;
+constexpr double kZRecMax = 2000., kZRecMin = 500., kYHeMax = 0.5, kYHeMin = 0.01;
+constexpr double kReferenceIntegralRule = +1.;   // see cpt_num::spline_cumulative_integral
 
-// ---- one-column spline helpers of tools/arrays.c on a row-major table: array[i*nc + col] ----
-void spline_col(const double* x, int n, double* arr, int nc, int iy, int idd) {   // array_spline_table_line_to_line :422-512, EST_DERIV
-  std::vector<double> u(n - 1);
-  auto Y = [&](int i) -> double& { return arr[(size_t)i * nc + iy]; };
-  auto D = [&](int i) -> double& { return arr[(size_t)i * nc + idd]; };
-  const double dy_first = ((x[2] - x[0]) * (x[2] - x[0]) * (Y(1) - Y(0)) - (x[1] - x[0]) * (x[1] - x[0]) * (Y(2) - Y(0))) / ((x[2] - x[0]) * (x[1] - x[0]) * (x[2] - x[1]));
-  D(0) = -0.5;
-  u[0] = (3. / (x[1] - x[0])) * ((Y(1) - Y(0)) / (x[1] - x[0]) - dy_first);
-  for (int i = 1; i < n - 1; i++) {
-    const double sig = (x[i] - x[i - 1]) / (x[i + 1] - x[i - 1]);
-    const double p = sig * D(i - 1) + 2.0;
-    D(i) = (sig - 1.0) / p;
-    u[i] = (Y(i + 1) - Y(i)) / (x[i + 1] - x[i]) - (Y(i) - Y(i - 1)) / (x[i] - x[i - 1]);
-    u[i] = (6.0 * u[i] / (x[i + 1] - x[i - 1]) - sig * u[i - 1]) / p;
-  }
-  const double dy_last = ((x[n - 3] - x[n - 1]) * (x[n - 3] - x[n - 1]) * (Y(n - 2) - Y(n - 1)) - (x[n - 2] - x[n - 1]) * (x[n - 2] - x[n - 1]) * (Y(n - 3) - Y(n - 1))) /
-                         ((x[n - 3] - x[n - 1]) * (x[n - 2] - x[n - 1]) * (x[n - 3] - x[n - 2]));
-  const double qn = 0.5, un = (3. / (x[n - 1] - x[n - 2])) * (dy_last - (Y(n - 1) - Y(n - 2)) / (x[n - 1] - x[n - 2]));
-  D(n - 1) = (un - qn * u[n - 2]) / (qn * D(n - 2) + 1.0);
-  for (int k = n - 2; k >= 0; k--) D(k) = D(k) * D(k + 1) + u[k];
-}
-void integrate_spline_col(const double* x, int n, double* arr, int nc, int iy, int idd, int iint) {   // :235-258
-  arr[iint] = 0.;
-  for (int i = 0; i < n - 1; i++) {
-    const double h = x[i + 1] - x[i];
-    arr[(size_t)(i + 1) * nc + iint] = arr[(size_t)i * nc + iint] + (arr[(size_t)i * nc + iy] + arr[(size_t)(i + 1) * nc + iy]) * h / 2. +
-                                        (arr[(size_t)i * nc + idd] + arr[(size_t)(i + 1) * nc + idd]) * h * h * h / 24.;
-  }
-}
-void derive_spline_col(const double* x, int n, double* arr, int nc, int iy, int idd, int idy) {   // :100-145
-  for (int i = 0; i < n - 1; i++) {
-    const double h = x[i + 1] - x[i];
-    arr[(size_t)i * nc + idy] = (arr[(size_t)(i + 1) * nc + iy] - arr[(size_t)i * nc + iy]) / h - h / 6. * (arr[(size_t)(i + 1) * nc + idd] + 2. * arr[(size_t)i * nc + idd]);
-  }
-  const double h = x[n - 1] - x[n - 2];
-  arr[(size_t)(n - 1) * nc + idy] = (arr[(size_t)(n - 1) * nc + iy] - arr[(size_t)(n - 2) * nc + iy]) / h + h / 6. * (2. * arr[(size_t)(n - 1) * nc + idd] + arr[(size_t)(n - 2) * nc + idd]);
-}
-void smooth_col(double* arr, int nc, int n, int col, int radius) {   // array_smooth :2762-2795
-  std::vector<double> sm(n);
-  for (int i = 0; i < n; i++) {
-    double s = 0., w = 0.;
-    const int jmin = std::max(i - radius, 0), jmax = std::min(i + radius, n - 1);
-    for (int j = jmin; j <= jmax; j++) { s += arr[(size_t)j * nc + col]; w += 1.; }
-    sm[i] = s / w;
-  }
-  for (int i = 0; i < n; i++) arr[(size_t)i * nc + col] = sm[i];
-}
-
-struct BgAccess {   // background_tau_of_z + background_at_tau on the host table
+// the host background table seen as functions of redshift
+struct Background {
   const cpt_background& bg;
   std::vector<double> row;
-  explicit BgAccess(const cpt_background& b) : bg(b), row(b.bg_size) {}
+  explicit Background(const cpt_background& b) : bg(b), row(b.bg_size) {}
   int tau_of_z(double z, double* tau) const { return cpt_host_background_tau_of_z(&bg, z, tau); }
   int at_tau(double tau) {
     if (interpolate_spline(bg.tau_table, bg.bt_size, bg.background_table, bg.d2background_dtau2_table, bg.bg_size, tau, row.data()))
       return fail_msg(CPT_ERR_INVALID, "background_at_tau: tau=%e out of range", tau);
     return CPT_OK;
   }
+  int at_z(double z) { double tau; const int rc = tau_of_z(z, &tau); return rc ? rc : at_tau(tau); }
   double H() const { return row[bg.index_bg_H]; }
   double Hp() const { return row[bg.index_bg_H_prime]; }
   double rho_g() const { return row[bg.index_bg_rho_g]; }
   double rho_b() const { return row[bg.index_bg_rho_b]; }
 };
 
-// recombination table columns (struct recombination, source/thermodynamics.h) and RECFAST workspace
-enum { RE_Z = 0, RE_XE, RE_TB, RE_WB, RE_CB2, RE_DKAPPADTAU, RE_DKAPPADZ, RE_D3KAPPADZ3, RE_SIZE };
-struct Reco {
-  double H0, YHe, Tnow, H_frac, fu, fHe, Nnow, CDB, CDB_He, CB1, CB1_He1, CB1_He2, CR, CK, CK_He, CL, CL_He, CT, Bfact;
-};
+// ---- RECFAST: the three-level-atom rate equations for x_H = n_p / n_H, x_He = n_HeII / n_He and the matter temperature ----
+// Spectroscopic data (wavenumbers in 1/m, Einstein coefficients in 1/s, cross sections in m^2)
+namespace atom {
+constexpr double H_ion = 1.096787737e7, H_lya = 8.225916453e6, H_2s_rate = 8.2245809;
+constexpr double He1_ion = 1.98310772e7, He2_ion = 4.389088863e7, He_2s = 1.66277434e7, He_2p = 1.71134891e7, He_2s_rate = 51.3;
+constexpr double He_2p_A = 1.798287e9, He_2pt_A = 177.58, He_2pt = 1.690871466e7, He_2st = 1.5985597526e7, He_2st_ion = 3.8454693845e6;
+constexpr double He_2ps_sigma = 1.436289e-22, He_2pt_sigma = 1.484872e-22;
+// case-B hydrogen recombination fit of Pequignot et al.; Verner & Ferland fits for singlet and triplet helium
+constexpr double ppb_a = 4.309, ppb_b = -0.6166, ppb_c = 0.6703, ppb_d = 0.5300, vf_b = 0.711, trip_b = 0.761;
+}  // namespace atom
 
-struct Recfast {
-  const cpt_cosmo_params& cp; const cpt_thermo_params& tp; Reco re; BgAccess& B;
-  int err = 0;
-  // thermodynamics_derivs_with_recfast, th.cpp:3727-3975 (no energy injection)
-  void derivs(double z, const double* y, double* dy) {
-    const double x_H = y[0], x_He = y[1], x = x_H + re.fHe * x_He, Tmat = y[2];
-    const double n = re.Nnow * (1. + z) * (1. + z) * (1. + z), n_He = re.fHe * n, Trad = re.Tnow * (1. + z);
-    double tau;
-    if (B.tau_of_z(z, &tau) || B.at_tau(tau)) { err = 1; dy[0] = dy[1] = dy[2] = 0.; return; }
-    const double Hz = B.H() * C_LIGHT / MPC_OVER_M;
-    const double Rdown = 1.e-19 * A_PPB * pow((Tmat / 1.e4), B_PPB) / (1. + C_PPB * pow((Tmat / 1.e4), D_PPB));
-    const double Rup = Rdown * pow((re.CR * Tmat), 1.5) * exp(-re.CDB / Tmat);
-    const double T_0 = pow(10., 0.477121), T_1 = pow(10., 5.114), a_VF = pow(10., -16.744), a_trip = pow(10., -16.306);
-    const double sq_0 = sqrt(Tmat / T_0), sq_1 = sqrt(Tmat / T_1);
-    const double Rdown_He = a_VF / (sq_0 * pow((1. + sq_0), (1. - B_VF)) * pow((1. + sq_1), (1. + B_VF)));
-    const double Rup_He = 4. * Rdown_He * pow((re.CR * Tmat), 1.5) * exp(-re.CDB_He / Tmat);
-    double K = re.CK / Hz;
-    if (tp.recfast_Hswitch)
-      K *= 1. + tp.recfast_AGauss1 * exp(-pow((log(1. + z) - tp.recfast_zGauss1) / tp.recfast_wGauss1, 2)) +
-           tp.recfast_AGauss2 * exp(-pow((log(1. + z) - tp.recfast_zGauss2) / tp.recfast_wGauss2, 2));
-    const double Rdown_trip = a_trip / (sq_0 * pow((1. + sq_0), (1. - B_TRIP)) * pow((1. + sq_1), (1. + B_TRIP)));
-    const double Rup_trip = Rdown_trip * exp(-H_P * C_LIGHT * L_HE2ST_ION / (K_B * Tmat)) * pow(re.CR * Tmat, 1.5) * 4. / 3.;
-    int Heflag;
-    if ((x_He < 5.e-9) || (x_He > tp.recfast_x_He0_trigger2)) Heflag = 0; else Heflag = tp.recfast_Heswitch;
-    double K_He, CfHe_t = 0.;
-    if (Heflag == 0) K_He = re.CK_He / Hz;
-    else {
-      const double tauHe_s = A2P_S * re.CK_He * 3. * n_He * (1. - x_He) / Hz;
-      const double pHe_s = (1. - exp(-tauHe_s)) / tauHe_s;
-      K_He = 1. / (A2P_S * pHe_s * 3. * n_He * (1. - x_He));
-      if (((Heflag == 2) || (Heflag >= 5)) && (x_H < 0.9999999)) {
-        double Doppler = 2. * K_B * Tmat / (M_HYDROGEN * NOT4 * C_LIGHT * C_LIGHT);
-        Doppler = C_LIGHT * L_HE_2P * sqrt(Doppler);
-        const double gamma_2Ps = 3. * A2P_S * re.fHe * (1. - x_He) * C_LIGHT * C_LIGHT / (sqrt(PI_) * SIGMA_HE_2PS * 8. * PI_ * Doppler * (1. - x_H)) / pow(C_LIGHT * L_HE_2P, 2);
-        const double pb = 0.36, qb = tp.recfast_fudge_He;
-        const double AHcon = A2P_S / (1. + pb * pow(gamma_2Ps, qb));
-        K_He = 1. / ((A2P_S * pHe_s + AHcon) * 3. * n_He * (1. - x_He));
+inline double smooth_step_cubic(double s) { return 0.5 - 0.75 * s * (s * s / 3. - 1.); }     // 0 -> 1 over s in [-1, 1]
+inline double smooth_step_quadratic(double s) { return 6. * s * s * (0.5 - s / 3.); }       // 0 -> 1 over s in [0, 1]
+
+class Recfast {
+ public:
+  Recfast(const cpt_cosmo_params& cp, const cpt_thermo_params& tp, Background& B) : cp_(cp), tp_(tp), B_(B) {
+    H0_ = cp.H0 * kC / kMpc;
+    T0_ = cp.T_cmb;
+    fudge_H_ = tp.recfast_fudge_H + (tp.recfast_Hswitch ? tp.recfast_delta_fudge_H : 0.);
+    fHe_ = tp.YHe / (kHe4OverH * (1. - tp.YHe));                      // n_He / n_H
+    nH0_ = 3. * H0_ * H0_ * cp.Omega0_b / (8. * kPi * kG * kMH / (1. - tp.YHe));   // hydrogen number density today
+    const double hc_over_k = kPlanck * kC / kBoltz;
+    T_ion_H_n2_ = hc_over_k * (atom::H_ion - atom::H_lya);            // binding energy of the n = 2 level / k
+    T_ion_He_n2_ = hc_over_k * (atom::He1_ion - atom::He_2s);
+    T_ion_H_ = hc_over_k * atom::H_ion; T_ion_He1_ = hc_over_k * atom::He1_ion; T_ion_He2_ = hc_over_k * atom::He2_ion;
+    T_lya_ = hc_over_k * atom::H_lya; T_He_2s_ = hc_over_k * atom::He_2s;
+    T_He_2p2s_ = hc_over_k * (atom::He_2p - atom::He_2s);
+    saha_prefactor_ = 2. * kPi * (kMe / kPlanck) * (kBoltz / kPlanck);           // (2 pi m_e k / h^2)
+    lya_escape_ = 1. / (8. * kPi * atom::H_lya * atom::H_lya * atom::H_lya);     // lambda^3 / 8 pi
+    He_escape_ = 1. / (8. * kPi * atom::He_2p * atom::He_2p * atom::He_2p);
+    compton_ = (8. / 3.) * (kSigmaT / (kMe * kC)) * (8. * std::pow(kPi, 5) * std::pow(kBoltz, 4) / 15. / std::pow(kPlanck, 3) / std::pow(kC, 3));
+  }
+  double fHe() const { return fHe_; }
+  double nH0() const { return nH0_; }
+  double T0() const { return T0_; }
+  bool failed() const { return failed_; }
+
+  // Saha equilibria: x_e for doubly -> singly ionised helium, and the ionised fractions of the last electron of He and of H
+  double saha_ratio(double z, double T_ion, double weight) const {
+    const double T = T0_ * (1. + z);
+    return weight * std::exp(1.5 * std::log(saha_prefactor_ * T0_ / (1. + z)) - T_ion / T) / nH0_;
+  }
+  double xe_saha_He2(double z) const { const double r = saha_ratio(z, T_ion_He2_, 1.), b = r - 1. - fHe_; return 0.5 * (std::sqrt(b * b + 4. * (1. + 2. * fHe_) * r) - b); }
+  double xe_saha_He1(double z) const { const double r = saha_ratio(z, T_ion_He1_, 4.), b = r - 1.; return 0.5 * (std::sqrt(b * b + 4. * (1. + fHe_) * r) - b); }
+  double xH_saha(double z) const { const double r = saha_ratio(z, T_ion_H_, 1.); return 0.5 * (std::sqrt(r * r + 4. * r) - r); }
+
+  // dy/dz for y = (x_H, x_He, T_matter)
+  void operator()(double z, const double* y, double* dy) {
+    const double xH = y[0], xHe = y[1], Tm = y[2], xe = xH + fHe_ * xHe;
+    const double opz = 1. + z, nH = nH0_ * opz * opz * opz, nHe = fHe_ * nH, Tr = T0_ * opz;
+    if (B_.at_z(z)) { failed_ = true; dy[0] = dy[1] = dy[2] = 0.; return; }
+    const double Hz = B_.H() * kC / kMpc, dt_dz_inv = Hz * opz;   // |dz/dt| = H (1 + z)
+    const double thermal = std::pow(saha_prefactor_ * Tm, 1.5);
+    // --- hydrogen: case-B recombination, photoionisation from n = 2, Peebles factor with the Lyman-alpha escape correction
+    const double t4 = Tm / 1.e4;
+    const double alpha_H = 1.e-19 * atom::ppb_a * std::pow(t4, atom::ppb_b) / (1. + atom::ppb_c * std::pow(t4, atom::ppb_d));
+    const double beta_H = alpha_H * thermal * std::exp(-T_ion_H_n2_ / Tm);
+    double K_H = lya_escape_ / Hz;
+    if (tp_.recfast_Hswitch) {
+      const double lz = std::log(opz), g1 = (lz - tp_.recfast_zGauss1) / tp_.recfast_wGauss1, g2 = (lz - tp_.recfast_zGauss2) / tp_.recfast_wGauss2;
+      K_H *= 1. + tp_.recfast_AGauss1 * std::exp(-g1 * g1) + tp_.recfast_AGauss2 * std::exp(-g2 * g2);
+    }
+    // --- helium singlets and triplets (Verner-Ferland fits)
+    const double s0 = std::sqrt(Tm / std::pow(10., 0.477121)), s1 = std::sqrt(Tm / std::pow(10., 5.114));
+    auto vf = [&](double amp, double b) { return amp / (s0 * std::pow(1. + s0, 1. - b) * std::pow(1. + s1, 1. + b)); };
+    const double alpha_He = vf(std::pow(10., -16.744), atom::vf_b), beta_He = 4. * alpha_He * thermal * std::exp(-T_ion_He_n2_ / Tm);
+    const double alpha_He_t = vf(std::pow(10., -16.306), atom::trip_b);
+    const double beta_He_t = alpha_He_t * std::exp(-kPlanck * kC * atom::He_2st_ion / (kBoltz * Tm)) * thermal * 4. / 3.;
+    const int he_mode = (xHe < 5.e-9 || xHe > tp_.recfast_x_He0_trigger2) ? 0 : tp_.recfast_Heswitch;
+    double K_He = He_escape_ / Hz, triplet_branch = 0.;
+    if (he_mode != 0) {
+      const double neutral_He = nHe * (1. - xHe);
+      const double doppler_width = std::sqrt(2. * kBoltz * Tm / (kMH * kHe4OverH * kC * kC));
+      // Sobolev escape probability of a line with optical depth tau
+      auto escape = [](double tau) { return (1. - std::exp(-tau)) / tau; };
+      // continuum opacity of neutral hydrogen inside a helium line (Kholupenko et al.): extra escape channel A / (1 + p gamma^q)
+      auto hydrogen_channel = [&](double A, double wavenumber, double sigma, double p, double q, double norm) {
+        const double width = kC * wavenumber * doppler_width;
+        const double gamma = norm * A * fHe_ * (1. - xHe) * kC * kC / (std::sqrt(kPi) * sigma * 8. * kPi * width * (1. - xH)) / std::pow(kC * wavenumber, 2);
+        return A / (1. + p * std::pow(gamma, q));
+      };
+      const double tau_s = atom::He_2p_A * He_escape_ * 3. * neutral_He / Hz, p_s = escape(tau_s);
+      double A_eff = atom::He_2p_A * p_s;
+      if ((he_mode == 2 || he_mode >= 5) && xH < 0.9999999) A_eff += hydrogen_channel(atom::He_2p_A, atom::He_2p, atom::He_2ps_sigma, 0.36, tp_.recfast_fudge_He, 3.);
+      K_He = 1. / (A_eff * 3. * neutral_He);
+      if (he_mode >= 3) {
+        const double tau_t = atom::He_2pt_A * neutral_He * 3. / (8. * kPi * Hz * std::pow(atom::He_2pt, 3)), p_t = escape(tau_t);
+        const double T_2p2s_t = kPlanck * kC * (atom::He_2pt - atom::He_2st) / kBoltz;
+        double A_t = atom::He_2pt_A * p_t;
+        if (!(he_mode == 3 || he_mode == 5 || xH >= 0.99999)) A_t += hydrogen_channel(atom::He_2pt_A, atom::He_2pt, atom::He_2pt_sigma, 0.66, 0.9, 3.) / 3.;
+        const double out_rate = A_t * std::exp(-T_2p2s_t / Tm);
+        triplet_branch = out_rate / (beta_He_t + out_rate);
       }
-      if (Heflag >= 3) {
-        const double tauHe_t = A2P_T * n_He * (1. - x_He) * 3. / (8. * PI_ * Hz * pow(L_HE_2PT, 3));
-        const double pHe_t = (1. - exp(-tauHe_t)) / tauHe_t;
-        const double CL_PSt = H_P * C_LIGHT * (L_HE_2PT - L_HE_2ST) / K_B;
-        if ((Heflag == 3) || (Heflag == 5) || (x_H >= 0.99999)) {
-          CfHe_t = A2P_T * pHe_t * exp(-CL_PSt / Tmat);
-          CfHe_t = CfHe_t / (Rup_trip + CfHe_t);
-        } else {
-          double Doppler = 2. * K_B * Tmat / (M_HYDROGEN * NOT4 * C_LIGHT * C_LIGHT);
-          Doppler = C_LIGHT * L_HE_2PT * sqrt(Doppler);
-          const double gamma_2Pt = 3. * A2P_T * re.fHe * (1. - x_He) * C_LIGHT * C_LIGHT / (sqrt(PI_) * SIGMA_HE_2PT * 8. * PI_ * Doppler * (1. - x_H)) / pow(C_LIGHT * L_HE_2PT, 2);
-          const double pb = 0.66, qb = 0.9;
-          const double AHcon = A2P_T / (1. + pb * pow(gamma_2Pt, qb)) / 3.;
-          CfHe_t = (A2P_T * pHe_t + AHcon) * exp(-CL_PSt / Tmat);
-          CfHe_t = CfHe_t / (Rup_trip + CfHe_t);
-        }
-      }
     }
-    const double timeTh = (1. / (re.CT * pow(Trad, 4))) * (1. + x + re.fHe) / x;
-    const double timeH = 2. / (3. * re.H0 * pow(1. + z, 1.5));
-    if (x_H > tp.recfast_x_H0_trigger) dy[0] = 0.;
+    // --- the three equations
+    if (xH > tp_.recfast_x_H0_trigger) dy[0] = 0.;
     else {
-      double C;
-      if (x_H < tp.recfast_x_H0_trigger2) C = (1. + K * LAMBDA_H * n * (1. - x_H)) / (1. / re.fu + K * LAMBDA_H * n * (1. - x_H) / re.fu + K * Rup * n * (1. - x_H));
-      else C = 1.;
-      dy[0] = (x * x_H * n * Rdown - Rup * (1. - x_H) * exp(-re.CL / Tmat)) * C / (Hz * (1. + z));
+      const double n1s = nH * (1. - xH);
+      const double peebles = (xH < tp_.recfast_x_H0_trigger2)
+                                 ? (1. + K_H * atom::H_2s_rate * n1s) / (1. / fudge_H_ + K_H * atom::H_2s_rate * n1s / fudge_H_ + K_H * beta_H * n1s)
+                                 : 1.;
+      dy[0] = (xe * xH * nH * alpha_H - beta_H * (1. - xH) * std::exp(-T_lya_ / Tm)) * peebles / dt_dz_inv;
     }
-    if (x_He < 1.e-15) dy[1] = 0.;
+    if (xHe < 1.e-15) dy[1] = 0.;
     else {
-      const double He_Boltz = (re.Bfact / Tmat < 680.) ? exp(re.Bfact / Tmat) : exp(680.);
-      dy[1] = ((x * x_He * n * Rdown_He - Rup_He * (1. - x_He) * exp(-re.CL_He / Tmat)) * (1. + K_He * LAMBDA_HE * n_He * (1. - x_He) * He_Boltz)) /
-              (Hz * (1 + z) * (1. + K_He * (LAMBDA_HE + Rup_He) * n_He * (1. - x_He) * He_Boltz));
-      if (Heflag >= 3)
-        dy[1] = dy[1] + (x * x_He * n * Rdown_trip - (1. - x_He) * 3. * Rup_trip * exp(-H_P * C_LIGHT * L_HE_2ST / (K_B * Tmat))) * CfHe_t / (Hz * (1. + z));
+      const double n1s = nHe * (1. - xHe), boltz = std::exp(std::min(T_He_2p2s_ / Tm, 680.));
+      dy[1] = (xe * xHe * nH * alpha_He - beta_He * (1. - xHe) * std::exp(-T_He_2s_ / Tm)) * (1. + K_He * atom::He_2s_rate * n1s * boltz) /
+              (dt_dz_inv * (1. + K_He * (atom::He_2s_rate + beta_He) * n1s * boltz));
+      if (he_mode >= 3)
+        dy[1] += (xe * xHe * nH * alpha_He_t - (1. - xHe) * 3. * beta_He_t * std::exp(-kPlanck * kC * atom::He_2st / (kBoltz * Tm))) * triplet_branch / dt_dz_inv;
     }
-    if (timeTh < re.H_frac * timeH) {
-      const double dHdz = -B.Hp() / B.H() / cp.a_today * C_LIGHT / MPC_OVER_M;
-      const double epsilon = Hz * (1. + x + re.fHe) / (re.CT * pow(Trad, 3) * x);
-      dy[2] = re.Tnow + epsilon * ((1. + re.fHe) / (1. + re.fHe + x)) * ((dy[0] + re.fHe * dy[1]) / x) - epsilon * dHdz / Hz + 3. * epsilon / (1. + z);
+    // matter temperature: tightly coupled to the radiation while Compton scattering is fast (first-order expansion in the
+    // coupling time), the full Compton + adiabatic equation afterwards
+    const double t_compton = (1. + xe + fHe_) / (compton_ * Tr * Tr * Tr * Tr * xe), t_hubble = 2. / (3. * H0_ * std::pow(opz, 1.5));
+    if (t_compton < tp_.recfast_H_frac * t_hubble) {
+      const double dlnH_dz = -B_.Hp() / B_.H() / cp_.a_today * kC / kMpc / Hz;
+      const double lag = Hz * (1. + xe + fHe_) / (compton_ * Tr * Tr * Tr * xe);
+      dy[2] = T0_ + lag * ((1. + fHe_) / (1. + fHe_ + xe)) * ((dy[0] + fHe_ * dy[1]) / xe) - lag * dlnH_dz + 3. * lag / opz;
     } else
-      dy[2] = re.CT * pow(Trad, 4) * x / (1. + x + re.fHe) * (Tmat - Trad) / (Hz * (1. + z)) + 2. * Tmat / (1. + z);
+      dy[2] = (Tm - Tr) / (t_compton * dt_dz_inv) + 2. * Tm / opz;
   }
+
+ private:
+  const cpt_cosmo_params& cp_;
+  const cpt_thermo_params& tp_;
+  Background& B_;
+  bool failed_ = false;
+  double H0_, T0_, fudge_H_, fHe_, nH0_, T_ion_H_n2_, T_ion_He_n2_, T_ion_H_, T_ion_He1_, T_ion_He2_, T_lya_, T_He_2s_, T_He_2p2s_, saha_prefactor_,
+      lya_escape_, He_escape_, compton_;
 };
 
-// generic_integrator / rkqs / rkck: tools/dei_rkck.c (Cash-Karp with step-doubling control), 3 equations
-struct Rkck {
-  double y[3], dydx[3], yscal[3], yerr[3], ytemp[3], ak2[3], ak3[3], ak4[3], ak5[3], ak6[3];
-  template <class F>
-  void rkck(F& f, double x, double h) {
-    for (int i = 0; i < 3; i++) ytemp[i] = y[i] + 0.2 * h * dydx[i];
-    f(x + 0.2 * h, ytemp, ak2);
-    for (int i = 0; i < 3; i++) ytemp[i] = y[i] + h * (3.0 / 40.0 * dydx[i] + 9.0 / 40.0 * ak2[i]);
-    f(x + 0.3 * h, ytemp, ak3);
-    for (int i = 0; i < 3; i++) ytemp[i] = y[i] + h * (0.3 * dydx[i] + -0.9 * ak2[i] + 1.2 * ak3[i]);
-    f(x + 0.6 * h, ytemp, ak4);
-    for (int i = 0; i < 3; i++) ytemp[i] = y[i] + h * (-11.0 / 54.0 * dydx[i] + 2.5 * ak2[i] + -70.0 / 27.0 * ak3[i] + 35.0 / 27.0 * ak4[i]);
-    f(x + 1.0 * h, ytemp, ak5);
-    for (int i = 0; i < 3; i++)
-      ytemp[i] = y[i] + h * (1631.0 / 55296.0 * dydx[i] + 175.0 / 512.0 * ak2[i] + 575.0 / 13824.0 * ak3[i] + 44275.0 / 110592.0 * ak4[i] + 253.0 / 4096.0 * ak5[i]);
-    f(x + 0.875 * h, ytemp, ak6);
-    for (int i = 0; i < 3; i++) ytemp[i] = y[i] + h * (37.0 / 378.0 * dydx[i] + 250.0 / 621.0 * ak3[i] + 125.0 / 594.0 * ak4[i] + 512.0 / 1771.0 * ak6[i]);
-    for (int i = 0; i < 3; i++)
-      yerr[i] = h * ((37.0 / 378.0 - 2825.0 / 27648.) * dydx[i] + (250.0 / 621.0 - 18575.0 / 48384.0) * ak3[i] + (125.0 / 594.0 - 13525.0 / 55296.0) * ak4[i] +
-                     -277.00 / 14336.0 * ak5[i] + (512.0 / 1771.0 - 0.25) * ak6[i]);
-  }
-  template <class F>
-  int integrate(F& f, double x1, double x2, double* ystart, double eps, double hmin) {
-    const double h1 = x2 - x1;
-    double x = x1, h = ((x2 - x1) > 0. ? h1 : -h1), hnext = 0.;
-    for (int i = 0; i < 3; i++) y[i] = ystart[i];
-    for (int nstp = 1; nstp <= 100000; nstp++) {
-      f(x, y, dydx);
-      for (int i = 0; i < 3; i++) yscal[i] = fabs(y[i]) + fabs(dydx[i] * h) + 1.0e-30;
-      if ((x + h - x2) * (x + h - x1) > 0.0) h = x2 - x;
-      {  // rkqs
-        double errmax, hh = h;
-        for (;;) {
-          rkck(f, x, hh);
-          errmax = 0.0;
-          for (int i = 0; i < 3; i++) errmax = std::max(errmax, fabs(yerr[i] / yscal[i]));
-          errmax /= eps;
-          if (errmax <= 1.0) break;
-          const double htemp = 0.9 * hh * pow(errmax, -0.25);
-          hh = (hh >= 0.0 ? std::max(htemp, 0.1 * hh) : std::min(htemp, 0.1 * hh));
-          if (x + hh == x) return fail_msg(CPT_ERR_RUNTIME, "stepsize underflow at x=%e", x);
-        }
-        if (errmax > 1.89e-4) hnext = 0.9 * hh * pow(errmax, -0.2); else hnext = 5.0 * hh;
-        x += hh;
-        for (int i = 0; i < 3; i++) y[i] = ytemp[i];
-      }
-      if ((x - x2) * (x2 - x1) >= 0.0) { for (int i = 0; i < 3; i++) ystart[i] = y[i]; return CPT_OK; }
-      if (fabs(hnext / x1) <= hmin) return fail_msg(CPT_ERR_RUNTIME, "Step size too small: step:%g, minimum:%g, in interval: [%g:%g]", fabs(hnext / x1), hmin, x1, x2);
-      h = hnext;
-    }
-    return fail_msg(CPT_ERR_RUNTIME, "Too many integration steps needed within interval [%g : %g]", x1, x2);
-  }
-};
+// recombination history on the uniform redshift grid z_i = z_initial i / Nz, i = 0..Nz-1 (ascending z), columns below
+enum { RE_Z = 0, RE_XE, RE_TB, RE_WB, RE_CB2, RE_DKAPPADTAU, RE_DKAPPADZ, RE_D3KAPPADZ3, RE_SIZE };
 
-// thermodynamics_recombination_with_recfast, th.cpp:3335-3697: table [Nz][RE_SIZE] in growing z
-int recombination(const cpt_cosmo_params& cp, const cpt_thermo_params& tp, BgAccess& B, Reco& re, std::vector<double>& tab) {
+// Going down in redshift the ionisation state is taken from Saha equilibria for as long as they hold (He III -> He II -> He I, then
+// hydrogen), each hand-over - between two equilibria, and from an equilibrium to the rate equations - blended over a finite
+// window so that x_e(z) has no kinks; the matter temperature follows the radiation until the rate equations take over.
+int recombination_history(const cpt_cosmo_params& cp, const cpt_thermo_params& tp, Background& B, Recfast& model, std::vector<double>& tab) {
   const int Nz = tp.recfast_Nz0;
   tab.assign((size_t)Nz * RE_SIZE, 0.);
-  re.H0 = cp.H0 * C_LIGHT / MPC_OVER_M;
-  re.YHe = tp.YHe; re.Tnow = cp.T_cmb; re.H_frac = tp.recfast_H_frac;
-  re.fu = tp.recfast_fudge_H;
-  if (tp.recfast_Hswitch) re.fu += tp.recfast_delta_fudge_H;
   if (tp.recfast_Heswitch < 0 || tp.recfast_Heswitch > 6) return fail_msg(CPT_ERR_INVALID, "RECFAST error: unknown He fudging scheme");
-  const double zinitial = tp.recfast_z_initial;
-  const double mu_H = 1. / (1. - re.YHe);
-  re.fHe = re.YHe / (NOT4 * (1. - re.YHe));
-  re.Nnow = 3. * re.H0 * re.H0 * cp.Omega0_b / (8. * PI_ * G_NEWTON * mu_H * M_HYDROGEN);
-  const double Lalpha = 1. / L_H_ALPHA, Lalpha_He = 1. / L_HE_2P;
-  const double DeltaB = H_P * C_LIGHT * (L_H_ION - L_H_ALPHA);
-  re.CDB = DeltaB / K_B;
-  const double DeltaB_He = H_P * C_LIGHT * (L_HE1_ION - L_HE_2S);
-  re.CDB_He = DeltaB_He / K_B;
-  re.CB1 = H_P * C_LIGHT * L_H_ION / K_B;
-  re.CB1_He1 = H_P * C_LIGHT * L_HE1_ION / K_B;
-  re.CB1_He2 = H_P * C_LIGHT * L_HE2_ION / K_B;
-  re.CR = 2. * PI_ * (M_ELECTRON / H_P) * (K_B / H_P);
-  re.CK = pow(Lalpha, 3) / (8. * PI_);
-  re.CK_He = pow(Lalpha_He, 3) / (8. * PI_);
-  re.CL = C_LIGHT * H_P / (K_B * Lalpha);
-  re.CL_He = C_LIGHT * H_P / (K_B / L_HE_2S);
-  re.CT = (8. / 3.) * (SIGMA_T / (M_ELECTRON * C_LIGHT)) * (8. * pow(PI_, 5) * pow(K_B, 4) / 15. / pow(H_P, 3) / pow(C_LIGHT, 3));
-  re.Bfact = H_P * C_LIGHT * (L_HE_2P - L_HE_2S) / K_B;
-  if (zinitial < tp.recfast_z_He_3) return fail_msg(CPT_ERR_INVALID, "increase zinitial, otherwise should get initial conditions from recfast's get_init routine");
-  Recfast R{cp, tp, re, B};
-  auto f = [&](double z, const double* y, double* dy) { R.derivs(z, y, dy); };
-  Rkck gi;
-  double y[3], dy[3];
-  double z = zinitial, x0 = 1. + 2. * re.fHe, x_H0 = 0., x_He0;
-  y[0] = 1.; y[1] = 1.; y[2] = re.Tnow * (1. + z);
-  const double smallest = cp.smallest_allowed_variation;
+  const double z_top = tp.recfast_z_initial, fHe = model.fHe();
+  if (z_top < tp.recfast_z_He_3) return fail_msg(CPT_ERR_INVALID, "increase zinitial, otherwise should get initial conditions from recfast's get_init routine");
+  cpt_num::Dopri5<3> ode;
+  ode.rtol = 1e-9;
+  ode.atol[0] = ode.atol[1] = 1e-14;
+  double y[3] = {1., 1., model.T0() * (1. + z_top)};
+  bool ode_running = false;
+  auto integrate_to = [&](double z_from, double z_to) -> int {
+    if (!ode_running) { ode.restart(); ode_running = true; }
+    ode.x = z_from;
+    for (int i = 0; i < 3; i++) ode.y[i] = y[i];
+    ode.restart();   // (the caller may have overwritten y with a Saha value)
+    if (!ode.advance(model, z_to) || model.failed()) return fail_msg(CPT_ERR_RUNTIME, "recfast: integration failed in [%g : %g]", z_from, z_to);
+    for (int i = 0; i < 3; i++) y[i] = ode.y[i];
+    return CPT_OK;
+  };
+  auto blend = [](double w, double fresh, double old) { return w * fresh + (1. - w) * old; };
+  double xe = 1. + 2. * fHe, xH_saha = 0.;
   for (int i = 0; i < Nz; i++) {
-    const double zstart = zinitial * (double)(Nz - i) / (double)Nz;
-    const double zend = zinitial * (double)(Nz - i - 1) / (double)Nz;
-    z = zend;
-    if (z > tp.recfast_z_He_1 + tp.recfast_delta_z_He_1) {
-      x_H0 = 1.; x_He0 = 1.; x0 = 1. + 2. * re.fHe;
-      y[0] = x_H0; y[1] = x_He0; y[2] = re.Tnow * (1. + z);
-    } else if (z > tp.recfast_z_He_2 + tp.recfast_delta_z_He_2) {
-      x_H0 = 1.; x_He0 = 1.;
-      const double rhs = exp(1.5 * log(re.CR * re.Tnow / (1. + z)) - re.CB1_He2 / (re.Tnow * (1. + z))) / re.Nnow;
-      if (z > tp.recfast_z_He_1 - tp.recfast_delta_z_He_1) {
-        const double x0_previous = 1. + 2. * re.fHe;
-        const double x0_new = 0.5 * (sqrt(pow((rhs - 1. - re.fHe), 2) + 4. * (1. + 2. * re.fHe) * rhs) - (rhs - 1. - re.fHe));
-        const double s = (tp.recfast_z_He_1 - z) / tp.recfast_delta_z_He_1, weight = f1(s);
-        x0 = weight * x0_new + (1. - weight) * x0_previous;
-      } else x0 = 0.5 * (sqrt(pow((rhs - 1. - re.fHe), 2) + 4. * (1. + 2. * re.fHe) * rhs) - (rhs - 1. - re.fHe));
-      y[0] = x_H0; y[1] = x_He0; y[2] = re.Tnow * (1. + z);
-    } else if (z > tp.recfast_z_He_3 + tp.recfast_delta_z_He_3) {
-      x_H0 = 1.; x_He0 = 1.;
-      if (z > tp.recfast_z_He_2 - tp.recfast_delta_z_He_2) {
-        const double rhs = exp(1.5 * log(re.CR * re.Tnow / (1. + z)) - re.CB1_He2 / (re.Tnow * (1. + z))) / re.Nnow;
-        const double x0_previous = 0.5 * (sqrt(pow((rhs - 1. - re.fHe), 2) + 4. * (1. + 2. * re.fHe) * rhs) - (rhs - 1. - re.fHe));
-        const double x0_new = 1. + re.fHe;
-        const double s = (tp.recfast_z_He_2 - z) / tp.recfast_delta_z_He_2, weight = f1(s);
-        x0 = weight * x0_new + (1. - weight) * x0_previous;
-      } else x0 = 1. + re.fHe;
-      y[0] = x_H0; y[1] = x_He0; y[2] = re.Tnow * (1. + z);
-    } else if (y[1] > tp.recfast_x_He0_trigger) {
-      x_H0 = 1.;
-      const double rhs = 4. * exp(1.5 * log(re.CR * re.Tnow / (1. + z)) - re.CB1_He1 / (re.Tnow * (1. + z))) / re.Nnow;
-      x_He0 = 0.5 * (sqrt(pow((rhs - 1.), 2) + 4. * (1. + re.fHe) * rhs) - (rhs - 1.));
-      if (z > tp.recfast_z_He_3 - tp.recfast_delta_z_He_3) {
-        const double x0_previous = 1. + re.fHe, x0_new = x_He0;
-        const double s = (tp.recfast_z_He_3 - z) / tp.recfast_delta_z_He_3, weight = f1(s);
-        x0 = weight * x0_new + (1. - weight) * x0_previous;
-      } else x0 = x_He0;
-      x_He0 = (x0 - 1.) / re.fHe;
-      y[0] = x_H0; y[1] = x_He0; y[2] = re.Tnow * (1. + z);
-    } else if (y[0] > tp.recfast_x_H0_trigger) {
-      double rhs = exp(1.5 * log(re.CR * re.Tnow / (1. + z)) - re.CB1 / (re.Tnow * (1. + z))) / re.Nnow;
-      x_H0 = 0.5 * (sqrt(pow(rhs, 2) + 4. * rhs) - rhs);
-      int rc = gi.integrate(f, zstart, zend, y, tp.tol_thermo_integration, smallest);
+    const double z_hi = z_top * (double)(Nz - i) / (double)Nz, z = z_top * (double)(Nz - i - 1) / (double)Nz;
+    const double Tr = model.T0() * (1. + z);
+    if (z > tp.recfast_z_He_1 + tp.recfast_delta_z_He_1) {                       // everything ionised
+      xe = 1. + 2. * fHe;
+      y[0] = 1.; y[1] = 1.; y[2] = Tr;
+    } else if (z > tp.recfast_z_He_2 + tp.recfast_delta_z_He_2) {                // He III -> He II in equilibrium
+      xe = model.xe_saha_He2(z);
+      if (z > tp.recfast_z_He_1 - tp.recfast_delta_z_He_1)
+        xe = blend(smooth_step_cubic((tp.recfast_z_He_1 - z) / tp.recfast_delta_z_He_1), xe, 1. + 2. * fHe);
+      y[0] = 1.; y[1] = 1.; y[2] = Tr;
+    } else if (z > tp.recfast_z_He_3 + tp.recfast_delta_z_He_3) {                // helium singly ionised
+      xe = 1. + fHe;
+      if (z > tp.recfast_z_He_2 - tp.recfast_delta_z_He_2)
+        xe = blend(smooth_step_cubic((tp.recfast_z_He_2 - z) / tp.recfast_delta_z_He_2), xe, model.xe_saha_He2(z));
+      y[0] = 1.; y[1] = 1.; y[2] = Tr;
+    } else if (y[1] > tp.recfast_x_He0_trigger) {                                // He II -> He I in equilibrium
+      const double x_saha = model.xe_saha_He1(z);
+      xe = x_saha;
+      if (z > tp.recfast_z_He_3 - tp.recfast_delta_z_He_3)
+        xe = blend(smooth_step_cubic((tp.recfast_z_He_3 - z) / tp.recfast_delta_z_He_3), x_saha, 1. + fHe);
+      y[0] = 1.; y[1] = (xe - 1.) / fHe; y[2] = Tr;
+    } else if (y[0] > tp.recfast_x_H0_trigger) {                                 // helium by the rate equations, hydrogen still in equilibrium
+      xH_saha = model.xH_saha(z);
+      int rc = integrate_to(z_hi, z);
       if (rc) return rc;
-      y[0] = x_H0;
-      if (tp.recfast_x_He0_trigger - y[1] < tp.recfast_x_He0_trigger_delta) {
-        rhs = 4. * exp(1.5 * log(re.CR * re.Tnow / (1. + z)) - re.CB1_He1 / (re.Tnow * (1. + z))) / re.Nnow;
-        const double x0_previous = 0.5 * (sqrt(pow((rhs - 1.), 2) + 4. * (1. + re.fHe) * rhs) - (rhs - 1.));
-        const double x0_new = y[0] + re.fHe * y[1];
-        const double s = (tp.recfast_x_He0_trigger - y[1]) / tp.recfast_x_He0_trigger_delta, weight = f2(s);
-        x0 = weight * x0_new + (1. - weight) * x0_previous;
-      } else x0 = y[0] + re.fHe * y[1];
-    } else {
-      if (tp.recfast_x_H0_trigger - y[0] < tp.recfast_x_H0_trigger_delta) {
-        const double rhs = exp(1.5 * log(re.CR * re.Tnow / (1. + z)) - re.CB1 / (re.Tnow * (1. + z))) / re.Nnow;
-        x_H0 = 0.5 * (sqrt(pow(rhs, 2) + 4. * rhs) - rhs);
-      }
-      int rc = gi.integrate(f, zstart, zend, y, tp.tol_thermo_integration, smallest);
+      y[0] = xH_saha;
+      xe = y[0] + fHe * y[1];
+      if (tp.recfast_x_He0_trigger - y[1] < tp.recfast_x_He0_trigger_delta)
+        xe = blend(smooth_step_quadratic((tp.recfast_x_He0_trigger - y[1]) / tp.recfast_x_He0_trigger_delta), xe, model.xe_saha_He1(z));
+    } else {                                                                      // everything by the rate equations
+      const bool near_switch_before = tp.recfast_x_H0_trigger - y[0] < tp.recfast_x_H0_trigger_delta;
+      if (near_switch_before) xH_saha = model.xH_saha(z);
+      int rc = integrate_to(z_hi, z);
       if (rc) return rc;
-      if (tp.recfast_x_H0_trigger - y[0] < tp.recfast_x_H0_trigger_delta) {
-        const double s = (tp.recfast_x_H0_trigger - y[0]) / tp.recfast_x_H0_trigger_delta, weight = f2(s);
-        x0 = weight * y[0] + (1. - weight) * x_H0 + re.fHe * y[1];
-      } else x0 = y[0] + re.fHe * y[1];
+      if (tp.recfast_x_H0_trigger - y[0] < tp.recfast_x_H0_trigger_delta)
+        xe = blend(smooth_step_quadratic((tp.recfast_x_H0_trigger - y[0]) / tp.recfast_x_H0_trigger_delta), y[0], xH_saha) + fHe * y[1];
+      else xe = y[0] + fHe * y[1];
     }
-    if (R.err) return fail_msg(CPT_ERR_RUNTIME, "recfast: background look-up failed at z=%e", z);
     double* row = &tab[(size_t)(Nz - i - 1) * RE_SIZE];
-    row[RE_Z] = zend; row[RE_XE] = x0; row[RE_TB] = y[2];
-    R.derivs(zend, y, dy);
-    row[RE_WB] = K_B / (C_LIGHT * C_LIGHT * M_HYDROGEN) * (1. + (1. / NOT4 - 1.) * re.YHe + x0 * (1. - re.YHe)) * y[2];
-    row[RE_CB2] = row[RE_WB] * (1. + (1. + zend) * dy[2] / y[2] / 3.);
-    row[RE_DKAPPADTAU] = (1. + zend) * (1. + zend) * re.Nnow * x0 * SIGMA_T * MPC_OVER_M;
+    double dy[3];
+    model(z, y, dy);
+    if (model.failed()) return fail_msg(CPT_ERR_RUNTIME, "recfast: background look-up failed at z=%e", z);
+    row[RE_Z] = z; row[RE_XE] = xe; row[RE_TB] = y[2];
+    row[RE_WB] = kBoltz / (kC * kC * kMH) * (1. + (1. / kHe4OverH - 1.) * tp.YHe + xe * (1. - tp.YHe)) * y[2];
+    row[RE_CB2] = row[RE_WB] * (1. + (1. + z) * dy[2] / y[2] / 3.);
+    row[RE_DKAPPADTAU] = (1. + z) * (1. + z) * model.nH0() * xe * kSigmaT * kMpc;
   }
   return CPT_OK;
 }
 
-// reionization: th.cpp:1893-1950 (CAMB-like tanh), 2668-2990 (adaptive sampling, T_b, optical depth)
-struct Reio { double xe_before, xe_after, z_reio, z_start, exponent, width, he_frac, he_z, he_width; };
-double reio_xe(const Reio& r, double z) {
-  if (z > r.z_start) return r.xe_before;
-  double argument = (pow((1. + r.z_reio), r.exponent) - pow((1. + z), r.exponent)) / (r.exponent * pow((1. + r.z_reio), (r.exponent - 1.))) / r.width;
-  double xe = (r.xe_after - r.xe_before) * (tanh(argument) + 1.) / 2. + r.xe_before;
-  argument = (r.he_z - z) / r.he_width;
-  xe += r.he_frac * (tanh(argument) + 1.) / 2.;
-  return xe;
-}
-int xe_before_reio(const std::vector<double>& reco, int Nz, double z, double* xe) {   // array_interpolate_one_growing_closeby from index 0
-  int inf = 0;
-  while (z < reco[(size_t)inf * RE_SIZE + RE_Z]) { inf--; if (inf < 0) return fail_msg(CPT_ERR_INVALID, "x=%e < x_min", z); }
-  int sup = inf + 1;
-  while (z > reco[(size_t)sup * RE_SIZE + RE_Z]) { sup++; if (sup > Nz - 1) return fail_msg(CPT_ERR_INVALID, "x=%e > x_max", z); }
-  inf = sup - 1;
-  const double weight = (z - reco[(size_t)inf * RE_SIZE + RE_Z]) / (reco[(size_t)sup * RE_SIZE + RE_Z] - reco[(size_t)inf * RE_SIZE + RE_Z]);
-  *xe = reco[(size_t)inf * RE_SIZE + RE_XE] * (1. - weight) + reco[(size_t)sup * RE_SIZE + RE_XE] * weight;
+// ---- reionization (CAMB-like): x_e(z) = tanh step in (1+z)^exponent for hydrogen + first helium electron, a second tanh for the
+//      second helium electron ----
+struct ReioModel {
+  double xe_before, xe_after, z_reio, z_start, exponent, width, he_frac, he_z, he_width;
+  double xe(double z) const {
+    if (z > z_start) return xe_before;
+    const double u = (std::pow(1. + z_reio, exponent) - std::pow(1. + z, exponent)) / (exponent * std::pow(1. + z_reio, exponent - 1.)) / width;
+    return (xe_after - xe_before) * 0.5 * (std::tanh(u) + 1.) + xe_before + he_frac * 0.5 * (std::tanh((he_z - z) / he_width) + 1.);
+  }
+};
+// x_e of the recombination table at z by linear interpolation between its nodes
+int xe_from_recombination(const std::vector<double>& reco, int Nz, double z, double* xe) {
+  if (z < reco[RE_Z] || z > reco[(size_t)(Nz - 1) * RE_SIZE + RE_Z]) return fail_msg(CPT_ERR_INVALID, "z=%e outside the recombination table", z);
+  int hi = 1;
+  while (z > reco[(size_t)hi * RE_SIZE + RE_Z]) hi++;
+  const double z0 = reco[(size_t)(hi - 1) * RE_SIZE + RE_Z], z1 = reco[(size_t)hi * RE_SIZE + RE_Z], w = (z - z0) / (z1 - z0);
+  *xe = (1. - w) * reco[(size_t)(hi - 1) * RE_SIZE + RE_XE] + w * reco[(size_t)hi * RE_SIZE + RE_XE];
   return CPT_OK;
 }
-int reio_sample(const cpt_cosmo_params& cp, const cpt_thermo_params& tp, BgAccess& B, const Reco& re, const std::vector<double>& reco, const Reio& r,
-                std::vector<double>& tab, int* rt_size, int* index_reco_when_reio_start, double* optical_depth) {
+
+// The reionization part of the table: redshifts chosen adaptively from z_start down to 0 so that the opacity changes by less than
+// `reionization_sampling` (relative, in kappa'(z) and kappa'(tau) together) from one node to the next - this rule fixes the nodes
+// of the final table, so it is the reference's; baryon temperature by explicit Euler steps on those nodes; optical depth from the
+// spline integral of dkappa/dz.  Output rows in ascending z.
+int reionization_history(const cpt_cosmo_params& cp, const cpt_thermo_params& tp, Background& B, double nH0, const std::vector<double>& reco, const ReioModel& R,
+                         std::vector<double>& tab, int* n_rows, int* first_reco_row_kept, double* optical_depth) {
   const int Nz = tp.recfast_Nz0;
-  const double Yp = tp.YHe, n_e = re.Nnow;
-  std::vector<double> grow;   // rows in decreasing z
-  double vec[RE_SIZE] = {0};
-  int i = 0;
-  while (reco[(size_t)i * RE_SIZE + RE_Z] < r.z_start) {
-    i++;
-    if (i == Nz) return fail_msg(CPT_ERR_INVALID, "reionization_z_start_max = %e > largest redshift in thermodynamics table", tp.reionization_z_start_max);
-  }
-  double z = reco[(size_t)i * RE_SIZE + RE_Z];
-  vec[RE_Z] = z;
-  *index_reco_when_reio_start = i;
-  double xe = reio_xe(r, z);
-  vec[RE_XE] = xe;
-  double tau;
+  int i0 = 0;
+  while (reco[(size_t)i0 * RE_SIZE + RE_Z] < R.z_start)
+    if (++i0 == Nz) return fail_msg(CPT_ERR_INVALID, "reionization_z_start_max = %e > largest redshift in thermodynamics table", tp.reionization_z_start_max);
+  *first_reco_row_kept = i0;
+  auto opacity = [&](double z, double xe) { return (1. + z) * (1. + z) * nH0 * xe * kSigmaT * kMpc; };   // kappa' = dkappa/dtau
+  struct Node { double z, xe, dk_dtau, dk_dz; };
+  std::vector<Node> nodes;   // descending z
   int rc;
-  if ((rc = B.tau_of_z(z, &tau)) || (rc = B.at_tau(tau))) return rc;
-  vec[RE_DKAPPADTAU] = (1. + z) * (1. + z) * n_e * xe * SIGMA_T * MPC_OVER_M;
+  double z = reco[(size_t)i0 * RE_SIZE + RE_Z];
+  if ((rc = B.at_z(z))) return rc;
   if (B.H() == 0.) return fail_msg(CPT_ERR_INVALID, "stop to avoid division by zero");
-  vec[RE_DKAPPADZ] = vec[RE_DKAPPADTAU] / B.H();
-  double dkappadz = vec[RE_DKAPPADZ], dkappadtau = vec[RE_DKAPPADTAU];
-  const double Tb = reco[(size_t)i * RE_SIZE + RE_TB];
-  vec[RE_TB] = Tb;
-  vec[RE_WB] = K_B / (C_LIGHT * C_LIGHT * M_HYDROGEN) * (1. + (1. / NOT4 - 1.) * Yp + xe * (1. - Yp)) * Tb;
-  vec[RE_CB2] = 5. / 3. * vec[RE_WB];
-  grow.insert(grow.end(), vec, vec + RE_SIZE);
-  int number_of_redshifts = 1;
-  const double dz_max = reco[(size_t)i * RE_SIZE + RE_Z] - reco[(size_t)(i - 1) * RE_SIZE + RE_Z];
+  nodes.push_back({z, R.xe(z), opacity(z, R.xe(z)), opacity(z, R.xe(z)) / B.H()});
+  const double dz_max = reco[(size_t)i0 * RE_SIZE + RE_Z] - reco[(size_t)(i0 - 1) * RE_SIZE + RE_Z];
   double dz = dz_max;
   while (z > 0.) {
     if (dz < cp.smallest_allowed_variation) return fail_msg(CPT_ERR_RUNTIME, "stuck in the loop for reionization sampling, as if you were trying to impose a discontinuous evolution for xe(z)");
-    double z_next = z - dz;
-    if (z_next < 0.) z_next = 0.;
-    const double xe_next = reio_xe(r, z_next);
-    if ((rc = B.tau_of_z(z_next, &tau)) || (rc = B.at_tau(tau))) return rc;
+    const double z_try = std::max(0., z - dz), xe_try = R.xe(z_try);
+    if ((rc = B.at_z(z_try))) return rc;
     if (B.H() == 0.) return fail_msg(CPT_ERR_INVALID, "stop to avoid division by zero");
-    const double dkappadz_next = (1. + z_next) * (1. + z_next) * n_e * xe_next * SIGMA_T * MPC_OVER_M / B.H();
-    const double dkappadtau_next = (1. + z_next) * (1. + z_next) * n_e * xe_next * SIGMA_T * MPC_OVER_M;
-    if ((dkappadz == 0.) || (dkappadtau == 0.)) return fail_msg(CPT_ERR_INVALID, "stop to avoid division by zero");
-    const double relative_variation = fabs((dkappadz_next - dkappadz) / dkappadz) + fabs((dkappadtau_next - dkappadtau) / dkappadtau);
-    if (relative_variation < tp.reionization_sampling) {
-      z = z_next; xe = xe_next; dkappadz = dkappadz_next; dkappadtau = dkappadtau_next;
-      if ((dkappadz == 0.) || (dkappadtau == 0.)) return fail_msg(CPT_ERR_INVALID, "dkappadz=%e, dkappadtau=%e, stop to avoid division by zero", dkappadz, dkappadtau);
-      vec[RE_Z] = z; vec[RE_XE] = xe; vec[RE_DKAPPADZ] = dkappadz; vec[RE_DKAPPADTAU] = dkappadz * B.H();
-      grow.insert(grow.end(), vec, vec + RE_SIZE);
-      number_of_redshifts++;
-      dz = std::min(0.9 * (tp.reionization_sampling / relative_variation), 5.) * dz;
-      dz = std::min(dz, dz_max);
-    } else dz = 0.9 * (tp.reionization_sampling / relative_variation) * dz;
+    const Node& prev = nodes.back();
+    if (prev.dk_dz == 0. || prev.dk_dtau == 0.) return fail_msg(CPT_ERR_INVALID, "stop to avoid division by zero");
+    const double dk_dtau = opacity(z_try, xe_try), dk_dz = dk_dtau / B.H();
+    const double change = std::fabs((dk_dz - prev.dk_dz) / prev.dk_dz) + std::fabs((dk_dtau - prev.dk_dtau) / prev.dk_dtau);
+    if (change < tp.reionization_sampling) {
+      z = z_try;
+      nodes.push_back({z, xe_try, dk_dz * B.H(), dk_dz});
+      dz = std::min(std::min(0.9 * (tp.reionization_sampling / change), 5.) * dz, dz_max);
+    } else dz *= 0.9 * (tp.reionization_sampling / change);
   }
-  const int n = number_of_redshifts;
+  const int n = (int)nodes.size();
+  *n_rows = n;
   tab.assign((size_t)n * RE_SIZE, 0.);
-  for (int j = 0; j < n; j++) memcpy(&tab[(size_t)j * RE_SIZE], &grow[(size_t)(n - j - 1) * RE_SIZE], RE_SIZE * sizeof(double));
-  *rt_size = n;
-  // baryon temperature by forward Euler in decreasing z (th.cpp:2871-2957)
+  for (int j = 0; j < n; j++) {
+    const Node& nd = nodes[n - 1 - j];
+    double* row = &tab[(size_t)j * RE_SIZE];
+    row[RE_Z] = nd.z; row[RE_XE] = nd.xe; row[RE_DKAPPADTAU] = nd.dk_dtau; row[RE_DKAPPADZ] = nd.dk_dz;
+  }
+  // baryon temperature: starts from the recombination value at z_start, explicit Euler towards z = 0 with Compton heating by the CMB
+  {
+    double* top = &tab[(size_t)(n - 1) * RE_SIZE];
+    top[RE_TB] = reco[(size_t)i0 * RE_SIZE + RE_TB];
+    top[RE_WB] = kBoltz / (kC * kC * kMH) * (1. + (1. / kHe4OverH - 1.) * tp.YHe + top[RE_XE] * (1. - tp.YHe)) * top[RE_TB];
+    top[RE_CB2] = 5. / 3. * top[RE_WB];
+  }
   for (int j = n - 1; j > 0; j--) {
-    const double zz = tab[(size_t)j * RE_SIZE + RE_Z];
-    if ((rc = B.tau_of_z(zz, &tau)) || (rc = B.at_tau(tau))) return rc;
-    const double dzz = tab[(size_t)j * RE_SIZE + RE_Z] - tab[(size_t)(j - 1) * RE_SIZE + RE_Z];
-    const double opacity = (1. + zz) * (1. + zz) * n_e * tab[(size_t)j * RE_SIZE + RE_XE] * SIGMA_T * MPC_OVER_M;
-    const double mu = M_HYDROGEN / (1. + (1. / NOT4 - 1.) * tp.YHe + tab[(size_t)j * RE_SIZE + RE_XE] * (1. - tp.YHe));
-    const double dTdz = 2. / (1 + zz) * tab[(size_t)j * RE_SIZE + RE_TB] -
-                        2. * mu / M_ELECTRON * 4. * B.rho_g() / 3. / B.rho_b() * opacity * (cp.T_cmb * (1. + zz) - tab[(size_t)j * RE_SIZE + RE_TB]) / B.H();
-    tab[(size_t)(j - 1) * RE_SIZE + RE_TB] = tab[(size_t)j * RE_SIZE + RE_TB] - dTdz * dzz;
-    tab[(size_t)(j - 1) * RE_SIZE + RE_WB] = K_B / (C_LIGHT * C_LIGHT * mu) * tab[(size_t)(j - 1) * RE_SIZE + RE_TB];
-    tab[(size_t)(j - 1) * RE_SIZE + RE_CB2] = tab[(size_t)(j - 1) * RE_SIZE + RE_WB] * (1. + (1 + zz) / 3. * dTdz / tab[(size_t)(j - 1) * RE_SIZE + RE_TB]);
+    double* here = &tab[(size_t)j * RE_SIZE];
+    double* below = &tab[(size_t)(j - 1) * RE_SIZE];
+    const double zz = here[RE_Z];
+    if ((rc = B.at_z(zz))) return rc;
+    const double mean_mass = kMH / (1. + (1. / kHe4OverH - 1.) * tp.YHe + here[RE_XE] * (1. - tp.YHe));
+    const double dT_dz = 2. / (1. + zz) * here[RE_TB] -
+                         2. * mean_mass / kMe * 4. * B.rho_g() / 3. / B.rho_b() * opacity(zz, here[RE_XE]) * (cp.T_cmb * (1. + zz) - here[RE_TB]) / B.H();
+    below[RE_TB] = here[RE_TB] - dT_dz * (here[RE_Z] - below[RE_Z]);
+    below[RE_WB] = kBoltz / (kC * kC * mean_mass) * below[RE_TB];
+    below[RE_CB2] = below[RE_WB] * (1. + (1. + zz) / 3. * dT_dz / below[RE_TB]);
   }
-  // optical depth: spline of dkappa/dz in z, integrated (array_spline + array_integrate_all_spline)
-  std::vector<double> zz(n);
-  for (int j = 0; j < n; j++) zz[j] = tab[(size_t)j * RE_SIZE + RE_Z];
-  spline_col(zz.data(), n, tab.data(), RE_SIZE, RE_DKAPPADZ, RE_D3KAPPADZ3);
-  double res = 0.;
-  for (int j = 0; j < n - 1; j++) {
-    const double h = zz[j + 1] - zz[j];
-    res += (tab[(size_t)j * RE_SIZE + RE_DKAPPADZ] + tab[(size_t)(j + 1) * RE_SIZE + RE_DKAPPADZ]) * h / 2. +
-           (tab[(size_t)j * RE_SIZE + RE_D3KAPPADZ3] + tab[(size_t)(j + 1) * RE_SIZE + RE_D3KAPPADZ3]) * h * h * h / 24.;
-  }
-  *optical_depth = res;
+  // optical depth = integral of dkappa/dz over the reionization nodes (spline rule)
+  std::vector<double> zz(n), f(n), m(n), cum(n);
+  for (int j = 0; j < n; j++) { zz[j] = tab[(size_t)j * RE_SIZE + RE_Z]; f[j] = tab[(size_t)j * RE_SIZE + RE_DKAPPADZ]; }
+  spline_table_lines(zz.data(), n, f.data(), 1, m.data());
+  for (int j = 0; j < n; j++) tab[(size_t)j * RE_SIZE + RE_D3KAPPADZ3] = m[j];
+  cpt_num::spline_cumulative_integral(zz.data(), n, f.data(), m.data(), 1, cum.data(), kReferenceIntegralRule);
+  *optical_depth = cum[n - 1];
   return CPT_OK;
+}
+
+// running average over [i - radius, i + radius] clipped to the table
+void box_smooth(double* table, int ncol, int n, int col, int radius) {
+  std::vector<double> prefix(n + 1, 0.);
+  for (int i = 0; i < n; i++) prefix[i + 1] = prefix[i] + table[(size_t)i * ncol + col];
+  for (int i = 0; i < n; i++) {
+    const int lo = std::max(i - radius, 0), hi = std::min(i + radius, n - 1);
+    table[(size_t)i * ncol + col] = (prefix[hi + 1] - prefix[lo]) / (double)(hi - lo + 1);
+  }
 }
 }  // namespace
 }  // namespace cpt_host
@@ -750,63 +623,53 @@ int cpt_host_thermodynamics(const cpt_cosmo_params* cpp, const cpt_thermo_params
   memset(out, 0, sizeof(*out));
   if (tp.reio_parametrization != CPT_REIO_NONE && tp.reio_parametrization != CPT_REIO_CAMB)
     return fail_msg(CPT_ERR_UNSUPPORTED, "host thermodynamics: reionization schemes none and camb only");
-  if ((tp.YHe < YHE_SMALL) || (tp.YHe > YHE_BIG)) return fail_msg(CPT_ERR_INVALID, "Y_He=%g out of bounds (%g<Y_He<%g)", tp.YHe, YHE_SMALL, YHE_BIG);
-  BgAccess B(*bg);
-  Reco re;
+  if ((tp.YHe < kYHeMin) || (tp.YHe > kYHeMax)) return fail_msg(CPT_ERR_INVALID, "Y_He=%g out of bounds (%g<Y_He<%g)", tp.YHe, kYHeMin, kYHeMax);
+  Background B(*bg);
+  Recfast model(cp, tp, B);
   std::vector<double> reco, reio;
-  int rc = recombination(cp, tp, B, re, reco);
+  int rc = recombination_history(cp, tp, B, model, reco);
   if (rc) return rc;
   const int Nz = tp.recfast_Nz0;
-  int rt_size = 0, index_reco_when_reio_start = -1;
+  int n_reio = 0, first_reco_kept = -1;
   double z_reionization = tp.z_reio, tau_reionization = tp.tau_reio;
-  if (tp.reio_parametrization == CPT_REIO_CAMB) {   // thermodynamics_reionization, th.cpp:2159-2320
-    Reio r;
-    r.xe_after = 1. + tp.YHe / (NOT4 * (1. - tp.YHe));
-    r.exponent = tp.reionization_exponent; r.width = tp.reionization_width;
-    r.he_frac = tp.YHe / (NOT4 * (1. - tp.YHe)); r.he_z = tp.helium_fullreio_redshift; r.he_width = tp.helium_fullreio_width;
-    if (r.exponent == 0 || r.width == 0 || r.he_width == 0) return fail_msg(CPT_ERR_INVALID, "stop to avoid division by zero");
-    auto start_of = [&](double zr) {
-      double zs = zr + tp.reionization_start_factor * tp.reionization_width;
-      if (zs < tp.helium_fullreio_redshift + tp.reionization_start_factor * tp.helium_fullreio_width)
-        zs = tp.helium_fullreio_redshift + tp.reionization_start_factor * tp.helium_fullreio_width;
-      return zs;
+  if (tp.reio_parametrization == CPT_REIO_CAMB) {
+    ReioModel R;
+    R.he_frac = tp.YHe / (kHe4OverH * (1. - tp.YHe));
+    R.xe_after = 1. + R.he_frac;
+    R.exponent = tp.reionization_exponent; R.width = tp.reionization_width; R.he_z = tp.helium_fullreio_redshift; R.he_width = tp.helium_fullreio_width;
+    if (R.exponent == 0 || R.width == 0 || R.he_width == 0) return fail_msg(CPT_ERR_INVALID, "stop to avoid division by zero");
+    const double helium_start = tp.helium_fullreio_redshift + tp.reionization_start_factor * tp.helium_fullreio_width;
+    // history for a given reionization redshift -> optical depth
+    auto history = [&](double z_reio, double z_start, double* depth) -> int {
+      R.z_reio = z_reio; R.z_start = z_start;
+      if (R.z_start > tp.reionization_z_start_max) return fail_msg(CPT_ERR_INVALID, "starting redshift for reionization > reionization_z_start_max = %e", tp.reionization_z_start_max);
+      int r = xe_from_recombination(reco, Nz, R.z_start, &R.xe_before);
+      if (r) return r;
+      return reionization_history(cp, tp, B, model.nH0(), reco, R, reio, &n_reio, &first_reco_kept, depth);
     };
-    double depth = 0.;
+    auto start_of = [&](double z_reio) { return std::max(z_reio + tp.reionization_start_factor * tp.reionization_width, helium_start); };
     if (!tp.reio_from_tau) {
-      r.z_reio = z_reionization; r.z_start = start_of(r.z_reio);
-      if (r.z_start > tp.reionization_z_start_max) return fail_msg(CPT_ERR_INVALID, "starting redshift for reionization > reionization_z_start_max = %e", tp.reionization_z_start_max);
-      if ((rc = xe_before_reio(reco, Nz, r.z_start, &r.xe_before))) return rc;
-      if ((rc = reio_sample(cp, tp, B, re, reco, r, reio, &rt_size, &index_reco_when_reio_start, &depth))) return rc;
-      tau_reionization = depth;
-    } else {
-      double z_sup = tp.reionization_z_start_max - tp.reionization_start_factor * tp.reionization_width;
-      if (z_sup < 0.) return fail_msg(CPT_ERR_INVALID, "parameters are such that reionization cannot take place before today while starting after z_start_max; need to increase z_start_max");
-      r.z_reio = z_sup; r.z_start = tp.reionization_z_start_max;
-      if ((rc = xe_before_reio(reco, Nz, r.z_start, &r.xe_before))) return rc;
-      if ((rc = reio_sample(cp, tp, B, re, reco, r, reio, &rt_size, &index_reco_when_reio_start, &depth))) return rc;
-      double tau_sup = depth;
-      if (tau_sup < tau_reionization) return fail_msg(CPT_ERR_INVALID, "parameters are such that reionization cannot start after z_start_max");
-      double z_inf = 0., tau_inf = 0.;
-      int counter = 0;
-      while ((tau_sup - tau_inf) > tau_reionization * tp.reionization_optical_depth_tol) {
-        const double z_mid = 0.5 * (z_sup + z_inf);
-        r.z_reio = z_mid; r.z_start = start_of(z_mid);
-        if (r.z_start > tp.reionization_z_start_max) return fail_msg(CPT_ERR_INVALID, "starting redshift for reionization > reionization_z_start_max = %e", tp.reionization_z_start_max);
-        if ((rc = xe_before_reio(reco, Nz, r.z_start, &r.xe_before))) return rc;
-        if ((rc = reio_sample(cp, tp, B, re, reco, r, reio, &rt_size, &index_reco_when_reio_start, &depth))) return rc;
-        const double tau_mid = depth;
-        if (tau_mid > tau_reionization) { z_sup = z_mid; tau_sup = tau_mid; } else { z_inf = z_mid; tau_inf = tau_mid; }
-        if (++counter > 10000) return fail_msg(CPT_ERR_RUNTIME, "while searching for reionization_optical_depth, maximum number of iterations exceeded");
+      if ((rc = history(z_reionization, start_of(z_reionization), &tau_reionization))) return rc;
+    } else {   // bisection on z_reio for the requested optical depth
+      double z_hi = tp.reionization_z_start_max - tp.reionization_start_factor * tp.reionization_width, z_lo = 0., tau_hi, tau_lo = 0.;
+      if (z_hi < 0.) return fail_msg(CPT_ERR_INVALID, "parameters are such that reionization cannot take place before today while starting after z_start_max; need to increase z_start_max");
+      if ((rc = history(z_hi, tp.reionization_z_start_max, &tau_hi))) return rc;
+      if (tau_hi < tau_reionization) return fail_msg(CPT_ERR_INVALID, "parameters are such that reionization cannot start after z_start_max");
+      for (int it = 0; (tau_hi - tau_lo) > tau_reionization * tp.reionization_optical_depth_tol; it++) {
+        if (it > 10000) return fail_msg(CPT_ERR_RUNTIME, "while searching for reionization_optical_depth, maximum number of iterations exceeded");
+        const double z_mid = 0.5 * (z_hi + z_lo);
+        double tau_mid;
+        if ((rc = history(z_mid, start_of(z_mid), &tau_mid))) return rc;
+        if (tau_mid > tau_reionization) { z_hi = z_mid; tau_hi = tau_mid; } else { z_lo = z_mid; tau_lo = tau_mid; }
       }
-      z_reionization = r.z_reio;
+      z_reionization = R.z_reio;
     }
   }
-  // ---- thermodynamics_merge_reco_and_reio, th.cpp:3977-4085 ----
+  // ---- merged table: reionization nodes, then the recombination nodes above them; the reference's 13 columns ----
   enum { TH_xe = 0, TH_dkappa, TH_tau_d, TH_ddkappa, TH_dddkappa, TH_exp_m_kappa, TH_g, TH_dg, TH_ddg, TH_Tb, TH_wb, TH_cb2, TH_rate, TH_SIZE };
-  if (rt_size > 0 && reco[(size_t)index_reco_when_reio_start * RE_SIZE + RE_Z] != reio[(size_t)(rt_size - 1) * RE_SIZE + RE_Z])
+  if (n_reio > 0 && reco[(size_t)first_reco_kept * RE_SIZE + RE_Z] != reio[(size_t)(n_reio - 1) * RE_SIZE + RE_Z])
     return fail_msg(CPT_ERR_RUNTIME, "mismatch which should never happen");
-  const int nt = Nz + rt_size - index_reco_when_reio_start - 1;
-  const int nc = TH_SIZE;
+  const int n_above = Nz - first_reco_kept - 1, nt = n_reio + n_above, nc = TH_SIZE;
   out->tt_size = nt; out->th_size = nc;
   out->z_table = (double*)malloc(sizeof(double) * nt);
   out->thermodynamics_table = (double*)calloc((size_t)nt * nc, sizeof(double));
@@ -814,83 +677,84 @@ int cpt_host_thermodynamics(const cpt_cosmo_params* cpp, const cpt_thermo_params
   if (!out->z_table || !out->thermodynamics_table || !out->d2thermodynamics_dz2_table) { cpt_host_thermo_free(out); return fail_msg(CPT_ERR_RUNTIME, "could not allocate the thermodynamics table"); }
   double* T = out->thermodynamics_table;
   double* zt = out->z_table;
-  for (int i = 0; i < rt_size; i++) {
-    zt[i] = reio[(size_t)i * RE_SIZE + RE_Z];
-    T[(size_t)i * nc + TH_xe] = reio[(size_t)i * RE_SIZE + RE_XE]; T[(size_t)i * nc + TH_dkappa] = reio[(size_t)i * RE_SIZE + RE_DKAPPADTAU];
-    T[(size_t)i * nc + TH_Tb] = reio[(size_t)i * RE_SIZE + RE_TB]; T[(size_t)i * nc + TH_wb] = reio[(size_t)i * RE_SIZE + RE_WB];
-    T[(size_t)i * nc + TH_cb2] = reio[(size_t)i * RE_SIZE + RE_CB2];
-  }
-  for (int i = 0; i < Nz - index_reco_when_reio_start - 1; i++) {
-    const int ith = i + rt_size, ire = i + index_reco_when_reio_start + 1;
-    zt[ith] = reco[(size_t)ire * RE_SIZE + RE_Z];
-    T[(size_t)ith * nc + TH_xe] = reco[(size_t)ire * RE_SIZE + RE_XE]; T[(size_t)ith * nc + TH_dkappa] = reco[(size_t)ire * RE_SIZE + RE_DKAPPADTAU];
-    T[(size_t)ith * nc + TH_Tb] = reco[(size_t)ire * RE_SIZE + RE_TB]; T[(size_t)ith * nc + TH_wb] = reco[(size_t)ire * RE_SIZE + RE_WB];
-    T[(size_t)ith * nc + TH_cb2] = reco[(size_t)ire * RE_SIZE + RE_CB2];
+  for (int i = 0; i < nt; i++) {
+    const double* src = (i < n_reio) ? &reio[(size_t)i * RE_SIZE] : &reco[(size_t)(i - n_reio + first_reco_kept + 1) * RE_SIZE];
+    double* row = T + (size_t)i * nc;
+    zt[i] = src[RE_Z];
+    row[TH_xe] = src[RE_XE]; row[TH_dkappa] = src[RE_DKAPPADTAU]; row[TH_Tb] = src[RE_TB]; row[TH_wb] = src[RE_WB]; row[TH_cb2] = src[RE_CB2];
   }
   auto bail = [&](int code) { cpt_host_thermo_free(out); return code; };
-  // ---- derived columns, th.cpp:456-790 ----
-  std::vector<double> tau_table(nt);
-  for (int i = 0; i < nt; i++) if ((rc = B.tau_of_z(zt[i], &tau_table[i]))) return bail(rc);
-  out->tau_ini = tau_table[nt - 1];
-  for (int i = 0; i < nt; i++) {   // minus the baryon drag rate -[1/R kappa'], temporarily in column ddkappa
-    if ((rc = B.at_tau(tau_table[i]))) return bail(rc);
-    const double R = 3. / 4. * B.rho_b() / B.rho_g();
-    T[(size_t)i * nc + TH_ddkappa] = -1. / R * T[(size_t)i * nc + TH_dkappa];
+  // ---- opacity integrals and derivatives along conformal time (columns are strided views of the table) ----
+  std::vector<double> tau(nt);
+  for (int i = 0; i < nt; i++) if ((rc = B.tau_of_z(zt[i], &tau[i]))) return bail(rc);
+  out->tau_ini = tau[nt - 1];
+  std::vector<double> f(nt), m(nt), cum(nt), d1(nt);
+  const cpt_num::ClampedSpline in_tau(tau.data(), nt);
+  // baryon drag depth tau_d = integral of kappa' / R, R = 3 rho_b / 4 rho_g, from today backwards
+  for (int i = 0; i < nt; i++) {
+    if ((rc = B.at_tau(tau[i]))) return bail(rc);
+    f[i] = -T[(size_t)i * nc + TH_dkappa] * (4. / 3.) * B.rho_g() / B.rho_b();
   }
-  spline_col(tau_table.data(), nt, T, nc, TH_ddkappa, TH_dddkappa);
-  integrate_spline_col(tau_table.data(), nt, T, nc, TH_ddkappa, TH_dddkappa, TH_tau_d);
-  spline_col(tau_table.data(), nt, T, nc, TH_dkappa, TH_dddkappa);           // kappa''' (as the spline's second derivative of kappa')
-  derive_spline_col(tau_table.data(), nt, T, nc, TH_dkappa, TH_dddkappa, TH_ddkappa);   // kappa''
-  integrate_spline_col(tau_table.data(), nt, T, nc, TH_dkappa, TH_dddkappa, TH_g);       // -kappa, temporarily in column g
-  for (int i = nt - 1; i >= 0; i--) {   // visibility and its derivatives, th.cpp:745-790
+  in_tau.moments(f.data(), 1, 1, m.data());
+  cpt_num::spline_cumulative_integral(tau.data(), nt, f.data(), m.data(), 1, cum.data(), kReferenceIntegralRule);
+  for (int i = 0; i < nt; i++) T[(size_t)i * nc + TH_tau_d] = cum[i];
+  // kappa''' (the spline's second derivative of kappa'), kappa'' (its first derivative at the nodes), -kappa (its integral)
+  for (int i = 0; i < nt; i++) f[i] = T[(size_t)i * nc + TH_dkappa];
+  in_tau.moments(f.data(), 1, 1, m.data());
+  cpt_num::spline_node_derivative(tau.data(), nt, f.data(), m.data(), 1, d1.data());
+  cpt_num::spline_cumulative_integral(tau.data(), nt, f.data(), m.data(), 1, cum.data(), kReferenceIntegralRule);
+  for (int i = 0; i < nt; i++) {
     double* r = T + (size_t)i * nc;
-    const double g = r[TH_dkappa] * exp(r[TH_g]);
-    r[TH_exp_m_kappa] = exp(r[TH_g]);
-    r[TH_dg] = (r[TH_ddkappa] + r[TH_dkappa] * r[TH_dkappa]) * exp(r[TH_g]);
-    r[TH_ddg] = (r[TH_dddkappa] + r[TH_dkappa] * r[TH_ddkappa] * 3. + r[TH_dkappa] * r[TH_dkappa] * r[TH_dkappa]) * exp(r[TH_g]);
-    r[TH_g] = g;
-    if (r[TH_dkappa] == 0.) return bail(fail_msg(CPT_ERR_RUNTIME, "variation rate diverges"));
-    r[TH_rate] = sqrt(pow(r[TH_dkappa], 2) + pow(r[TH_ddkappa] / r[TH_dkappa], 2) + fabs(r[TH_dddkappa] / r[TH_dkappa]));
+    const double k1 = r[TH_dkappa], k2 = d1[i], k3 = m[i], damp = std::exp(cum[i]);   // cum = -kappa (tau decreases with the index)
+    if (k1 == 0.) return bail(fail_msg(CPT_ERR_RUNTIME, "variation rate diverges"));
+    r[TH_ddkappa] = k2; r[TH_dddkappa] = k3;
+    r[TH_exp_m_kappa] = damp;
+    r[TH_g] = k1 * damp;                                     // visibility and its first two derivatives
+    r[TH_dg] = (k2 + k1 * k1) * damp;
+    r[TH_ddg] = (k3 + 3. * k1 * k2 + k1 * k1 * k1) * damp;
+    r[TH_rate] = std::sqrt(k1 * k1 + (k2 / k1) * (k2 / k1) + std::fabs(k3 / k1));
   }
-  smooth_col(T, nc, nt, TH_rate, tp.thermo_rate_smoothing_radius);
+  box_smooth(T, nc, nt, TH_rate, tp.thermo_rate_smoothing_radius);
   spline_table_lines(zt, nt, T, nc, out->d2thermodynamics_dz2_table);
-  // ---- recombination time and the scalars derived from it, th.cpp:1000-1060 ----
+  // ---- recombination = maximum of the visibility function below z = 2000, located by the parabola through the three nodes around it ----
+  auto G = [&](int i) { return T[(size_t)i * nc + TH_g]; };
   int it = nt - 1;
-  while (zt[it] > Z_REC_MAX) it--;
-  if (T[(size_t)(it + 1) * nc + TH_g] > T[(size_t)it * nc + TH_g])
-    return bail(fail_msg(CPT_ERR_RUNTIME, "found a recombination redshift greater or equal to the maximum value imposed in thermodynamics.h, z_rec_max=%g", Z_REC_MAX));
-  while (T[(size_t)(it + 1) * nc + TH_g] < T[(size_t)it * nc + TH_g]) it--;
-  const double g_max = T[(size_t)it * nc + TH_g];
-  const int index_tau_max = it;
-  out->z_rec = zt[it + 1] + 0.5 * (zt[it + 1] - zt[it]) * (T[(size_t)it * nc + TH_g] - 1. * T[(size_t)(it + 2) * nc + TH_g]) /
-                                (T[(size_t)it * nc + TH_g] - 2. * T[(size_t)(it + 1) * nc + TH_g] + T[(size_t)(it + 2) * nc + TH_g]);
-  if (out->z_rec + cp.smallest_allowed_variation >= Z_REC_MAX || out->z_rec - cp.smallest_allowed_variation <= Z_REC_MIN)
-    return bail(fail_msg(CPT_ERR_RUNTIME, "recombination redshift %g outside [%g, %g]", out->z_rec, Z_REC_MIN, Z_REC_MAX));
+  while (zt[it] > kZRecMax) it--;
+  if (G(it + 1) > G(it)) return bail(fail_msg(CPT_ERR_RUNTIME, "found a recombination redshift greater or equal to the maximum value imposed in thermodynamics.h, z_rec_max=%g", kZRecMax));
+  while (G(it + 1) < G(it)) it--;
+  const int i_peak = it;
+  const double g_peak = G(it);
+  out->z_rec = zt[it + 1] + 0.5 * (zt[it + 1] - zt[it]) * (G(it) - G(it + 2)) / (G(it) - 2. * G(it + 1) + G(it + 2));
+  if (out->z_rec + cp.smallest_allowed_variation >= kZRecMax || out->z_rec - cp.smallest_allowed_variation <= kZRecMin)
+    return bail(fail_msg(CPT_ERR_RUNTIME, "recombination redshift %g outside [%g, %g]", out->z_rec, kZRecMin, kZRecMax));
   if ((rc = B.tau_of_z(out->z_rec, &out->tau_rec)) || (rc = B.at_tau(out->tau_rec))) return bail(rc);
   out->rs_rec = B.row[bg->index_bg_rs];
-  const double da_rec = B.row[bg->index_bg_ang_distance];
-  out->ra_rec = da_rec * (1. + out->z_rec) / cp.a_today;
+  out->ra_rec = B.row[bg->index_bg_ang_distance] * (1. + out->z_rec) / cp.a_today;
   out->angular_rescaling = out->ra_rec / (bg->conformal_age - out->tau_rec);
-  // free streaming time, th.cpp:1065-1078
-  double tau;
-  if ((rc = B.tau_of_z(zt[it], &tau))) return bail(rc);
-  while ((1. / T[(size_t)it * nc + TH_dkappa] / tau < tp.radiation_streaming_trigger_tau_c_over_tau) && (it > 0)) {
-    it--;
-    if ((rc = B.tau_of_z(zt[it], &tau))) return bail(rc);
+  // time after which photons free-stream: 1 / kappa' exceeds the trigger fraction of tau (searched from the visibility peak down in z)
+  {
+    double tau_here;
+    if ((rc = B.tau_of_z(zt[it], &tau_here))) return bail(rc);
+    while (it > 0 && 1. / T[(size_t)it * nc + TH_dkappa] / tau_here < tp.radiation_streaming_trigger_tau_c_over_tau) {
+      it--;
+      if ((rc = B.tau_of_z(zt[it], &tau_here))) return bail(rc);
+    }
+    out->tau_free_streaming = tau_here;
   }
-  out->tau_free_streaming = tau;
-  // z_star, z_d (th.cpp:1130-1175)
-  it = 0;
-  while ((T[(size_t)it * nc + TH_exp_m_kappa] > 1. / E_) && (it < nt)) it++;
-  out->z_star = zt[it - 1] + (1. / E_ - T[(size_t)(it - 1) * nc + TH_exp_m_kappa]) / (T[(size_t)it * nc + TH_exp_m_kappa] - T[(size_t)(it - 1) * nc + TH_exp_m_kappa]) * (zt[it] - zt[it - 1]);
-  it = 0;
-  while ((T[(size_t)it * nc + TH_tau_d] < 1.) && (it < nt)) it++;
-  out->z_d = zt[it - 1] + (1. - T[(size_t)(it - 1) * nc + TH_tau_d]) / (T[(size_t)it * nc + TH_tau_d] - T[(size_t)(it - 1) * nc + TH_tau_d]) * (zt[it] - zt[it - 1]);
-  // visibility cut, th.cpp:1215-1222
-  it = index_tau_max;
-  while ((T[(size_t)it * nc + TH_g] > g_max * tp.neglect_CMB_sources_below_visibility) && (it > 0)) it--;
+  // redshifts of unit optical depth (z_star) and unit drag depth (z_d), by linear interpolation between nodes
+  auto crossing = [&](int col, double level, bool falling) {
+    int i = 0;
+    while (i < nt && (falling ? T[(size_t)i * nc + col] > level : T[(size_t)i * nc + col] < level)) i++;
+    const double v0 = T[(size_t)(i - 1) * nc + col], v1 = T[(size_t)i * nc + col];
+    return zt[i - 1] + (level - v0) / (v1 - v0) * (zt[i] - zt[i - 1]);
+  };
+  out->z_star = crossing(TH_exp_m_kappa, 1. / kEuler, true);
+  out->z_d = crossing(TH_tau_d, 1., false);
+  // time before which the CMB sources are negligible: visibility below a fraction of its peak value
+  it = i_peak;
+  while (it > 0 && G(it) > g_peak * tp.neglect_CMB_sources_below_visibility) it--;
   if ((rc = B.tau_of_z(zt[it], &out->tau_cut))) return bail(rc);
-  out->YHe = tp.YHe; out->n_e = re.Nnow; out->z_reionization = z_reionization; out->tau_reionization = tau_reionization;
+  out->YHe = tp.YHe; out->n_e = model.nH0(); out->z_reionization = z_reionization; out->tau_reionization = tau_reionization;
   out->index_th_xe = TH_xe; out->index_th_dkappa = TH_dkappa; out->index_th_tau_d = TH_tau_d; out->index_th_ddkappa = TH_ddkappa;
   out->index_th_dddkappa = TH_dddkappa; out->index_th_exp_m_kappa = TH_exp_m_kappa; out->index_th_g = TH_g; out->index_th_dg = TH_dg;
   out->index_th_ddg = TH_ddg; out->index_th_Tb = TH_Tb; out->index_th_wb = TH_wb; out->index_th_cb2 = TH_cb2; out->index_th_rate = TH_rate;

@@ -8,7 +8,7 @@
 #include <cstddef>
 #include <vector>
 
-namespace cpt_host {
+namespace orc_host {
 
 // ---- ndf15: ev.cpp:62-705 (+ numjac :1213-1539 in its dense mode, dense LU :1001-1064) ----
 struct Ndf {
@@ -396,4 +396,4 @@ int ndf15(F&& f, O&& output, double t0, double tfinal, double* y_inout, const in
   return 0;
 }
 
-}  // namespace cpt_host
+}  // namespace orc_host

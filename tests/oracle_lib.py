@@ -191,3 +191,76 @@ def sigma(k, pk, R, k_per_decade=80.0):
     k = np.ascontiguousarray(k, dtype=np.float64); pk = np.ascontiguousarray(pk, dtype=np.float64)
     assert L.orc_sigma(dptr(k), dptr(pk), k.size, float(R), float(k_per_decade), C.byref(out)) == 0
     return out.value
+
+
+# ---- the bit-exact restatement of the reference's background / thermodynamics modules (oracle/restate/host/) ----
+# Same C structs as the product's host library (include/cpt_host.h), entry points prefixed orc_host_.
+def _host_api():
+    from classpp_public_amd import hostlib as H
+    L = lib()
+    L.orc_host_error.restype = C.c_char_p
+    L.orc_host_cosmo_defaults.argtypes = [C.POINTER(H.CptCosmoParams)]
+    L.orc_host_cosmo_defaults.restype = None
+    L.orc_host_background.argtypes = [C.POINTER(H.CptCosmoParams), C.POINTER(H.CptBackground)]
+    L.orc_host_background_free.argtypes = [C.POINTER(H.CptBackground)]
+    L.orc_host_background_free.restype = None
+    L.orc_host_thermo_defaults.argtypes = [C.POINTER(H.CptThermoParams)]
+    L.orc_host_thermo_defaults.restype = None
+    L.orc_host_thermodynamics.argtypes = [C.POINTER(H.CptCosmoParams), C.POINTER(H.CptThermoParams), C.POINTER(H.CptBackground), C.POINTER(H.CptThermo)]
+    L.orc_host_thermo_free.argtypes = [C.POINTER(H.CptThermo)]
+    L.orc_host_thermo_free.restype = None
+    L.orc_host_set_background_rtol.argtypes = [_d]
+    L.orc_host_set_background_rtol.restype = None
+    return L, H
+
+
+def _host_check(L, rc):
+    if rc != 0:
+        raise ValueError(L.orc_host_error().decode())
+
+
+def host_background(inp, p=None, rtol=None):
+    """the oracle's background table (bit-exact restatement of the reference at rtol = 1e-6, its own tolerance)"""
+    L, H = _host_api()
+    p = p or H.cosmo_params(inp)
+    bg = H.CptBackground()
+    if rtol is not None:
+        L.orc_host_set_background_rtol(float(rtol))
+    try:
+        _host_check(L, L.orc_host_background(C.byref(p), C.byref(bg)))
+    finally:
+        L.orc_host_set_background_rtol(1e-6)
+    n, m = bg.bt_size, bg.bg_size
+    out = {"bg.bt_size": n, "bg.bg_size": m,
+           "bg.tau_table": np.ctypeslib.as_array(bg.tau_table, (n,)).copy(), "bg.z_table": np.ctypeslib.as_array(bg.z_table, (n,)).copy(),
+           "bg.background_table": np.ctypeslib.as_array(bg.background_table, (n, m)).copy(),
+           "bg.d2background_dtau2_table": np.ctypeslib.as_array(bg.d2background_dtau2_table, (n, m)).copy()}
+    for name, _ in H.CptBackground._fields_:
+        if name.startswith("index_bg_"):
+            out["bg." + name] = getattr(bg, name)
+    for name in ("conformal_age", "age", "Neff", "Omega0_m", "Omega0_r", "Omega0_de"):
+        out["bg." + name] = getattr(bg, name)
+    L.orc_host_background_free(C.byref(bg))
+    return out
+
+
+def host_thermodynamics(inp, cp=None, tp=None):
+    L, H = _host_api()
+    cp = cp or H.cosmo_params(inp)
+    tp = tp or H.thermo_params(inp)
+    bg = H.CptBackground()
+    _host_check(L, L.orc_host_background(C.byref(cp), C.byref(bg)))
+    th = H.CptThermo()
+    rc = L.orc_host_thermodynamics(C.byref(cp), C.byref(tp), C.byref(bg), C.byref(th))
+    L.orc_host_background_free(C.byref(bg))
+    _host_check(L, rc)
+    n, m = th.tt_size, th.th_size
+    out = {"th.tt_size": n, "th.th_size": m, "th.z_table": np.ctypeslib.as_array(th.z_table, (n,)).copy(),
+           "th.thermodynamics_table": np.ctypeslib.as_array(th.thermodynamics_table, (n, m)).copy(),
+           "th.d2thermodynamics_dz2_table": np.ctypeslib.as_array(th.d2thermodynamics_dz2_table, (n, m)).copy()}
+    for c in H._TH_COLS:
+        out["th.index_th_" + c] = getattr(th, "index_th_" + c)
+    for s in H._TH_SCALARS:
+        out["th." + s] = getattr(th, s)
+    L.orc_host_thermo_free(C.byref(th))
+    return out

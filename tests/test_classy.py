@@ -169,13 +169,17 @@ def test_scenario_host_side_equals_the_reference(cfg):
     c = classy.Class(_pars(cfg))
     c.compute(["thermodynamics"])
     r = c._runs["s"]
-    assert np.array_equal(r.inp.k, ref["pt.k"])                      # bit-exact sampling in k
+    # the grid rules are the reference's (bit-exact on the reference's tables, tests/test_host_grids.py); fed with this library's own
+    # background / thermodynamics they give the same number of points, values within the reference's integration error (3e-6 in tau,
+    # tests/test_host_cosmo.py)
+    assert r.inp.k.shape == ref["pt.k"].shape and np.max(np.abs(r.inp.k / ref["pt.k"] - 1)) < 5e-6
     assert c.h() == float(ref["pba.h"][0])
-    for name, get in (("th.z_reionization", c.z_reio), ("th.tau_reionization", c.tau_reio), ("th.z_rec", c.z_rec), ("bg.age", c.age),
-                      ("bg.conformal_age", c.conformal_age), ("bg.Neff", c.Neff), ("bg.Omega0_m", c.Omega_m)):
+    for name, get, tol in (("th.z_reionization", c.z_reio, 1e-14), ("th.tau_reionization", c.tau_reio, 3e-6), ("th.z_rec", c.z_rec, 2e-6),
+                           ("bg.age", c.age, 2e-6), ("bg.conformal_age", c.conformal_age, 2e-6), ("bg.Neff", c.Neff, 1e-12), ("bg.Omega0_m", c.Omega_m, 1e-14)):
         if name in ref.files:
-            assert get() == float(ref[name].reshape(-1)[0]), name    # bit-exact host modules
-    assert c.theta_s_100() == 100. * float(ref["th.rs_rec"][0]) / float(ref["th.ra_rec"][0])
+            want = float(ref[name].reshape(-1)[0])
+            assert abs(get() - want) <= tol * abs(want), name
+    assert abs(c.theta_s_100() / (100. * float(ref["th.rs_rec"][0]) / float(ref["th.ra_rec"][0])) - 1) < 2e-6
 
 
 @pytest.mark.gpu
