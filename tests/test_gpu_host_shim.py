@@ -64,13 +64,16 @@ def test_shim_modules(tmp_path, cfg):
     rc, out = run_demo(exe, ipath, opath)
     assert rc == 0, out
     print(out)
-    with open(opath, "rb") as f:
-        hdr = np.frombuffer(f.read(32), dtype=np.int32)
-        nk, nkcl, ntau, ntp, nq, nl, ntt = [int(x) for x in hdr[:7]]
-        k = np.frombuffer(f.read(8 * nk)); tau = np.frombuffer(f.read(8 * ntau))
-        src = np.frombuffer(f.read(8 * ntp * ntau * nk)).reshape(ntp, ntau, nk)
-        q = np.frombuffer(f.read(8 * nq)); l = np.frombuffer(f.read(4 * nl), dtype=np.int32)
-        tr = np.frombuffer(f.read(8 * ntt * nl * nq)).reshape(ntt, nl, nq)
+    def read_out(path):
+        with open(path, "rb") as f:
+            hdr = np.frombuffer(f.read(32), dtype=np.int32)
+            nk, nkcl, ntau, ntp, nq, nl, ntt = [int(x) for x in hdr[:7]]
+            k = np.frombuffer(f.read(8 * nk)); tau = np.frombuffer(f.read(8 * ntau))
+            src = np.frombuffer(f.read(8 * ntp * ntau * nk)).reshape(ntp, ntau, nk)
+            q = np.frombuffer(f.read(8 * nq)); l = np.frombuffer(f.read(4 * nl), dtype=np.int32)
+            tr = np.frombuffer(f.read(8 * ntt * nl * nq)).reshape(ntt, nl, nq)
+        return nkcl, k, tau, src, q, l, tr
+    nkcl, k, tau, src, q, l, tr = read_out(opath)
     d = inp.d
     assert np.array_equal(k, d["pt.k"]) and nkcl == int(d["pt.k_size_cl"][0]) and np.array_equal(tau, d["pt.tau_sampling"])
     assert np.array_equal(q, d["tr.q"]) and np.array_equal(l, d["tr.l"])
@@ -80,12 +83,17 @@ def test_shim_modules(tmp_path, cfg):
     scale[scale == 0] = 1
     assert np.max(np.abs(tr - ref) / scale) < 1e-3  # coarse tau sampling of `small` amplifies the source noise
     if not inp.config.has_ncdm:
-        # the same through cpt::HostTables: background and thermodynamics recomputed on the host from parameters (bit-identical
-        # tables => bit-identical outputs)
+        # the same through cpt::HostTables: background and thermodynamics recomputed on the host from parameters by the library's own
+        # integrators (tables within the reference's integration error of the reference's, tests/test_host_cosmo.py): same grid
+        # sizes, grids within 5e-6, transfer functions within the same bound of the reference as above
         opath2 = str(tmp_path / "out2.bin")
         rc, out = run_demo(exe, ipath, opath2, flag=3)
         assert rc == 0, out
-        assert open(opath2, "rb").read() == open(opath, "rb").read()
+        nkcl2, k2, tau2, src2, q2, l2, tr2 = read_out(opath2)
+        assert nkcl2 == nkcl and k2.shape == k.shape and tau2.shape == tau.shape and q2.shape == q.shape and np.array_equal(l2, l)
+        for a, b in ((k2, k), (tau2, tau), (q2, q)):
+            assert np.max(np.abs(a / b - 1)) < 5e-6
+        assert np.max(np.abs(tr2 - ref) / scale) < 1e-3
     if cfg != "small":
         return
     # error mapping
