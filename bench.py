@@ -31,7 +31,7 @@ sys.path.insert(0, ROOT)
 
 from classpp_public_amd.backend import Backend  # noqa: E402
 from classpp_public_amd.inputs import Inputs  # noqa: E402
-from classpp_public_amd.sharded import GpuCompute, densify_k, sharded_step  # noqa: E402
+from classpp_public_amd.sharded import GpuCompute, densify_k, sharded_step, sharded_step_cabi  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 BYTES_PER_FEVAL = 800  # 384 B background row gather + 416 B thermodynamics row gather per RHS evaluation
@@ -91,6 +91,10 @@ def main():
                     help="torch.distributed backend: nccl (= RCCL over xGMI, one GPU per rank; the measured configuration) or gloo "
                          "(rehearsal of the multi-process path on a box with fewer GPUs than ranks: ranks share GPUs, the two "
                          "exchanges are staged through host memory; not a performance number)")
+    ap.add_argument("--collectives", default="torch", choices=["torch", "cabi"],
+                    help="N > 1: who runs the two exchanges - torch.distributed (nccl = RCCL) on torch tensors, or the library itself behind "
+                         "the C ABI (cpt_allgather_sources / cpt_gather_transfer, RCCL on the handle's stream; torch.distributed then only "
+                         "carries the rendezvous over gloo)")
     ap.add_argument("--from-parameters", action="store_true",
                     help="compute the spline tables and grids on the host from the cosmological parameters (classpp_public_amd/pipeline.py) "
                          "instead of loading them from tests/golden; the host stage is timed and reported as stage_ms.host_tables")
@@ -111,10 +115,12 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if args.backend == "gloo":
+        if args.backend == "gloo" or args.collectives == "cabi":
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if args.collectives == "cabi":
+            xdev = torch.device("cpu")   # (only the timing all_reduce goes through torch.distributed)
 
     if args.config is None:
         args.config = "explanatory_mpk" if world == 1 else "ncdm_k3000"
@@ -127,6 +133,10 @@ def main():
     host_tables_ms = (time.perf_counter() - t_host0) * 1e3 if args.from_parameters else None
     be = Backend(inp, device)
     comp = GpuCompute(be)
+    if world > 1 and args.collectives == "cabi":
+        ids = [be.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(ids, src=0)
+        be.comm_init(ids[0], rank, world)
     weak = args.weak and world > 1
     k_all = densify_k(inp.k, world) if weak else np.ascontiguousarray(inp.k, dtype=np.float64)
     k_size_cl = (inp.k_size_cl - 1) * world + 1 if weak else inp.k_size_cl
@@ -147,7 +157,10 @@ def main():
             # one library call (cpt_step): every stage enqueued back to back, sources and tables stay in HBM, one synchronisation
             r = be.step(lensing=lens_args, want_pk=has_pk)
             return (r["cl_lensed"] if has_lensing else r["cl"]), r["pk"]
-        out, _ = sharded_step(comp, k_all, inp.l, rank, world, device, k_size_cl, exchange_device=xdev)
+        if args.collectives == "cabi":
+            out, comp.stats = sharded_step_cabi(be, k_all, inp.l, rank, world, k_size_cl)
+        else:
+            out, _ = sharded_step(comp, k_all, inp.l, rank, world, device, k_size_cl, exchange_device=xdev)
         if rank == 0:   # the same closing steps as on one GPU: C_l (+ lensing), P(k) from the gathered sources now resident in the handle
             cl = be.cl(out)
             if has_lensing:
@@ -220,7 +233,7 @@ def main():
                                        ("; lensed C_l" if has_lensing else "") +
                                        ("" if world == 1 else ("; k grid densified %dx and sharded round-robin" % world if weak else
                                                                "; the fixed k grid sharded round-robin over %d ranks" % world))),
-                       "parallelism": ("k-sharded x%d, l-sharded transfer, 2 %s exchanges" % (world, "RCCL" if args.backend == "nccl" else "gloo (REHEARSAL: ranks share GPUs)")) if world > 1 else "1 GPU",
+                       "parallelism": ("k-sharded x%d, l-sharded transfer, 2 %s exchanges" % (world, "RCCL (inside the library, C ABI)" if args.collectives == "cabi" else "RCCL (torch.distributed)" if args.backend == "nccl" else "gloo (REHEARSAL: ranks share GPUs)")) if world > 1 else "1 GPU",
                        "multi_gpu_note": "explanatory.ini / lcdm.ini: replicas only (all k-modes are resident on one GPU; wall time = the longest mode's "
                                          "dependency chain, SURVEY S8e); the sharded path is measured on ncdm_k3000 (BASELINE configs[2])"},
             "stage_ms": {"perturb_kernel": k_ms, "los_kernel": t_ms, "step_wall": ms_step, "gpu_span": gpu_ms,

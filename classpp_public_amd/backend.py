@@ -145,6 +145,45 @@ class Backend:
         self._check(self.lib.cpt_step(self.h, C.byref(st["io"])))
         return st
 
+    # ---- multi-GPU: the two exchanges of the sharded path as RCCL operations behind the C ABI (csrc/cpt_comm.hip) ----
+    def comm_unique_id(self):
+        """rank 0: the id every rank passes to comm_init (distribute the 128 bytes by any means)"""
+        buf = C.create_string_buffer(128)
+        rc = self.lib.cpt_comm_get_unique_id(buf)
+        if rc != capi.CPT_OK:
+            raise CptError(self.lib.cpt_create_error().decode())
+        return buf.raw
+
+    def comm_init(self, unique_id, rank, world):
+        self._check(self.lib.cpt_comm_init(self.h, C.c_char_p(unique_id), int(rank), int(world)))
+        self.rank, self.world = int(rank), int(world)
+
+    def allgather_sources(self, nk_all, ntau=None):
+        """every rank has integrated its k shard (perturb_solve(k=k_all[rank::world], want_sources=False)): afterwards the full sources are resident"""
+        self._check(self.lib.cpt_allgather_sources(self.h, int(nk_all), int(self.inp.ntau if ntau is None else ntau)))
+
+    def gather_transfer(self, local, nl_all):
+        """local: device [tt][nl_local][nq] of this rank's multipoles -> on rank 0 the full device table [tt][nl_all][nq], None elsewhere"""
+        assert local.is_cuda and local.is_contiguous()
+        out = torch.empty((local.shape[0], int(nl_all), local.shape[2]), dtype=torch.float64, device=self.device) if self.rank == 0 else None
+        self._fence()
+        self._check(self.lib.cpt_gather_transfer(self.h, C.c_void_p(local.data_ptr()), int(nl_all), int(local.shape[2]),
+                                                 C.c_void_p(out.data_ptr()) if out is not None else None))
+        return out
+
+    def dbg_pad_rows(self, x, n_max):
+        out = torch.empty((x.shape[0], n_max, x.shape[2]), dtype=torch.float64, device=self.device)
+        self._fence()
+        self._check(self.lib.cpt_dbg_pad_rows(self.h, C.c_void_p(x.data_ptr()), C.c_void_p(out.data_ptr()), x.shape[0], x.shape[1], n_max, x.shape[2]))
+        return out
+
+    def dbg_uninterleave(self, blocks, n_all):
+        world, nb, n_max, ninner = blocks.shape
+        out = torch.empty((nb, n_all, ninner), dtype=torch.float64, device=self.device)
+        self._fence()
+        self._check(self.lib.cpt_dbg_uninterleave(self.h, C.c_void_p(blocks.data_ptr()), C.c_void_p(out.data_ptr()), world, nb, n_max, n_all, ninner))
+        return out
+
     def step_gpu_ms(self):
         """milliseconds from the first to the last kernel of the last step() on the library's stream"""
         return self.kernel_ms(3)[0]

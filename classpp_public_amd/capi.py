@@ -107,6 +107,8 @@ EXPORTS = [
     "cpt_transfer_batch", "cpt_get_sources", "cpt_last_kernel_ms", "cpt_last_transfer_work",
     "cpt_dbg_lookup", "cpt_dbg_derivs", "cpt_dbg_solve", "cpt_dbg_bessel", "cpt_cl_batch", "cpt_pk_linear", "cpt_sigma", "cpt_pk_cb_linear", "cpt_sigma_cb",
     "cpt_lensing_l_size", "cpt_lensing_batch", "cpt_step",
+    "cpt_comm_get_unique_id", "cpt_comm_init", "cpt_comm_destroy", "cpt_allgather_sources", "cpt_gather_transfer",
+    "cpt_dbg_pad_rows", "cpt_dbg_uninterleave",
 ]
 
 _lib = None
@@ -160,6 +162,20 @@ def lib():
     L.cpt_lensing_batch.restype = _i
     L.cpt_step.argtypes = [vp, C.POINTER(CptStepIo)]
     L.cpt_step.restype = _i
+    L.cpt_comm_get_unique_id.argtypes = [vp]
+    L.cpt_comm_get_unique_id.restype = _i
+    L.cpt_comm_init.argtypes = [vp, vp, _i, _i]
+    L.cpt_comm_init.restype = _i
+    L.cpt_comm_destroy.argtypes = [vp]
+    L.cpt_comm_destroy.restype = _i
+    L.cpt_allgather_sources.argtypes = [vp, _i, _i]
+    L.cpt_allgather_sources.restype = _i
+    L.cpt_gather_transfer.argtypes = [vp, vp, _i, _i, vp]
+    L.cpt_gather_transfer.restype = _i
+    L.cpt_dbg_pad_rows.argtypes = [vp, vp, vp, _i, _i, _i, _i]
+    L.cpt_dbg_pad_rows.restype = _i
+    L.cpt_dbg_uninterleave.argtypes = [vp, vp, vp, _i, _i, _i, _i, _i]
+    L.cpt_dbg_uninterleave.restype = _i
     L.cpt_dbg_lookup.argtypes = [vp, _pd, _i, _pd]
     L.cpt_dbg_lookup.restype = _i
     L.cpt_dbg_derivs.argtypes = [vp, _d, _d, _i, _i, _i, _pd, _pd, pi]

@@ -316,6 +316,9 @@ void cpt_destroy(cpt_handle* h) {
     if (tm.a) (void)hipEventDestroy(tm.a);
     if (tm.b) (void)hipEventDestroy(tm.b);
   }
+  (void)cpt_comm_destroy(h);
+  if (h->d_xsend) (void)hipFree(h->d_xsend);
+  if (h->d_xrecv) (void)hipFree(h->d_xrecv);
   if (h->d_clw) (void)hipFree(h->d_clw);
   if (h->d_pk_k) (void)hipFree(h->d_pk_k);
   cpt_pin_reset(h);

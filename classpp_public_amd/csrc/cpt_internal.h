@@ -122,6 +122,11 @@ struct cpt_handle {
   std::vector<double> geo_cl_q; double geo_cl_sp[4] = {0, 0, 0, 0}; bool geo_cl_valid = false;
   double* d_pk_k = nullptr;
   size_t pk_k_cap = 0;
+  // multi-GPU (cpt_comm.hip): RCCL communicator of this rank (null: single GPU) and the padded exchange buffers
+  void* comm = nullptr;
+  int comm_rank = 0, comm_world = 1;
+  double *d_xsend = nullptr, *d_xrecv = nullptr;
+  size_t xsend_cap = 0, xrecv_cap = 0;
 };
 
 // stage `bytes` of host memory in the pinned arena and return the staged copy (valid until the next call on the handle begins)

@@ -121,3 +121,15 @@ class GpuCompute:
 
     def transfer(self, sources_full, k_all, l_subset, k_size_cl):
         return self.be.transfer(sources_full.contiguous(), k=k_all, l=l_subset, k_size_cl=k_size_cl)
+
+
+def sharded_step_cabi(be, k_all, l_all, rank, world, k_size_cl=None):
+    """The same pass with the two exchanges inside the library (include/cpt.h: cpt_allgather_sources, cpt_gather_transfer - RCCL over
+    xGMI on the handle's stream): nothing but the shard bookkeeping is left to the host language.  `be` must have joined a
+    communicator (Backend.comm_init).  Returns the full transfer table on rank 0 (None elsewhere)."""
+    nk, nl = len(k_all), len(l_all)
+    my_k, my_l = shard_indices(nk, rank, world), shard_indices(nl, rank, world)
+    _, stats, _ = be.perturb_solve(k=k_all[my_k], want_sources=False)
+    be.allgather_sources(nk)
+    tr_local = be.transfer(None, k=k_all, l=l_all[my_l], k_size_cl=nk if k_size_cl is None else k_size_cl)
+    return be.gather_transfer(tr_local, nl), stats

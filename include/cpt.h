@@ -281,6 +281,26 @@ typedef struct cpt_step_io {
 } cpt_step_io;
 int cpt_step(cpt_handle* h, const cpt_step_io* io);
 
+/* ---- multi-GPU: one process per GPU, RCCL over xGMI on the handle's stream -------------------------------------
+ * The path shards in two stages with one exchange after each (classpp_public_amd/csrc/cpt_comm.hip):
+ *   rank r integrates k_all[r], k_all[r + W], ...  (cpt_perturb_solve_batch on that subset, sources_dev = NULL)
+ *   cpt_allgather_sources        -> every rank holds the full k-major sources, resident
+ *   rank r computes the multipoles l_all[r], l_all[r + W], ...  (cpt_transfer_batch with sources_dev = NULL and that l subset)
+ *   cpt_gather_transfer          -> rank 0 holds transfer_[tt][nl_all][nq]
+ * The reference has no counterpart (one process, a thread pool: pm.cpp:668-718, tm.cpp:287-318 are its two parallel loops).
+ * Rendezvous is the caller's business: rank 0 obtains an id, every rank receives its CPT_COMM_ID_BYTES by any means (a file, MPI,
+ * torch.distributed's store) and joins.  RCCL is bound at run time: librccl.so of the process (CPT_RCCL_PATH overrides). */
+#define CPT_COMM_ID_BYTES 128
+int cpt_comm_get_unique_id(void* id /* CPT_COMM_ID_BYTES bytes, host */);
+int cpt_comm_init(cpt_handle* h, const void* id, int rank, int world);   /* collective over the `world` ranks */
+int cpt_comm_destroy(cpt_handle* h);
+/* nk_all: size of the full k grid.  On entry the handle holds the sources of this rank's shard (its last cpt_perturb_solve_batch);
+ * on return those of all nk_all modes, in the order of k_all. */
+int cpt_allgather_sources(cpt_handle* h, int nk_all, int ntau);
+/* transfer_local_dev: device [tt_size][nl_local][nq] of this rank's multipoles; transfer_full_dev: device [tt_size][nl_all][nq],
+ * written on rank 0 only (may be NULL elsewhere) */
+int cpt_gather_transfer(cpt_handle* h, const double* transfer_local_dev, int nl_all, int nq, double* transfer_full_dev);
+
 /* Device-side copy of the resident sources into the reference layout [tp_size][ntau][nk] (device pointer). */
 int cpt_get_sources(cpt_handle* h, double* sources_dev);
 
@@ -306,6 +326,9 @@ int cpt_dbg_derivs(cpt_handle* h, double k, double tau, int tca_on, int rsa_on, 
  * factorisation; b[neq], x[neq] in the reference's index order (arrays of 64 doubles) */
 int cpt_dbg_solve(cpt_handle* h, double k, double tau, int tca_on, int rsa_on, int ufa_on, double hg, const double* b,
                   double* x);
+/* the packing / un-interleaving kernels of the two exchanges on caller-provided device buffers ([nbatch][n][ninner] blocks) */
+int cpt_dbg_pad_rows(cpt_handle* h, const double* in_dev, double* out_dev, int nbatch, int n_local, int n_max, int ninner);
+int cpt_dbg_uninterleave(cpt_handle* h, const double* blocks_dev, double* full_dev, int world, int nbatch, int n_max, int n_all, int ninner);
 /* flat spherical Bessel table phi[nl][nx], dphi[nl][nx] and chi_at_phimin[nl] as built for (l, xmax) */
 int cpt_dbg_bessel(cpt_handle* h, const int* l, int nl, double xmax, int* nx, double* phi, double* dphi,
                    double* chi_at_phimin, int cap_nx);

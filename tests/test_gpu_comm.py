@@ -1,0 +1,77 @@
+"""The multi-GPU exchanges behind the C ABI (include/cpt.h, classpp_public_amd/csrc/cpt_comm.hip) as far as ONE GPU can check them:
+  * the packing / un-interleaving kernels of both exchanges against numpy, for 2, 3 and 8 simulated ranks;
+  * the whole sharded pass through a real RCCL communicator of world size 1 (init, all-gather, gather, destroy) against the
+    unsharded pass;
+  * a simulated world of 2 on one device: both ranks' shards run in turn, the blocks an all-gather would deliver are assembled by hand,
+    un-interleaved by the library's kernel, and must reproduce the unsharded sources and transfer functions.
+Runs with more than one rank need one GPU per process (RCCL refuses two ranks on one device): that is the driver's scaling run."""
+import numpy as np
+import pytest
+import torch
+
+from classpp_public_amd.backend import Backend
+from classpp_public_amd.inputs import Inputs
+from classpp_public_amd.sharded import shard_indices, sharded_step_cabi
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def be():
+    b = Backend(Inputs("small"), "cuda:0")
+    yield b
+    b.close()
+
+
+@pytest.mark.parametrize("world", [2, 3, 8])
+def test_pad_and_uninterleave_kernels(be, world):
+    rng = np.random.default_rng(world)
+    nb, n_all, ninner = 3, 37, 11
+    full = rng.standard_normal((nb, n_all, ninner))
+    n_max = (n_all + world - 1) // world
+    blocks = []
+    for r in range(world):
+        idx = shard_indices(n_all, r, world)
+        local = torch.from_numpy(np.ascontiguousarray(full[:, idx, :])).cuda()
+        padded = be.dbg_pad_rows(local, n_max)
+        want = np.zeros((nb, n_max, ninner)); want[:, : idx.size, :] = full[:, idx, :]
+        assert np.array_equal(padded.cpu().numpy(), want)
+        blocks.append(padded)
+    got = be.dbg_uninterleave(torch.stack(blocks).contiguous(), n_all)
+    assert np.array_equal(got.cpu().numpy(), full)
+
+
+def test_world_of_one_through_rccl(be):
+    inp = be.inp
+    src, _, _ = be.perturb_solve()
+    tr = be.transfer(None).cpu().numpy()
+    be.comm_init(be.comm_unique_id(), 0, 1)
+    try:
+        out, stats = sharded_step_cabi(be, inp.k, inp.l, 0, 1, inp.k_size_cl)
+        assert np.array_equal(out.cpu().numpy(), tr)
+        assert np.array_equal(be.get_sources(inp.ntau, inp.nk).cpu().numpy(), src.cpu().numpy())
+    finally:
+        be.lib.cpt_comm_destroy(be.h)
+
+
+def test_simulated_world_of_two_on_one_device(be):
+    inp = be.inp
+    world, nk, nl = 2, inp.nk, inp.l.size
+    src_ref, _, _ = be.perturb_solve()
+    tr_ref = be.transfer(None).cpu().numpy()
+    # stage A on every "rank", exchange 1 assembled by hand (what ncclAllGather delivers: the padded k-major blocks, rank-major)
+    n_max = (nk + world - 1) // world
+    blocks = []
+    for r in range(world):
+        local, _, _ = be.perturb_solve(k=inp.k[shard_indices(nk, r, world)])          # [tp][ntau][nk_local]
+        blocks.append(be.dbg_pad_rows(local.permute(0, 2, 1).contiguous(), n_max))   # k-major, padded
+    full_kmajor = be.dbg_uninterleave(torch.stack(blocks).contiguous(), nk)           # [tp][nk][ntau]
+    full = full_kmajor.permute(0, 2, 1).contiguous()
+    assert np.array_equal(full.cpu().numpy(), src_ref.cpu().numpy())                 # modes are independent units: bit for bit
+    # stage B on every "rank", exchange 2 by hand
+    l_max = (nl + world - 1) // world
+    tblocks = [be.dbg_pad_rows(be.transfer(full, l=inp.l[shard_indices(nl, r, world)]), l_max) for r in range(world)]
+    tr = be.dbg_uninterleave(torch.stack(tblocks).contiguous(), nl).cpu().numpy()
+    scale = np.max(np.abs(tr_ref), axis=-1, keepdims=True)
+    scale[scale == 0] = 1
+    assert np.array_equal(tr == 0, tr_ref == 0) and np.max(np.abs(tr - tr_ref) / scale) < 1e-10

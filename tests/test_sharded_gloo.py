@@ -91,3 +91,66 @@ def test_densify_and_shards_partition_the_grid():
     for world in (1, 2, 3, 8):
         idx = np.concatenate([shard_indices(d.size, r, world) for r in range(world)])
         assert sorted(idx.tolist()) == list(range(d.size))
+
+
+# ---- the HIP-shaped interface under real torch.distributed: sharded_step drives classpp_public_amd.sharded.GpuCompute, the class that
+#      wraps the HIP Backend on a GPU box, exactly as bench.py --gpus N does.  Here the Backend is a stand-in with the SAME methods and
+#      argument conventions (perturb_solve(k=...) -> (tensor, stats, status), transfer(sources, k=, l=, k_size_cl=)) computing with the
+#      oracle, so the plumbing between GpuCompute and Backend - keyword names, shapes, dtypes, contiguity - is what is under test. ----
+class BackendStandIn:
+    def __init__(self, inp):
+        self.inp = inp
+        self.calls = []
+
+    def perturb_solve(self, k=None, tau=None, want_sources=True):
+        import oracle_lib
+        assert tau is None and want_sources
+        k = np.ascontiguousarray(self.inp.k if k is None else k, dtype=np.float64)
+        src, stats, status, rc = oracle_lib.perturb(self.inp, k=k, threads=2)
+        assert rc == 0
+        self.calls.append(("perturb_solve", k.size))
+        return torch.from_numpy(src), stats, status
+
+    def transfer(self, sources=None, k=None, tau=None, q=None, l=None, k_size_cl=None):
+        assert sources is not None and sources.is_contiguous() and sources.dtype == torch.float64 and tau is None and q is None
+        assert tuple(sources.shape) == (self.inp.config.tp_size, self.inp.ntau, len(k))
+        self.calls.append(("transfer", len(l)))
+        return OracleCompute(self.inp).transfer(sources, k, l, k_size_cl)
+
+
+def _worker_gpu_shaped(rank, world, port, ret):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from classpp_public_amd.inputs import Inputs
+    from classpp_public_amd.sharded import GpuCompute, sharded_step
+    inp = Inputs("small")
+    k_all = np.ascontiguousarray(inp.k[::4])          # a FIXED grid, sharded (strong scaling, as bench.py --gpus N does by default)
+    be = BackendStandIn(inp)
+    out, full = sharded_step(GpuCompute(be), k_all, inp.l, rank, world, torch.device("cpu"), k_all.size)
+    ret["calls%d" % rank] = be.calls
+    if rank == 0:
+        ret["sharded"] = out.numpy()
+        ret["k_all"] = k_all
+    dist.destroy_process_group()
+
+
+def test_gpu_compute_interface_two_ranks():
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from classpp_public_amd.inputs import Inputs
+    from classpp_public_amd.sharded import GpuCompute, shard_indices, sharded_step
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    port = 29500 + ((os.getpid() + 7) % 1000)
+    mp.spawn(_worker_gpu_shaped, args=(2, port, ret), nprocs=2, join=True)
+    inp = Inputs("small")
+    k_all = ret["k_all"]
+    for r in range(2):   # each rank integrated its round-robin shard of the k grid and projected its shard of the multipoles
+        assert ret["calls%d" % r] == [("perturb_solve", shard_indices(k_all.size, r, 2).size), ("transfer", shard_indices(inp.l.size, r, 2).size)]
+    single, _ = sharded_step(GpuCompute(BackendStandIn(inp)), k_all, inp.l, 0, 1, torch.device("cpu"), k_all.size)
+    a, b = ret["sharded"], single.numpy()
+    scale = np.max(np.abs(b), axis=-1, keepdims=True)
+    scale[scale == 0] = 1
+    assert np.array_equal(a == 0, b == 0) and np.max(np.abs(a - b) / scale) < 1e-10
