@@ -94,11 +94,23 @@ PerturbationsModule::PerturbationsModule(const Inputs& in) {
   rc = cpt_create(&c, &in.tables, &h_);
   if (rc) { snprintf(error_message_, sizeof(error_message_), "%s", cpt_create_error()); raise(rc, error_message_); }
   const int nk = k_size_[0], ntp = c.tp_size;
+  shard_ = in.shard;
+  if (shard_.world < 1 || shard_.rank < 0 || shard_.rank >= shard_.world) raise(CPT_ERR_INVALID, "Shard: rank outside [0, world)");
   stats_ = xalloc<cpt_stepstat>(nk);
+  memset(stats_, 0, sizeof(cpt_stepstat) * nk);
   double* d_src = nullptr;
   const size_t nsrc = (size_t)ntp * tau_size_ * nk;
   if (hipMalloc((void**)&d_src, nsrc * sizeof(double)) != hipSuccess) raise(CPT_ERR_RUNTIME, "hipMalloc failed");
-  rc = cpt_perturb_solve_batch(h_, k_[0], nk, tau_sampling_, tau_size_, d_src, stats_, nullptr);
+  if (shard_.comm_id) {
+    // this rank's share of the k loop, then exchange 1: afterwards the handle holds the sources of every mode
+    rc = cpt_comm_init(h_, shard_.comm_id, shard_.rank, shard_.world);
+    std::vector<double> mine;
+    for (int i = shard_.rank; i < nk; i += shard_.world) mine.push_back(k_[0][i]);
+    if (!rc) rc = cpt_perturb_solve_batch(h_, mine.data(), (int)mine.size(), tau_sampling_, tau_size_, nullptr, stats_, nullptr);
+    if (!rc) rc = cpt_allgather_sources(h_, nk, tau_size_);
+    if (!rc) rc = cpt_get_sources(h_, d_src);
+  } else
+    rc = cpt_perturb_solve_batch(h_, k_[0], nk, tau_sampling_, tau_size_, d_src, stats_, nullptr);
   if (rc) {
     snprintf(error_message_, sizeof(error_message_), "%s", cpt_last_error(h_));
     (void)hipFree(d_src);
@@ -176,17 +188,41 @@ TransferModule::TransferModule(const Inputs& in, std::shared_ptr<const Perturbat
   const size_t ntr = (size_t)c.tt_size * nl * q_size_;
   double* d_tr = nullptr;
   if (hipMalloc((void**)&d_tr, ntr * sizeof(double)) != hipSuccess) raise(CPT_ERR_RUNTIME, "hipMalloc failed");
-  rc = cpt_transfer_batch(P.handle(), nullptr, P.k_[0], P.k_size_[0], P.k_size_cl_[0], P.tau_sampling_, P.tau_size_, q_, q_size_,
-                          l_, nl, d_tr);
-  if (rc) {
-    snprintf(error_message_, sizeof(error_message_), "%s", cpt_last_error(P.handle()));
-    (void)hipFree(d_tr);
-    raise(rc, error_message_);
-  }
   transfer_ = xalloc<double*>(1);
   transfer_[0] = xalloc<double>(ntr);
-  hipError_t e = hipMemcpy(transfer_[0], d_tr, ntr * sizeof(double), hipMemcpyDeviceToHost);
+  const Shard& sh = P.shard_;
+  hipError_t e = hipSuccess;
+  if (sh.comm_id) {
+    // this rank's share of the multipoles, then exchange 2: the full table lands on rank 0
+    std::vector<int> mine;
+    for (int i = sh.rank; i < nl; i += sh.world) mine.push_back(l_[i]);
+    const int nl_local = (int)mine.size();
+    double* d_local = nullptr;
+    if (hipMalloc((void**)&d_local, (size_t)c.tt_size * nl_local * q_size_ * sizeof(double)) != hipSuccess) { (void)hipFree(d_tr); raise(CPT_ERR_RUNTIME, "hipMalloc failed"); }
+    rc = cpt_transfer_batch(P.handle(), nullptr, P.k_[0], P.k_size_[0], P.k_size_cl_[0], P.tau_sampling_, P.tau_size_, q_, q_size_, mine.data(), nl_local, d_local);
+    if (!rc) rc = cpt_gather_transfer(P.handle(), d_local, nl, q_size_, sh.rank == 0 ? d_tr : nullptr);
+    if (!rc) {
+      if (sh.rank == 0) e = hipMemcpy(transfer_[0], d_tr, ntr * sizeof(double), hipMemcpyDeviceToHost);
+      else {   // the other ranks keep their own rows
+        memset(transfer_[0], 0, ntr * sizeof(double));
+        std::vector<double> local((size_t)c.tt_size * nl_local * q_size_);
+        e = hipMemcpy(local.data(), d_local, local.size() * sizeof(double), hipMemcpyDeviceToHost);
+        for (int t = 0; t < c.tt_size; t++)
+          for (int j = 0; j < nl_local; j++)
+            memcpy(transfer_[0] + ((size_t)t * nl + (sh.rank + (size_t)j * sh.world)) * q_size_, local.data() + ((size_t)t * nl_local + j) * q_size_, sizeof(double) * q_size_);
+      }
+    }
+    (void)hipFree(d_local);
+  } else {
+    rc = cpt_transfer_batch(P.handle(), nullptr, P.k_[0], P.k_size_[0], P.k_size_cl_[0], P.tau_sampling_, P.tau_size_, q_, q_size_,
+                            l_, nl, d_tr);
+    if (!rc) e = hipMemcpy(transfer_[0], d_tr, ntr * sizeof(double), hipMemcpyDeviceToHost);
+  }
   (void)hipFree(d_tr);
+  if (rc) {
+    snprintf(error_message_, sizeof(error_message_), "%s", cpt_last_error(P.handle()));
+    raise(rc, error_message_);
+  }
   if (e != hipSuccess) raise(CPT_ERR_RUNTIME, "hipMemcpy of the transfer functions failed");
 }
 

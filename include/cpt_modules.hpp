@@ -16,10 +16,21 @@
 
 namespace cpt {
 
+// One process per GPU: rank `rank` of `world` integrates the k-modes k_[rank], k_[rank + world], ... and projects the
+// multipoles l_[rank], l_[rank + world], ...; the two exchanges run inside libcpt.so (RCCL, include/cpt.h).  comm_id: the
+// CPT_COMM_ID_BYTES that rank 0 obtained from cpt_comm_get_unique_id() and handed to every rank (a file, MPI, any launcher).
+// After construction every rank's PerturbationsModule holds the FULL sources_ (the transfer stage needs every k); the full transfer_
+// table is assembled on rank 0, the other ranks keep their own multipoles (rows of the others are zero).
+struct Shard {
+  int rank = 0, world = 1;
+  const void* comm_id = nullptr;
+};
+
 struct Inputs {
   cpt_config config;
   cpt_tables tables;      // host pointers into the caller's (reference modules') tables; only read during construction
   cpt_grid_params grid;
+  Shard shard;            // default: single GPU
 };
 
 // Background + thermodynamics tables computed on the host (include/cpt_host.h) instead of taken from the
@@ -67,8 +78,10 @@ class PerturbationsModule {
 
  private:
   cpt_handle* h_ = nullptr;
-  cpt_stepstat* stats_ = nullptr;
+  cpt_stepstat* stats_ = nullptr;   // (sharded: the counters of this rank's modes, in the order k_[rank], k_[rank + world], ...)
   int* k_size_cmb_ = nullptr;
+  Shard shard_;
+  friend class TransferModule;
 };
 
 class TransferModule {

@@ -52,6 +52,13 @@ int main(int argc, char** argv) {
     host_tables = std::make_unique<cpt::HostTables>(cosmo, thermo);
     host_tables->fill(in);
   }
+  // flag 4: the sharded constructors (cpt::Shard) with a communicator of ONE rank - everything a multi-GPU run executes
+  // (cpt_comm_init, shard of the k loop, RCCL all-gather, shard of the multipoles, RCCL gather) on the one GPU a test box has
+  char comm_id[CPT_COMM_ID_BYTES];
+  if (bad_flag == 4) {
+    if (cpt_comm_get_unique_id(comm_id)) { fprintf(stderr, "cpt_comm_get_unique_id failed\n"); return 11; }
+    in.shard.rank = 0; in.shard.world = 1; in.shard.comm_id = comm_id;
+  }
   if (bad_flag == 1) in.config.has_fld = 1;             // must raise std::invalid_argument
   if (bad_flag == 2) in.grid.k_step_transition = 0.;    // must raise std::invalid_argument (reference: class_test)
   try {

@@ -94,6 +94,12 @@ def test_shim_modules(tmp_path, cfg):
         for a, b in ((k2, k), (tau2, tau), (q2, q)):
             assert np.max(np.abs(a / b - 1)) < 5e-6
         assert np.max(np.abs(tr2 - ref) / scale) < 1e-3
+    if cfg == "small":
+        # the sharded constructors with a one-rank RCCL communicator: bit-identical outputs
+        opath4 = str(tmp_path / "out4.bin")
+        rc, out = run_demo(exe, ipath, opath4, flag=4)
+        assert rc == 0, out
+        assert open(opath4, "rb").read() == open(opath, "rb").read()
     if cfg != "small":
         return
     # error mapping
