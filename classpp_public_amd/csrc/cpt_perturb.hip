@@ -36,6 +36,7 @@ struct PtParams {
   int l_max_g_ten, l_max_pol_g_ten, evolve_tensor_ur; double gw_ini;  // tensor modes
   int ic; double entropy_ini;  // initial condition of the mode (CPT_IC_*), isocurvature normalisation
   int has_ncdm, nfa_method, tp_dcb; double nfa_trig, tol_ncdm_w;  // non-cold species (massive neutrinos)
+  int ncdm_compact;            // use the single-wave integrator for the last interval (rsa + ufa + ncdmfa); CPT_NCDM_COMPACT=0 switches it off
   NcdmDev nc;
   int switch_sw, switch_eisw, switch_lisw, switch_dop, switch_pol;
   double eisw_lisw_split_z, three_ceff2_ur, three_cvis2_ur;
@@ -2074,15 +2075,98 @@ static __device__ __forceinline__ int ndf15(const PtParams& P, const Layout& L, 
   return 0;
 }
 
+// ---- non-cold species, last interval: radiation streaming + ur fluid + ncdm fluid all on (rsa, ufa, ncdmfa) -----------------------
+// What is left of the system is baryons, cdm, eta and (delta, theta, sigma) of every non-cold species: 4 + 3 N variables (7 or 13)
+// that still oscillate until today - 70 % of the steps of the heaviest mode.  The general ncdm machinery (one wave per three momentum
+// bins, three block barriers per RHS and per solve, block-wide norms) costs the same per step whatever the size of the system, so
+// this interval gets a path of its own: the chain waves hand their three fluid variables per species to the core wave and retire;
+// the core wave integrates alone (ndf15s<1>: no barrier, no chain, dense register LU) with the fluid variables in core lanes that
+// the radiation-streaming approximation has vacated - species 0 in the lanes of (delta_g, theta_g, shear_g), species 1 in those of the
+// polarisation multipoles 0..2, species 2 in those of (delta_ur, theta_ur, shear_ur).
+static __device__ __forceinline__ int fluid_lane(int species, int j) { return ((species == 0) ? LN_DG : (species == 1) ? LN_P0 : LN_DUR) + j; }
+static __device__ __forceinline__ bool compact_present(const PtParams& P, int i) {
+  if (i == LN_DB || i == LN_TB || i == LN_ETA) return true;
+  if (i == LN_DC) return P.has_cdm != 0;
+  for (int n = 0; n < P.nc.n_species; n++) if (i >= fluid_lane(n, 0) && i <= fluid_lane(n, 2)) return true;
+  return false;
+}
+// perturb_derivs in this regime (pm.cpp:7861-9218 with perturb_einstein, perturb_total_stress_energy, perturb_rsa_delta_and_theta and the
+// fluid equations of pm.cpp:8737-8823 folded in); synchronous gauge.  Leaves M and N describing (tau, y) for the sources.
+static __device__ __forceinline__ double rhs_compact(const PtParams& P, Lookup& Q, Metric& M, NcIn& N, double k, double inv_k2, double tau, double y, int lane) {
+  lookup(P, Q, tau, lane);
+  const double a2 = Q.a2, aH = Q.aH, k2 = k * k, kap = Q.kap, cb2 = Q.cb2;
+  const double db = bcast(y, LN_DB), tb = bcast(y, LN_TB), dc = bcast(y, LN_DC), eta = bcast(y, LN_ETA);
+  const int ln = opaque(lane);
+  // the non-cold fluids: integrals for the Einstein equations, and this lane's species (wave-uniform per species, selected per lane)
+  double D = 0., T = 0., S = 0., rho_l = 1., p_l = 1., pp_l = 1.;
+  for (int n = 0; n < P.nc.n_species; n++) {
+    const double rho = bcast(Q.vnc, 3 * n), pr = bcast(Q.vnc, 3 * n + 1), pp = bcast(Q.vnc, 3 * n + 2);
+    const int l0 = fluid_lane(n, 0);
+    D = fma(rho, bcast(y, l0), D); T = fma(rho + pr, bcast(y, l0 + 1), T); S = fma(rho + pr, bcast(y, l0 + 2), S);
+    const bool mine = (ln >= l0) && (ln <= l0 + 2);
+    rho_l = mine ? rho : rho_l; p_l = mine ? pr : p_l; pp_l = mine ? pp : pp_l;
+  }
+  N.D = D; N.T = T; N.S = S;
+  double delta_rho = Q.rb * db + D, rpt = Q.rb * tb + T, rps = S;
+  if (P.has_cdm) delta_rho += Q.rc * dc;
+  const double hp = (Q.k2s2 * eta + 1.5 * a2 * delta_rho) * Q.two_over_aH;                       // pm.cpp:5913-5914
+  // radiation streaming: photons and ur follow the metric (pm.cpp:9530-9636)
+  double rdg = 0., rtg = 0., rdur = 0., rtur = 0.;
+  if (P.rsa_method != CPT_RSA_NULL) { rdg = 4. * inv_k2 * (aH * hp - k2 * eta); rtg = -0.5 * hp; }
+  if (P.rsa_method == CPT_RSA_MD_WITH_REIO) {
+    rdg += -4. * inv_k2 * kap * (tb + 0.5 * hp);
+    rtg += 3. * inv_k2 * (Q.ddkappa * (tb + 0.5 * hp) + kap * (-aH * tb + cb2 * k2 * db - aH * hp + k2 * eta));
+  }
+  if (P.has_ur && P.rsa_method != CPT_RSA_NULL) { rdur = 4. * inv_k2 * (aH * hp - k2 * eta); rtur = -0.5 * hp; }
+  delta_rho += Q.rg * rdg;
+  rpt += Q.rg43 * rtg;
+  if (P.has_ur) { delta_rho += Q.ru * rdur; rpt += Q.ru43 * rtur; }
+  const double etap = (1.5 * a2 * rpt + (CURV ? 0.5 * P.K * hp : 0.)) * Q.inv_k2s2;             // pm.cpp:5938
+  const double alpha = (hp + 6. * etap) * 0.5 * inv_k2;
+  const double alphap = -2. * aH * alpha + eta - 4.5 * (a2 * inv_k2) * rps;
+  M.hp = hp; M.etap = etap; M.alpha = alpha; M.alphap = alphap; M.rsa_dg = rdg; M.rsa_tg = rtg;
+  const double mc = 0.5 * hp, ms = k2 * alpha;
+  const double dtb = -aH * tb + k2 * cb2 * db + Q.R * kap * (rtg - tb);                          // pm.cpp:8108-8113 with the streaming theta_g
+  // this lane's equation
+  double dy = 0.;
+  dy = (ln == LN_DB) ? -(tb + mc) : dy;
+  dy = (ln == LN_TB) ? dtb : dy;
+  dy = (ln == LN_DC && P.has_cdm) ? -mc : dy;
+  dy = (ln == LN_ETA) ? etap : dy;
+  {  // fluid lanes (pm.cpp:8737-8823): j = 0 delta, 1 theta, 2 sigma; ym / yp: the species' neighbouring variable
+    const int j = (ln <= LN_SG) ? ln - LN_DG : (ln <= LN_P2) ? ln - LN_P0 : ln - LN_DUR;
+    const int sp = (ln <= LN_SG) ? 0 : (ln <= LN_P2) ? 1 : 2;
+    const bool fluid = (j >= 0) && (j <= 2) && (ln == fluid_lane(sp, j)) && (sp < P.nc.n_species);
+    const double ym = lane_below(y), yp = lane_above(y);
+    const double w = p_l * fast_rcp(rho_l), inv_1pw = fast_rcp(1. + w), pp_over_p = pp_l * fast_rcp(p_l);
+    const double ca2 = w / 3. * inv_1pw * (5. - pp_over_p), ceff2 = ca2;
+    const double cvis2 = (P.nfa_method == CPT_NCDMFA_HU) ? w : 3. * w * ca2;
+    const double s2 = CURV ? sqrt(fmax(1.0 - 3. * P.K / k2, 0.)) : 1.;
+    double f;
+    if (j == 0) f = -(1. + w) * (yp + mc) - 3. * aH * (ceff2 - w) * y;
+    else if (j == 1) f = ceff2 * inv_1pw * k2 * ym - k2 * yp - aH * (1. - 3. * ca2) * y;
+    else {
+      const double src = 8. / 3. * cvis2 * inv_1pw * s2;
+      if (P.nfa_method == CPT_NCDMFA_HU) f = src * (ym + ms) - 3. * aH * ca2 * fast_rcp(w) * y;
+      else f = src * (ym + ((P.nfa_method == CPT_NCDMFA_MB) ? ms : mc)) - 3. * (aH * (2. / 3. - ca2 - pp_over_p / 3.) + Q.inv_tau) * y;
+    }
+    dy = fluid ? f : dy;
+  }
+  return dy;
+}
+
 // evolver_ndf15 (ev.cpp:62-705) for the INTEGRATOR wave of the two-wave kernels (NCDM = 0), one interval of constant
 // approximation scheme.  Same algorithm and same arithmetic as ndf15<ROLE> above (which the multi-wave ncdm kernels keep: their
 // waves must walk through one barrier sequence), written as structured code: now that the table look-ups live on the helper wave
 // an inlined RHS is ~300 instructions, so the flat one-call-site loop with its state flags - every variable live everywhere, a
 // dozen register moves at every merge point - is no longer worth its price.  Returns 0 / error code (1 step too small,
 // 2 singular, 4 budget, 5 helper unresponsive).
+// COMPACT = 1: the core wave of the ncdm kernels alone in the last interval (rhs_compact above): own table look-ups, samples
+// evaluated in place, no helper.
+template <int COMPACT>
 static __device__ __forceinline__ int ndf15s(const PtParams& P, const Layout& L, const LaneEq& e, Ctx& C, Lookup& Q, Metric& M, double k, double inv_k2,
                                              double t0, double tfinal, double& y_io, Stat& st, int lane, int& budget, double* jac_lds,
-                                             double2* fw_lds, unsigned long long* prof) {
+                                             double2* fw_lds, unsigned long long* prof, int ik = 0) {
   PROF_DECL;
   const double eps = 1e-16, threshold = 1e-15, rtol = P.rtol, inv_rtol = 1.0 / rtol;
   const int maxit = 4, maxk = 5;
@@ -2107,15 +2191,19 @@ static __device__ __forceinline__ int ndf15s(const PtParams& P, const Layout& L,
   while (next < tres && ts[next] < t0) next++;
   double tnext = (next < tres) ? ts[next] : 1e300, tnext2 = (next + 1 < tres) ? ts[next + 1] : 1e300;
 
+  NcIn N = {0., 0., 0., nullptr, 0};
   auto eval = [&](double tq, double yq) {
     st.fevals++;
-    return rhs<true>(P, L, e, Q, M, k, inv_k2, tq, yq, lane);
+    if constexpr (COMPACT != 0) return rhs_compact(P, Q, M, N, k, inv_k2, tq, yq, lane);
+    else return rhs<true>(P, L, e, Q, M, k, inv_k2, tq, yq, lane);
   };
+  auto request = [&](double tq) { if constexpr (COMPACT == 0) mb_request(Q, tq, lane); };
+  const double no_alpha[4] = {0., 0., 0., 0.};
   // J e_r = f(t, e_r): exact, the system is linear and homogeneous; idle variables have no column; tails analytic
   auto jacobian = [&](double tq) {
     const double keep = M.tca_shear_g;
     for (int r = 0; r < NC; r++) {
-      if (!core_present(P, L, r)) continue;
+      if (COMPACT ? !compact_present(P, r) : !core_present(P, L, r)) continue;
       const double col = eval(tq, (lane == r) ? 1.0 : 0.0);
       J.Jc[r * 64 + lane] = (lane < NC) ? col : 0.;
     }
@@ -2172,7 +2260,7 @@ static __device__ __forceinline__ int ndf15s(const PtParams& P, const Layout& L,
     }
     // the time of this step is known: ask the helper for its table row now (a no-op when the step size did not change - the row
     // was requested a whole step ago - and otherwise early enough to arrive behind the factorisation)
-    mb_request(Q, done ? tfinal : t + h, lane);
+    request(done ? tfinal : t + h);
     bool nofailed = true;
     PROF_STOP(13);
     for (;;) {   // -------------------------------------------- attempts at this step
@@ -2180,7 +2268,7 @@ static __device__ __forceinline__ int ndf15s(const PtParams& P, const Layout& L,
       if (need_fact) {
         need_fact = false;
         PROF_START();
-        if (!factorise(e, J, hinvGak, maxlen, lane, F)) return 2;
+        if (!factorise(e, J, hinvGak, maxlen, lane, F, no_alpha, 0., 0.)) return 2;
         PROF_STOP(2);
         st.lus++;
         havrate = false;
@@ -2217,7 +2305,7 @@ static __device__ __forceinline__ int ndf15s(const PtParams& P, const Layout& L,
         PROF_START();
         fnewton = eval(tnew, ynew);
         // the row of THIS step is in registers: speculate that the step size stays and ask for the next one (t' + h' = tnew + absh)
-        if (iter == 1 && !done) mb_request(Q, tnew + absh, lane);
+        if (iter == 1 && !done) request(tnew + absh);
         PROF_STOP(0);
 #ifdef CPT_PROFILE
         t_inner += clock64() - pf_t0;
@@ -2270,7 +2358,7 @@ static __device__ __forceinline__ int ndf15s(const PtParams& P, const Layout& L,
         absh = fmax(0.3 * absh, hmin);
         h = absh;
         done = false;
-        mb_request(Q, t + h, lane);
+        request(t + h);
         adjust_stepsize(dif, absh * fast_rcp(abshlast), kk);
         hinvGak = h * iga;
         nconhk = 0;
@@ -2298,7 +2386,7 @@ static __device__ __forceinline__ int ndf15s(const PtParams& P, const Layout& L,
       } else absh = fmax(hmin, 0.5 * absh);
       h = absh;
       if (uni(absh < abshlast)) done = false;
-      mb_request(Q, done ? tfinal : t + h, lane);
+      request(done ? tfinal : t + h);
       adjust_stepsize(dif, absh * fast_rcp(abshlast), kk);
       hinvGak = h * iga;
       nconhk = 0;
@@ -2342,6 +2430,11 @@ static __device__ __forceinline__ int ndf15s(const PtParams& P, const Layout& L,
           }
           ypi *= inv_h;
         }
+        if constexpr (COMPACT != 0) {               // no helper: perturb_sources right here
+          (void)eval(tnext, yi);
+          store_sources(P, L, Q, M, k, inv_k2, yi, ypi, tca_keep, next, ik, lane, N);
+          M.tca_shear_g = tca_keep;
+        } else {
         if (C.posted - C.tail_seen >= MB_NSLOT) {   // ring full: wait for the helper (it is certain to consume)
           int spins = 0;
           while (C.posted - (C.tail_seen = mb_load(&C.mb->tail)) >= MB_NSLOT) {
@@ -2355,6 +2448,7 @@ static __device__ __forceinline__ int ndf15s(const PtParams& P, const Layout& L,
         C.posted++;
         mb_store(&C.mb->head, C.posted);
         st.fevals++;                             // (the evaluation is counted where the reference makes it)
+        }
         next++;
         tnext = tnext2;
         tnext2 = (next + 1 < tres) ? ts[next + 1] : 1e300;
@@ -2559,6 +2653,8 @@ static __device__ __forceinline__ int run_intervals(const PtParams& P, Ctx& C, c
 #ifdef CPT_PROFILE
     prof[6] = clock64() - t_begin;  // schedule search + initial conditions
 #endif
+    bool compact = false;
+    const int getenv_compact = P.ncdm_compact;
     for (int iv = 0; iv <= nsw && status == 0; iv++) {
       const double ta = (iv == 0) ? tau_ini : (iv == 1) ? sw0 : (iv == 2) ? sw1 : (iv == 3) ? sw2 : sw3;
       const double tb = (iv == nsw) ? tau_end : (iv == 0) ? sw0 : (iv == 1) ? sw1 : (iv == 2) ? sw2 : sw3;
@@ -2612,13 +2708,30 @@ static __device__ __forceinline__ int run_intervals(const PtParams& P, Ctx& C, c
             else yn = 0.;
           }
         }
+        if (NCDM) {
+          // the last interval with radiation streaming, ur fluid and ncdm fluid all on: the chain waves pass (delta, theta, sigma) of
+          // every species to the core wave and retire (see rhs_compact)
+          compact = (iv == nsw) && (ap == 1) && L.rsa && L.ufa && L.nfa && !L.tca && (getenv_compact != 0);
+          if (compact) {
+            if (ROLE == 1 && ce.holder) C.sh->ho[ce.species][ce.l] = y;
+            __syncthreads();
+            if (ROLE == 1) break;          // nothing left for a chain wave to do: no barrier follows
+            const int ln = opaque(lane);
+            for (int n = 0; n < P.nc.n_species; n++)
+              for (int j = 0; j < 3; j++)
+                if (ln == fluid_lane(n, j)) yn = C.sh->ho[n][j];
+          }
+        }
         y = yn;
         C.tau_pub = -1.;   // (the chain coefficients cached for this time belong to the old scheme)
       }
       n_regimes++;
       int rc;
-      if constexpr (SAMPLER) rc = ndf15s(P, L, e, C, Q, M, k, inv_k2, ta, tb, y, st, lane, budget, jacw, fww, prof);
-      else rc = ndf15<ROLE>(P, L, e, ce, C, Q, M, k, inv_k2, ik, ta, tb, y, st, lane, budget, jacw, fww, prof);
+      if constexpr (SAMPLER) rc = ndf15s<0>(P, L, e, C, Q, M, k, inv_k2, ta, tb, y, st, lane, budget, jacw, fww, prof);
+      else if constexpr (NCDM != 0 && ROLE == 0) {
+        if (compact) rc = ndf15s<1>(P, L, e, C, Q, M, k, inv_k2, ta, tb, y, st, lane, budget, jacw, fww, prof, ik);
+        else rc = ndf15<ROLE>(P, L, e, ce, C, Q, M, k, inv_k2, ik, ta, tb, y, st, lane, budget, jacw, fww, prof);
+      } else rc = ndf15<ROLE>(P, L, e, ce, C, Q, M, k, inv_k2, ik, ta, tb, y, st, lane, budget, jacw, fww, prof);
       if (rc) status = 10 + rc;
     }
   }
@@ -2918,6 +3031,8 @@ void fill_params(const cpt_handle* h, PtParams& P) {
   P.has_ncdm = c.has_ncdm; P.nfa_method = c.ncdm_fluid_approximation; P.nfa_trig = c.ncdm_fluid_trigger_tau_over_tau_k;
   P.tol_ncdm_w = c.has_ncdm ? c.tol_ncdm_initial_w : 1e300; P.tp_dcb = c.has_ncdm ? c.index_tp_delta_cb : -1;
   P.nc = h->ncdm;
+  P.ncdm_compact = 1;
+  if (const char* ev = getenv("CPT_NCDM_COMPACT")) P.ncdm_compact = atoi(ev) != 0;
   P.max_steps = 400000;
   // one tail per 16-lane row when each fits (defaults: 10 / 8 / 15 lanes), else the packed lane map with sequential sweeps
   P.rows = (c.mode == CPT_MODE_SCALARS && !c.has_ncdm && c.l_max_g - 2 <= 16 && c.l_max_pol_g - 2 <= 16 && (!c.has_ur || c.l_max_ur - 2 <= 16)) ? 1 : 0;
