@@ -175,10 +175,11 @@ static int validate(const cpt_config* c) {
     if (c->index_tp_t0 >= 0 || c->index_tp_t1 >= 0 || c->index_tp_delta_m >= 0 || c->index_tp_phi_plus_psi >= 0)
       return cpt_fail(nullptr, CPT_ERR_INVALID, "tensor modes have the source types t2 and p only (pm.cpp:7243-7280)");
   }
-  // lane map of cpt_perturb.hip: 14 core lanes + the three l >= 3 tails
-  if (14 + (c->l_max_g - 2) + (c->l_max_pol_g - 2) + (c->has_ur ? c->l_max_ur - 2 : 0) > CPT_WAVE)
+  // lane map of cpt_perturb.hip: 14 core lanes (22 with non-cold species) + the three l >= 3 tails
+  const int core_lanes = c->has_ncdm ? 13 + 3 * CPT_MAX_NCDM : 14;
+  if (core_lanes + (c->l_max_g - 2) + (c->l_max_pol_g - 2) + (c->has_ur ? c->l_max_ur - 2 : 0) > CPT_WAVE)
     return cpt_fail(nullptr, CPT_ERR_UNSUPPORTED,
-                    "hierarchy too large: one wavefront (64 lanes) owns one k-mode, need 14 + tails <= 64 lanes");
+                    "hierarchy too large: one wavefront (64 lanes) owns one k-mode, need %d + tails <= 64 lanes", core_lanes);
   if (c->tp_size < 1 || c->tp_size > 8) return cpt_fail(nullptr, CPT_ERR_INVALID, "tp_size=%d out of range", c->tp_size);
   const int tps[6] = {c->index_tp_t0, c->index_tp_t1, c->index_tp_t2, c->index_tp_p, c->index_tp_delta_m,
                       c->index_tp_phi_plus_psi};

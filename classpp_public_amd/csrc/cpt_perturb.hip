@@ -36,7 +36,7 @@ struct PtParams {
   int l_max_g_ten, l_max_pol_g_ten, evolve_tensor_ur; double gw_ini;  // tensor modes
   int ic; double entropy_ini;  // initial condition of the mode (CPT_IC_*), isocurvature normalisation
   int has_ncdm, nfa_method, tp_dcb; double nfa_trig, tol_ncdm_w;  // non-cold species (massive neutrinos)
-  int ncdm_compact;            // use the single-wave integrator for the last interval (rsa + ufa + ncdmfa); CPT_NCDM_COMPACT=0 switches it off
+  int ncdm_compact;            // last interval of the ncdm kernels (rsa + ufa + ncdmfa): 0 all waves, 1 the core wave alone, 2 core wave + helper wave
   NcdmDev nc;
   int switch_sw, switch_eisw, switch_lisw, switch_dop, switch_pol;
   double eisw_lisw_split_z, three_ceff2_ur, three_cvis2_ur;
@@ -190,6 +190,7 @@ __device__ inline double ndf_erconst(int i) {
 enum Role : int {
   R_NONE = 0, R_DELTA_G, R_THETA_G, R_SHEAR_G, R_LG /* l>=3 photon temperature */, R_POL /* l>=0 polarisation */,
   R_DELTA_B, R_THETA_B, R_DELTA_CDM, R_DELTA_UR, R_THETA_UR, R_SHEAR_UR, R_LUR /* l>=3 ur */, R_ETA, R_THETA_CDM, R_GW, R_GWDOT,
+  R_FLUID /* delta, theta or sigma of a non-cold species in the fluid approximation, held by the core wave */,
   R_NCD, R_NCT /* auxiliary unknowns of the Newton system: delta rho and (rho+p) theta summed over the ncdm species */
 };
 
@@ -228,6 +229,7 @@ struct NcShared {
   double z[2];                 // Newton solve: increments of (metric_continuity, metric_shear)
   double alpha[NCW_MAX][4];    // factorisation: Schur terms of the two auxiliary rows
   double ho[CPT_MAX_NCDM * CPT_MAX_Q_NCDM][3];   // hand-over to the fluid regime: per-chain integrals
+  double hf[CPT_MAX_NCDM][3];  // hand-over of (delta, theta, sigma) of every species to the core wave (see "the core wave alone")
   int abort;
 };
 
@@ -245,7 +247,7 @@ struct NcShared {
 // executes a wave's operations in order).  The helper never waits for the integrator except by polling, and leaves when `done` is
 // set and the ring is drained; the integrator only waits for work the helper is certain to finish: no cycle, every wave exits.
 constexpr int MB_NSLOT = 4;      // sample ring
-constexpr int MB_NANS = 24;      // doubles of a look-up answer
+constexpr int MB_NANS = 32;      // doubles of a look-up answer (22 + {rho, p, pseudo_p} of up to three non-cold species)
 struct Mailbox {
   double yi[MB_NSLOT][64], ypi[MB_NSLOT][64];   // dense output at the sample time, one entry per lane
   double tca_keep[MB_NSLOT];                    // tight-coupling shear left by the evolver's last RHS call (pm.cpp:6810)
@@ -257,6 +259,10 @@ struct Mailbox {
 };
 __device__ inline int mb_load(const int* p) { return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP); }
 __device__ inline void mb_store(int* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP); }
+
+// dynamic LDS of an ncdm launch with a helper wave: its two table windows (background + thermodynamics, ncdm) and the mailbox
+constexpr size_t CPT_NCDM_HELPER_WINDOWS = sizeof(double2) * 64 * (BG_NCOL + TH_NCOL + NCB_NCOL);
+constexpr size_t CPT_NCDM_HELPER_LDS = CPT_NCDM_HELPER_WINDOWS + sizeof(Mailbox);
 
 template <int GAUGE, int CURV, int MODE, int NCDM = 0, int ROWS = 0>
 struct PT {
@@ -271,9 +277,13 @@ static constexpr bool SAMPLER = (NCDM == 0);
 // structure, fixed per regime and shared by all modes, is what the linear algebra below exploits.
 // LN_ETA holds eta (synchronous gauge) or phi (Newtonian gauge, pm.cpp:3470-3478); LN_TC = theta_cdm exists in the Newtonian gauge only
 enum Lane : int { LN_DG = 0, LN_TG, LN_SG, LN_P0, LN_P1, LN_P2, LN_DB, LN_TB, LN_DC, LN_DUR, LN_TUR, LN_SUR, LN_ETA, LN_TC };
-static constexpr int NC = MODE ? 17 : ((GAUGE == CPT_GAUGE_NEWTONIAN) ? 14 : 13) + (NCDM ? 2 : 0);
-static_assert(!NCDM || NC <= 16, "the core must fit one DPP row");
-static constexpr int LN_ND = NC - 2, LN_NT = NC - 1;   // (NCDM only) auxiliary unknowns: ncdm density / momentum sums
+// (NCDM: nine more core lanes, 13..21.  While the momentum hierarchies are integrated the first two hold the auxiliary unknowns of the
+//  bordered Newton system; once the ncdm fluid approximation is on and the core wave integrates alone they hold (delta, theta, sigma)
+//  of up to three species - see "the core wave alone" below.  An idle core lane costs nothing: Layout::pmask.)
+static constexpr int NC = MODE ? 17 : ((GAUGE == CPT_GAUGE_NEWTONIAN) ? 14 : 13) + (NCDM ? 3 * CPT_MAX_NCDM : 0);
+static constexpr int LN_ND = 13, LN_NT = 14;   // (NCDM only) auxiliary unknowns: ncdm density / momentum sums
+static constexpr int LN_F0 = 13;               // (NCDM only, fluids in the core) delta of species 0; species n, moment j at LN_F0 + 3 n + j
+static_assert(!NCDM || CPT_MAX_NCDM == 3, "lane map of the ncdm kernels");
 // Tensor modes (MODE = 1; pm.cpp:3519-3586): the same three ladders plus the gravitational wave (gw, gw').  The photon
 // source P^(2) reads the l = 4 multipoles of temperature and polarisation and the gravitational-wave source reads the
 // l = 4 multipoles of photons and ur, so the core holds every ladder up to l = 4 and the tails start at l = 5.
@@ -287,14 +297,15 @@ static constexpr bool PCR = (ROWS != 0) && (MODE == 0) && (NCDM == 0);
 
 struct Layout {
   int tca, rsa, ufa, nfa;
+  int fic;                     // (NCDM) the ncdm fluids live in core lanes LN_F0.. of the core wave (which then integrates alone)
   int g3, gN, q3, qN, u3, uN;  // tails: lane of l=3 and length (lengths are 0 when the scheme drops the tail)
   int lmg, lmp, lmu;
   int maxlen;                  // longest tail present
 };
 
-static __device__ __forceinline__ Layout make_layout(const PtParams& P, int tca, int rsa, int ufa, int nfa = 0) {
+static __device__ __forceinline__ Layout make_layout(const PtParams& P, int tca, int rsa, int ufa, int nfa = 0, int fic = 0) {
   Layout L;
-  L.tca = tca; L.rsa = rsa; L.ufa = ufa; L.nfa = nfa;
+  L.tca = tca; L.rsa = rsa; L.ufa = ufa; L.nfa = nfa; L.fic = fic;
   if (MODE) {  // tensors: photons are evolved when neither approximation is on; ur always (pm.cpp:3529-3560)
     L.ufa = 0;
     L.lmg = P.l_max_g_ten; L.lmp = P.l_max_pol_g_ten; L.lmu = P.l_max_ur;
@@ -320,7 +331,7 @@ static __device__ __forceinline__ Layout make_layout(const PtParams& P, int tca,
 // is core variable `i` evolved in this scheme?  (i wave-uniform)
 static __device__ __forceinline__ bool core_present(const PtParams& P, const Layout& L, int i) {
   if (MODE) return (i <= TL_P4) ? (!L.rsa && !L.tca) : (i <= TL_U4) ? (P.evolve_tensor_ur != 0) : true;
-  if (NCDM && i >= LN_ND) return true;
+  if (NCDM && i >= LN_ND) return L.fic ? (i - LN_F0 < 3 * P.nc.n_species) : (i <= LN_NT);
   switch (i) {
     case LN_DG: case LN_TG: return !L.rsa;
     case LN_SG: case LN_P0: case LN_P1: case LN_P2: return !L.rsa && !L.tca;
@@ -329,6 +340,13 @@ static __device__ __forceinline__ bool core_present(const PtParams& P, const Lay
     case LN_DUR: case LN_TUR: case LN_SUR: return P.has_ur && !L.rsa;
     default: return true;  // delta_b, theta_b, eta
   }
+}
+
+static __device__ __forceinline__ unsigned present_mask(const PtParams& P, const Layout& L) {
+  unsigned m = 0;
+#pragma unroll
+  for (int i = 0; i < NC; i++) if (core_present(P, L, i)) m |= 1u << i;
+  return (unsigned)__builtin_amdgcn_readfirstlane((int)m);
 }
 
 // (role, multipole) of lane i in the current scheme; R_NONE = not evolved
@@ -348,6 +366,7 @@ static __device__ __forceinline__ void role_of(const PtParams& P, const Layout& 
     return;
   }
   const bool g = !L.rsa, hi = !L.rsa && !L.tca, ur = P.has_ur && !L.rsa;
+  if (NCDM && L.fic && i >= LN_F0 && i < NC) { if (i - LN_F0 < 3 * P.nc.n_species) *role = R_FLUID; return; }
   if (NCDM && i == LN_ND) { *role = R_NCD; return; }
   if (NCDM && i == LN_NT) { *role = R_NCT; return; }
   if (i == LN_DG) { if (g) *role = R_DELTA_G; return; }
@@ -488,6 +507,7 @@ struct Lookup {
   double k2s2, inv_k2s2, s2, s2sq, kcot;  // per-mode curvature factors (set_mode) and k cotK_gen(tau_cached); flat: k^2, 1/k^2, 1, 1, 1/tau
   // (integrator wave of the two-wave kernels) the rows come from the helper wave: mailbox, number of requests posted, time of the last one
   Mailbox* mb; int my_req; double req_tau;
+  double ncv[NCDM ? NCB_NCOL : 1];   // (rows from the helper, ncdm kernels) {rho, p, pseudo_p} of every species, wave-uniform
 #ifdef CPT_PROFILE
   unsigned long long* prof;
 #endif
@@ -693,6 +713,10 @@ static __device__ __forceinline__ bool mb_fetch(Lookup& Q, double tau, int lane)
   Q.rg = a[0]; Q.rb = a[1]; Q.rc = a[2]; Q.ru = a[3]; Q.kap = a[4]; Q.ddkappa = a[5]; Q.cb2 = a[6]; Q.a2 = a[7];
   Q.aH = a[8]; Q.two_over_aH = a[9]; Q.R = a[10]; Q.inv_1pR = a[11]; Q.inv_R = a[12]; Q.tau_c = a[13]; Q.dtau_c = a[14]; Q.F = a[15];
   Q.Fp = a[16]; Q.app = a[17]; Q.inv_tau = a[18]; Q.rg43 = a[19]; Q.ru43 = a[20]; Q.kcot = a[21];
+  if (NCDM) {
+#pragma unroll
+    for (int i = 0; i < NCB_NCOL; i++) Q.ncv[i] = a[22 + i];
+  }
   Q.tau_cached = tau;
   return true;
 }
@@ -716,6 +740,8 @@ struct LaneEq {
   double Bpar;         // core parents of a present tail: B (their coupling to the tail's l=3 element); else 0
   double A, B, D, G, Gt;   // G multiplies k cotK_gen(tau) (hierarchy truncation), Gt multiplies 1/tau (ur fluid): equal in flat space
   double Xmc, Xms, XP, X4, Xeta, Xtb, Xeu;   // Xeu multiplies metric_euler = k^2 psi (Newtonian gauge; 0 in synchronous)
+  unsigned pmask;      // (wave-uniform) bit i: core variable i is evolved in this scheme.  An idle core lane is an identity row AND column
+                       // of the Newton matrix: the factorisation and the substitutions skip its pivot altogether.
 };
 
 static __device__ __forceinline__ LaneEq make_lane_eq(const PtParams& P, const Layout& L, int lane, double k) {
@@ -757,6 +783,7 @@ static __device__ __forceinline__ LaneEq make_lane_eq(const PtParams& P, const L
     const bool is_parent = (lane < NC) && (up >= NC);
     e.first_addr = (is_parent ? up : lane) * 4;
     e.Bpar = is_parent ? e.B : 0.;
+    e.pmask = present_mask(P, L);
     return e;
   }
   if (e.role == R_LG) { e.chain = 1; lm = L.lmg; e.D = 1.; parent = LN_SG; }
@@ -812,6 +839,7 @@ static __device__ __forceinline__ LaneEq make_lane_eq(const PtParams& P, const L
   const bool is_parent = (lane < NC) && (up >= NC);   // its ladder continues in a tail
   e.first_addr = (is_parent ? up : lane) * 4;
   e.Bpar = is_parent ? e.B : 0.;
+  e.pmask = present_mask(P, L);
   return e;
 }
 
@@ -878,10 +906,11 @@ static __device__ __forceinline__ void store_sources_tensor(const PtParams& P, c
 // perturb_rsa_delta_and_theta (pm.cpp:9530-9636) and perturb_tca_slip_and_shear (pm.cpp:9229-9516) folded in;
 // synchronous gauge, K = 0.  y: this lane's component (named components are broadcast with v_readlane).
 // Returns dy of this lane and leaves M describing the state (tau, y).
-template <bool VIA_HELPER = false>
+// LK: where the row of the tables comes from - 0 this wave's own look-up, 1 the helper wave, 2 it is in Q already
+template <int LK = 0>
 static __device__ __forceinline__ double rhs(const PtParams& P, const Layout& L, const LaneEq& e, Lookup& Q, Metric& M, double k,
                                       double inv_k2, double tau, double y, int lane, NcIn* Np = nullptr) {
-  if (MODE) return rhs_tensor<VIA_HELPER>(P, L, e, Q, M, k, tau, y, lane);
+  if (MODE) return rhs_tensor<(LK == 1)>(P, L, e, Q, M, k, tau, y, lane);
 #ifdef CPT_PROFILE
   unsigned long long* prof = Q.prof;
   PROF_DECL;
@@ -889,8 +918,8 @@ static __device__ __forceinline__ double rhs(const PtParams& P, const Layout& L,
 #endif
   // (a helper that never answers - impossible unless the kernel is broken - poisons the result: the step then fails its norm
   //  tests, shrinks to the minimal step and the mode ends with "step size too small" instead of spinning for ever)
-  if (VIA_HELPER) { if (!mb_fetch(Q, tau, lane)) return nan(""); }
-  else lookup(P, Q, tau, lane);
+  if (LK == 1) { if (!mb_fetch(Q, tau, lane)) return nan(""); }
+  else if (LK == 0) lookup(P, Q, tau, lane);
 #ifdef CPT_PROFILE
   PROF_STOP(8); PROF_START();
 #endif
@@ -1347,6 +1376,44 @@ static __device__ __forceinline__ void chain_factor(const ChainCoef& jc, const C
 //   * the Schur complement on the core changes 3 diagonal entries only; the core matrix (<= 16 x 16) lives in
 //     registers, one row per lane, and is factorised with threshold-diagonal pivoting (tools/sparse.c:171) by
 //     fully unrolled readlane/fma code.
+// f(j) for the core variables j = lo..NC-1 in ascending order (for_core) or NC-1..0 in descending order (for_core_down).  The ncdm
+// kernels, whose core has 22 lanes of which a scheme uses 7 to 16, skip the lane groups that a scheme leaves idle as a whole - photons
+// 0..5, ur 9..11, the three ncdm fluids 13.., 16.., 19.. - by ONE scalar branch per group (Layout: an idle core variable is an identity row
+// and column of the Newton matrix).  A test per lane would break the unrolled substitution chains into 22 basic blocks: measured
+// on the 13-lane core of the two-wave kernels, 11.1 -> 13.9 ms.
+template <int A, int B, class F>
+static __device__ __forceinline__ void core_run(int lo, F&& f) {
+#pragma unroll
+  for (int j = A; j <= B; j++) if (j >= lo) f(j);
+}
+template <int A, int B, class F>
+static __device__ __forceinline__ void core_run_down(F&& f) {
+#pragma unroll
+  for (int j = B; j >= A; j--) f(j);
+}
+template <class F>
+static __device__ __forceinline__ void for_core(unsigned pm, int lo, F&& f) {
+  if (!NCDM) { core_run<0, NC - 1>(lo, f); return; }
+  if (lo <= 5 && (pm & 0x3Fu)) core_run<0, 5>(lo, f);
+  if (lo <= 8) core_run<6, 8>(lo, f);
+  if (lo <= 11 && (pm & 0xE00u)) core_run<9, 11>(lo, f);
+  if (lo <= 12) core_run<12, 12>(lo, f);
+  if (lo <= 15 && (pm & (7u << 13))) core_run<13, (NCDM ? 15 : 0)>(lo, f);
+  if (lo <= 18 && (pm & (7u << 16))) core_run<16, (NCDM ? 18 : 0)>(lo, f);
+  if (pm & (7u << 19)) core_run<19, (NCDM ? 21 : 0)>(lo, f);
+}
+template <class F>
+static __device__ __forceinline__ void for_core_down(unsigned pm, F&& f) {
+  if (!NCDM) { core_run_down<0, NC - 1>(f); return; }
+  if (pm & (7u << 19)) core_run_down<19, (NCDM ? 21 : 0)>(f);
+  if (pm & (7u << 16)) core_run_down<16, (NCDM ? 18 : 0)>(f);
+  if (pm & (7u << 13)) core_run_down<13, (NCDM ? 15 : 0)>(f);
+  core_run_down<12, 12>(f);
+  if (pm & 0xE00u) core_run_down<9, 11>(f);
+  core_run_down<6, 8>(f);
+  if (pm & 0x3Fu) core_run_down<0, 5>(f);
+}
+
 struct Jac {
   double* Jc;      // LDS [NC][64]: Jc[j * 64 + i] = J_cc(i, j) for lane i < NC, 0 on the other lanes.  Only the (rare)
                    // Jacobian refresh writes it and only the factorisation reads it: no reason to pin 26 VGPRs
@@ -1457,8 +1524,8 @@ static __device__ __forceinline__ bool factorise(const LaneEq& e, const Jac& J, 
   int rowperm = lane, permuted = 0;
   double rpivc = 1.;
   bool ok = true;
-#pragma unroll
-  for (int j = 0; j < NC; j++) {
+  const unsigned pm = e.pmask;
+  for_core(pm, 0, [&](const int j) {
     const double mag = (lane >= j) ? fabs(A[j]) : 0.;      // rows >= NC hold zeros in the core columns
     const double diag = bcast(mag, j);
     if (__ballot(mag > 1e3 * diag) != 0ull || diag == 0.) {  // rare: the diagonal is not an acceptable pivot
@@ -1483,12 +1550,11 @@ static __device__ __forceinline__ bool factorise(const LaneEq& e, const Jac& J, 
     if (lane == j) rpivc = rp;
     const double m = (lane > j) ? A[j] * rp : 0.;
     if (lane > j) A[j] = m;
-#pragma unroll
-    for (int cidx = j + 1; cidx < NC; cidx++) {
+    for_core(pm, j + 1, [&](const int cidx) {
       const double pj = bcast(A[cidx], j);
       A[cidx] = fma(-m, pj, A[cidx]);   // m = 0 on rows <= j
-    }
-  }
+    });
+  });
   // unit-diagonal U: scale the upper part of every row by its reciprocal pivot
 #pragma unroll
   for (int j = 0; j < NC; j++) A[j] = (j > lane) ? A[j] * rpivc : A[j];
@@ -1532,19 +1598,18 @@ static __device__ __forceinline__ double lu_solve(const LaneEq& e, const LuReg& 
   // Row i keeps its L entries (columns j < i) and its U entries (j > i) in ONE register array, so each substitution step must
   // switch the entry off on the rows it does not concern.  Clearing the HIGH word alone does that in one v_cndmask instead of
   // two: what is left is a subnormal (|m| < 2^-1022), and m * xj then vanishes against x unless |xj / x| > 2^970.
-#pragma unroll
-  for (int j = 0; j < NC; j++) {   // forward, unit lower
+  const unsigned pm = e.pmask;
+  for_core(pm, 0, [&](const int j) {   // forward, unit lower
     const double xj = bcast(x, j);
     const double m = __hiloint2double((lane > j) ? __double2hiint(Ac[j]) : 0, __double2loint(Ac[j]));
     x = fma(-m, xj, x);
-  }
+  });
   x *= F.rpivc;   // 1 outside the core
-#pragma unroll
-  for (int j = NC - 1; j >= 0; j--) {  // backward, unit upper
+  for_core_down(pm, [&](const int j) {  // backward, unit upper
     const double xj = bcast(x, j);
     const double uj = __hiloint2double((lane < j) ? __double2hiint(Ac[j]) : 0, __double2loint(Ac[j]));
     x = fma(-uj, xj, x);
-  }
+  });
   // 4. tails, upward sweep: x_l = b'_l / d'_l - (a_l / d'_l) x_{l-1}; the l=3 element takes x_{l-1} from its core parent
   if (maxlen > 0) {
     double xpar;
@@ -2075,82 +2140,89 @@ static __device__ __forceinline__ int ndf15(const PtParams& P, const Layout& L, 
   return 0;
 }
 
-// ---- non-cold species, last interval: radiation streaming + ur fluid + ncdm fluid all on (rsa, ufa, ncdmfa) -----------------------
-// What is left of the system is baryons, cdm, eta and (delta, theta, sigma) of every non-cold species: 4 + 3 N variables (7 or 13)
-// that still oscillate until today - 70 % of the steps of the heaviest mode.  The general ncdm machinery (one wave per three momentum
-// bins, three block barriers per RHS and per solve, block-wide norms) costs the same per step whatever the size of the system, so
-// this interval gets a path of its own: the chain waves hand their three fluid variables per species to the core wave and retire;
-// the core wave integrates alone (ndf15s<1>: no barrier, no chain, dense register LU) with the fluid variables in core lanes that
-// the radiation-streaming approximation has vacated - species 0 in the lanes of (delta_g, theta_g, shear_g), species 1 in those of the
-// polarisation multipoles 0..2, species 2 in those of (delta_ur, theta_ur, shear_ur).
-static __device__ __forceinline__ int fluid_lane(int species, int j) { return ((species == 0) ? LN_DG : (species == 1) ? LN_P0 : LN_DUR) + j; }
-static __device__ __forceinline__ bool compact_present(const PtParams& P, int i) {
-  if (i == LN_DB || i == LN_TB || i == LN_ETA) return true;
-  if (i == LN_DC) return P.has_cdm != 0;
-  for (int n = 0; n < P.nc.n_species; n++) if (i >= fluid_lane(n, 0) && i <= fluid_lane(n, 2)) return true;
-  return false;
-}
-// perturb_derivs in this regime (pm.cpp:7861-9218 with perturb_einstein, perturb_total_stress_energy, perturb_rsa_delta_and_theta and the
-// fluid equations of pm.cpp:8737-8823 folded in); synchronous gauge.  Leaves M and N describing (tau, y) for the sources.
-static __device__ __forceinline__ double rhs_compact(const PtParams& P, Lookup& Q, Metric& M, NcIn& N, double k, double inv_k2, double tau, double y, int lane) {
-  lookup(P, Q, tau, lane);
-  const double a2 = Q.a2, aH = Q.aH, k2 = k * k, kap = Q.kap, cb2 = Q.cb2;
-  const double db = bcast(y, LN_DB), tb = bcast(y, LN_TB), dc = bcast(y, LN_DC), eta = bcast(y, LN_ETA);
+// ---- non-cold species: the core wave alone -----------------------------------------------------------------------------------
+// Once the ncdm fluid approximation is on (and tight coupling off) every species is three variables (delta, theta, sigma) - yet these
+// intervals hold 90 % of the steps of the heaviest mode (the fluids oscillate until today), and the general ncdm machinery (one wave per
+// three momentum bins, three block barriers per RHS and per solve, block-wide norms) costs the same per step whatever the size of the
+// system.  So at that switch the chain waves hand their fluid variables to the core wave and retire (the first of them stays as the
+// helper wave when the launch is latency-bound, PtParams::ncdm_compact); the core wave integrates alone with the structured integrator
+// ndf15s - no barrier, no chain, no auxiliary unknowns: the fluid variables are ordinary members of the dense core in lanes LN_F0...
+//   SYS = 2: any scheme of the other species (photon / ur hierarchies still running): the general RHS + the fluid equations
+//   SYS = 1: radiation streaming and the ur fluid on as well (the last interval): baryons, cdm, eta and the fluids are all that is left,
+//            4 + 3 N variables, and the RHS is written out for exactly that
+static __device__ __forceinline__ int fluid_lane(int species, int j) { return LN_F0 + 3 * species + j; }
+// perturb_derivs (pm.cpp:7861-9218 with perturb_einstein, perturb_total_stress_energy, perturb_rsa_delta_and_theta and the fluid
+// equations of pm.cpp:8737-8823 folded in); synchronous gauge.  Leaves M and N describing (tau, y) for the sources.
+template <int SYS, int LK>
+static __device__ __forceinline__ double rhs_fluid(const PtParams& P, const Layout& L, const LaneEq& e, Lookup& Q, Metric& M, NcIn& N, double k, double inv_k2,
+                                                   double tau, double y, int lane) {
+  if (LK == 1) { if (!mb_fetch(Q, tau, lane)) return nan(""); }
+  else lookup(P, Q, tau, lane);
+  const double aH = Q.aH, k2 = k * k;
   const int ln = opaque(lane);
   // the non-cold fluids: integrals for the Einstein equations, and this lane's species (wave-uniform per species, selected per lane)
   double D = 0., T = 0., S = 0., rho_l = 1., p_l = 1., pp_l = 1.;
   for (int n = 0; n < P.nc.n_species; n++) {
-    const double rho = bcast(Q.vnc, 3 * n), pr = bcast(Q.vnc, 3 * n + 1), pp = bcast(Q.vnc, 3 * n + 2);
+    double rho, pr, pp;
+    if (LK == 1) { rho = reg_get(Q.ncv, 3 * n); pr = reg_get(Q.ncv, 3 * n + 1); pp = reg_get(Q.ncv, 3 * n + 2); }
+    else { rho = bcast(Q.vnc, 3 * n); pr = bcast(Q.vnc, 3 * n + 1); pp = bcast(Q.vnc, 3 * n + 2); }
     const int l0 = fluid_lane(n, 0);
     D = fma(rho, bcast(y, l0), D); T = fma(rho + pr, bcast(y, l0 + 1), T); S = fma(rho + pr, bcast(y, l0 + 2), S);
     const bool mine = (ln >= l0) && (ln <= l0 + 2);
     rho_l = mine ? rho : rho_l; p_l = mine ? pr : p_l; pp_l = mine ? pp : pp_l;
   }
-  N.D = D; N.T = T; N.S = S;
-  double delta_rho = Q.rb * db + D, rpt = Q.rb * tb + T, rps = S;
-  if (P.has_cdm) delta_rho += Q.rc * dc;
-  const double hp = (Q.k2s2 * eta + 1.5 * a2 * delta_rho) * Q.two_over_aH;                       // pm.cpp:5913-5914
-  // radiation streaming: photons and ur follow the metric (pm.cpp:9530-9636)
-  double rdg = 0., rtg = 0., rdur = 0., rtur = 0.;
-  if (P.rsa_method != CPT_RSA_NULL) { rdg = 4. * inv_k2 * (aH * hp - k2 * eta); rtg = -0.5 * hp; }
-  if (P.rsa_method == CPT_RSA_MD_WITH_REIO) {
-    rdg += -4. * inv_k2 * kap * (tb + 0.5 * hp);
-    rtg += 3. * inv_k2 * (Q.ddkappa * (tb + 0.5 * hp) + kap * (-aH * tb + cb2 * k2 * db - aH * hp + k2 * eta));
+  N.D = D; N.T = T; N.S = S; N.sh = nullptr; N.nw = 0;
+  double dy, mc, ms;
+  if (SYS == 2) {
+    dy = rhs<2>(P, L, e, Q, M, k, inv_k2, tau, y, lane, &N);   // (0 on the fluid lanes: their LaneEq is empty)
+    mc = 0.5 * M.hp; ms = k2 * M.alpha;
+  } else {
+    const double a2 = Q.a2, kap = Q.kap, cb2 = Q.cb2;
+    const double db = bcast(y, LN_DB), tb = bcast(y, LN_TB), dc = bcast(y, LN_DC), eta = bcast(y, LN_ETA);
+    double delta_rho = Q.rb * db + D, rpt = Q.rb * tb + T;
+    const double rps = S;
+    if (P.has_cdm) delta_rho += Q.rc * dc;
+    const double hp = (Q.k2s2 * eta + 1.5 * a2 * delta_rho) * Q.two_over_aH;                       // pm.cpp:5913-5914
+    // radiation streaming: photons and ur follow the metric (pm.cpp:9530-9636)
+    double rdg = 0., rtg = 0., rdur = 0., rtur = 0.;
+    if (P.rsa_method != CPT_RSA_NULL) { rdg = 4. * inv_k2 * (aH * hp - k2 * eta); rtg = -0.5 * hp; }
+    if (P.rsa_method == CPT_RSA_MD_WITH_REIO) {
+      rdg += -4. * inv_k2 * kap * (tb + 0.5 * hp);
+      rtg += 3. * inv_k2 * (Q.ddkappa * (tb + 0.5 * hp) + kap * (-aH * tb + cb2 * k2 * db - aH * hp + k2 * eta));
+    }
+    if (P.has_ur && P.rsa_method != CPT_RSA_NULL) { rdur = 4. * inv_k2 * (aH * hp - k2 * eta); rtur = -0.5 * hp; }
+    delta_rho += Q.rg * rdg;
+    rpt += Q.rg43 * rtg;
+    if (P.has_ur) { delta_rho += Q.ru * rdur; rpt += Q.ru43 * rtur; }
+    const double etap = (1.5 * a2 * rpt + (CURV ? 0.5 * P.K * hp : 0.)) * Q.inv_k2s2;             // pm.cpp:5938
+    const double alpha = (hp + 6. * etap) * 0.5 * inv_k2;
+    const double alphap = -2. * aH * alpha + eta - 4.5 * (a2 * inv_k2) * rps;
+    M.hp = hp; M.etap = etap; M.alpha = alpha; M.alphap = alphap; M.rsa_dg = rdg; M.rsa_tg = rtg;
+    mc = 0.5 * hp; ms = k2 * alpha;
+    const double dtb = -aH * tb + k2 * cb2 * db + Q.R * kap * (rtg - tb);                          // pm.cpp:8108-8113 with the streaming theta_g
+    dy = 0.;
+    dy = (ln == LN_DB) ? -(tb + mc) : dy;
+    dy = (ln == LN_TB) ? dtb : dy;
+    dy = (ln == LN_DC && P.has_cdm) ? -mc : dy;
+    dy = (ln == LN_ETA) ? etap : dy;
   }
-  if (P.has_ur && P.rsa_method != CPT_RSA_NULL) { rdur = 4. * inv_k2 * (aH * hp - k2 * eta); rtur = -0.5 * hp; }
-  delta_rho += Q.rg * rdg;
-  rpt += Q.rg43 * rtg;
-  if (P.has_ur) { delta_rho += Q.ru * rdur; rpt += Q.ru43 * rtur; }
-  const double etap = (1.5 * a2 * rpt + (CURV ? 0.5 * P.K * hp : 0.)) * Q.inv_k2s2;             // pm.cpp:5938
-  const double alpha = (hp + 6. * etap) * 0.5 * inv_k2;
-  const double alphap = -2. * aH * alpha + eta - 4.5 * (a2 * inv_k2) * rps;
-  M.hp = hp; M.etap = etap; M.alpha = alpha; M.alphap = alphap; M.rsa_dg = rdg; M.rsa_tg = rtg;
-  const double mc = 0.5 * hp, ms = k2 * alpha;
-  const double dtb = -aH * tb + k2 * cb2 * db + Q.R * kap * (rtg - tb);                          // pm.cpp:8108-8113 with the streaming theta_g
-  // this lane's equation
-  double dy = 0.;
-  dy = (ln == LN_DB) ? -(tb + mc) : dy;
-  dy = (ln == LN_TB) ? dtb : dy;
-  dy = (ln == LN_DC && P.has_cdm) ? -mc : dy;
-  dy = (ln == LN_ETA) ? etap : dy;
   {  // fluid lanes (pm.cpp:8737-8823): j = 0 delta, 1 theta, 2 sigma; ym / yp: the species' neighbouring variable
-    const int j = (ln <= LN_SG) ? ln - LN_DG : (ln <= LN_P2) ? ln - LN_P0 : ln - LN_DUR;
-    const int sp = (ln <= LN_SG) ? 0 : (ln <= LN_P2) ? 1 : 2;
-    const bool fluid = (j >= 0) && (j <= 2) && (ln == fluid_lane(sp, j)) && (sp < P.nc.n_species);
+    const int f = ln - LN_F0, sp = (f >= 6) ? 2 : (f >= 3) ? 1 : 0, j = f - 3 * sp;
+    const bool fluid = (f >= 0) && (sp < P.nc.n_species) && (ln < NC);
     const double ym = lane_below(y), yp = lane_above(y);
     const double w = p_l * fast_rcp(rho_l), inv_1pw = fast_rcp(1. + w), pp_over_p = pp_l * fast_rcp(p_l);
     const double ca2 = w / 3. * inv_1pw * (5. - pp_over_p), ceff2 = ca2;
     const double cvis2 = (P.nfa_method == CPT_NCDMFA_HU) ? w : 3. * w * ca2;
     const double s2 = CURV ? sqrt(fmax(1.0 - 3. * P.K / k2, 0.)) : 1.;
-    double f;
-    if (j == 0) f = -(1. + w) * (yp + mc) - 3. * aH * (ceff2 - w) * y;
-    else if (j == 1) f = ceff2 * inv_1pw * k2 * ym - k2 * yp - aH * (1. - 3. * ca2) * y;
+    double fv;
+    if (j == 0) fv = -(1. + w) * (yp + mc) - 3. * aH * (ceff2 - w) * y;
+    else if (j == 1) fv = ceff2 * inv_1pw * k2 * ym - k2 * yp - aH * (1. - 3. * ca2) * y;
     else {
       const double src = 8. / 3. * cvis2 * inv_1pw * s2;
-      if (P.nfa_method == CPT_NCDMFA_HU) f = src * (ym + ms) - 3. * aH * ca2 * fast_rcp(w) * y;
-      else f = src * (ym + ((P.nfa_method == CPT_NCDMFA_MB) ? ms : mc)) - 3. * (aH * (2. / 3. - ca2 - pp_over_p / 3.) + Q.inv_tau) * y;
+      if (P.nfa_method == CPT_NCDMFA_HU) fv = src * (ym + ms) - 3. * aH * ca2 * fast_rcp(w) * y;
+      else fv = src * (ym + ((P.nfa_method == CPT_NCDMFA_MB) ? ms : mc)) - 3. * (aH * (2. / 3. - ca2 - pp_over_p / 3.) + Q.inv_tau) * y;
     }
-    dy = fluid ? f : dy;
+    dy = fluid ? fv : dy;
   }
   return dy;
 }
@@ -2161,9 +2233,11 @@ static __device__ __forceinline__ double rhs_compact(const PtParams& P, Lookup& 
 // an inlined RHS is ~300 instructions, so the flat one-call-site loop with its state flags - every variable live everywhere, a
 // dozen register moves at every merge point - is no longer worth its price.  Returns 0 / error code (1 step too small,
 // 2 singular, 4 budget, 5 helper unresponsive).
-// COMPACT = 1: the core wave of the ncdm kernels alone in the last interval (rhs_compact above): own table look-ups, samples
-// evaluated in place, no helper.
-template <int COMPACT>
+// SYS = 0: the integrator wave of the two-wave kernels.  SYS = 1, 2: the core wave of the ncdm kernels on its own (rhs_fluid above);
+// HELPED: with the first chain wave kept as its helper (launches that are resident at once: latency is all that counts) - or without,
+// own table look-ups and samples evaluated in place (the form for grids larger than the chip, where a retired wave makes room for
+// the next k-mode).
+template <int SYS, bool HELPED = true>
 static __device__ __forceinline__ int ndf15s(const PtParams& P, const Layout& L, const LaneEq& e, Ctx& C, Lookup& Q, Metric& M, double k, double inv_k2,
                                              double t0, double tfinal, double& y_io, Stat& st, int lane, int& budget, double* jac_lds,
                                              double2* fw_lds, unsigned long long* prof, int ik = 0) {
@@ -2194,16 +2268,16 @@ static __device__ __forceinline__ int ndf15s(const PtParams& P, const Layout& L,
   NcIn N = {0., 0., 0., nullptr, 0};
   auto eval = [&](double tq, double yq) {
     st.fevals++;
-    if constexpr (COMPACT != 0) return rhs_compact(P, Q, M, N, k, inv_k2, tq, yq, lane);
-    else return rhs<true>(P, L, e, Q, M, k, inv_k2, tq, yq, lane);
+    if constexpr (SYS != 0) return rhs_fluid<SYS, HELPED ? 1 : 0>(P, L, e, Q, M, N, k, inv_k2, tq, yq, lane);
+    else return rhs<1>(P, L, e, Q, M, k, inv_k2, tq, yq, lane);
   };
-  auto request = [&](double tq) { if constexpr (COMPACT == 0) mb_request(Q, tq, lane); };
+  auto request = [&](double tq) { if constexpr (HELPED) mb_request(Q, tq, lane); };
   const double no_alpha[4] = {0., 0., 0., 0.};
   // J e_r = f(t, e_r): exact, the system is linear and homogeneous; idle variables have no column; tails analytic
   auto jacobian = [&](double tq) {
     const double keep = M.tca_shear_g;
     for (int r = 0; r < NC; r++) {
-      if (COMPACT ? !compact_present(P, r) : !core_present(P, L, r)) continue;
+      if (!((e.pmask >> r) & 1u)) continue;
       const double col = eval(tq, (lane == r) ? 1.0 : 0.0);
       J.Jc[r * 64 + lane] = (lane < NC) ? col : 0.;
     }
@@ -2430,7 +2504,7 @@ static __device__ __forceinline__ int ndf15s(const PtParams& P, const Layout& L,
           }
           ypi *= inv_h;
         }
-        if constexpr (COMPACT != 0) {               // no helper: perturb_sources right here
+        if constexpr (!HELPED) {                    // no helper: perturb_sources right here
           (void)eval(tnext, yi);
           store_sources(P, L, Q, M, k, inv_k2, yi, ypi, tca_keep, next, ik, lane, N);
           M.tca_shear_g = tca_keep;
@@ -2592,9 +2666,10 @@ static __device__ __noinline__ double initial_conditions(DevTables T, int has_cd
 // the integration of one mode over its intervals of constant approximation scheme, for one role (see sync_tau): the core wave
 // and the chain waves run separate instantiations, so neither carries the other's state
 struct Sched { double tau_ini, tau_end, sw0, sw1, sw2, sw3; int nsw, ap0, ap1, ap2, ap3, fi0, fi1, fi2, fi3; };
+struct HelperWindows { double2 *bgw2, *thw2, *ncw2; };   // second set of table windows (the helper's sample look-ups)
 template <int ROLE>
 static __device__ __forceinline__ int run_intervals(const PtParams& P, Ctx& C, const Sched& sc, double k, double inv_k2, int ik, int lane,
-                                                    double2* bgw, double2* thw, double2* ncw, double* jacw, double2* fww, Stat& st, int& n_regimes,
+                                                    double2* bgw, double2* thw, double2* ncw, const HelperWindows& hw, double* jacw, double2* fww, Stat& st, int& n_regimes,
                                                     int& budget, unsigned long long* prof
 #ifdef CPT_PROFILE
                                                     , unsigned long long t_begin
@@ -2653,8 +2728,8 @@ static __device__ __forceinline__ int run_intervals(const PtParams& P, Ctx& C, c
 #ifdef CPT_PROFILE
     prof[6] = clock64() - t_begin;  // schedule search + initial conditions
 #endif
-    bool compact = false;
-    const int getenv_compact = P.ncdm_compact;
+    int single = 0;                        // (NCDM) the core wave integrates alone, the ncdm fluids in its core lanes
+    const int cmode = P.ncdm_compact;
     for (int iv = 0; iv <= nsw && status == 0; iv++) {
       const double ta = (iv == 0) ? tau_ini : (iv == 1) ? sw0 : (iv == 2) ? sw1 : (iv == 3) ? sw2 : sw3;
       const double tb = (iv == nsw) ? tau_end : (iv == 0) ? sw0 : (iv == 1) ? sw1 : (iv == 2) ? sw2 : sw3;
@@ -2664,7 +2739,11 @@ static __device__ __forceinline__ int run_intervals(const PtParams& P, Ctx& C, c
         const int was_tca = L.tca;
         const int ap = (iv == 1) ? ap0 : (iv == 2) ? ap1 : (iv == 3) ? ap2 : ap3;
         if (ap == 0) f_tca ^= 1; else if (ap == 1) f_rsa ^= 1; else if (ap == 2) f_ufa ^= 1; else f_nfa ^= 1;
-        L = make_layout(P, f_tca, f_rsa, f_ufa, f_nfa);
+        // (NCDM) from the first scheme with the ncdm fluids on and tight coupling off the core wave goes on alone; a launch too
+        // large to be resident at once (cmode 1) waits for radiation streaming and the ur fluid as well
+        bool entering = false;
+        if (NCDM && !single && cmode != 0 && f_nfa && !f_tca && (cmode == 2 || (f_rsa && f_ufa))) { entering = true; single = 1; }
+        L = make_layout(P, f_tca, f_rsa, f_ufa, f_nfa, single);
         e = make_lane_eq(P, L, ROLE == 1 ? -1 : lane, k);
         double yn = (e.role == R_NONE) ? 0. : y;
         if (ROLE == 1) yn = y;          // the momentum hierarchies ride through the photon / ur switches (pm.cpp:3968-3975 etc.)
@@ -2708,31 +2787,44 @@ static __device__ __forceinline__ int run_intervals(const PtParams& P, Ctx& C, c
             else yn = 0.;
           }
         }
-        if (NCDM) {
-          // the last interval with radiation streaming, ur fluid and ncdm fluid all on: the chain waves pass (delta, theta, sigma) of
-          // every species to the core wave and retire (see rhs_compact)
-          compact = (iv == nsw) && (ap == 1) && L.rsa && L.ufa && L.nfa && !L.tca && (getenv_compact != 0);
-          if (compact) {
-            if (ROLE == 1 && ce.holder) C.sh->ho[ce.species][ce.l] = y;
-            __syncthreads();
-            if (ROLE == 1) break;          // nothing left for a chain wave to do: no barrier follows
-            const int ln = opaque(lane);
-            for (int n = 0; n < P.nc.n_species; n++)
-              for (int j = 0; j < 3; j++)
-                if (ln == fluid_lane(n, j)) yn = C.sh->ho[n][j];
+        if (NCDM && entering) {
+          // the chain waves pass (delta, theta, sigma) of every species to the core wave and retire (see "the core wave alone")
+          if (ROLE == 1 && ce.holder) C.sh->hf[ce.species][ce.l] = yn;
+          __syncthreads();
+          if (ROLE == 1) {
+            // the first chain wave stays as the core wave's helper (table look-ups one step ahead, source samples) when the launch is
+            // latency-bound; the others have nothing left to do: no barrier follows
+            if (C.wave == 1 && cmode == 2) run_helper(P, C.mb, k, inv_k2, ik, lane, hw.bgw2, hw.thw2, bgw, thw, hw.ncw2, ncw);
+            break;
           }
+          if (cmode == 2) { Q.mb = C.mb; Q.my_req = 0; Q.req_tau = -1.; Q.tau_cached = -1.; }   // from here on the rows come from the helper
+          const int ln = opaque(lane);
+          for (int n = 0; n < P.nc.n_species; n++)
+            for (int j = 0; j < 3; j++)
+              if (ln == fluid_lane(n, j)) yn = C.sh->hf[n][j];
         }
         y = yn;
         C.tau_pub = -1.;   // (the chain coefficients cached for this time belong to the old scheme)
       }
       n_regimes++;
       int rc;
+#ifdef CPT_PROFILE_INTERVALS
+      const unsigned long long iv_t0 = clock64(); const int iv_s0 = st.steps;
+#endif
       if constexpr (SAMPLER) rc = ndf15s<0>(P, L, e, C, Q, M, k, inv_k2, ta, tb, y, st, lane, budget, jacw, fww, prof);
       else if constexpr (NCDM != 0 && ROLE == 0) {
-        if (compact) rc = ndf15s<1>(P, L, e, C, Q, M, k, inv_k2, ta, tb, y, st, lane, budget, jacw, fww, prof, ik);
-        else rc = ndf15<ROLE>(P, L, e, ce, C, Q, M, k, inv_k2, ik, ta, tb, y, st, lane, budget, jacw, fww, prof);
+        if (single) {
+          if (cmode != 2) rc = ndf15s<1, false>(P, L, e, C, Q, M, k, inv_k2, ta, tb, y, st, lane, budget, jacw, fww, prof, ik);
+          else if (L.rsa && L.ufa) rc = ndf15s<1, true>(P, L, e, C, Q, M, k, inv_k2, ta, tb, y, st, lane, budget, jacw, fww, prof, ik);
+          else rc = ndf15s<2, true>(P, L, e, C, Q, M, k, inv_k2, ta, tb, y, st, lane, budget, jacw, fww, prof, ik);
+        } else rc = ndf15<ROLE>(P, L, e, ce, C, Q, M, k, inv_k2, ik, ta, tb, y, st, lane, budget, jacw, fww, prof);
       } else rc = ndf15<ROLE>(P, L, e, ce, C, Q, M, k, inv_k2, ik, ta, tb, y, st, lane, budget, jacw, fww, prof);
       if (rc) status = 10 + rc;
+#ifdef CPT_PROFILE_INTERVALS
+      if (lane == 0 && blockIdx.x == 0 && ROLE == 0)
+        printf("interval %d [%g, %g] tca %d rsa %d ufa %d nfa %d single %d: %d steps, %llu cycles\n", iv, ta, tb, L.tca, L.rsa, L.ufa, L.nfa, single,
+               st.steps - iv_s0, clock64() - iv_t0);
+#endif
     }
   }
   return status;
@@ -2741,12 +2833,13 @@ static __device__ __forceinline__ int run_intervals(const PtParams& P, Ctx& C, c
 // the helper wave (SAMPLER, see Mailbox): answers the integrator's table look-ups and evaluates perturb_sources
 // (pm.cpp:6731-7285) for every sample the integrator posts.  Two sets of table windows: the samples walk monotonically through
 // the sample times, the look-ups run one step ahead of the integration.
+// (NCDM: the helper of the core wave on its own - the first chain wave; samples go through rhs_fluid, answers carry the ncdm columns)
 static __device__ __forceinline__ void run_helper(const PtParams& P, Mailbox* mb, double k, double inv_k2, int ik, int lane, double2* bgw_s, double2* thw_s,
-                                                  double2* bgw_p, double2* thw_p) {
+                                                  double2* bgw_p, double2* thw_p, double2* ncw_s = nullptr, double2* ncw_p = nullptr) {
   Lookup Q, Qp;
-  lookup_init(P, Q, bgw_s, thw_s, lane);
+  lookup_init(P, Q, bgw_s, thw_s, lane, ncw_s);
   lookup_set_mode(P, Q, k);
-  lookup_init(P, Qp, bgw_p, thw_p, lane);
+  lookup_init(P, Qp, bgw_p, thw_p, lane, ncw_p);
   lookup_set_mode(P, Qp, k);
 #ifdef CPT_PROFILE
   unsigned long long sprof[16];
@@ -2756,8 +2849,9 @@ static __device__ __forceinline__ void run_helper(const PtParams& P, Mailbox* mb
   M.hp = M.etap = M.alpha = M.alphap = 0.; M.psi = M.phip = 0.;
   M.tca_shear_g = 0.; M.rsa_dg = M.rsa_tg = 0.;
   int flags = -1, tail = 0, answered = 0;
-  Layout L = make_layout(P, 1, 0, 0);
+  Layout L = NCDM ? make_layout(P, 0, 1, 1, 1, 1) : make_layout(P, 1, 0, 0);
   LaneEq e = make_lane_eq(P, L, lane, k);
+  NcIn N = {0., 0., 0., nullptr, 0};
   for (;;) {
     // look-ups first: the integrator may be waiting for one, a sample never holds it up while the ring has room
     const int rq = mb_load(&mb->req_seq);
@@ -2770,6 +2864,7 @@ static __device__ __forceinline__ void run_helper(const PtParams& P, Mailbox* mb
         a[8] = Qp.aH; a[9] = Qp.two_over_aH; a[10] = Qp.R; a[11] = Qp.inv_1pR; a[12] = Qp.inv_R; a[13] = Qp.tau_c; a[14] = Qp.dtau_c; a[15] = Qp.F;
         a[16] = Qp.Fp; a[17] = Qp.app; a[18] = Qp.inv_tau; a[19] = Qp.rg43; a[20] = Qp.ru43; a[21] = Qp.kcot;
       }
+      if (NCDM && lane < NCB_NCOL) mb->ans[22 + lane] = Qp.vnc;   // lane c holds column c of the ncdm row
       answered = rq;
       mb_store(&mb->ans_seq, rq);
       continue;
@@ -2781,12 +2876,17 @@ static __device__ __forceinline__ void run_helper(const PtParams& P, Mailbox* mb
       const double yi = mb->yi[slot][lane], ypi = mb->ypi[slot][lane], tca_keep = mb->tca_keep[slot];
       tail++;
       mb_store(&mb->tail, tail);                 // (the slot's content is in registers: the integrator may refill it)
+      const double tn = P.tau_s[it];
       if (f != flags) {                          // the integrator entered another approximation scheme
         flags = f;
-        L = make_layout(P, f & 1, (f >> 1) & 1, (f >> 2) & 1);
+        L = make_layout(P, f & 1, (f >> 1) & 1, (f >> 2) & 1, NCDM ? 1 : 0, NCDM ? 1 : 0);
         e = make_lane_eq(P, L, lane, k);
       }
-      const double tn = P.tau_s[it];
+      if (NCDM) {
+        (void)rhs_fluid<2, 0>(P, L, e, Q, M, N, k, inv_k2, tn, yi, lane);
+        store_sources(P, L, Q, M, k, inv_k2, yi, ypi, tca_keep, it, ik, lane, N);
+        continue;
+      }
       (void)rhs<false>(P, L, e, Q, M, k, inv_k2, tn, yi, lane);   // leaves Q and M describing (tn, yi)
       store_sources(P, L, Q, M, k, inv_k2, yi, ypi, tca_keep, it, ik, lane);
       continue;
@@ -2806,8 +2906,16 @@ static __device__ __forceinline__ void body_perturb(const PtParams& P) {
   __shared__ __attribute__((aligned(16))) double2 fwsh[FW_PAIRS * 64];   // the integrator / core wave's factors (LuReg)
   __shared__ __attribute__((aligned(16))) double2 ncw[NCDM ? 64 * NCB_NCOL : 1];
   __shared__ __attribute__((aligned(8))) char ncsh_raw[NCDM ? sizeof(NcShared) : 8];
-  __shared__ __attribute__((aligned(16))) double2 tabw2[SAMPLER ? 64 * (BG_NCOL + TH_NCOL) : 1];   // the helper's second set of table windows
-  __shared__ __attribute__((aligned(16))) Mailbox mbox[1];
+  // the helper's second set of table windows and the mailbox: static in the two-wave kernels; dynamic in the ncdm kernels, which
+  // only allocate them when the launch runs with a helper (CPT_NCDM_HELPER_LDS bytes, cpt_perturb_impl)
+  __shared__ __attribute__((aligned(16))) double2 tabw2_s[SAMPLER ? 64 * (BG_NCOL + TH_NCOL) : 1];
+  __shared__ __attribute__((aligned(16))) unsigned char mbox_s[SAMPLER ? sizeof(Mailbox) : 16];
+  extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];
+  double2* tabw2 = SAMPLER ? tabw2_s : (double2*)dyn_lds;
+  double2* ncw2 = tabw2 + 64 * (BG_NCOL + TH_NCOL);
+  Mailbox* mbox = SAMPLER ? (Mailbox*)mbox_s : (Mailbox*)(dyn_lds + CPT_NCDM_HELPER_WINDOWS);
+  const bool has_helper = SAMPLER || P.ncdm_compact == 2;
+  const HelperWindows hwin = {tabw2, tabw2 + 64 * BG_NCOL, ncw2};
   const int lane = threadIdx.x & 63;
   const int ik = P.order[blockIdx.x];
   const double k = P.k[ik];
@@ -2817,7 +2925,7 @@ static __device__ __forceinline__ void body_perturb(const PtParams& P) {
   Ctx C;
   C.wave = (int)(threadIdx.x >> 6); C.nw = NCDM ? (int)(blockDim.x >> 6) - 1 : 0;
   C.mb = mbox; C.posted = 0; C.tail_seen = 0;
-  if (SAMPLER) {   // (the only barrier of the two-wave kernels: the counters are zero before either wave looks at them)
+  if (has_helper) {   // (the only barrier of the two-wave kernels: the counters are zero before any wave looks at them)
     if (threadIdx.x == 0) { mbox->head = mbox->tail = mbox->done = mbox->req_seq = mbox->ans_seq = 0; mbox->req_tau = -1.; }
     __syncthreads();
   }
@@ -2873,9 +2981,9 @@ static __device__ __forceinline__ void body_perturb(const PtParams& P) {
   if (status == 0) {
     const Sched sc = {tau_ini, tau_end, sw0, sw1, sw2, sw3, nsw, ap0, ap1, ap2, ap3, fi0, fi1, fi2, fi3};
 #ifdef CPT_PROFILE
-#define CPT_RUN_ARGS P, C, sc, k, inv_k2, ik, lane, bgw, thw, ncw, jacw, fwsh, st, n_regimes, budget, prof, t_begin
+#define CPT_RUN_ARGS P, C, sc, k, inv_k2, ik, lane, bgw, thw, ncw, hwin, jacw, fwsh, st, n_regimes, budget, prof, t_begin
 #else
-#define CPT_RUN_ARGS P, C, sc, k, inv_k2, ik, lane, bgw, thw, ncw, jacw, fwsh, st, n_regimes, budget, prof
+#define CPT_RUN_ARGS P, C, sc, k, inv_k2, ik, lane, bgw, thw, ncw, hwin, jacw, fwsh, st, n_regimes, budget, prof
 #endif
     if constexpr (NCDM != 0) { if (C.wave > 0) status = run_intervals<1>(CPT_RUN_ARGS); else status = run_intervals<0>(CPT_RUN_ARGS); }
     else { if (C.wave == 0) status = run_intervals<0>(CPT_RUN_ARGS); }
@@ -2884,7 +2992,7 @@ static __device__ __forceinline__ void body_perturb(const PtParams& P) {
   if (SAMPLER) {   // every path of wave 0 ends here: tell the helper (which polls `done` whatever happened above) to drain and leave
     if (C.wave == 0) mb_store(&mbox->done, 1);
     else run_helper(P, mbox, k, inv_k2, ik, lane, tabw2, tabw2 + 64 * BG_NCOL, bgw, thw);
-  }
+  } else if (NCDM && has_helper && C.wave == 0) mb_store(&mbox->done, 1);   // (the helper of the core wave on its own, if it got that far)
 #ifdef CPT_PROFILE
   prof[7] = clock64() - t_begin;
 #ifndef CPT_PROFILE_WAVE
@@ -3031,8 +3139,7 @@ void fill_params(const cpt_handle* h, PtParams& P) {
   P.has_ncdm = c.has_ncdm; P.nfa_method = c.ncdm_fluid_approximation; P.nfa_trig = c.ncdm_fluid_trigger_tau_over_tau_k;
   P.tol_ncdm_w = c.has_ncdm ? c.tol_ncdm_initial_w : 1e300; P.tp_dcb = c.has_ncdm ? c.index_tp_delta_cb : -1;
   P.nc = h->ncdm;
-  P.ncdm_compact = 1;
-  if (const char* ev = getenv("CPT_NCDM_COMPACT")) P.ncdm_compact = atoi(ev) != 0;
+  P.ncdm_compact = 1;   // (cpt_perturb_impl picks 1 or 2 from the size of the launch)
   P.max_steps = 400000;
   // one tail per 16-lane row when each fits (defaults: 10 / 8 / 15 lanes), else the packed lane map with sequential sweeps
   P.rows = (c.mode == CPT_MODE_SCALARS && !c.has_ncdm && c.l_max_g - 2 <= 16 && c.l_max_pol_g - 2 <= 16 && (!c.has_ur || c.l_max_ur - 2 <= 16)) ? 1 : 0;
@@ -3118,12 +3225,17 @@ int cpt_perturb_impl(cpt_handle* h, const double* k, int nk, const double* tau, 
     (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, h->device);   // (256 stays if the query fails)
     bool half_regs = nw > 3 || nk > 3 * n_cu;
     if (const char* e = getenv("CPT_NCDM_WAVES_PER_SIMD")) half_regs = nw > 3 || atoi(e) >= 2;
+    // last interval: a launch that is resident at once is latency-bound and keeps a helper wave beside the core wave; a larger one
+    // lets every chain wave retire, which makes room for the next k-mode (measured on 2988 modes: 130 ms against 152 ms with helpers)
+    P.ncdm_compact = (nk <= 3 * n_cu) ? 2 : 1;
+    if (const char* e = getenv("CPT_NCDM_COMPACT")) P.ncdm_compact = atoi(e);
+    const size_t dyn = (P.ncdm_compact == 2) ? CPT_NCDM_HELPER_LDS : 0;
     if (c.K != 0.) {
-      if (!half_regs) hipLaunchKernelGGL((k_perturb_ncdm<1, 3>), dim3(nk), dim3(64 * (1 + nw)), 0, h->stream, P);
-      else hipLaunchKernelGGL((k_perturb_ncdm<1, NCW_MAX>), dim3(nk), dim3(64 * (1 + nw)), 0, h->stream, P);
+      if (!half_regs) hipLaunchKernelGGL((k_perturb_ncdm<1, 3>), dim3(nk), dim3(64 * (1 + nw)), dyn, h->stream, P);
+      else hipLaunchKernelGGL((k_perturb_ncdm<1, NCW_MAX>), dim3(nk), dim3(64 * (1 + nw)), dyn, h->stream, P);
     } else {
-      if (!half_regs) hipLaunchKernelGGL((k_perturb_ncdm<0, 3>), dim3(nk), dim3(64 * (1 + nw)), 0, h->stream, P);
-      else hipLaunchKernelGGL((k_perturb_ncdm<0, NCW_MAX>), dim3(nk), dim3(64 * (1 + nw)), 0, h->stream, P);
+      if (!half_regs) hipLaunchKernelGGL((k_perturb_ncdm<0, 3>), dim3(nk), dim3(64 * (1 + nw)), dyn, h->stream, P);
+      else hipLaunchKernelGGL((k_perturb_ncdm<0, NCW_MAX>), dim3(nk), dim3(64 * (1 + nw)), dyn, h->stream, P);
     }
   } else
   CPT_PT_DISPATCH(c, P.rows, k_perturb, dim3(nk), dim3(128), 0, h->stream, P);
