@@ -27,10 +27,20 @@ struct Shard {
 };
 
 struct Inputs {
-  cpt_config config;
+  cpt_config config;      // physics, precision and index maps of the first mode (scalars when present, else tensors); config.ic: its
+                          // initial condition when n_ic == 1
   cpt_tables tables;      // host pointers into the caller's (reference modules') tables; only read during construction
   cpt_grid_params grid;
   Shard shard;            // default: single GPU
+  // ---- more than one initial condition / mode (perturb_indices_of_perturbs, pm.cpp:843-1235) ----
+  // scalar initial conditions in the reference's order ad, bi, cdi, nid, niv (pm.cpp:1153-1170): ic_size_[scalars] = n_ic.  Every
+  // initial condition is its own device handle (the modes of different initial conditions are independent integrations).
+  int n_ic = 1;
+  int ic[5] = {CPT_IC_AD, CPT_IC_BI, CPT_IC_CDI, CPT_IC_NID, CPT_IC_NIV};   // read when n_ic > 1
+  // modes = s,t: md_size_ = 2, index_md_scalars_ = 0, index_md_tensors_ = 1; config_tensors is the tensor mode's own config
+  // (mode = CPT_MODE_TENSORS, its source / transfer index maps, l_max_*_ten, ...)
+  bool with_tensors = false;
+  cpt_config config_tensors;
 };
 
 // Background + thermodynamics tables computed on the host (include/cpt_host.h) instead of taken from the
@@ -52,13 +62,14 @@ class PerturbationsModule {
   ~PerturbationsModule();
   PerturbationsModule(const PerturbationsModule&) = delete;
 
-  // ---- data contract of source/perturbations_module.h (scalar mode, adiabatic ic) ----
-  int index_md_scalars_ = 0, md_size_ = 1;
-  int index_ic_ad_ = 0;
-  int* ic_size_ = nullptr;
+  // ---- data contract of source/perturbations_module.h ----
+  int index_md_scalars_ = 0, index_md_tensors_ = 0, md_size_ = 1;   // (tensors-only: both 0, like the reference's index counter)
+  short has_scalars_ = 1, has_tensors_ = 0;
+  int index_ic_ad_ = -1, index_ic_bi_ = -1, index_ic_cdi_ = -1, index_ic_nid_ = -1, index_ic_niv_ = -1, index_ic_ten_ = 0;
+  int* ic_size_ = nullptr;                                          // [md]
   int index_tp_t0_ = -1, index_tp_t1_ = -1, index_tp_t2_ = -1, index_tp_p_ = -1, index_tp_delta_m_ = -1,
       index_tp_phi_plus_psi_ = -1, index_tp_delta_cb_ = -1;   // (delta_cb: requested with delta_m when ncdm is present, pm.cpp:996)
-  int* tp_size_ = nullptr;
+  int* tp_size_ = nullptr;                                          // [md]
   short has_source_t_ = 0, has_source_p_ = 0, has_source_delta_m_ = 0, has_source_phi_plus_psi_ = 0;
   double*** sources_ = nullptr;  // sources_[md][ic*tp_size+tp][index_tau*k_size+index_k]
   double* ln_tau_ = nullptr;
@@ -72,12 +83,13 @@ class PerturbationsModule {
   mutable char error_message_[2048];
 
   // ---- extras of this backend ----
-  cpt_handle* handle() const { return h_; }       // device handle holding the sources resident in HBM (k-major)
-  const cpt_stepstat* stepstat() const { return stats_; }  // per-k work counters (the evolver's stepstat[6])
-  double kernel_ms() const;
+  // device handle of (mode, initial condition) holding its sources resident in HBM (k-major); handle() = the first one
+  cpt_handle* handle(int index_md = 0, int index_ic = 0) const { return h_[index_md][index_ic]; }
+  const cpt_stepstat* stepstat() const { return stats_; }  // per-k work counters (the evolver's stepstat[6]) of the first (mode, ic)
+  double kernel_ms() const;                                // summed over the handles
 
  private:
-  cpt_handle* h_ = nullptr;
+  cpt_handle* h_[2][5] = {{nullptr, nullptr, nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr, nullptr, nullptr}};
   cpt_stepstat* stats_ = nullptr;   // (sharded: the counters of this rank's modes, in the order k_[rank], k_[rank + world], ...)
   int* k_size_cmb_ = nullptr;
   Shard shard_;

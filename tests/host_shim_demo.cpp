@@ -59,6 +59,20 @@ int main(int argc, char** argv) {
     if (cpt_comm_get_unique_id(comm_id)) { fprintf(stderr, "cpt_comm_get_unique_id failed\n"); return 11; }
     in.shard.rank = 0; in.shard.world = 1; in.shard.comm_id = comm_id;
   }
+  // flag 5: two initial conditions in one module pair (adiabatic + cdm isocurvature): ic_size_[scalars] = 2
+  if (bad_flag == 5) { in.n_ic = 2; in.ic[0] = CPT_IC_AD; in.ic[1] = CPT_IC_CDI; }
+  // flag 6: modes = s,t in one module pair: md_size_ = 2; the tensor mode's config is the head of a second inputs file (argv[4])
+  if (bad_flag == 6) {
+    if (argc < 5) { fprintf(stderr, "flag 6 needs the tensor inputs file\n"); return 2; }
+    FILE* g = fopen(argv[4], "rb");
+    if (!g) { perror("open"); return 2; }
+    rd(g, &in.config_tensors, sizeof(in.config_tensors));
+    cpt_tables unused_tables; cpt_grid_params gt;
+    rd(g, &unused_tables, sizeof(unused_tables)); rd(g, &gt, sizeof(gt));
+    fclose(g);
+    in.with_tensors = true;
+    in.grid.l_tensor_max = gt.l_tensor_max;
+  }
   if (bad_flag == 1) in.config.has_fld = 1;             // must raise std::invalid_argument
   if (bad_flag == 2) in.grid.k_step_transition = 0.;    // must raise std::invalid_argument (reference: class_test)
   try {
@@ -74,6 +88,20 @@ int main(int argc, char** argv) {
     fwrite(tr.q_, 8, hdr[4], o);
     fwrite(tr.l_, 4, hdr[5], o);
     fwrite(tr.transfer_[md], 8, (size_t)hdr[6] * hdr[5] * hdr[4], o);
+    if (bad_flag == 5) {   // the second initial condition: sources_[md][1 * tp_size + tp], transfer_[md] + 1 * tt_size * l_size * q_size
+      if (pt->ic_size_[md] != 2 || pt->index_ic_ad_ != 0 || pt->index_ic_cdi_ != 1) { fprintf(stderr, "ic bookkeeping\n"); return 12; }
+      for (int tp = 0; tp < hdr[3]; tp++) fwrite(pt->sources_[md][hdr[3] + tp], 8, (size_t)hdr[2] * hdr[0], o);
+      fwrite(tr.transfer_[md] + (size_t)hdr[6] * hdr[5] * hdr[4], 8, (size_t)hdr[6] * hdr[5] * hdr[4], o);
+    }
+    if (bad_flag == 6) {   // the tensor mode
+      if (pt->md_size_ != 2 || pt->index_md_tensors_ != 1 || tr.l_size_max_ != std::max(tr.l_size_[0], tr.l_size_[1])) { fprintf(stderr, "mode bookkeeping\n"); return 12; }
+      const int mt = pt->index_md_tensors_;
+      int hdr2[8] = {pt->k_size_[mt], pt->k_size_cl_[mt], pt->tp_size_[mt], tr.l_size_[mt], tr.tt_size_[mt], pt->ic_size_[mt], 0, 0};
+      fwrite(hdr2, sizeof(int), 8, o);
+      fwrite(pt->k_[mt], 8, hdr2[0], o);
+      for (int tp = 0; tp < hdr2[2]; tp++) fwrite(pt->sources_[mt][tp], 8, (size_t)hdr[2] * hdr2[0], o);
+      fwrite(tr.transfer_[mt], 8, (size_t)hdr2[4] * hdr2[3] * hdr[4], o);
+    }
     fclose(o);
     printf("ok perturb %.2f ms transfer(LOS) %.3f ms\n", pt->kernel_ms(), tr.kernel_ms());
   } catch (std::invalid_argument& e) {

@@ -44,13 +44,74 @@ def write_inputs(inp, path):
             f.write(bytes(hostlib.cosmo_params(inp))); f.write(bytes(hostlib.thermo_params(inp)))
 
 
-def run_demo(exe, inp_path, out_path, flag=0):
+def run_demo(exe, inp_path, out_path, flag=0, extra=None):
     import torch
     env = dict(os.environ)
     # one HIP runtime per process: use the one PyTorch ships, like the Python host layer does
     env["LD_LIBRARY_PATH"] = os.path.join(os.path.dirname(torch.__file__), "lib") + ":" + env.get("LD_LIBRARY_PATH", "")
-    p = subprocess.run([exe, inp_path, out_path, str(flag)], capture_output=True, text=True, env=env)
+    p = subprocess.run([exe, inp_path, out_path, str(flag)] + ([extra] if extra else []), capture_output=True, text=True, env=env)
     return p.returncode, p.stdout + p.stderr
+
+
+def _rel(a, ref):
+    scale = np.max(np.abs(ref), axis=-1, keepdims=True)
+    scale[scale == 0] = 1
+    return np.max(np.abs(a - ref) / scale)
+
+
+def test_shim_two_initial_conditions_and_two_modes(tmp_path):
+    """perturb_indices_of_perturbs with more than one entry per axis (pm.cpp:843-1235): ic_size_[scalars] = 2 (ad + cdi) and
+    md_size_ = 2 (scalars + tensors) through one PerturbationsModule / TransferModule pair, laid out as the reference lays them out -
+    sources_[md][ic * tp_size + tp], transfer_[md][((ic * tt_size + tt) * l_size + l) * q_size + q].  The modes and initial
+    conditions are independent integrations, so every block must equal the single-mode run of the reference (fixtures small,
+    iso_cdi, tens: one cosmology, one precision file)."""
+    small, cdi, tens = Inputs("small"), Inputs("iso_cdi"), Inputs("tens")
+    exe = build_demo(str(tmp_path))
+    ipath, tpath, opath = str(tmp_path / "in.bin"), str(tmp_path / "tens.bin"), str(tmp_path / "out.bin")
+    write_inputs(small, ipath)
+    write_inputs(tens, tpath)
+    d = small.d
+    nk, ntau, ntp = d["pt.k"].size, d["pt.tau_sampling"].size, small.config.tp_size
+    nq, nl, ntt = d["tr.q"].size, d["tr.l"].size, small.config.tt_size
+    head = 32 + 8 * (nk + ntau + ntp * ntau * nk + nq) + 4 * nl + 8 * ntt * nl * nq
+
+    # ---- two initial conditions ----
+    assert np.array_equal(cdi.d["pt.k"], d["pt.k"]) and np.array_equal(cdi.d["pt.tau_sampling"], d["pt.tau_sampling"])
+    rc, out = run_demo(exe, ipath, opath, flag=5)
+    assert rc == 0, out
+    raw = open(opath, "rb").read()
+    rc, out = run_demo(exe, ipath, str(tmp_path / "single.bin"))
+    assert rc == 0, out
+    assert raw[:head] == open(str(tmp_path / "single.bin"), "rb").read()          # ic = ad: the single-ic module, bit for bit
+    src1 = np.frombuffer(raw, dtype=np.float64, count=ntp * ntau * nk, offset=head).reshape(ntp, ntau, nk)
+    tr1 = np.frombuffer(raw, dtype=np.float64, count=ntt * nl * nq, offset=head + 8 * ntp * ntau * nk).reshape(ntt, nl, nq)
+    ks = cdi.d["pt.sources_k_index"]
+    check_sources(cdi.config, src1[:, :, ks], cdi.d["pt.sources_subset"])
+    assert _rel(tr1[:, cdi.d["tr.transfer_l_index"], :], cdi.d["tr.transfer_at_l"]) < 1e-3
+
+    # ---- scalars + tensors ----
+    rc, out = run_demo(exe, ipath, opath, flag=6, extra=tpath)
+    assert rc == 0, out
+    raw = open(opath, "rb").read()
+    td = tens.d
+    nkt, nkclt, ntpt, nlt, nttt, nict = [int(x) for x in np.frombuffer(raw, dtype=np.int32, count=6, offset=head)]
+    assert (nkt, nkclt, ntpt, nttt, nict) == (td["pt.k"].size, int(td["pt.k_size_cl"][0]), tens.config.tp_size, tens.config.tt_size, 1)
+    off = head + 32
+    kt = np.frombuffer(raw, dtype=np.float64, count=nkt, offset=off); off += 8 * nkt
+    srct = np.frombuffer(raw, dtype=np.float64, count=ntpt * ntau * nkt, offset=off).reshape(ntpt, ntau, nkt); off += 8 * ntpt * ntau * nkt
+    trt = np.frombuffer(raw, dtype=np.float64, count=nttt * nlt * nq, offset=off).reshape(nttt, nlt, nq)
+    # one multipole list for both modes, up to the larger l_max; the tensor mode stops two entries after the first l >= its l_max
+    # (tm.cpp:858-866) - here that is the whole list; the tensor-only run shares all but its last entry (= its l_max exactly)
+    ncommon = td["tr.l"].size - 1
+    assert np.array_equal(kt, td["pt.k"]) and nlt == nl and np.array_equal(td["tr.l"][:ncommon], d["tr.l"][:ncommon])
+    check_sources(tens.config, srct, td["pt.sources"])
+    # one q list for both modes (tm.cpp:898-906: up to the largest k of the C_l's): the tensor-only run's list is its head
+    nqt = td["tr.q"].size
+    assert nqt <= nq and np.array_equal(td["tr.q"][:-1], d["tr.q"][:nqt - 1])
+    assert _rel(trt[:, :ncommon, :nqt - 1], td["tr.transfer"][:, :ncommon, :nqt - 1]) < 1e-3
+    assert not np.any(trt[:, :, nqt:])                    # beyond the tensor mode's last C_l wavenumber: zero (tm.cpp:1541)
+    # the scalar block is the scalars-only module, bit for bit
+    assert raw[:head] == open(str(tmp_path / "single.bin"), "rb").read()
 
 
 @pytest.mark.parametrize("cfg", ["small", "curved", "tens", "ncdm_small"])
