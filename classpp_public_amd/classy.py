@@ -22,7 +22,7 @@ import numpy as np
 
 from . import hostlib
 from .defaults import DEFAULT_PRECISION
-from .pipeline import ParameterInputs, density_parameters
+from .pipeline import ParameterInputs, density_parameters, ncdm_from_ini
 
 
 class CosmoError(Exception):
@@ -44,7 +44,8 @@ _VERBOSE = tuple(m + "_verbose" for m in ("input", "background", "thermodynamics
 _KNOWN = {"h", "H0", "T_cmb", "omega_b", "Omega_b", "omega_cdm", "Omega_cdm", "Omega_k", "N_ur", "N_eff", "YHe", "recombination",
           "reio_parametrization", "z_reio", "tau_reio", "output", "lensing", "modes", "ic", "gauge", "P_k_ini type", "k_pivot", "A_s",
           "ln10^{10}A_s", "n_s", "alpha_s", "r", "n_t", "alpha_t", "l_max_scalars", "l_max_tensors", "P_k_max_h/Mpc", "P_k_max_1/Mpc", "z_pk",
-          "z_max_pk", "non linear", "threads", "class_dir", "N_ncdm", "tensor method", "delta_l_max", "accurate_lensing", "num_mu_minus_lmax"} | set(_VERBOSE)
+          "z_max_pk", "non linear", "threads", "class_dir", "N_ncdm", "m_ncdm", "Omega_ncdm", "omega_ncdm", "T_ncdm", "ksi_ncdm", "deg_ncdm",
+          "tensor method", "delta_l_max", "accurate_lensing", "num_mu_minus_lmax"} | set(_VERBOSE)
 _LEVELS = ("background", "thermodynamics", "perturb", "primordial", "nonlinear", "transfer", "spectra", "lensing")
 
 
@@ -71,8 +72,11 @@ def build_parameters(pars, mode):
         except (TypeError, ValueError):
             raise CosmoSevereError("could not read a number for '%s' (got %r)" % (key, pars[key]))
 
-    if int(num("N_ncdm", 0)) != 0:
-        raise CosmoSevereError("non-cold species: give their momentum samplings through pipeline.ParameterInputs (see DESIGN.md), not through this surface")
+    N_ncdm = int(num("N_ncdm", 0))
+    if N_ncdm < 0 or N_ncdm > 3:
+        raise CosmoSevereError("N_ncdm: 0 to 3 non-cold species")
+    if N_ncdm == 0 and any(k in pars for k in ("m_ncdm", "Omega_ncdm", "omega_ncdm", "T_ncdm", "ksi_ncdm", "deg_ncdm")):
+        raise CosmoSevereError("Class did not read input parameter(s): non-cold species parameters without N_ncdm\n")
     if str(pars.get("non linear", "")).strip().lower() not in ("", "none", "no"):
         raise CosmoSevereError("non-linear corrections are outside the accelerated path")
     if str(pars.get("recombination", "RECFAST")).strip().upper() != "RECFAST":
@@ -95,8 +99,21 @@ def build_parameters(pars, mode):
     if gauge not in ("synchronous", "newtonian"):
         raise CosmoSevereError("gauge: synchronous or newtonian")
     opt = lambda key: num(key, 0.) if key in pars else None
+    # non-cold species (input_module.cpp:1014-1110): the momentum samplings and the mass <-> density relation, on the host
+    ncdm_ini, Omega_ncdm_tot = {}, 0.
+    if N_ncdm:
+        if gauge != "synchronous":
+            raise CosmoSevereError("non-cold species are integrated in the synchronous gauge only")
+        ncdm_ini = {k: pars[k] for k in ("N_ncdm", "m_ncdm", "Omega_ncdm", "omega_ncdm", "T_ncdm", "ksi_ncdm", "deg_ncdm", "tol_ncdm_synchronous",
+                                         "tol_ncdm_bg", "tol_M_ncdm") if k in pars}
+        try:
+            _, Om_species, _ = ncdm_from_ini(ncdm_ini, num("T_cmb", 2.7255), h, 1)
+        except ValueError as e:
+            raise CosmoSevereError(str(e))
+        Omega_ncdm_tot = float(sum(Om_species))
     dens = density_parameters(h, opt("omega_b"), opt("omega_cdm"), num("Omega_k", 0.), N_ur, num("T_cmb", 2.7255),
-                              Omega_b=opt("Omega_b"), Omega_cdm=opt("Omega_cdm"), gauge_synchronous=(gauge == "synchronous"))
+                              Omega_b=opt("Omega_b"), Omega_cdm=opt("Omega_cdm"), gauge_synchronous=(gauge == "synchronous"),
+                              Omega_ncdm=Omega_ncdm_tot)
     omega_b = dens["Omega0_b"] * h * h
     if h <= 0 or dens["Omega0_b"] <= 0 or dens["Omega0_cdm"] < 0 or N_ur < 0:
         raise CosmoSevereError("h and omega_b must be positive, omega_cdm and N_ur non-negative")
@@ -107,7 +124,7 @@ def build_parameters(pars, mode):
     d["pba.has_cdm"] = _arr(int(dens["Omega0_cdm"] != 0.), True)
     d["pba.has_ur"] = _arr(int(dens["Omega0_ur"] != 0.), True)
     d["pba.has_curvature"] = _arr(int(dens["sgnK"] != 0), True)
-    for f, v in (("has_ncdm", 0), ("has_lambda", 1), ("has_fld", 0), ("N_ncdm", 0)):
+    for f, v in (("has_ncdm", int(N_ncdm > 0)), ("has_lambda", 1), ("has_fld", 0), ("N_ncdm", N_ncdm)):
         d["pba." + f] = _arr(v, True)
 
     # ---- thermodynamics switches
@@ -115,7 +132,7 @@ def build_parameters(pars, mode):
     if reio not in ("reio_camb", "reio_none"):
         raise CosmoSevereError("reio_parametrization: reio_camb or reio_none")
     d["pth.reio_parametrization"] = _arr(1 if reio == "reio_camb" else 0, True)
-    ini = {}
+    ini = {k: (v if isinstance(v, str) else ", ".join(repr(float(x)) for x in np.atleast_1d(v))) for k, v in ncdm_ini.items()}
     if "YHe" in pars and str(pars["YHe"]).strip().upper() != "BBN":
         ini["YHe"] = repr(num("YHe", 0.))
     elif abs(omega_b / 0.022032 - 1.) < 1e-12 and N_ur == 3.046:
@@ -172,12 +189,16 @@ def build_parameters(pars, mode):
         raise CosmoSevereError("tensor method: massless or photons (exact needs non-cold species)")
     d["ppt.tensor_method"] = _arr(1 if tmeth == "massless" else 0, True)
     d["pt.mode_tensors"] = _arr(int(tens), True)
-    d["pt.evolve_tensor_ur"] = _arr(int(tens and tmeth == "massless" and dens["Omega0_ur"] != 0.), True)
+    d["pt.evolve_tensor_ur"] = _arr(int(tens and tmeth == "massless" and (dens["Omega0_ur"] != 0. or N_ncdm > 0)), True)   # pm.cpp:590-611
     d["ptr.lcmb_rescale"] = _arr(1.); d["ptr.lcmb_tilt"] = _arr(0.); d["ptr.lcmb_pivot"] = _arr(0.1)
 
     # ---- primordial (input_module.cpp:2380-2470; tensors: A_t = r A_s, 'scc' = the self-consistency conditions)
     A_s = num("A_s", 2.215e-9) if "ln10^{10}A_s" not in pars else np.exp(num("ln10^{10}A_s", 3.)) * 1e-10
     n_s, alpha_s, k_pivot = num("n_s", 0.9619), num("alpha_s", 0.), num("k_pivot", 0.05)
+    if "s" not in all_modes:
+        # a run without scalar modes does not read the scalar tilt and running (input_module.cpp:1972-2012): they keep their defaults,
+        # also inside the self-consistency conditions for n_t and alpha_t below
+        n_s, alpha_s = 0.9619, 0.
     d["ppm.A_s"] = _arr(A_s); d["ppm.n_s"] = _arr(n_s); d["ppm.alpha_s"] = _arr(alpha_s); d["ppm.k_pivot"] = _arr(k_pivot)
     if tens:
         r = num("r", 1.)
@@ -193,7 +214,7 @@ def build_parameters(pars, mode):
     # ---- index maps, in the order the modules define them
     tp, n = {}, 0
     for name, on in (("t2", has_t or has_p), ("p", has_p), ("t0", has_t and not tens), ("t1", has_t and not tens),
-                     ("delta_m", has_pk and not tens), ("delta_cb", False), ("phi_plus_psi", has_l and not tens)):
+                     ("delta_m", has_pk and not tens), ("delta_cb", has_pk and not tens and N_ncdm > 0), ("phi_plus_psi", has_l and not tens)):
         tp[name] = n if on else -1
         n += int(on)
     for name, idx in tp.items():

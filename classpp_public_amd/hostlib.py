@@ -42,6 +42,20 @@ class CptCosmoParams(C.Structure):
 _pdd = C.POINTER(_d)
 
 
+class CptNcdmParams(C.Structure):
+    """struct cpt_ncdm_params (include/cpt_host.h)"""
+    _fields_ = [("N_ncdm", _i), ("T_cmb", _d), ("h", _d), ("m_ncdm_in_eV", _d * 3), ("Omega0_ncdm", _d * 3), ("T_ncdm", _d * 3),
+                ("ksi_ncdm", _d * 3), ("deg_ncdm", _d * 3), ("tol_ncdm", _d), ("tol_ncdm_bg", _d), ("tol_M_ncdm", _d)]
+
+
+class CptNcdm(C.Structure):
+    """struct cpt_ncdm (include/cpt_host.h): arrays owned by the library (cpt_host_ncdm_free)"""
+    _fields_ = [("N_ncdm", _i), ("q_size_ncdm", _i * 3), ("q_size_ncdm_bg", _i * 3), ("q_ncdm", C.POINTER(_d) * 3), ("w_ncdm", C.POINTER(_d) * 3),
+                ("dlnf0_dlnq_ncdm", C.POINTER(_d) * 3), ("q_ncdm_bg", C.POINTER(_d) * 3), ("w_ncdm_bg", C.POINTER(_d) * 3),
+                ("M_ncdm", _d * 3), ("factor_ncdm", _d * 3), ("Omega0_ncdm", _d * 3), ("m_ncdm_in_eV", _d * 3), ("deg_ncdm", _d * 3),
+                ("Omega0_ncdm_tot", _d)]
+
+
 class CptBackground(C.Structure):
     """struct cpt_background (include/cpt_host.h): arrays owned by the library (cpt_host_background_free)"""
     _fields_ = [("bt_size", _i), ("bg_size", _i), ("tau_table", _pdd), ("z_table", _pdd), ("d2tau_dz2_table", _pdd),
@@ -75,6 +89,11 @@ def lib():
         L.cpt_host_background_free.argtypes = [C.POINTER(CptBackground)]
         L.cpt_host_background_free.restype = None
         L.cpt_host_background_tau_of_z.argtypes = [C.POINTER(CptBackground), _d, _pdd]
+        L.cpt_host_ncdm_defaults.argtypes = [C.POINTER(CptNcdmParams)]
+        L.cpt_host_ncdm_defaults.restype = None
+        L.cpt_host_ncdm.argtypes = [C.POINTER(CptNcdmParams), C.POINTER(CptNcdm)]
+        L.cpt_host_ncdm_free.argtypes = [C.POINTER(CptNcdm)]
+        L.cpt_host_ncdm_free.restype = None
         _lib = L
     return _lib
 
@@ -101,6 +120,45 @@ def grid_params(inp):
         g.l_tensor_max = int(d["ppt.l_tensor_max"][0]) if "ppt.l_tensor_max" in d else (int(inp.l[-1]) if inp.config.mode == 1 and inp.has_cls else 0)
     g.q_logstep_trapzd = float(d["ppr.q_logstep_trapzd"].reshape(-1)[0]); g.q_numstep_transition = float(d["ppr.q_numstep_transition"].reshape(-1)[0])
     return g
+
+
+def ncdm_species(T_cmb, h, m_ncdm=None, Omega_ncdm=None, T_ncdm=None, ksi_ncdm=None, deg_ncdm=None, tol_ncdm=1e-3, tol_ncdm_bg=1e-5,
+                 tol_M_ncdm=1e-7):
+    """The non-cold species from their physical parameters (cpt_host_ncdm): -> (dict keyed like the reference's table dump - ncdm.q_<n>,
+    ncdm.w_<n>, ncdm.dlnf0_dlnq_<n>, ncdm.q_bg_<n>, ncdm.w_bg_<n>, ncdm.M, ncdm.factor - , Omega0 of every species, masses in eV).
+    m_ncdm [eV] and / or Omega_ncdm: one sequence entry per species (0 / None = not given)."""
+    n = len(m_ncdm) if m_ncdm is not None else len(Omega_ncdm)
+    p = CptNcdmParams()
+    lib().cpt_host_ncdm_defaults(C.byref(p))
+    p.N_ncdm, p.T_cmb, p.h = n, float(T_cmb), float(h)
+    p.tol_ncdm, p.tol_ncdm_bg, p.tol_M_ncdm = float(tol_ncdm), float(tol_ncdm_bg), float(tol_M_ncdm)
+    if n > 3:
+        raise ValueError("at most 3 non-cold species")
+    for i in range(n):
+        p.m_ncdm_in_eV[i] = float(m_ncdm[i]) if m_ncdm is not None and m_ncdm[i] else 0.
+        p.Omega0_ncdm[i] = float(Omega_ncdm[i]) if Omega_ncdm is not None and Omega_ncdm[i] else 0.
+        if T_ncdm is not None:
+            p.T_ncdm[i] = float(T_ncdm[i])
+        if ksi_ncdm is not None:
+            p.ksi_ncdm[i] = float(ksi_ncdm[i])
+        if deg_ncdm is not None:
+            p.deg_ncdm[i] = float(deg_ncdm[i])
+    o = CptNcdm()
+    _check(lib().cpt_host_ncdm(C.byref(p), C.byref(o)))
+    try:
+        out = {}
+        for i in range(n):
+            nq, nb = o.q_size_ncdm[i], o.q_size_ncdm_bg[i]
+            out["ncdm.q_%d" % i] = np.ctypeslib.as_array(o.q_ncdm[i], (nq,)).copy()
+            out["ncdm.w_%d" % i] = np.ctypeslib.as_array(o.w_ncdm[i], (nq,)).copy()
+            out["ncdm.dlnf0_dlnq_%d" % i] = np.ctypeslib.as_array(o.dlnf0_dlnq_ncdm[i], (nq,)).copy()
+            out["ncdm.q_bg_%d" % i] = np.ctypeslib.as_array(o.q_ncdm_bg[i], (nb,)).copy()
+            out["ncdm.w_bg_%d" % i] = np.ctypeslib.as_array(o.w_ncdm_bg[i], (nb,)).copy()
+        out["ncdm.M"] = np.array([o.M_ncdm[i] for i in range(n)])
+        out["ncdm.factor"] = np.array([o.factor_ncdm[i] for i in range(n)])
+        return out, [o.Omega0_ncdm[i] for i in range(n)], [o.m_ncdm_in_eV[i] for i in range(n)]
+    finally:
+        lib().cpt_host_ncdm_free(C.byref(o))
 
 
 def _check(rc):

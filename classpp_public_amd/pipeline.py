@@ -26,7 +26,48 @@ def read_ini(path):
     return out
 
 
-def density_parameters(h, omega_b=None, omega_cdm=None, Omega_k=0.0, N_ur=3.046, T_cmb=2.7255, Omega_b=None, Omega_cdm=None, gauge_synchronous=True):
+def _list(ini, key, n, default=None):
+    """comma-separated entry of an .ini / parameter dictionary -> n floats (input_module.cpp:1040-1075: one value per species)"""
+    if key not in ini:
+        return None if default is None else [default] * n
+    v = ini[key]
+    vals = [float(x) for x in str(v).replace("[", "").replace("]", "").split(",")] if isinstance(v, str) else [float(x) for x in np.atleast_1d(v)]
+    if len(vals) != n:
+        raise ValueError("%s: %d values for N_ncdm = %d species" % (key, len(vals), n))
+    return vals
+
+
+def ncdm_from_ini(ini, T_cmb, h, gauge, d=None):
+    """The non-cold species of an .ini / parameter dictionary (N_ncdm, m_ncdm | Omega_ncdm | omega_ncdm, T_ncdm, ksi_ncdm, deg_ncdm;
+    input_module.cpp:1014-1110) -> (ncdm.* table entries, Omega0 per species, mass in eV per species).  gauge: 1 synchronous, 0 newtonian
+    (the momentum sampling of the perturbations is finer in the Newtonian gauge, input_module.cpp:1088-1092)."""
+    n = int(float(ini.get("N_ncdm", 0)))
+    if n < 1:
+        raise ValueError("N_ncdm must be given (>= 1) to describe non-cold species")
+    for key in ("ncdm_psd_filenames", "use_ncdm_psd_files", "Number of momentum bins", "Quadrature strategy", "Maximum q"):
+        if key in ini and str(ini[key]).strip() not in ("", "0", "no"):
+            raise ValueError("%s: distributions from files and manual momentum samplings are outside this package" % key)
+    m = _list(ini, "m_ncdm", n)
+    Om = _list(ini, "Omega_ncdm", n)
+    om = _list(ini, "omega_ncdm", n)
+    if Om is not None and om is not None:
+        raise ValueError("In input, you can only enter one of Omega_ncdm or omega_ncdm, choose one")
+    if om is not None:
+        Om = [x / h / h for x in om]
+    if m is None and Om is None:
+        raise ValueError("non-cold species need m_ncdm or Omega_ncdm / omega_ncdm")
+
+    def prec(name, default):
+        if name in ini:
+            return float(ini[name])
+        return float(d["ppr." + name][0]) if d is not None and ("ppr." + name) in d else default
+    tol = prec("tol_ncdm_synchronous", 1e-3) if gauge == 1 else prec("tol_ncdm_newtonian", 1e-5)
+    return hostlib.ncdm_species(T_cmb, h, m_ncdm=m, Omega_ncdm=Om, T_ncdm=_list(ini, "T_ncdm", n, 0.71611), ksi_ncdm=_list(ini, "ksi_ncdm", n, 0.),
+                                deg_ncdm=_list(ini, "deg_ncdm", n, 1.), tol_ncdm=tol, tol_ncdm_bg=prec("tol_ncdm_bg", 1e-5), tol_M_ncdm=prec("tol_M_ncdm", 1e-7))
+
+
+def density_parameters(h, omega_b=None, omega_cdm=None, Omega_k=0.0, N_ur=3.046, T_cmb=2.7255, Omega_b=None, Omega_cdm=None, gauge_synchronous=True,
+                       Omega_ncdm=0.0):
     """The budget equation of the reference's input module for LambdaCDM + massless neutrinos (source/input_module.cpp:593-603, 702,
     786, 1191 and the closure Omega_Lambda = 1 - Omega_k - sum): -> dict of the struct background entries the host modules read."""
     c, G, k_B, h_P, Mpc = 2.99792458e8, 6.67428e-11, 1.3806504e-23, 6.62606896e-34, 3.085677581282e22
@@ -40,7 +81,8 @@ def density_parameters(h, omega_b=None, omega_cdm=None, Omega_k=0.0, N_ur=3.046,
     Omega0_cdm = Omega_cdm if Omega_cdm is not None else (omega_cdm / h / h if omega_cdm is not None else 0.12038 / (0.67556 * 0.67556))
     if gauge_synchronous and Omega0_cdm == 0.:
         Omega0_cdm = 1.e-10
-    Omega0_lambda = 1. - Omega_k - (((Omega0_g + Omega0_b) + Omega0_ur) + Omega0_cdm)   # same accumulation order (Omega_tot, :725-874, 1238)
+    # same accumulation order as the reference's Omega_tot (:725-874, 1238; the non-cold species come last, :1110)
+    Omega0_lambda = 1. - Omega_k - ((((Omega0_g + Omega0_b) + Omega0_ur) + Omega0_cdm) + Omega_ncdm)
     K = -Omega_k * H0 ** 2
     return {"H0": H0, "h": h, "T_cmb": T_cmb, "Omega0_g": Omega0_g, "Omega0_ur": Omega0_ur, "Omega0_b": Omega0_b, "Omega0_cdm": Omega0_cdm,
             "Omega0_lambda": Omega0_lambda, "Omega0_k": Omega_k, "K": K, "sgnK": 0 if K == 0 else (1 if K > 0 else -1)}
@@ -72,11 +114,10 @@ class ParameterInputs(Inputs):
             ini.pop("z_reio", None); ini["tau_reio"] = repr(tau_reio)
         ncdm = None
         if int(self.d["pba.has_ncdm"][0]):
-            # non-cold species: their momentum samplings, masses and normalisations are inputs (the ncdm.* entries; the adaptive
-            # quadrature and the mass <-> density solve of the reference's ncdm module stay outside)
-            tname = "tables_ncdm3.npz" if name.startswith("ncdm3") else "tables_ncdm1.npz"
-            full = np.load(os.path.join(golden_dir, tname))
-            ncdm = {k: full[k] for k in full.files if k.startswith("ncdm.")}
+            # non-cold species from their physical parameters (hostlib.ncdm_species: momentum samplings, mass <-> density)
+            ncdm, _, _ = ncdm_from_ini(ini, float(self.d["pba.T_cmb"][0]), float(self.d["pba.h"][0]), int(self.d["ppt.gauge"][0]), self.d)
+            if len(ncdm["ncdm.M"]) != int(self.d["pba.N_ncdm"][0]):
+                raise ValueError("N_ncdm = %d but %d species described" % (int(self.d["pba.N_ncdm"][0]), len(ncdm["ncdm.M"])))
         cp = hostlib.cosmo_params(self, ncdm=ncdm)            # struct background values (pba.* of the dump)
         tp = hostlib.CptThermoParams()
         hostlib.lib().cpt_host_thermo_defaults.argtypes = [hostlib.C.POINTER(hostlib.CptThermoParams)]

@@ -132,6 +132,37 @@ void cpt_host_thermo_defaults(cpt_thermo_params* p);
 int cpt_host_thermodynamics(const cpt_cosmo_params* cp, const cpt_thermo_params* tp, const cpt_background* bg, cpt_thermo* out);
 void cpt_host_thermo_free(cpt_thermo* th);
 
+/* Non-cold species (massive neutrinos etc.) from their physical parameters: what NonColdDarkMatter holds after its own initialisation
+ * (tools/non_cold_dark_matter.cpp:202-790 with the sampling search of tools/quadrature.c:69-360) - the momentum samplings of the
+ * perturbations (q_ncdm, w_ncdm, d ln f0 / d ln q) and of the background (q_ncdm_bg, w_ncdm_bg), the mass over the temperature M_ncdm,
+ * the normalisation factor_ncdm and the mass <-> density relation.  Fermi-Dirac distribution with chemical potential (the reference's
+ * built-in f0); distributions read from files and decaying species: CPT_ERR_UNSUPPORTED.  Feeds cpt_cosmo_params (background) and
+ * cpt_tables (perturbations). */
+typedef struct cpt_ncdm_params {
+  int N_ncdm;
+  double T_cmb, h;
+  double m_ncdm_in_eV[CPT_MAX_NCDM];   /* 0 = not given: the mass follows from Omega0_ncdm                                  */
+  double Omega0_ncdm[CPT_MAX_NCDM];    /* 0 = not given: the density follows from the mass; both given: deg is rescaled     */
+  double T_ncdm[CPT_MAX_NCDM];         /* temperature in units of T_cmb (default 0.71611)                                   */
+  double ksi_ncdm[CPT_MAX_NCDM];       /* chemical potential over the temperature (default 0)                               */
+  double deg_ncdm[CPT_MAX_NCDM];       /* degeneracy (default 1)                                                            */
+  double tol_ncdm, tol_ncdm_bg, tol_M_ncdm;   /* include/precisions.h:34-54; tol_ncdm = tol_ncdm_synchronous | _newtonian  */
+} cpt_ncdm_params;
+typedef struct cpt_ncdm {
+  int N_ncdm;
+  int q_size_ncdm[CPT_MAX_NCDM], q_size_ncdm_bg[CPT_MAX_NCDM];
+  double* q_ncdm[CPT_MAX_NCDM];            /* arrays owned by this struct: cpt_host_ncdm_free */
+  double* w_ncdm[CPT_MAX_NCDM];
+  double* dlnf0_dlnq_ncdm[CPT_MAX_NCDM];
+  double* q_ncdm_bg[CPT_MAX_NCDM];
+  double* w_ncdm_bg[CPT_MAX_NCDM];
+  double M_ncdm[CPT_MAX_NCDM], factor_ncdm[CPT_MAX_NCDM], Omega0_ncdm[CPT_MAX_NCDM], m_ncdm_in_eV[CPT_MAX_NCDM], deg_ncdm[CPT_MAX_NCDM];
+  double Omega0_ncdm_tot;
+} cpt_ncdm;
+void cpt_host_ncdm_defaults(cpt_ncdm_params* p);
+int cpt_host_ncdm(const cpt_ncdm_params* p, cpt_ncdm* out);
+void cpt_host_ncdm_free(cpt_ncdm* o);
+
 #ifdef __cplusplus
 }
 #endif
