@@ -176,10 +176,17 @@ static int validate(const cpt_config* c) {
       return cpt_fail(nullptr, CPT_ERR_INVALID, "tensor modes have the source types t2 and p only (pm.cpp:7243-7280)");
   }
   // lane map of cpt_perturb.hip: 14 core lanes (22 with non-cold species) + the three l >= 3 tails
+  // Longer hierarchies of the synchronous scalar system without non-cold species run with one extra wavefront per tail ("long tails"
+  // in cpt_perturb.hip): each tail must then fit a wavefront of its own.
   const int core_lanes = c->has_ncdm ? 13 + 3 * CPT_MAX_NCDM : 14;
-  if (core_lanes + (c->l_max_g - 2) + (c->l_max_pol_g - 2) + (c->has_ur ? c->l_max_ur - 2 : 0) > CPT_WAVE)
-    return cpt_fail(nullptr, CPT_ERR_UNSUPPORTED,
-                    "hierarchy too large: one wavefront (64 lanes) owns one k-mode, need %d + tails <= 64 lanes", core_lanes);
+  if (core_lanes + (c->l_max_g - 2) + (c->l_max_pol_g - 2) + (c->has_ur ? c->l_max_ur - 2 : 0) > CPT_WAVE) {
+    const bool long_ok = c->mode == CPT_MODE_SCALARS && !c->has_ncdm && c->gauge == CPT_GAUGE_SYNCHRONOUS && c->l_max_g - 2 <= CPT_WAVE &&
+                         c->l_max_pol_g - 2 <= CPT_WAVE && (!c->has_ur || c->l_max_ur - 2 <= CPT_WAVE);
+    if (!long_ok)
+      return cpt_fail(nullptr, CPT_ERR_UNSUPPORTED,
+                      "hierarchy too large: %d + tails > 64 lanes; hierarchies longer than one wavefront run for synchronous-gauge scalars without "
+                      "non-cold species and l_max_g, l_max_pol_g, l_max_ur <= 66 only", core_lanes);
+  }
   if (c->tp_size < 1 || c->tp_size > 8) return cpt_fail(nullptr, CPT_ERR_INVALID, "tp_size=%d out of range", c->tp_size);
   const int tps[6] = {c->index_tp_t0, c->index_tp_t1, c->index_tp_t2, c->index_tp_p, c->index_tp_delta_m,
                       c->index_tp_phi_plus_psi};
@@ -268,6 +275,14 @@ int cpt_create(const cpt_config* cfg, const cpt_tables* t, cpt_handle** out) {
   if (!up(&h->d_tau_table, t->tau_table, t->bt_size) || !up(&h->d_bg, bg.data(), bg.size()) ||
       !up(&h->d_z_table, t->z_table, t->tt_size) || !up(&h->d_th, th.data(), th.size()))
     return bail(cpt_fail(h, CPT_ERR_NO_DEVICE, "table upload failed"));
+  if (!cfg->has_ncdm && cfg->mode == CPT_MODE_SCALARS &&
+      14 + (cfg->l_max_g - 2) + (cfg->l_max_pol_g - 2) + (cfg->has_ur ? cfg->l_max_ur - 2 : 0) > CPT_WAVE) {
+    // hierarchies longer than one wavefront run on the multi-wavefront kernels of the non-cold species with zero species: those read
+    // the (then empty) ncdm columns of the background
+    ncb.assign((size_t)t->bt_size * NCB_NCOL * 2, 0.);
+    if (!up(&h->d_ncb, ncb.data(), ncb.size())) return bail(cpt_fail(h, CPT_ERR_NO_DEVICE, "table upload failed"));
+    h->tabs.ncb = h->d_ncb;
+  }
   if (cfg->has_ncdm) {
     if (!up(&h->d_ncb, ncb.data(), ncb.size())) return bail(cpt_fail(h, CPT_ERR_NO_DEVICE, "table upload failed"));
     h->tabs.ncb = h->d_ncb;

@@ -36,6 +36,8 @@ struct PtParams {
   int l_max_g_ten, l_max_pol_g_ten, evolve_tensor_ur; double gw_ini;  // tensor modes
   int ic; double entropy_ini;  // initial condition of the mode (CPT_IC_*), isocurvature normalisation
   int has_ncdm, nfa_method, tp_dcb; double nfa_trig, tol_ncdm_w;  // non-cold species (massive neutrinos)
+  int long_tails;              // hierarchies longer than one wavefront: the three l >= 3 tails live on chain waves of their own (see "long tails")
+  int long_len;                // ... and the longest of them
   int ncdm_compact;            // last interval of the ncdm kernels (rsa + ufa + ncdmfa): 0 all waves, 1 the core wave alone, 2 core wave + helper wave
   NcdmDev nc;
   int switch_sw, switch_eisw, switch_lisw, switch_dop, switch_pol;
@@ -221,12 +223,12 @@ __device__ unsigned long long g_prof[16];
 // the block through LDS, and the Newton system is solved as a bordered system (see the ncdm section below).
 constexpr int NCW_MAX = 5;   // chain waves per block (=> at most 6 waves: two per SIMD at most)
 struct NcShared {
-  double bc[4 + NCB_NCOL];     // a^2, a'/a, k cotK, 1/tau, {rho, p, pseudo_p} of every species at the published tau
+  double bc[5 + NCB_NCOL];     // a^2, a'/a, k cotK, 1/tau, {rho, p, pseudo_p} of every species at the published tau, kappa' (long tails)
   double sums[NCW_MAX][4];     // per chain wave: partial sums of delta rho, (rho+p) theta, (rho+p) sigma
-  double metric[2];            // metric_continuity, metric_shear of the current RHS evaluation
+  double metric[5];            // metric_continuity, metric_shear of the current RHS evaluation; (long tails) shear_g, pol2, shear_ur
   double red[2][1 + NCW_MAX];  // block max, double-buffered
   double ssum[NCW_MAX][2];     // Newton solve: weighted sums of T^-1 r over the chains
-  double z[2];                 // Newton solve: increments of (metric_continuity, metric_shear)
+  double z[5];                 // Newton solve: increments of (metric_continuity, metric_shear); (long tails) of the three parents
   double alpha[NCW_MAX][4];    // factorisation: Schur terms of the two auxiliary rows
   double ho[CPT_MAX_NCDM * CPT_MAX_Q_NCDM][3];   // hand-over to the fluid regime: per-chain integrals
   double hf[CPT_MAX_NCDM][3];  // hand-over of (delta, theta, sigma) of every species to the core wave (see "the core wave alone")
@@ -267,6 +269,10 @@ constexpr size_t CPT_NCDM_HELPER_LDS = CPT_NCDM_HELPER_WINDOWS + sizeof(Mailbox)
 template <int GAUGE, int CURV, int MODE, int NCDM = 0, int ROWS = 0>
 struct PT {
 static constexpr bool SAMPLER = (NCDM == 0);
+// NCDM = 2: the multi-wavefront machinery of the non-cold species with ZERO species and the chain waves carrying the three l >= 3 tails
+// instead ("long tails": hierarchies longer than one wavefront).  An instantiation of its own, so that the ncdm kernels proper pay
+// nothing for it (as run-time branches it cost them 6 - 10 %).
+static constexpr bool LONG = (NCDM == 2);
 // Lane map.  One lane per equation of pm.cpp:3302-3481, at a FIXED lane whatever the approximation scheme: the (at most
 // 13) densely coupled variables - densities, velocities, shears, polarisation l<=2, metric - are the CORE in lanes
 // 0..12, followed by the three free-streaming hierarchy tails (photon temperature l>=3, polarisation l>=3, ur l>=3)
@@ -298,6 +304,7 @@ static constexpr bool PCR = (ROWS != 0) && (MODE == 0) && (NCDM == 0);
 struct Layout {
   int tca, rsa, ufa, nfa;
   int fic;                     // (NCDM) the ncdm fluids live in core lanes LN_F0.. of the core wave (which then integrates alone)
+  int lng;                     // (NCDM kernels, long tails) the tails live on chain waves; core lanes 13..15 hold their l = 3 elements as auxiliary unknowns
   int g3, gN, q3, qN, u3, uN;  // tails: lane of l=3 and length (lengths are 0 when the scheme drops the tail)
   int lmg, lmp, lmu;
   int maxlen;                  // longest tail present
@@ -305,7 +312,7 @@ struct Layout {
 
 static __device__ __forceinline__ Layout make_layout(const PtParams& P, int tca, int rsa, int ufa, int nfa = 0, int fic = 0) {
   Layout L;
-  L.tca = tca; L.rsa = rsa; L.ufa = ufa; L.nfa = nfa; L.fic = fic;
+  L.tca = tca; L.rsa = rsa; L.ufa = ufa; L.nfa = nfa; L.fic = fic; L.lng = 0;
   if (MODE) {  // tensors: photons are evolved when neither approximation is on; ur always (pm.cpp:3529-3560)
     L.ufa = 0;
     L.lmg = P.l_max_g_ten; L.lmp = P.l_max_pol_g_ten; L.lmu = P.l_max_ur;
@@ -325,12 +332,15 @@ static __device__ __forceinline__ Layout make_layout(const PtParams& P, int tca,
   L.qN = hi ? P.l_max_pol_g - 2 : 0;
   L.uN = (P.has_ur && !rsa && !ufa) ? P.l_max_ur - 2 : 0;
   L.maxlen = max(L.gN, max(L.qN, L.uN));
+  L.lng = LONG ? 1 : 0;
+  if (L.lng) { L.g3 = L.q3 = L.u3 = 64; L.maxlen = 0; }   // no tail lane in the core wave (gN, qN, uN still say which tails exist)
   return L;
 }
 
 // is core variable `i` evolved in this scheme?  (i wave-uniform)
 static __device__ __forceinline__ bool core_present(const PtParams& P, const Layout& L, int i) {
   if (MODE) return (i <= TL_P4) ? (!L.rsa && !L.tca) : (i <= TL_U4) ? (P.evolve_tensor_ur != 0) : true;
+  if (NCDM && L.lng && i >= LN_ND) return (i == LN_ND) ? L.gN > 0 : (i == LN_ND + 1) ? L.qN > 0 : (i == LN_ND + 2) ? L.uN > 0 : false;
   if (NCDM && i >= LN_ND) return L.fic ? (i - LN_F0 < 3 * P.nc.n_species) : (i <= LN_NT);
   switch (i) {
     case LN_DG: case LN_TG: return !L.rsa;
@@ -367,6 +377,7 @@ static __device__ __forceinline__ void role_of(const PtParams& P, const Layout& 
   }
   const bool g = !L.rsa, hi = !L.rsa && !L.tca, ur = P.has_ur && !L.rsa;
   if (NCDM && L.fic && i >= LN_F0 && i < NC) { if (i - LN_F0 < 3 * P.nc.n_species) *role = R_FLUID; return; }
+  if (NCDM && L.lng && i >= LN_ND && i < NC) { if (core_present(P, L, i)) *role = R_NCD; return; }
   if (NCDM && i == LN_ND) { *role = R_NCD; return; }
   if (NCDM && i == LN_NT) { *role = R_NCT; return; }
   if (i == LN_DG) { if (g) *role = R_DELTA_G; return; }
@@ -740,6 +751,7 @@ struct LaneEq {
   double Bpar;         // core parents of a present tail: B (their coupling to the tail's l=3 element); else 0
   double A, B, D, G, Gt;   // G multiplies k cotK_gen(tau) (hierarchy truncation), Gt multiplies 1/tau (ur fluid): equal in flat space
   double Xmc, Xms, XP, X4, Xeta, Xtb, Xeu;   // Xeu multiplies metric_euler = k^2 psi (Newtonian gauge; 0 in synchronous)
+  int rem;             // (long tails) 1, 2, 3: this lane is the parent of the photon / polarisation / ur tail, whose l = 3 element lives on a chain wave
   unsigned pmask;      // (wave-uniform) bit i: core variable i is evolved in this scheme.  An idle core lane is an identity row AND column
                        // of the Newton matrix: the factorisation and the substitutions skip its pivot altogether.
 };
@@ -779,6 +791,7 @@ static __device__ __forceinline__ LaneEq make_lane_eq(const PtParams& P, const L
       if (l == 0) { e.Xmc = pol ? 0. : 1.; e.XP = photon ? -1. : pol ? 1. : 0.; }           // + sqrt6 gw' ;  -/+ kappa' sqrt6 P2
     } else if (role == R_GW) { e.A = 1.; dn = TL_GWD; }
     else if (role == R_GWDOT) e.Xtb = 1.;
+    e.rem = 0;
     e.dn = dn * 4; e.up = up * 4; e.parent_addr = parent * 4;
     const bool is_parent = (lane < NC) && (up >= NC);
     e.first_addr = (is_parent ? up : lane) * 4;
@@ -833,6 +846,8 @@ static __device__ __forceinline__ LaneEq make_lane_eq(const PtParams& P, const L
       default: break;
     }
   }
+  e.rem = 0;
+  if (NCDM && L.lng && up >= 64) { e.rem = (lane == LN_SG) ? 1 : (lane == LN_P2) ? 2 : 3; up = lane; }
   e.dn = dn * 4;
   e.up = up * 4;
   e.parent_addr = parent * 4;
@@ -854,7 +869,7 @@ struct Metric {
 // (NCDM) what the non-cold species contribute to the Einstein equations in this RHS evaluation: delta rho, (rho+p) theta,
 // (rho+p) sigma summed over species (pm.cpp:6317-6432).  `sh` != null: publish (metric_continuity, metric_shear) for the
 // chain waves and meet them at the block barrier as soon as the metric is known.
-struct NcIn { double D, T, S; NcShared* sh; int nw; };
+struct NcIn { double D, T, S; NcShared* sh; int nw; double y3[3]; };   // y3: (long tails) the l = 3 elements of the photon / polarisation / ur tails
 
 // y of another lane (per-lane byte address): two ds_bpermute_b32, executed by every lane
 static __device__ __forceinline__ double gather(double v, int addr) {
@@ -953,9 +968,14 @@ static __device__ __forceinline__ double rhs(const PtParams& P, const Layout& L,
 #ifdef CPT_PROFILE
       Q.prof[9] += clock64() - t_b0;
 #endif
+      if (LONG) {   // the chain waves are the tails: wave 1 + t carries tail t, its first lane the l = 3 element
+        N.D = N.T = N.S = 0.;
+        for (int t = 0; t < N.nw; t++) N.y3[t] = N.sh->sums[t][0];
+      } else {
       double D = 0., T = 0., S = 0.;
       for (int w = 0; w < N.nw; w++) { D += N.sh->sums[w][0]; T += N.sh->sums[w][1]; S += N.sh->sums[w][2]; }
       N.D = D; N.T = T; N.S = S;
+      }
     }
     delta_rho += N.D; rpt += N.T; rps += N.S;
   }
@@ -985,7 +1005,10 @@ static __device__ __forceinline__ double rhs(const PtParams& P, const Layout& L,
     M.hp = hp; M.etap = etap; M.alpha = alpha; M.alphap = alphap;
     mc = 0.5 * hp; me = 0.; ms = k2 * alpha; msp = k2 * alphap; mdot = etap;
     if (NCDM && Np->sh) {   // (C) the chain waves wait for exactly these two numbers
-      if (lane == 0) { Np->sh->metric[0] = mc; Np->sh->metric[1] = ms; }
+      if (lane == 0) {
+        Np->sh->metric[0] = mc; Np->sh->metric[1] = ms;
+        if (LONG) { Np->sh->metric[2] = sg; Np->sh->metric[3] = p2; Np->sh->metric[4] = sur; }
+      }
       __syncthreads();
     }
   } else {
@@ -1033,7 +1056,9 @@ static __device__ __forceinline__ double rhs(const PtParams& P, const Layout& L,
   PROF_STOP(10); PROF_START();
 #endif
   // ---- every equation: streaming + damping + sources ----
-  double dy = e.A * ym - e.B * yp - (e.D * kap + e.G * Q.kcot + (CURV ? e.Gt * Q.inv_tau : 0.)) * y;
+  double yup = yp;
+  if (NCDM) { if (LONG) { const int rem = opaque(e.rem); yup = (rem == 1) ? Np->y3[0] : (rem == 2) ? Np->y3[1] : (rem == 3) ? Np->y3[2] : yp; } }
+  double dy = e.A * ym - e.B * yup - (e.D * kap + e.G * Q.kcot + (CURV ? e.Gt * Q.inv_tau : 0.)) * y;
   dy = fma(e.Xmc, mc, dy);
   dy = fma(e.Xms, ms, dy);
   dy = fma(e.XP, SP, dy);
@@ -1135,7 +1160,7 @@ static __device__ __forceinline__ void approx_flags(const PtParams& P, double k,
   }
   *rsa = ((tau * k > P.rsa_trig) && (tau > P.tau_free_streaming) && (P.rsa_method != CPT_RSA_NONE)) ? 1 : 0;
   *ufa = (!MODE && P.has_ur && (tau * k > P.ufa_trig) && (P.ufa_method != CPT_UFA_NONE)) ? 1 : 0;   // no ur fluid for tensors
-  *nfa = (NCDM && (tau * k > P.nfa_trig) && (P.nfa_method != CPT_NCDMFA_NONE)) ? 1 : 0;             // pm.cpp:5606-5614
+  *nfa = (NCDM && !LONG && (tau * k > P.nfa_trig) && (P.nfa_method != CPT_NCDMFA_NONE)) ? 1 : 0;             // pm.cpp:5606-5614
 }
 
 // 64-ary search for the time at which a monotone predicate flips between lo (false) and hi (true):
@@ -1175,11 +1200,13 @@ struct Ctx {
   NcShared* sh;
   int parity, abort;
   double tau_pub;              // time at which sh->bc was last published (and read by everybody)
+  double kap;                                  // chain waves, long tails: kappa' of the published block
   double a2, aH, kcot, inv_tau, rho, pr, pp;   // chain waves: copy of the published block (rho, p, pseudo_p of the lane's species)
   double ca, cb, cd, cxmc, cxms, cwt;          // chain waves: this lane's coefficients at tau_pub (they depend on tau only)
   Mailbox* mb; int posted, tail_seen;          // (SAMPLER) mailbox, samples posted so far, last value read of the helper's tail
 };
 struct ChainEq {
+  int ch;                      // which published scalar drives the chain's first source term: 0 metric_continuity (momentum bins), 2.. the parent of a tail
   int l, cidx, species;
   bool valid, first, last, holder;
   double A, B, G, qk, q2, M2, Xmc, Xms, sw;
@@ -1188,6 +1215,26 @@ struct ChainCoef { double a, b, d, xmc, xms, wt; };   // dy = a y[l-1] - b y[l+1
 
 static __device__ __forceinline__ ChainEq make_chain_eq(const PtParams& P, const Ctx& C, int lane, double k) {
   ChainEq c;
+  c.ch = 0;
+  if (LONG) {
+    // ---- long tails: chain wave 1 + t carries tail t (0 photon temperature, 1 polarisation, 2 ur), lane i its multipole l = 3 + i.
+    //      Streaming coefficients of make_lane_eq; the coupling to the parent (shear_g / pol2 / shear_ur, in the core wave) is the
+    //      first lane's source term, its own value the chain's only output (weight 1).
+    const int t = C.wave - 1, lm = (t == 0) ? P.l_max_g : (t == 1) ? P.l_max_pol_g : P.l_max_ur, l = 3 + lane;
+    const double k2 = k * k;
+    auto S = [&](int ll) { return CURV ? sqrt(fmax(1.0 - P.K * (ll * ll - 1.0) / k2, 0.)) : 1.0; };
+    c.l = lane; c.cidx = t; c.species = t; c.ch = 2 + t;
+    c.valid = (C.wave > 0) && (t < 3) && (l <= lm) && (t < 2 || P.has_ur);
+    c.first = c.valid && lane == 0; c.last = c.valid && l == lm; c.holder = false;
+    c.A = c.B = c.G = c.Xmc = c.Xms = c.sw = 0.; c.qk = c.q2 = c.M2 = 0.;
+    if (c.valid) {
+      if (l == 3 && t != 1) { c.A = 6. * k * S(3) * S(2) / 7.; c.B = 4. * k * S(4) / 7.; }        // pm.cpp:8158-8161: F_2 = 2 s_2 shear
+      else if (l < lm) { c.A = k * l * S(l) / (2. * l + 1.); c.B = k * (l + 1.) * S(l + 1) / (2. * l + 1.); }
+      else { c.A = k * S(l); c.G = 1. + l; }                                                      // pm.cpp:8171-8176
+      if (lane == 0) c.sw = 1.;
+    }
+    return c;
+  }
   const int slot = lane / C.len;
   c.l = lane - slot * C.len;
   c.cidx = (C.wave - 1) * C.cpw + slot;
@@ -1215,6 +1262,15 @@ static __device__ __forceinline__ ChainEq make_chain_eq(const PtParams& P, const
 // coefficients of this lane's equation at the published time (also the chain's Jacobian: the equations are linear)
 static __device__ __forceinline__ ChainCoef chain_coef(const PtParams& P, const Layout& L, const ChainEq& c, const Ctx& C, double k) {
   ChainCoef o;
+  if (LONG) {
+    // (the tail exists only in the schemes that evolve it: idle otherwise, like an idle lane of the core wave)
+    const int t = opaque(c.species);
+    const bool on = c.valid && ((t == 0) ? L.gN > 0 : (t == 1) ? L.qN > 0 : L.uN > 0);
+    o.a = (on && !c.first) ? c.A : 0.; o.b = on ? c.B : 0.;
+    o.d = on ? ((t == 2 ? 0. : C.kap) + c.G * C.kcot) : 0.;
+    o.xmc = (on && c.first) ? c.A : 0.; o.xms = 0.; o.wt = on ? c.sw : 0.;
+    return o;
+  }
   if (!L.nfa) {
     const double eps = fast_sqrt(c.q2 + C.a2 * c.M2), inv_eps = fast_rcp(eps), f = c.qk * inv_eps, inv_a4 = fast_rcp(C.a2 * C.a2);
     o.a = f * c.A; o.b = f * c.B; o.d = c.G * C.kcot; o.xmc = c.Xmc; o.xms = c.Xms;
@@ -1267,13 +1323,15 @@ static __device__ __forceinline__ void sync_tau(const PtParams& P, const Layout&
 #endif
     const int i = opaque(lane);
     const double vn = shfl_all(Q.vnc, (lane - 4) & 63);   // (own statement: every lane must execute the cross-lane read)
-    const double v = (i == 0) ? Q.a2 : (i == 1) ? Q.aH : (i == 2) ? Q.kcot : (i == 3) ? Q.inv_tau : vn;
-    if (lane < 4 + NCB_NCOL) C.sh->bc[lane] = v;
+    double v = (i == 0) ? Q.a2 : (i == 1) ? Q.aH : (i == 2) ? Q.kcot : (i == 3) ? Q.inv_tau : vn;
+    if (LONG) v = (i == 4 + NCB_NCOL) ? Q.kap : v;
+    if (lane < (LONG ? 5 : 4) + NCB_NCOL) C.sh->bc[lane] = v;
   }
   __syncthreads();
   if (ROLE == 1) {
     const double* bc = C.sh->bc;
     C.a2 = bc[0]; C.aH = bc[1]; C.kcot = bc[2]; C.inv_tau = bc[3];
+    if (LONG) C.kap = bc[4 + NCB_NCOL];
     C.rho = bc[4 + 3 * ce.species]; C.pr = bc[5 + 3 * ce.species]; C.pp = bc[6 + 3 * ce.species];
     const ChainCoef cc = chain_coef(P, L, ce, C, k);
     C.ca = cc.a; C.cb = cc.b; C.cd = cc.d; C.cxmc = cc.xmc; C.cxms = cc.xms; C.cwt = cc.wt;
@@ -1309,7 +1367,7 @@ static __device__ __forceinline__ double rhs_all(const PtParams& P, const Layout
 #endif
   __syncthreads();                           // (B)
   __syncthreads();                           // (C) wave 0 has published the metric
-  const double mc = C.sh->metric[0], ms = C.sh->metric[1];
+  const double mc = C.sh->metric[LONG ? ce.ch : 0], ms = C.sh->metric[1];   // (a tail: its parent in the place of metric_continuity, xms = 0)
   double dy = cc.a * ym - cc.b * yp - cc.d * y;
   dy = fma(cc.xmc, mc, dy);
   dy = fma(cc.xms, ms, dy);
@@ -1471,7 +1529,7 @@ static __device__ __forceinline__ void pcr_level(double& a, double& c, double& d
 }
 
 static __device__ __forceinline__ bool factorise(const LaneEq& e, const Jac& J, double hg, int maxlen, int lane, LuReg& F,
-                                                 const double* al = nullptr, double gmc = 0., double gms = 0.) {
+                                                 const double* al = nullptr, double gmc = 0., double gms = 0., int long_tails = 0) {
   lane = opaque(lane);
   const int chain = opaque(e.chain);
   // ---- tails ----
@@ -1517,9 +1575,17 @@ static __device__ __forceinline__ bool factorise(const LaneEq& e, const Jac& J, 
 #pragma unroll
   for (int j = 0; j < NC; j++) A[j] = ((j == lane) ? 1.0 - schur : 0.0) - hg * J.Jc[j * 64 + lane];   // J.Jc = 0 outside the core
   if (NCDM) {
+    if (long_tails) {
+      // (long tails) auxiliary unknown u_t = l = 3 element of tail t, in lane LN_ND + t: u_t - alpha_t x_parent(t) = [T_t^-1 r_t]_first,
+      // alpha_t = hg [T_t^-1 (a_first e_first)]_first from the tail's wave
+      A[LN_SG] -= (lane == LN_ND) ? al[0] : 0.;
+      A[LN_P2] -= (lane == LN_ND + 1) ? al[1] : 0.;
+      A[LN_SUR] -= (lane == LN_ND + 2) ? al[2] : 0.;
+    } else if (al != nullptr) {
     const double c1 = (lane == LN_ND) ? al[0] : (lane == LN_NT) ? al[2] : 0., c2 = (lane == LN_ND) ? al[1] : (lane == LN_NT) ? al[3] : 0.;
 #pragma unroll
     for (int j = 0; j < NC; j++) A[j] -= c1 * bcast(gmc, j) + c2 * bcast(gms, j);
+    }
   }
   int rowperm = lane, permuted = 0;
   double rpivc = 1.;
@@ -1635,21 +1701,23 @@ static __device__ __forceinline__ double lu_solve(const LaneEq& e, const LuReg& 
 // the core with its two auxiliary unknowns second, the chains are back-substituted last
 template <int ROLE>
 static __device__ __forceinline__ void fact_all(const LaneEq& e, const ChainEq& ce, const Jac& J, const ChainCoef& jc, double hg, int maxlen,
-                                                int lane, Ctx& C, LuReg& F, ChainLu& CF, double gmc, double gms, bool* ok) {
+                                                int lane, Ctx& C, LuReg& F, ChainLu& CF, double gmc, double gms, bool* ok, int long_tails = 0) {
   if (!NCDM) { *ok = factorise(e, J, hg, maxlen, lane, F); return; }
   *ok = true;
   if (ROLE == 1) { chain_factor(jc, ce, hg, maxlen, C, lane, CF); __syncthreads(); return; }   // (chain waves: maxlen = sweeps of their chains)
   __syncthreads();
   double al[4] = {0., 0., 0., 0.};
+  if (long_tails) { for (int t = 0; t < C.nw; t++) al[t] = C.sh->alpha[t][0]; }
+  else
   for (int w = 0; w < C.nw; w++)
 #pragma unroll
     for (int i = 0; i < 4; i++) al[i] += C.sh->alpha[w][i];
-  const bool good = factorise(e, J, hg, maxlen, lane, F, al, gmc, gms);
+  const bool good = factorise(e, J, hg, maxlen, lane, F, al, gmc, gms, long_tails);
   if (!good && lane == 0) C.sh->abort = 1;   // every wave leaves at the next block_max
 }
 template <int ROLE>
 static __device__ __forceinline__ double solve_all(const LaneEq& e, const ChainEq& ce, const LuReg& F, const ChainLu& CF, double hg, int maxlen,
-                                                   double b, int lane, Ctx& C, double gmc, double gms) {
+                                                   double b, int lane, Ctx& C, double gmc, double gms, int long_tails = 0) {
   if (!NCDM) return lu_solve(e, F, maxlen, b, lane);
   if (ROLE == 1) {
     const double x = chain_solve(CF, ce, b, maxlen);
@@ -1658,8 +1726,20 @@ static __device__ __forceinline__ double solve_all(const LaneEq& e, const ChainE
     if (lane == 0) { C.sh->ssum[C.wave - 1][0] = sD; C.sh->ssum[C.wave - 1][1] = sT; }
     __syncthreads();
     __syncthreads();
-    const double z1 = C.sh->z[0], z2 = C.sh->z[1];
+    const double z1 = C.sh->z[LONG ? ce.ch : 0], z2 = C.sh->z[1];
     return x + hg * (CF.pv * z1 + CF.sv * z2);
+  }
+  if (long_tails) {
+    // (long tails) the auxiliary rows take [T_t^-1 r_t]_first from tail wave t; the tails then want the increments of their parents
+    __syncthreads();
+    const int ln = opaque(lane);
+    const double s0 = C.sh->ssum[0][0], s1 = C.sh->ssum[1][0], s2 = (C.nw > 2) ? C.sh->ssum[2][0] : 0.;
+    const double bb = (ln == LN_ND) ? s0 : (ln == LN_ND + 1) ? s1 : (ln == LN_ND + 2) ? s2 : b;
+    const double x = lu_solve(e, F, maxlen, bb, lane);
+    const double x0 = bcast(x, LN_SG), x1 = bcast(x, LN_P2), x2 = bcast(x, LN_SUR);
+    if (lane == 0) { C.sh->z[2] = x0; C.sh->z[3] = x1; C.sh->z[4] = x2; }
+    __syncthreads();
+    return (ln >= LN_ND && ln <= LN_ND + 2) ? 0. : x;
   }
   __syncthreads();
   double sD = 0., sT = 0.;
@@ -1743,7 +1823,7 @@ static __device__ __forceinline__ int ndf15(const PtParams& P, const Layout& L, 
   const double* ts = P.tau_s;
   const int tres = P.ntau;
   const double htspan = fabs(tfinal - t0), hmax = (tfinal - t0) / 10.0;
-  const int maxlen = (ROLE == 1) ? (L.nfa ? 3 : C.len) : L.maxlen;   // sweeps of the tails / of the chains
+  const int maxlen = (ROLE == 1) ? (LONG ? P.long_len : L.nfa ? 3 : C.len) : L.maxlen;   // sweeps of the tails / of the chains
   enum { B_NONE = 0, B_JAC, B_F0, B_F1, B_JF0, B_SAMPLE, B_FINAL };
 
   Jac J;
@@ -1839,7 +1919,8 @@ static __device__ __forceinline__ int ndf15(const PtParams& P, const Layout& L, 
         else { tq = tnew; yq = ynew; }
         double dyq;
         if (NCDM && ROLE == 0 && batch == B_JAC) {   // wave 0 alone: unit ncdm integrals for the two auxiliary columns, no block barrier
-          NcIn Nj = {r == LN_ND ? 1. : 0., r == LN_NT ? 1. : 0., 0., nullptr, 0};
+          NcIn Nj = {r == LN_ND ? 1. : 0., r == LN_NT ? 1. : 0., 0., nullptr, 0, {0., 0., 0.}};
+          if (LONG) { Nj.D = Nj.T = 0.; Nj.y3[0] = (r == LN_ND) ? 1. : 0.; Nj.y3[1] = (r == LN_ND + 1) ? 1. : 0.; Nj.y3[2] = (r == LN_ND + 2) ? 1. : 0.; }
           dyq = rhs(P, L, e, Q, M, k, inv_k2, tq, yq, lane, &Nj);
           if (lane == r) { gmc = 0.5 * M.hp; gms = k * k * M.alpha; }
         } else dyq = rhs_all<ROLE>(P, L, e, ce, Q, M, C, N, k, inv_k2, tq, yq, lane);
@@ -1979,7 +2060,7 @@ static __device__ __forceinline__ int ndf15(const PtParams& P, const Layout& L, 
       need_fact = false;
       PROF_START();
       bool fact_ok;
-      fact_all<ROLE>(e, ce, J, jc, hinvGak, maxlen, lane, C, F, CF, gmc, gms, &fact_ok);
+      fact_all<ROLE>(e, ce, J, jc, hinvGak, maxlen, lane, C, F, CF, gmc, gms, &fact_ok, LONG ? 1 : 0);
       if (!fact_ok) return 2;
       PROF_STOP(2);
       st.lus++;
@@ -2028,7 +2109,7 @@ static __device__ __forceinline__ int ndf15(const PtParams& P, const Layout& L, 
       st.fevals++;
       const double rhsv = hinvGak * fnewton - (psi + difkp1);
       PROF_START();
-      const double del = solve_all<ROLE>(e, ce, F, CF, hinvGak, maxlen, rhsv, lane, C, gmc, gms);
+      const double del = solve_all<ROLE>(e, ce, F, CF, hinvGak, maxlen, rhsv, lane, C, gmc, gms, LONG ? 1 : 0);
       PROF_STOP(1);
 #ifdef CPT_PROFILE
       t_inner += clock64() - pf_t0;
@@ -2342,7 +2423,7 @@ static __device__ __forceinline__ int ndf15s(const PtParams& P, const Layout& L,
       if (need_fact) {
         need_fact = false;
         PROF_START();
-        if (!factorise(e, J, hinvGak, maxlen, lane, F, no_alpha, 0., 0.)) return 2;
+        if (!factorise(e, J, hinvGak, maxlen, lane, F, nullptr, 0., 0.)) return 2;
         PROF_STOP(2);
         st.lus++;
         havrate = false;
@@ -2714,6 +2795,10 @@ static __device__ __forceinline__ int run_intervals(const PtParams& P, Ctx& C, c
           if (P.K < 0.) y = (k2 + 3. * P.K >= 0.) ? y * sqrt(tanh(1.5707963267948966 * sqrt(k2 + 3. * P.K) / sqrt(-P.K))) : 0.;
         }
       }
+    } else if (ROLE == 1 && LONG) {   // (long tails) only the ur ladder starts with a non-zero l = 3 element (pm.cpp:4863-4941)
+      y = 0.;
+      if (ce.valid && ce.species == 2 && ce.l == 0)
+        y = initial_conditions(P.tabs, P.has_cdm, P.has_ur, P.curvature_ini, P.K, P.ic, P.entropy_ini, GAUGE, R_LUR, 3, k, tau_ini);
     } else if (ROLE == 1) {   // pm.cpp:5229-5256: the relativistic-relic series times the momentum dependence of f0
       const int l = ce.l;
       const int role = (l == 0) ? R_DELTA_UR : (l == 1) ? R_THETA_UR : (l == 2) ? R_SHEAR_UR : (l == 3) ? R_LUR : R_NONE;
@@ -2747,6 +2832,23 @@ static __device__ __forceinline__ int run_intervals(const PtParams& P, Ctx& C, c
         e = make_lane_eq(P, L, ROLE == 1 ? -1 : lane, k);
         double yn = (e.role == R_NONE) ? 0. : y;
         if (ROLE == 1) yn = y;          // the momentum hierarchies ride through the photon / ur switches (pm.cpp:3968-3975 etc.)
+        if (NCDM && LONG) {
+          // (long tails) a tail the new scheme drops is zeroed; when tight coupling ends the photon tails are seeded from the
+          // tight-coupling shear, which the core wave knows (pm.cpp:3893-3916)
+          if (ROLE == 0 && lane == 0) { C.sh->hf[0][0] = M.tca_shear_g; C.sh->hf[0][1] = k * Q.tau_c; }
+          __syncthreads();
+          if (ROLE == 1) {
+            const int t = ce.species;
+            const bool on = ce.valid && ((t == 0) ? L.gN > 0 : (t == 1) ? L.qN > 0 : L.uN > 0);
+            yn = on ? y : 0.;
+            if (was_tca && !L.tca && on && ce.first) {
+              const double sh = C.sh->hf[0][0], kod = C.sh->hf[0][1];
+              const double s3 = CURV ? sqrt(fmax(1. - 8. * P.K / (k * k), 0.)) : 1.;
+              if (t == 0) yn = 6. / 7. * kod * s3 * sh;
+              else if (t == 1) yn = kod * 3. * s3 / 14. * sh;
+            }
+          }
+        }
         if (NCDM && ap == 3) {
           // fluid approximation switched on (pm.cpp:4479-4517): integrate every chain into its species' delta, theta, sigma.
           // The published block still holds the background at the switch time (the final RHS evaluation of the last interval).
@@ -2787,7 +2889,7 @@ static __device__ __forceinline__ int run_intervals(const PtParams& P, Ctx& C, c
             else yn = 0.;
           }
         }
-        if (NCDM && entering) {
+        if constexpr (NCDM == 1) if (entering) {
           // the chain waves pass (delta, theta, sigma) of every species to the core wave and retire (see "the core wave alone")
           if (ROLE == 1 && ce.holder) C.sh->hf[ce.species][ce.l] = yn;
           __syncthreads();
@@ -2812,7 +2914,7 @@ static __device__ __forceinline__ int run_intervals(const PtParams& P, Ctx& C, c
       const unsigned long long iv_t0 = clock64(); const int iv_s0 = st.steps;
 #endif
       if constexpr (SAMPLER) rc = ndf15s<0>(P, L, e, C, Q, M, k, inv_k2, ta, tb, y, st, lane, budget, jacw, fww, prof);
-      else if constexpr (NCDM != 0 && ROLE == 0) {
+      else if constexpr (NCDM == 1 && ROLE == 0) {
         if (single) {
           if (cmode != 2) rc = ndf15s<1, false>(P, L, e, C, Q, M, k, inv_k2, ta, tb, y, st, lane, budget, jacw, fww, prof, ik);
           else if (L.rsa && L.ufa) rc = ndf15s<1, true>(P, L, e, C, Q, M, k, inv_k2, ta, tb, y, st, lane, budget, jacw, fww, prof, ik);
@@ -2929,9 +3031,9 @@ static __device__ __forceinline__ void body_perturb(const PtParams& P) {
     if (threadIdx.x == 0) { mbox->head = mbox->tail = mbox->done = mbox->req_seq = mbox->ans_seq = 0; mbox->req_tau = -1.; }
     __syncthreads();
   }
-  C.len = NCDM ? P.nc.lmax + 1 : 64; C.cpw = 64 / C.len;
+  C.len = (NCDM && !LONG) ? P.nc.lmax + 1 : 64; C.cpw = 64 / C.len;   // (long tails: one tail per chain wave)
   C.sh = (NcShared*)ncsh_raw; C.parity = 0; C.abort = 0; C.tau_pub = -1.;
-  C.a2 = C.aH = C.kcot = C.inv_tau = C.rho = C.pr = C.pp = 1.;
+  C.a2 = C.aH = C.kcot = C.inv_tau = C.rho = C.pr = C.pp = C.kap = 1.;
   if (NCDM) { if (threadIdx.x == 0) C.sh->abort = 0; __syncthreads(); }
 
   Stat st = {0, 0, 0, 0, 0, 0};
@@ -3107,6 +3209,9 @@ __global__ void __launch_bounds__(128) k_perturb(PtParams P) { PT<GAUGE, CURV, M
 //  waves share a SIMD and the kernel is compiled for half the registers)
 template <int CURV, int NW>
 __global__ void __launch_bounds__(64 * (1 + NW)) k_perturb_ncdm(PtParams P) { PT<CPT_GAUGE_SYNCHRONOUS, CURV, 0, 1>::body_perturb(P); }
+// hierarchies longer than one wavefront: the core wave + one wave per l >= 3 tail (photon temperature, polarisation, ur)
+template <int CURV>
+__global__ void __launch_bounds__(256) k_perturb_long(PtParams P) { PT<CPT_GAUGE_SYNCHRONOUS, CURV, 0, 2>::body_perturb(P); }
 template <int GAUGE, int CURV, int MODE, int ROWS>
 __global__ void __launch_bounds__(64) k_dbg_lookup(PtParams P, const double* tau, int n, double* out) { PT<GAUGE, CURV, MODE, 0, ROWS>::body_dbg_lookup(P, tau, n, out); }
 template <int GAUGE, int CURV, int MODE, int ROWS>
@@ -3141,8 +3246,15 @@ void fill_params(const cpt_handle* h, PtParams& P) {
   P.nc = h->ncdm;
   P.ncdm_compact = 1;   // (cpt_perturb_impl picks 1 or 2 from the size of the launch)
   P.max_steps = 400000;
+  // hierarchies longer than one wavefront (synchronous scalars without non-cold species): the tails go to chain waves of their own
+  {
+    const int lanes = 14 + (c.l_max_g - 2) + (c.l_max_pol_g - 2) + (c.has_ur ? c.l_max_ur - 2 : 0);
+    P.long_tails = (c.mode == CPT_MODE_SCALARS && !c.has_ncdm && lanes > CPT_WAVE) ? 1 : 0;
+    if (const char* e = getenv("CPT_LONG_TAILS")) P.long_tails = (c.mode == CPT_MODE_SCALARS && !c.has_ncdm && atoi(e) != 0) ? 1 : P.long_tails;
+    P.long_len = max(c.l_max_g - 2, max(c.l_max_pol_g - 2, c.has_ur ? c.l_max_ur - 2 : 0));
+  }
   // one tail per 16-lane row when each fits (defaults: 10 / 8 / 15 lanes), else the packed lane map with sequential sweeps
-  P.rows = (c.mode == CPT_MODE_SCALARS && !c.has_ncdm && c.l_max_g - 2 <= 16 && c.l_max_pol_g - 2 <= 16 && (!c.has_ur || c.l_max_ur - 2 <= 16)) ? 1 : 0;
+  P.rows = (c.mode == CPT_MODE_SCALARS && !c.has_ncdm && !P.long_tails && c.l_max_g - 2 <= 16 && c.l_max_pol_g - 2 <= 16 && (!c.has_ur || c.l_max_ur - 2 <= 16)) ? 1 : 0;
   if (const char* e = getenv("CPT_TAIL_ROWS")) P.rows = P.rows && atoi(e) != 0;
   P.k = nullptr; P.tau_s = nullptr; P.order = nullptr; P.nk = 0; P.ntau = 0; P.src = nullptr; P.stats = nullptr; P.status = nullptr;
 }
@@ -3214,8 +3326,8 @@ int cpt_perturb_impl(cpt_handle* h, const double* k, int nk, const double* tau, 
   CPT_HIP(h, hipMemsetAsync(h->d_src, 0, nsrc * sizeof(double), h->stream));  // pm.cpp:2767-2771 zero tail
   P.k = d_k; P.tau_s = d_tau; P.order = d_order; P.nk = nk; P.ntau = ntau; P.src = h->d_src; P.stats = d_stats; P.status = d_status;
   cpt_timer_start(h, CPT_T_PERTURB);
-  if (c.has_ncdm && c.mode == CPT_MODE_SCALARS) {
-    const int cpw = 64 / (c.l_max_ncdm + 1), nw = (h->ncdm.nchains + cpw - 1) / cpw;
+  if ((c.has_ncdm || P.long_tails) && c.mode == CPT_MODE_SCALARS) {
+    const int cpw = 64 / (c.l_max_ncdm + 1), nw = P.long_tails ? (c.has_ur ? 3 : 2) : (h->ncdm.nchains + cpw - 1) / cpw;
     if (nw > NCW_MAX)
       return cpt_fail(h, CPT_ERR_UNSUPPORTED, "%d ncdm momentum bins need %d chain wavefronts per k-mode (at most %d)", h->ncdm.nchains, nw, NCW_MAX);
     // register budget: a launch with more k-modes than one per CU can hold at a time (3 - 4 wavefronts x 512 registers fill a CU)
@@ -3227,9 +3339,13 @@ int cpt_perturb_impl(cpt_handle* h, const double* k, int nk, const double* tau, 
     if (const char* e = getenv("CPT_NCDM_WAVES_PER_SIMD")) half_regs = nw > 3 || atoi(e) >= 2;
     // last interval: a launch that is resident at once is latency-bound and keeps a helper wave beside the core wave; a larger one
     // lets every chain wave retire, which makes room for the next k-mode (measured on 2988 modes: 130 ms against 152 ms with helpers)
-    P.ncdm_compact = (nk <= 3 * n_cu) ? 2 : 1;
+    P.ncdm_compact = P.long_tails ? 0 : (nk <= 3 * n_cu) ? 2 : 1;
     if (const char* e = getenv("CPT_NCDM_COMPACT")) P.ncdm_compact = atoi(e);
     const size_t dyn = (P.ncdm_compact == 2) ? CPT_NCDM_HELPER_LDS : 0;
+    if (P.long_tails) {
+      if (c.K != 0.) hipLaunchKernelGGL((k_perturb_long<1>), dim3(nk), dim3(64 * (1 + nw)), 0, h->stream, P);
+      else hipLaunchKernelGGL((k_perturb_long<0>), dim3(nk), dim3(64 * (1 + nw)), 0, h->stream, P);
+    } else
     if (c.K != 0.) {
       if (!half_regs) hipLaunchKernelGGL((k_perturb_ncdm<1, 3>), dim3(nk), dim3(64 * (1 + nw)), dyn, h->stream, P);
       else hipLaunchKernelGGL((k_perturb_ncdm<1, NCW_MAX>), dim3(nk), dim3(64 * (1 + nw)), dyn, h->stream, P);

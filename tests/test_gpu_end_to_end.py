@@ -16,7 +16,7 @@ pytestmark = pytest.mark.gpu
 
 @pytest.mark.parametrize("cfg", ["small", "lcdm", "explanatory", "iso_cdi", "iso_nid", "newt", "tens", "tens_curved", "curved_full",
                                  "ncdm_small", "ncdm3_small", "ncdm", "ncdm3", "ncdm3_tens", "ncdm_k3000",
-                                 "newt_full", "iso_bi_full", "iso_niv_full", "tens_full"])
+                                 "newt_full", "iso_bi_full", "iso_niv_full", "tens_full", "long_small", "long_full"])
 def test_cl_and_pk_match_reference(cfg):
     """(ncdm, ncdm3 + ncdm3_tens = BASELINE configs 3 and 4: one / three massive neutrino species, scalars and tensors)"""
     from classpp_public_amd.backend import Backend
@@ -33,8 +33,9 @@ def test_cl_and_pk_match_reference(cfg):
     # sampling, 3x coarser k steps): there the reference moves its own C_l^TT by 7.9e-5 when its rtol is halved.
     # (newt_full, iso_bi_full, iso_niv_full, tens_full: Newtonian gauge, baryon / neutrino-velocity isocurvature and tensor modes at the
     #  reference's DEFAULT precision, l_max = 2500 / 500)
+    # (long_small / long_full: l_max_g = l_max_pol_g = l_max_ur = 50, hierarchies longer than one wavefront)
     tol = 1e-4 if cfg in ("lcdm", "explanatory", "curved_full", "ncdm", "ncdm3", "ncdm_k3000", "newt_full", "iso_bi_full", "iso_niv_full",
-                          "tens_full") else 3e-4   # small and iso_cdi / iso_nid / newt / tens share the coarse precision file
+                          "tens_full", "long_full") else 3e-4   # small and iso_cdi / iso_nid / newt / tens share the coarse precision file
     for name, idx, kind in (("tt", sp.index_ct_tt, "rel"), ("ee", sp.index_ct_ee, "rel"), ("pp", sp.index_ct_pp, "rel"),
                             ("bb", sp.index_ct_bb if inp.config.mode == 1 else -1, "rel"),
                             ("te", sp.index_ct_te, "abs"), ("tp", sp.index_ct_tp, "abs"), ("ep", sp.index_ct_ep, "abs")):

@@ -88,7 +88,7 @@ def test_perturb_small_all_modes(small):
     print("\n[small] perturb kernel %.3f ms for %d modes, %d steps" % (ms, inp.nk, gs))
 
 
-@pytest.mark.parametrize("cfg", ["lcdm", "explanatory", "iso_cdi", "iso_nid", "newt", "ncdm", "ncdm3", "ncdm_k3000"])
+@pytest.mark.parametrize("cfg", ["lcdm", "explanatory", "iso_cdi", "iso_nid", "newt", "ncdm", "ncdm3", "ncdm_k3000", "long_full"])
 def test_perturb_full_size(cfg):
     """BASELINE configs 1-2: every k-mode integrated on the GPU; the 16 golden columns are compared with the reference."""
     from classpp_public_amd.backend import Backend
@@ -103,7 +103,10 @@ def test_perturb_full_size(cfg):
     if inp.config.index_tp_delta_m >= 0:  # delta_m(k, tau0) for every k: the P(k) input
         dm, ref_dm = got[inp.config.index_tp_delta_m, -1, :], inp.d["pt.delta_m_today"]
         if inp.config.ic == 0:
-            assert np.max(np.abs(dm / ref_dm - 1)) < 1e-5
+            # (long_full: one isolated mode of 603 at 2.5e-5, the others below 3e-6 - inside the band by which the reference's own delta_m
+            #  moves when its tolerance is halved, 3e-5; P(k) end to end 4.7e-5)
+            assert np.max(np.abs(dm / ref_dm - 1)) < (1e-5 if cfg != "long_full" else 5e-5)
+            assert np.median(np.abs(dm / ref_dm - 1)) < 1e-6
         else:  # isocurvature delta_m(k) changes sign: relative to the column maximum
             assert np.max(np.abs(dm - ref_dm)) < 1e-5 * np.max(np.abs(ref_dm))
     ms, n = be.kernel_ms(0)
@@ -309,6 +312,30 @@ def test_tensor_sources_match_reference(tens):
 # ---- massive neutrinos (BASELINE configs 3-4): 1 + NW wavefronts per k-mode, the momentum hierarchies Psi_l(q) in the chain waves,
 # bordered Newton system (pm.cpp:8725-8879, 6317-6432, 5229-5256, 4479-4517).  ncdm_small / ncdm3_small hold the reference's full
 # sources_ for one / three species of 0.06 eV at the coarse precision of `small`.
+def test_hierarchies_longer_than_one_wavefront():
+    """l_max_g = l_max_pol_g = l_max_ur = 50 (cl_permille-class): 14 + 3 x 48 = 158 equations per k-mode.  The three l >= 3 tails run on
+    chain wavefronts of their own (cpt_perturb.hip "long tails"): sources against the reference (fixture long_small), work against the
+    dense CPU restatement, and - the tails being longer versions of the same ladders - close to the default-hierarchy sources."""
+    from classpp_public_amd.backend import Backend
+    inp = Inputs("long_small")
+    assert inp.config.l_max_g == 50 and inp.config.l_max_pol_g == 50 and inp.config.l_max_ur == 50
+    be = Backend(inp)
+    src, stats, status = be.perturb_solve()
+    assert not status.any()
+    got = src.cpu().numpy()
+    assert np.all(np.isfinite(got))
+    check_sources(inp.config, got, inp.d["pt.sources"])
+    ks = np.arange(0, inp.nk, 9)
+    _, ostats, _, _ = oracle_lib.perturb(inp, k=inp.k[ks])
+    gs, os_ = sum(stats[i].steps for i in ks), sum(s.steps for s in ostats)
+    assert abs(gs - os_) < 0.02 * os_, (gs, os_)
+    assert [stats[i].n_regimes for i in ks] == [s.n_regimes for s in ostats]
+    assert np.allclose([stats[i].tau_ini for i in ks], [s.tau_ini for s in ostats], rtol=1e-9)
+    ms, n = be.kernel_ms(0)
+    print("\n[long_small] perturb kernel %.1f ms for %d modes, %d steps" % (ms, inp.nk, sum(s.steps for s in stats)))
+    be.close()
+
+
 @pytest.mark.parametrize("cfg", ["ncdm_small", "ncdm3_small"])
 def test_ncdm_sources_match_reference(cfg):
     from classpp_public_amd.backend import Backend
