@@ -158,10 +158,10 @@ static int validate(const cpt_config* c) {
                     "synchronous gauge needs cdm (the reference rejects this too, perturbations_module.cpp:560)");
   if (c->gauge != CPT_GAUGE_SYNCHRONOUS && c->gauge != CPT_GAUGE_NEWTONIAN)
     return cpt_fail(nullptr, CPT_ERR_INVALID, "gauge=%d is neither newtonian (0) nor synchronous (1)", c->gauge);
-  if (c->tight_coupling_approximation != CPT_TCA_COMPROMISE_CLASS &&
-      c->tight_coupling_approximation != CPT_TCA_FIRST_ORDER_CAMB)
-    return cpt_fail(nullptr, CPT_ERR_UNSUPPORTED, "tight_coupling_approximation=%d is not implemented",
-                    c->tight_coupling_approximation);
+  if (c->tight_coupling_approximation != CPT_TCA_COMPROMISE_CLASS && c->tight_coupling_approximation != CPT_TCA_FIRST_ORDER_CAMB &&
+      c->tight_coupling_approximation != CPT_TCA_FIRST_ORDER_MB)
+    return cpt_fail(nullptr, CPT_ERR_UNSUPPORTED, "tight_coupling_approximation=%d is not implemented (first_order_MB, first_order_CAMB and "
+                    "compromise_CLASS are; first_order_CLASS and the second-order schemes need the derivatives of c_b^2)", c->tight_coupling_approximation);
   if (c->l_max_g < 4 || c->l_max_pol_g < 4 || (c->has_ur && c->l_max_ur < 4))
     return cpt_fail(nullptr, CPT_ERR_INVALID, "l_max_g, l_max_pol_g, l_max_ur must be at least 4 (pm.cpp:3302-3330)");
   if (c->mode != CPT_MODE_SCALARS && c->mode != CPT_MODE_TENSORS) return cpt_fail(nullptr, CPT_ERR_INVALID, "mode=%d is neither scalars (0) nor tensors (1)", c->mode);

@@ -1038,7 +1038,9 @@ static __device__ __forceinline__ double rhs(const PtParams& P, const Layout& L,
     S4 = kap * tb;
   } else {
     const double tau_c = Q.tau_c, dtau_c = Q.dtau_c, F = Q.F;
-    double slip = (dtau_c * kap - 2. * aH * Q.inv_1pR) * (tb - tg) +
+    // first order: dkappa ~ a^-2 assumed (Ma & Bertschinger, pm.cpp:9351-9361) or not (CAMB form, :9364-9373)
+    const double slip_c = (P.tca_method == CPT_TCA_FIRST_ORDER_MB) ? 2. * R * Q.inv_1pR * aH : dtau_c * kap - 2. * aH * Q.inv_1pR;
+    double slip = slip_c * (tb - tg) +
                   F * (-Q.app * tb + k2 * (-aH * dg * 0.5 + cb2 * (-tb - mc) - (-tg - mc) * (1. / 3.)) - aH * me);
     double shear = 16. / 45. * tau_c * (tg + ms);
     const double theta_prime = (-aH * tb + k2 * (cb2 * db + R * 0.25 * dg)) * Q.inv_1pR + me;

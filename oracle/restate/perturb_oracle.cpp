@@ -351,7 +351,7 @@ void einstein(const Model& m, double k, const double* y, const Layout& L, Work& 
   w.delta_cb += 3. * bg.a * bg.H * w.theta_cb / k2;   // pm.cpp:5992-5993
 }
 
-// perturb_tca_slip_and_shear, pm.cpp:9229-9516 (first_order_CAMB and compromise_CLASS)
+// perturb_tca_slip_and_shear, pm.cpp:9229-9516 (first_order_MB, first_order_CAMB and compromise_CLASS)
 void tca_slip_and_shear(const Model& m, double k, const double* y, const Layout& L, Work& w) {
   const cpt_config& c = *m.c;
   const Bg& bg = w.bg; const Th& th = w.th;
@@ -365,7 +365,9 @@ void tca_slip_and_shear(const Model& m, double k, const double* y, const Layout&
   double F_prime = dtau_c / (1 + R) + tau_c * a_prime_over_a * R / (1 + R) / (1 + R);
   double metric_continuity = w.h_prime / 2., metric_euler = 0., metric_shear = k2 * w.alpha, metric_shear_prime = k2 * w.alpha_prime;
   if (c.gauge == CPT_GAUGE_NEWTONIAN) { metric_continuity = -3. * w.phi_prime; metric_euler = k2 * w.psi; metric_shear = 0.; metric_shear_prime = 0.; }
-  double slip = (dtau_c / tau_c - 2. * a_prime_over_a / (1. + R)) * (theta_b - theta_g) +
+  const double slip_c = (c.tight_coupling_approximation == CPT_TCA_FIRST_ORDER_MB) ? 2. * R / (1. + R) * a_prime_over_a   // pm.cpp:9351-9361
+                                                                                    : dtau_c / tau_c - 2. * a_prime_over_a / (1. + R);
+  double slip = slip_c * (theta_b - theta_g) +
                 F * (-a_primeprime_over_a * theta_b +
                      k2 * (-a_prime_over_a * delta_g / 2. + cb2 * (-theta_b - metric_continuity) -
                            4. / 3. * (-theta_g - metric_continuity) / 4.) -

@@ -312,6 +312,21 @@ def test_tensor_sources_match_reference(tens):
 # ---- massive neutrinos (BASELINE configs 3-4): 1 + NW wavefronts per k-mode, the momentum hierarchies Psi_l(q) in the chain waves,
 # bordered Newton system (pm.cpp:8725-8879, 6317-6432, 5229-5256, 4479-4517).  ncdm_small / ncdm3_small hold the reference's full
 # sources_ for one / three species of 0.06 eV at the coarse precision of `small`.
+def test_first_order_mb_tight_coupling(small):
+    """tight_coupling_approximation = first_order_MB (pm.cpp:9351-9361) against the reference (fixture tca_mb = small.ini with that scheme);
+    the scheme matters at the level the test resolves: the default scheme's t0 sources miss this fixture by more than its tolerance"""
+    from classpp_public_amd.backend import Backend
+    inp = Inputs("tca_mb")
+    assert inp.config.tight_coupling_approximation == 0
+    be = Backend(inp)
+    src, stats, status = be.perturb_solve()
+    assert not status.any()
+    check_sources(inp.config, src.cpu().numpy(), inp.d["pt.sources"])
+    be.close()
+    with pytest.raises(AssertionError):
+        check_sources(inp.config, small[0].d["pt.sources"], inp.d["pt.sources"])
+
+
 def test_hierarchies_longer_than_one_wavefront():
     """l_max_g = l_max_pol_g = l_max_ur = 50 (cl_permille-class): 14 + 3 x 48 = 158 equations per k-mode.  The three l >= 3 tails run on
     chain wavefronts of their own (cpt_perturb.hip "long tails"): sources against the reference (fixture long_small), work against the
