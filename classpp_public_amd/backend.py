@@ -199,6 +199,21 @@ class Backend:
                                           C.c_void_p(out.data_ptr())))
         return out
 
+    def cl_cross(self, transfer1, transfer2, amplitude, tilt, running, q=None):
+        """the cross-correlation spectra of two scalar initial conditions (cpt_cl_cross_batch): transfer tables [tt][nl][nq] of the two
+        (device), amplitude / tilt / running of the primordial cross spectrum -> [nl][ct_size] on device"""
+        import copy
+        q = np.ascontiguousarray(self.inp.q if q is None else q, dtype=np.float64)
+        nl = transfer1.shape[1]
+        assert transfer1.shape == transfer2.shape and transfer1.is_contiguous() and transfer2.is_contiguous()
+        sp = copy.copy(self.inp.spectra)
+        sp.A_s, sp.n_s, sp.alpha_s = float(amplitude), float(tilt), float(running)
+        out = torch.empty((nl, sp.ct_size), dtype=torch.float64, device=self.device)
+        self._fence()
+        self._check(self.lib.cpt_cl_cross_batch(self.h, C.byref(sp), C.c_void_p(transfer1.data_ptr()), C.c_void_p(transfer2.data_ptr()), _dptr(q),
+                                                q.size, nl, C.c_void_p(out.data_ptr())))
+        return out
+
     def lensed_cl(self, cl, l_unlensed_max, delta_l_max=500, accurate=False, num_mu_minus_lmax=70, tol_gauss_legendre=0.0, l=None):
         """unlensed C_l table [nl][ct] (device) -> lensed table [l_size][ct] on device (cpt_lensing_batch)"""
         from .capi import CptLensingParams

@@ -105,7 +105,7 @@ class CptStepIo(C.Structure):
 EXPORTS = [
     "cpt_create", "cpt_destroy", "cpt_last_error", "cpt_create_error", "cpt_perturb_solve_batch",
     "cpt_transfer_batch", "cpt_get_sources", "cpt_last_kernel_ms", "cpt_last_transfer_work",
-    "cpt_dbg_lookup", "cpt_dbg_derivs", "cpt_dbg_solve", "cpt_dbg_bessel", "cpt_cl_batch", "cpt_pk_linear", "cpt_sigma", "cpt_pk_cb_linear", "cpt_sigma_cb",
+    "cpt_dbg_lookup", "cpt_dbg_derivs", "cpt_dbg_solve", "cpt_dbg_bessel", "cpt_cl_batch", "cpt_cl_cross_batch", "cpt_sigma_of_pk", "cpt_pk_linear", "cpt_sigma", "cpt_pk_cb_linear", "cpt_sigma_cb",
     "cpt_lensing_l_size", "cpt_lensing_batch", "cpt_step",
     "cpt_comm_get_unique_id", "cpt_comm_init", "cpt_comm_destroy", "cpt_allgather_sources", "cpt_gather_transfer",
     "cpt_dbg_pad_rows", "cpt_dbg_uninterleave",
@@ -148,6 +148,10 @@ def lib():
     L.cpt_last_transfer_work.restype = _i
     L.cpt_cl_batch.argtypes = [vp, C.POINTER(CptSpectraParams), vp, _pd, _i, _i, vp]
     L.cpt_cl_batch.restype = _i
+    L.cpt_cl_cross_batch.argtypes = [vp, C.POINTER(CptSpectraParams), vp, vp, _pd, _i, _i, vp]
+    L.cpt_cl_cross_batch.restype = _i
+    L.cpt_sigma_of_pk.argtypes = [_pd, _pd, _i, C.c_double, C.c_double, C.POINTER(C.c_double)]
+    L.cpt_sigma_of_pk.restype = _i
     L.cpt_pk_linear.argtypes = [vp, C.POINTER(CptSpectraParams), _pd, _i, vp]
     L.cpt_pk_linear.restype = _i
     L.cpt_sigma.argtypes = [vp, C.POINTER(CptSpectraParams), _pd, _i, _d, _d, C.POINTER(_d)]

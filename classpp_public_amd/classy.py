@@ -45,7 +45,10 @@ _KNOWN = {"h", "H0", "T_cmb", "omega_b", "Omega_b", "omega_cdm", "Omega_cdm", "O
           "reio_parametrization", "z_reio", "tau_reio", "output", "lensing", "modes", "ic", "gauge", "P_k_ini type", "k_pivot", "A_s",
           "ln10^{10}A_s", "n_s", "alpha_s", "r", "n_t", "alpha_t", "l_max_scalars", "l_max_tensors", "P_k_max_h/Mpc", "P_k_max_1/Mpc", "z_pk",
           "z_max_pk", "non linear", "threads", "class_dir", "N_ncdm", "m_ncdm", "Omega_ncdm", "omega_ncdm", "T_ncdm", "ksi_ncdm", "deg_ncdm",
-          "tensor method", "delta_l_max", "accurate_lensing", "num_mu_minus_lmax"} | set(_VERBOSE)
+          "tensor method", "delta_l_max", "accurate_lensing", "num_mu_minus_lmax"} | set(_VERBOSE) | {
+              p + "_" + ic for ic in ("bi", "cdi", "nid", "niv") for p in ("f", "n", "alpha")} | {
+              p + "_" + a + "_" + b for a, b in (("ad", "bi"), ("ad", "cdi"), ("ad", "nid"), ("ad", "niv"), ("bi", "cdi"), ("bi", "nid"), ("bi", "niv"),
+                                                 ("cdi", "nid"), ("cdi", "niv"), ("nid", "niv")) for p in ("c", "n", "alpha")}
 _LEVELS = ("background", "thermodynamics", "perturb", "primordial", "nonlinear", "transfer", "spectra", "lensing")
 
 
@@ -57,7 +60,51 @@ def _yes(v):
     return str(v).strip().lower() in ("yes", "y", "true", "1")
 
 
-def build_parameters(pars, mode):
+_IC_NAMES = ("ad", "bi", "cdi", "nid", "niv")     # the reference's order (perturbations_module.cpp:1153-1170); codes = CPT_IC_*
+
+
+def initial_conditions(pars):
+    """'ic' of a classy dictionary -> the requested scalar initial conditions in the reference's order (input_module.cpp:1832-1870)"""
+    want = [t.strip().lower() for t in str(pars.get("ic", "ad")).replace("&", ",").split(",") if t.strip()]
+    full = {"ad": "ad", "bi": "bi", "cdi": "cdi", "nid": "nid", "niv": "niv"}
+    if not want or any(t not in full for t in want):
+        raise CosmoSevereError("ic: a list of ad, bi, cdi, nid, niv")
+    return [n for n in _IC_NAMES if n in want]
+
+
+def primordial_pairs(pars, ics):
+    """(amplitude, tilt, running) of the primordial spectrum of every pair of initial conditions - diagonal: A_s f_ic^2, n_ic, alpha_ic;
+    off-diagonal: c_12 sqrt(A_11 A_22), (n_11 + n_22) / 2 + n_12, (alpha_11 + alpha_22) / 2 + alpha_12 (input_module.cpp:1880-1960,
+    primordial_module.cpp:716-890) -> {(i, j): (A, n, alpha)}, i <= j indices into ics; vanishing cross-correlations are left out"""
+    def num(key, default):
+        try:
+            return float(pars[key]) if key in pars else default
+        except (TypeError, ValueError):
+            raise CosmoSevereError("could not read a number for '%s' (got %r)" % (key, pars[key]))
+    A_s = num("A_s", 2.215e-9) if "ln10^{10}A_s" not in pars else np.exp(num("ln10^{10}A_s", 3.)) * 1e-10
+    n_s, alpha_s = num("n_s", 0.9619), num("alpha_s", 0.)
+    out = {}
+    for i, a in enumerate(ics):
+        if a == "ad":
+            out[(i, i)] = (A_s, n_s, alpha_s)
+        else:
+            f = num("f_" + a, 1.)
+            if f == 0.:
+                raise CosmoSevereError("f_%s = 0: remove %s from ic instead" % (a, a))
+            out[(i, i)] = (A_s * f * f, num("n_" + a, 1.), num("alpha_" + a, 0.))
+    for i, a in enumerate(ics):
+        for j in range(i + 1, len(ics)):
+            b = ics[j]
+            c = num("c_%s_%s" % (a, b), 0.)
+            if abs(c) > 1.:
+                raise CosmoSevereError("c_%s_%s must lie in [-1, 1]" % (a, b))
+            if c != 0.:
+                out[(i, j)] = (np.sqrt(out[(i, i)][0] * out[(j, j)][0]) * c, 0.5 * (out[(i, i)][1] + out[(j, j)][1]) + num("n_%s_%s" % (a, b), 0.),
+                               0.5 * (out[(i, i)][2] + out[(j, j)][2]) + num("alpha_%s_%s" % (a, b), 0.))
+    return out
+
+
+def build_parameters(pars, mode, ic="ad"):
     """classy-style dictionary -> (entries, ini) for one mode ('s' | 't'): entries keyed like the reference's input structs
     (pba.*, pth.*, ppt.*, ppr.*, ppm.*, ptr.*, pt.index_tp_*, tr.index_tt_*, sp.index_ct_*; input_module.cpp:549-3148 for the defaults
     and the derived values, perturbations_module.cpp:250-420 / transfer_module.cpp:560-640 / spectra_module.cpp:470-560 for the index
@@ -83,8 +130,9 @@ def build_parameters(pars, mode):
         raise CosmoSevereError("recombination = RECFAST is the code built here (HyRec is outside the path)")
     if str(pars.get("P_k_ini type", "analytic_Pk")).strip() != "analytic_Pk":
         raise CosmoSevereError("P_k_ini type = analytic_Pk only")
-    if str(pars.get("ic", "ad")).strip() != "ad":
-        raise CosmoSevereError("ic = ad only through this surface (single isocurvature modes: Inputs / the C ABI)")
+    ics_all = initial_conditions(pars)
+    if ic not in ics_all and mode == "s":
+        raise CosmoSevereError("initial condition %s is not among ic = %s" % (ic, ",".join(ics_all)))
     if num("z_pk", 0.) != 0. or num("z_max_pk", 0.) != 0.:
         raise CosmoSevereError("P(k) at z = 0 only")
     for a, b in (("h", "H0"), ("omega_b", "Omega_b"), ("omega_cdm", "Omega_cdm"), ("z_reio", "tau_reio"), ("A_s", "ln10^{10}A_s"),
@@ -160,9 +208,9 @@ def build_parameters(pars, mode):
     ppr_delta_l_max = int(num("delta_l_max", 500))
     d["ppt.gauge"] = _arr(1 if gauge == "synchronous" else 0, True)
     d["ppt.has_scalars"] = _arr(int(not tens), True); d["ppt.has_tensors"] = _arr(int(tens), True)
-    d["ppt.has_ad"] = _arr(1, True)
-    for f in ("has_bi", "has_cdi", "has_nid", "has_niv"):
-        d["ppt." + f] = _arr(0, True)
+    # (one device handle integrates one initial condition: the entries describe the run of `ic` alone)
+    for f in _IC_NAMES:
+        d["ppt.has_" + f] = _arr(int(f == (ic if not tens else "ad")), True)
     d["ppt.has_cl_cmb_temperature"] = _arr(int(has_t), True)
     d["ppt.has_cl_cmb_polarization"] = _arr(int(has_p), True)
     d["ppt.has_cl_cmb_lensing_potential"] = _arr(int(has_l and not tens), True)
@@ -209,7 +257,8 @@ def build_parameters(pars, mode):
         alpha_t = r / 8. * (r / 8. + n_s - 1.) if scc("alpha_t") else num("alpha_t", 0.)
         d["ppm.amplitude0"] = _arr(r * A_s); d["ppm.tilt0"] = _arr(n_t + 1.); d["ppm.running0"] = _arr(alpha_t)
     else:
-        d["ppm.amplitude0"] = _arr(A_s); d["ppm.tilt0"] = _arr(n_s); d["ppm.running0"] = _arr(alpha_s)
+        amp, tilt, run = primordial_pairs(pars, [ic])[(0, 0)]
+        d["ppm.amplitude0"] = _arr(amp); d["ppm.tilt0"] = _arr(tilt); d["ppm.running0"] = _arr(run)
 
     # ---- index maps, in the order the modules define them
     tp, n = {}, 0
@@ -288,10 +337,12 @@ def spline_to_integer_l(l, table, lmax):
 class _ModeRun:
     """one device handle (one mode): perturbations -> transfer -> C_l table on the multipole grid, P(k) on the k grid"""
 
-    def __init__(self, pars, mode, device, level):
+    def __init__(self, pars, mode, device, level, ic="ad", keep=False):
+        """keep: several initial conditions are combined afterwards - hold on to the transfer table and delta_m(k, tau_0)"""
         from .backend import Backend, CptError, CptInputError
-        self.mode = mode
-        d, ini = build_parameters(pars, mode)
+        self.mode, self.ic = mode, ic
+        self.tr = self.dm = None
+        d, ini = build_parameters(pars, mode, ic)
         try:
             self.inp = ParameterInputs("classy-" + mode, params=d, ini=ini)
         except ValueError as e:   # libcpt_host.so refused the point (e.g. tau_reio out of reach, unphysical densities)
@@ -301,11 +352,16 @@ class _ModeRun:
             return
         try:
             self.be = Backend(self.inp, device=device)
-            self.be.perturb_solve(want_sources=False)
+            src = self.be.perturb_solve(want_sources=keep)[0]
             if self.inp.has_cls and level not in ("perturb", "primordial", "nonlinear"):
-                self.cl = self.be.cl(self.be.transfer(None))
+                tr = self.be.transfer(None)
+                self.cl = self.be.cl(tr)
+                if keep:
+                    self.tr = tr
             if self.inp.config.index_tp_delta_m >= 0:
                 self.pk = self.be.pk_linear().cpu().numpy()
+                if keep:
+                    self.dm = src[self.inp.config.index_tp_delta_m, -1, :].cpu().numpy().copy()
         except CptInputError as e:
             raise CosmoSevereError(str(e))
         except CptError as e:
@@ -333,6 +389,7 @@ class Class:
         for r in self._runs.values():
             r.close()
         self._runs, self._level, self._cache = {}, None, {}
+        self._ics, self._pairs = ["ad"], {}
         self.parameters_changed = True
 
     def empty(self):
@@ -366,8 +423,15 @@ class Class:
         if self._runs and not self.parameters_changed and _LEVELS.index(self._level) >= _LEVELS.index(level):
             return self
         self.struct_cleanup()
+        ics = initial_conditions(self._pars)
+        self._ics, self._pairs = ics, primordial_pairs(self._pars, ics)
         for m in self._modes():
-            self._runs[m] = _ModeRun(self._pars, m, self._device, level)
+            if m == "s":
+                # one device handle per initial condition (independent integrations); "s" = the first, "s:<ic>" the others
+                for i, name in enumerate(ics):
+                    self._runs["s" if i == 0 else "s:" + name] = _ModeRun(self._pars, "s", self._device, level, ic=name, keep=len(ics) > 1)
+            else:
+                self._runs[m] = _ModeRun(self._pars, m, self._device, level)
         self._level = level
         self.parameters_changed = False
         return self
@@ -381,15 +445,26 @@ class Class:
     def _total_unlensed(self, lmax):
         """per-mode tables splined to every l and summed (spectra_module.cpp cl_output: the sum over modes) -> {name: [lmax+1]}"""
         tot = {}
-        for r in self._runs.values():
+
+        def add(r, table, factor):
             sp = r.inp.spectra
-            full = spline_to_integer_l(r.inp.l, r.cl.cpu().numpy(), min(lmax, int(r.inp.l[-1])))
+            full = spline_to_integer_l(r.inp.l, table.cpu().numpy(), min(lmax, int(r.inp.l[-1])))
             for name in ("tt", "ee", "te", "bb", "pp", "tp", "ep"):
                 idx = getattr(sp, "index_ct_" + name)
                 if idx >= 0:
                     acc = tot.setdefault(name, np.zeros(lmax + 1))
-                    acc[: full.shape[1]] += full[idx]
+                    acc[: full.shape[1]] += factor * full[idx]
+        for r in self._runs.values():
+            add(r, r.cl, 1.)
+        # correlated initial conditions: twice the cross spectra (spectra_module.cpp cl_output: sum over the symmetric ic x ic matrix)
+        for (i, j), (amp, tilt, run) in self._pairs.items():
+            if i != j:
+                ri, rj = self._scalar_run(i), self._scalar_run(j)
+                add(ri, ri.be.cl_cross(ri.tr, rj.tr, amp, tilt, run), 2.)
         return tot
+
+    def _scalar_run(self, i):
+        return self._runs["s" if i == 0 else "s:" + self._ics[i]]
 
     def _l_max_tot(self):
         return max(int(r.inp.d["sp.l_max_tot"][0]) for r in self._runs.values())
@@ -423,10 +498,10 @@ class Class:
             raise CosmoSevereError("Can only compute up to lmax=%d" % top)
         if "lensed" not in self._cache:
             table = r.cl
-            if len(self._runs) > 1:   # s,t: the total unlensed spectra on the scalar multipole grid
+            if len(self._runs) > 1:   # s,t and / or several initial conditions: the total unlensed spectra on the scalar multipole grid
                 tot = self._total_unlensed(int(r.inp.l[-1]))
                 table = r.cl.clone()
-                for name in ("tt", "ee", "te", "bb"):
+                for name in ("tt", "ee", "te", "bb", "pp", "tp", "ep"):
                     idx = getattr(sp, "index_ct_" + name)
                     if idx >= 0:
                         table[:, idx] = torch.as_tensor(tot[name][r.inp.l], device=table.device)
@@ -455,6 +530,39 @@ class Class:
             raise CosmoSevereError("Power spectrum not computed. You must add mPk to the list of outputs.")
         return r
 
+    def _pk_total(self):
+        """P(k) on the k grid, summed over the initial conditions: sum_i P_ii + 2 sum_{i<j} P_ij with
+        P_ij = 2 pi^2 / k^3 calP_ij(k) delta_i(k) delta_j(k) (nonlinear_module.cpp:1886-2040; one initial condition: the device's P(k))"""
+        r = self._pk_run()
+        if len(self._ics) == 1:
+            return r.pk
+        if "pk_total" not in self._cache:
+            k = r.inp.k
+            tot = np.zeros_like(r.pk)
+            kp = float(r.inp.d["ppm.k_pivot"][0])
+            for (i, j), (amp, tilt, run) in self._pairs.items():
+                ri, rj = self._scalar_run(i), self._scalar_run(j)
+                if i == j:
+                    tot += ri.pk
+                else:
+                    lk = np.log(k / kp)
+                    tot += 2. * (2. * np.pi ** 2 / k ** 3) * amp * np.exp((tilt - 1.) * lk + 0.5 * run * lk * lk) * ri.dm * rj.dm
+            self._cache["pk_total"] = tot
+        return self._cache["pk_total"]
+
+    def _sigma_total(self, R):
+        r = self._pk_run()
+        if len(self._ics) == 1:
+            return r.be.sigma(float(R))
+        import ctypes as C
+        from . import capi
+        k, pk = np.ascontiguousarray(r.inp.k), np.ascontiguousarray(self._pk_total())
+        out = C.c_double()
+        pd = C.POINTER(C.c_double)
+        if capi.lib().cpt_sigma_of_pk(k.ctypes.data_as(pd), pk.ctypes.data_as(pd), k.size, float(R), 80., C.byref(out)) != 0:
+            raise CosmoComputationError("sigma(R): the total P(k) is not positive everywhere")
+        return out.value
+
     def pk_lin(self, k, z=0.):
         """linear total-matter P(k) [Mpc^3] at k [1/Mpc], z = 0: natural cubic spline of ln P in ln k over the k grid
         (nonlinear_module.cpp:2041-2212 nonlinear_pk_at_k_and_z)"""
@@ -466,7 +574,7 @@ class Class:
             raise CosmoSevereError("k=%e out of bounds [%e:%e]" % (k, kk[0], kk[-1]))
         if "lnpk" not in self._cache:
             from scipy.interpolate import CubicSpline
-            self._cache["lnpk"] = CubicSpline(np.log(kk), np.log(r.pk), bc_type="natural")
+            self._cache["lnpk"] = CubicSpline(np.log(kk), np.log(self._pk_total()), bc_type="natural")
         return float(np.exp(self._cache["lnpk"](np.log(k))))
 
     pk = pk_lin
@@ -479,7 +587,7 @@ class Class:
     def get_pk_and_k(self):
         """the k grid [1/Mpc] and P(k) [Mpc^3] on it, as computed on the device (no interpolation)"""
         r = self._pk_run()
-        return r.pk.copy(), r.inp.k.copy()
+        return self._pk_total().copy(), r.inp.k.copy()
 
     def sigma(self, R, z=0.):
         if z != 0.:
@@ -487,11 +595,11 @@ class Class:
         r = self._pk_run()
         if float(r.inp.d["ppt.k_max_for_pk"][0]) < self.h():
             raise CosmoSevereError("In order to get sigma(R,z) you must set 'P_k_max_h/Mpc' to 1 or bigger, in order to have k_max > 1 h/Mpc.")
-        return r.be.sigma(float(R))
+        return self._sigma_total(R)
 
     def sigma8(self):
         """the nonlinear module's sigma8_ (no k_max check here, classy.pyx:805-809)"""
-        return self._pk_run().be.sigma(8. / self.h())
+        return self._sigma_total(8. / self.h())
 
     # -- scalars (classy.pyx:744-825, 1079-1092, 1771-1776)
     def _t(self, key, level="thermodynamics"):

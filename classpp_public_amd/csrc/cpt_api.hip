@@ -393,6 +393,22 @@ int cpt_cl_batch(cpt_handle* h, const cpt_spectra_params* sp, const double* tran
   return cpt_finish(h);
 }
 
+int cpt_cl_cross_batch(cpt_handle* h, const cpt_spectra_params* sp, const double* transfer1_dev, const double* transfer2_dev, const double* q,
+                       int nq, int nl, double* cl_dev) {
+  CPT_ENTER(h);
+  if (!sp || !transfer1_dev || !transfer2_dev || !q || !cl_dev || nq < 3 || nl < 1) return cpt_fail(h, CPT_ERR_INVALID, "bad arguments to cpt_cl_cross_batch");
+  int rc = cpt_cl_impl(h, sp, transfer1_dev, q, nq, nl, cl_dev, transfer2_dev);
+  if (rc) { (void)hipStreamSynchronize(h->stream); return rc; }
+  return cpt_finish(h);
+}
+
+int cpt_sigma_of_pk(const double* k, const double* pk, int nk, double R, double k_per_decade, double* sigma) {
+  if (!k || !pk || !sigma || nk < 3 || !(R >= 0.) || !(k_per_decade > 0.)) return CPT_ERR_INVALID;
+  for (int i = 0; i < nk; i++) if (!(pk[i] > 0.) || (i && !(k[i] > k[i - 1]))) return CPT_ERR_INVALID;
+  *sigma = cpt_sigma_of_R(k, pk, nk, R, k_per_decade);
+  return CPT_OK;
+}
+
 int cpt_sigma(cpt_handle* h, const cpt_spectra_params* sp, const double* k, int nk, double R, double k_per_decade, double* sigma) {
   CPT_ENTER(h);
   if (!sp || !k || !sigma || nk < 3 || !(R >= 0.) || !(k_per_decade > 0.)) return cpt_fail(h, CPT_ERR_INVALID, "bad arguments to cpt_sigma");

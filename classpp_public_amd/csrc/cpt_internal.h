@@ -171,8 +171,9 @@ int cpt_lensing_impl(cpt_handle* h, const cpt_spectra_params* sp, const cpt_lens
 int cpt_bessel_build(cpt_handle* h, const int* l, int nl, double xmax);
 int cpt_perturb_impl(cpt_handle* h, const double* k, int nk, const double* tau_sampling, int ntau, double* sources_dev,
                      cpt_stepstat* stats, int* status);
+double cpt_sigma_of_R(const double* k, const double* pk, int nk, double R, double k_per_decade);   // host: sigma(R) of a tabulated P(k)
 int cpt_cl_impl(cpt_handle* h, const cpt_spectra_params* sp, const double* transfer_dev, const double* q, int nq, int nl,
-                double* cl_dev);
+                double* cl_dev, const double* transfer2_dev = nullptr);
 int cpt_pk_impl(cpt_handle* h, const cpt_spectra_params* sp, const double* k, int nk, double* pk_dev, int cb);
 int cpt_sigma_impl(cpt_handle* h, const cpt_spectra_params* sp, const double* k, int nk, double R, double k_per_decade, double* sigma, int cb);
 int cpt_dbg_lookup_impl(cpt_handle* h, const double* tau, int n, double* out);

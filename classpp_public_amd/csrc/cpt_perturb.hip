@@ -1484,7 +1484,8 @@ struct Jac {
 // 256 VGPRs, and every use then costs a v_accvgpr_read per dword; from LDS a ds_read_b128 brings two doubles per instruction,
 // issued ahead of their use.  Layout: pair p of lane l at fw[p * 64 + l] (conflict-free b128 accesses).
 static constexpr int FW_ACP = (NC + 1) / 2;      // pairs holding Ac[0..NC-1]
-static constexpr int FW_PAIRS = FW_ACP + 4;      // + (al, ga) of the four reduction levels
+static constexpr int FW_PAIRS = FW_ACP + (PCR ? 4 : 0);   // + (al, ga) of the four reduction levels (row layout only: LDS is what limits
+                                                         // the resident k-modes of the ncdm kernels)
 struct LuReg {
   double2* fw;     // LDS [FW_PAIRS][64]
   double rpivc;    // lane j < nc: reciprocal of the j-th core pivot

@@ -9,6 +9,7 @@
 
 struct ClParams {
   const double* tr;  // [tt][nl][nq]
+  const double* tr2; // second initial condition of a cross-correlation spectrum (same layout), or null: tr with itself
   const double* w;   // [nq]: quadrature weight of the integrand spline x primordial spectrum x 4 pi / q
   double* cl;        // [nl][ct]
   int nq, nl, ct_size;
@@ -36,6 +37,20 @@ __global__ void __launch_bounds__(256) k_cl(ClParams P) {
     if (P.tt_e >= 0) e = P.tr[P.tt_e * st + row + iq];
     if (!P.tensors && P.tt_lcmb >= 0) lc = P.tr[P.tt_lcmb * st + row + iq];
     const double w = P.w[iq];
+    if (P.tr2) {
+      // two initial conditions (scalars): Delta^X_ic1 Delta^Y_ic2, symmetrised for X != Y (spectra_module.cpp:1137-1185)
+      double temp2 = 0., e2 = 0., lc2 = 0.;
+      if (P.tt_t0 >= 0) temp2 = P.tr2[P.tt_t0 * st + row + iq] + P.tr2[P.tt_t1 * st + row + iq] + P.tr2[P.tt_t2 * st + row + iq];
+      if (P.tt_e >= 0) e2 = P.tr2[P.tt_e * st + row + iq];
+      if (P.tt_lcmb >= 0) lc2 = P.tr2[P.tt_lcmb * st + row + iq];
+      acc[0] = fma(w, temp * temp2, acc[0]);
+      acc[1] = fma(w, e * e2, acc[1]);
+      acc[2] = fma(w, 0.5 * (temp * e2 + e * temp2), acc[2]);
+      acc[3] = fma(w, lc * lc2, acc[3]);
+      acc[4] = fma(w, 0.5 * (temp * lc2 + lc * temp2), acc[4]);
+      acc[5] = fma(w, 0.5 * (e * lc2 + lc * e2), acc[5]);
+      continue;
+    }
     acc[0] = fma(w, temp * temp, acc[0]);
     acc[1] = fma(w, e * e, acc[1]);
     acc[2] = fma(w, temp * e, acc[2]);
@@ -131,8 +146,9 @@ __global__ void k_pk(const double* __restrict__ src, const double* __restrict__ 
 }
 
 int cpt_cl_impl(cpt_handle* h, const cpt_spectra_params* sp, const double* transfer_dev, const double* q, int nq, int nl,
-                double* cl_dev) {
+                double* cl_dev, const double* transfer2_dev) {
   const cpt_config& c = h->cfg;
+  if (transfer2_dev && c.mode == CPT_MODE_TENSORS) return cpt_fail(h, CPT_ERR_INVALID, "tensor modes have one initial condition: no cross-correlation spectra");
   if (sp->ct_size < 1 || sp->ct_size > 8) return cpt_fail(h, CPT_ERR_INVALID, "ct_size=%d out of range", sp->ct_size);
   const int cts[7] = {sp->index_ct_tt, sp->index_ct_ee, sp->index_ct_te, sp->index_ct_bb, sp->index_ct_pp, sp->index_ct_tp, sp->index_ct_ep};
   for (int i = 0; i < 7; i++)
@@ -181,7 +197,7 @@ int cpt_cl_impl(cpt_handle* h, const cpt_spectra_params* sp, const double* trans
     h->geo_cl_valid = true;
   }
   ClParams P;
-  P.tr = transfer_dev; P.w = h->d_clw; P.cl = cl_dev; P.nq = nq; P.nl = nl; P.ct_size = sp->ct_size;
+  P.tr = transfer_dev; P.tr2 = transfer2_dev; P.w = h->d_clw; P.cl = cl_dev; P.nq = nq; P.nl = nl; P.ct_size = sp->ct_size;
   P.tt_t0 = c.index_tt_t0; P.tt_t1 = c.index_tt_t1; P.tt_t2 = c.index_tt_t2; P.tt_e = c.index_tt_e; P.tt_lcmb = c.index_tt_lcmb;
   P.tt_b = c.index_tt_b; P.tensors = (c.mode == CPT_MODE_TENSORS) ? 1 : 0;
   P.ct_tt = sp->index_ct_tt; P.ct_ee = sp->index_ct_ee; P.ct_te = sp->index_ct_te; P.ct_bb = sp->index_ct_bb;
@@ -212,7 +228,7 @@ static void spline_est_deriv(const double* x, const double* y, int n, double* dd
   dd[n - 1] = (un - qn * u[n - 2]) / (qn * dd[n - 2] + 1.0);
   for (int k = n - 2; k >= 0; k--) dd[k] = dd[k] * dd[k + 1] + u[k];
 }
-static double sigma_of_R(const double* kk, const double* pk, int nk, double R, double k_per_decade) {
+double cpt_sigma_of_R(const double* kk, const double* pk, int nk, double R, double k_per_decade) {
   const double PI = 3.1415926535897932384626433832795e0;
   std::vector<double> lnk(nk), lnpk(nk), dd(nk);
   for (int i = 0; i < nk; i++) { lnk[i] = log(kk[i]); lnpk[i] = log(pk[i]); }
@@ -259,7 +275,7 @@ int cpt_sigma_impl(cpt_handle* h, const cpt_spectra_params* sp, const double* k,
   (void)hipFree(d_pk);
   if (rc) return rc;
   for (int i = 0; i < nk; i++) if (!(pk[i] > 0.)) return cpt_fail(h, CPT_ERR_RUNTIME, "P(k) is not positive at k[%d]", i);
-  *sigma = sigma_of_R(k, pk.data(), nk, R, k_per_decade);
+  *sigma = cpt_sigma_of_R(k, pk.data(), nk, R, k_per_decade);
   return CPT_OK;
 }
 

@@ -231,6 +231,13 @@ typedef struct cpt_spectra_params {
  *   cl_dev        device [nl][ct_size] = cl_[md][(l*ic_ic+0)*ct_size+ct]                                        */
 int cpt_cl_batch(cpt_handle* h, const cpt_spectra_params* sp, const double* transfer_dev, const double* q, int nq, int nl,
                  double* cl_dev);
+/* the same for a PAIR of scalar initial conditions (the ic1 != ic2 terms of the ic x ic loop, spectra_module.cpp:958-1353):
+ * C_l^{XY,(12)} = 4 pi int dk/k P_12(k) 1/2 [Delta_l^{X,1} Delta_l^{Y,2} + Delta_l^{Y,1} Delta_l^{X,2}], with sp->A_s, n_s, alpha_s holding the
+ * amplitude (may be negative: anticorrelation), tilt and running of the cross spectrum (primordial_module.cpp:770-890).  transfer1_dev and
+ * transfer2_dev: device tables [tt_size][nl][nq] of the two initial conditions (two handles of one cosmology; the call may be made
+ * on either).  The total is sum_i C^(ii) + 2 sum_{i<j} C^(ij) (spectra_module.cpp cl_output). */
+int cpt_cl_cross_batch(cpt_handle* h, const cpt_spectra_params* sp, const double* transfer1_dev, const double* transfer2_dev, const double* q,
+                       int nq, int nl, double* cl_dev);
 /* linear matter power spectrum today P(k) = 2 pi^2/k^3 delta_m(k,tau0)^2 P_R(k) from the sources resident in the handle
  * (NonlinearModule::nonlinear_pk_linear, source/nonlinear_module.cpp:1886-2040); pk_dev device [nk]               */
 int cpt_pk_linear(cpt_handle* h, const cpt_spectra_params* sp, const double* k, int nk, double* pk_dev);
@@ -238,6 +245,9 @@ int cpt_pk_linear(cpt_handle* h, const cpt_spectra_params* sp, const double* k, 
  * (NonlinearModule::nonlinear_sigmas_at_z / nonlinear_sigmas, source/nonlinear_module.cpp:926-963, 2041-2180;
  * k_per_decade: ppr->sigma_k_per_decade, default 80).  Needs resident sources with delta_m like cpt_pk_linear. */
 int cpt_sigma(cpt_handle* h, const cpt_spectra_params* sp, const double* k, int nk, double R, double k_per_decade, double* sigma);
+/* sigma(R) of ANY tabulated linear spectrum P(k) > 0 on an increasing k grid (host arrays; no device work, no handle): the rule of
+ * cpt_sigma applied to a spectrum assembled by the caller, e.g. the total over several correlated initial conditions. */
+int cpt_sigma_of_pk(const double* k, const double* pk, int nk, double R, double k_per_decade, double* sigma);
 /* the same two for baryons + cold dark matter only, P_cb(k) and sigma_cb(R), from the delta_cb source: defined when non-cold species
  * are present (NonlinearModule has_pk_cb_ / index_pk_cb_, source/nonlinear_module.cpp:1749-1760; classy pk_cb, sigma8_cb)           */
 int cpt_pk_cb_linear(cpt_handle* h, const cpt_spectra_params* sp, const double* k, int nk, double* pk_dev);

@@ -168,7 +168,7 @@ def test_class_scalars_plus_tensors_and_reuse():
 # ---- scenarios: other outputs / gauges / cosmologies / precision settings, against the reference's classy-level outputs
 # (tests/golden/sc_*.ini run through the reference by oracle/make_fixtures.py; the scenario matrix follows python/test_class.py)
 SCENARIOS = ["sc_newt_lens", "sc_tcl", "sc_pcl_mpk_noreio", "sc_st_lens", "sc_prec", "sc_mpk_only", "sc_tcl_lcl_mpk", "sc_no_ur",
-             "sc_closed_big", "sc_open_big", "sc_highk"]
+             "sc_closed_big", "sc_open_big", "sc_highk", "sc_iso_mixed"]   # sc_iso_mixed: ic = ad,cdi with a cross-correlation (c_ad_cdi = -0.5)
 
 
 @pytest.mark.parametrize("cfg", SCENARIOS)
