@@ -235,7 +235,10 @@ def main():
                                                                "; the fixed k grid sharded round-robin over %d ranks" % world))),
                        "parallelism": ("k-sharded x%d, l-sharded transfer, 2 %s exchanges" % (world, "RCCL (inside the library, C ABI)" if args.collectives == "cabi" else "RCCL (torch.distributed)" if args.backend == "nccl" else "gloo (REHEARSAL: ranks share GPUs)")) if world > 1 else "1 GPU",
                        "multi_gpu_note": "explanatory.ini / lcdm.ini: replicas only (all k-modes are resident on one GPU; wall time = the longest mode's "
-                                         "dependency chain, SURVEY S8e); the sharded path is measured on ncdm_k3000 (BASELINE configs[2])"},
+                                         "dependency chain, SURVEY S8e); the sharded path is measured on ncdm_k3000 (BASELINE configs[2]), strong scaling: "
+                                         "one GPU is throughput-bound at 2988 k-modes, a shard of <= 768 modes is resident at once and its time "
+                                         "is again the dependency chain of its heaviest mode (ode_work.max_steps_per_mode x us_per_step), "
+                                         "which no further sharding shortens"},
             "stage_ms": {"perturb_kernel": k_ms, "los_kernel": t_ms, "step_wall": ms_step, "gpu_span": gpu_ms,
                          "host_overhead": (ms_step - gpu_ms) if gpu_ms is not None else None, "host_tables": host_tables_ms},
             "cl_wall_ms": ms_step,
