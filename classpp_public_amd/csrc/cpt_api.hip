@@ -275,8 +275,9 @@ int cpt_create(const cpt_config* cfg, const cpt_tables* t, cpt_handle** out) {
   if (!up(&h->d_tau_table, t->tau_table, t->bt_size) || !up(&h->d_bg, bg.data(), bg.size()) ||
       !up(&h->d_z_table, t->z_table, t->tt_size) || !up(&h->d_th, th.data(), th.size()))
     return bail(cpt_fail(h, CPT_ERR_NO_DEVICE, "table upload failed"));
+  const char* force_long = getenv("CPT_LONG_TAILS");   // (diagnostic: run any synchronous scalar configuration on the long-hierarchy kernel)
   if (!cfg->has_ncdm && cfg->mode == CPT_MODE_SCALARS &&
-      14 + (cfg->l_max_g - 2) + (cfg->l_max_pol_g - 2) + (cfg->has_ur ? cfg->l_max_ur - 2 : 0) > CPT_WAVE) {
+      (14 + (cfg->l_max_g - 2) + (cfg->l_max_pol_g - 2) + (cfg->has_ur ? cfg->l_max_ur - 2 : 0) > CPT_WAVE || (force_long && atoi(force_long) != 0))) {
     // hierarchies longer than one wavefront run on the multi-wavefront kernels of the non-cold species with zero species: those read
     // the (then empty) ncdm columns of the background
     ncb.assign((size_t)t->bt_size * NCB_NCOL * 2, 0.);

@@ -1819,6 +1819,13 @@ template <int ROLE>
 static __device__ __forceinline__ int ndf15(const PtParams& P, const Layout& L, const LaneEq& e, const ChainEq& ce, Ctx& C, Lookup& Q, Metric& M, double k,
                                      double inv_k2, int ik, double t0, double tfinal, double& y_io, Stat& st, int lane,
                                      int& budget, double* jac_lds, double2* fw_lds, unsigned long long* prof) {
+  // Every wave of the block runs this control flow on ITS OWN copy of the control state (t, h, absh, the order, ...), fed by the same
+  // block-wide norms: the copies must stay bit-identical, or one wave takes a branch (and with it a block barrier) that another does
+  // not.  The two roles are separate instantiations, and with floating-point contraction left to the optimiser each may fuse a
+  // multiply-add of the step control differently - so no implicit contraction in this function: what is written is what is computed,
+  // in both roles (fma() where a fused operation is meant).  [Found the hard way: adding unrelated code to the kernel changed the
+  // one-species results at high k from run to run.]
+#pragma clang fp contract(off)
   PROF_DECL;
   const double eps = 1e-16, threshold = 1e-15, rtol = P.rtol, inv_rtol = 1.0 / rtol;
   const int maxit = 4, maxk = 5;
