@@ -231,6 +231,9 @@ def main():
                                        "+mPk" if inp.config.index_tp_delta_m >= 0 else "", nk_total, inp.ntau, inp.config.tp_size,
                                        inp.q.size, inp.l.size, inp.config.tt_size,
                                        ("; lensed C_l" if has_lensing else "") +
+                                       ("; cosmology of the reference's base_2018_plikHM_TTTEEE_lowl_lowE_lensing.ini, k and l sampling set by name to "
+                                        "the size BASELINE configs[2] quotes (the reference tree has no cl_permille.pre); its `non linear = halofit` "
+                                        "is dropped: non-linear corrections are outside the path (SURVEY S8)" if args.config == "ncdm_k3000" else "") +
                                        ("" if world == 1 else ("; k grid densified %dx and sharded round-robin" % world if weak else
                                                                "; the fixed k grid sharded round-robin over %d ranks" % world))),
                        "parallelism": ("k-sharded x%d, l-sharded transfer, 2 %s exchanges" % (world, "RCCL (inside the library, C ABI)" if args.collectives == "cabi" else "RCCL (torch.distributed)" if args.backend == "nccl" else "gloo (REHEARSAL: ranks share GPUs)")) if world > 1 else "1 GPU",
