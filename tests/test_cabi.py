@@ -107,3 +107,17 @@ def test_host_header_symbols_and_struct_layouts():
             for name in m.group(3).split(","):
                 fields.append(re.sub(r"\[.*?\]", "", name).strip().lstrip("*").strip())
         assert fields == [f[0] for f in cls._fields_], (cname, [a for a, b in zip(fields, [f[0] for f in cls._fields_]) if a != b][:3])
+
+
+def test_cxx_boundary_headers_compile_standalone(tmp_path):
+    """include/cpt.h is C (compiled as C11), include/cpt_host.h + cpt_modules.hpp are the C++ boundary: each must compile on its own,
+    and the shim demo (the reference-side usage of tests/test_gpu_host_shim.py) must compile against them - without a GPU."""
+    import subprocess
+    inc = os.path.join(ROOT, "include")
+    c_src = tmp_path / "abi.c"
+    c_src.write_text('#include "cpt.h"\n#include "cpt_host.h"\nint main(void) { cpt_config c; cpt_grid_params g; (void)c; (void)g; return 0; }\n')
+    subprocess.check_call(["gcc", "-std=c11", "-Wall", "-Werror", "-fsyntax-only", "-I" + inc, str(c_src)])
+    cpp_src = tmp_path / "shim.cpp"
+    cpp_src.write_text('#include "cpt_modules.hpp"\nint main() { cpt::Inputs in{}; return in.n_ic == 1 ? 0 : 1; }\n')
+    subprocess.check_call(["g++", "-std=c++17", "-Wall", "-Werror", "-fsyntax-only", "-I" + inc, str(cpp_src)])
+    subprocess.check_call(["g++", "-std=c++17", "-fsyntax-only", os.path.join(ROOT, "tests", "host_shim_demo.cpp")])
