@@ -57,7 +57,7 @@ class _Plan:
 _plan = None
 
 
-def sharded_step(compute, k_all, l_all, rank, world, device, k_size_cl=None, exchange_device=None):
+def sharded_step(compute, k_all, l_all, rank, world, device, k_size_cl=None, exchange_device=None, force_exchange=False):
     """One pass of the hot path over `world` ranks.
 
     compute.perturb(k_subset) -> torch f64 [tp][ntau][len(k_subset)] on `device`
@@ -65,6 +65,7 @@ def sharded_step(compute, k_all, l_all, rank, world, device, k_size_cl=None, exc
     Returns the full transfer table [tt][nl][nq] on rank 0 (None elsewhere) and the full sources.
     exchange_device: where the collectives run (default: `device`, i.e. RCCL on GPU tensors; torch.device("cpu") stages the two
     exchanges through host memory - the gloo rehearsal of bench.py --backend gloo on a box with fewer GPUs than ranks).
+    force_exchange: run both collectives even in a group of one (the test of the RCCL code path that a one-GPU box can make).
     """
     global _plan
     xdev = device if exchange_device is None else exchange_device
@@ -75,7 +76,7 @@ def sharded_step(compute, k_all, l_all, rank, world, device, k_size_cl=None, exc
     my_k = shard_indices(nk, rank, world)
     local = compute.perturb(k_all[my_k])
     ntp, ntau = local.shape[0], local.shape[1]
-    if world == 1:
+    if world == 1 and not force_exchange:
         full = local
     else:
         # ---- exchange 1: all_gather (pad to the largest shard so that every block has the same shape) ----
@@ -90,7 +91,7 @@ def sharded_step(compute, k_all, l_all, rank, world, device, k_size_cl=None, exc
             full.index_copy_(2, idx, blocks[r][:, :, : idx.numel()].to(device))
     my_l = shard_indices(nl, rank, world)
     tr_local = compute.transfer(full, k_all, l_all[my_l], nk if k_size_cl is None else k_size_cl)
-    if world == 1:
+    if world == 1 and not force_exchange:
         return tr_local, full
     # ---- exchange 2: gather on rank 0 ----
     ntt, nq = tr_local.shape[0], tr_local.shape[2]

@@ -75,3 +75,24 @@ def test_simulated_world_of_two_on_one_device(be):
     scale = np.max(np.abs(tr_ref), axis=-1, keepdims=True)
     scale[scale == 0] = 1
     assert np.array_equal(tr == 0, tr_ref == 0) and np.max(np.abs(tr - tr_ref) / scale) < 1e-10
+
+
+def test_torch_distributed_exchanges_over_rccl_in_a_group_of_one(be):
+    """classpp_public_amd/sharded.py::sharded_step - what bench.py --gpus N runs by default - with backend "nccl" (= RCCL) on GPU tensors:
+    a process group of one rank, both collectives forced (all_gather of the padded source block, gather of the transfer block on rank 0,
+    the index_copy_ scatter into the full tables).  The N > 1 runs are the driver's; this is the same code on the same library."""
+    import os
+    import torch.distributed as dist
+    from classpp_public_amd.sharded import GpuCompute, sharded_step
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", str(29700 + os.getpid() % 200))
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    try:
+        inp = be.inp
+        dev = torch.device("cuda:0")
+        want, want_src = sharded_step(GpuCompute(be), inp.k, inp.l, 0, 1, dev, inp.k_size_cl)
+        want, want_src = want.cpu().numpy().copy(), want_src.cpu().numpy().copy()
+        got, got_src = sharded_step(GpuCompute(be), inp.k, inp.l, 0, 1, dev, inp.k_size_cl, force_exchange=True)
+        assert np.array_equal(got_src.cpu().numpy(), want_src) and np.array_equal(got.cpu().numpy(), want)
+    finally:
+        dist.destroy_process_group()
