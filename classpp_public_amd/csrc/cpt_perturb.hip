@@ -1391,8 +1391,43 @@ static __device__ __forceinline__ double block_max(double v, Ctx& C, int lane) {
 }
 
 // factors of one wave's chains: T = I - hg J_chain, tridiagonal per chain (same continued fraction as the tails, no parent)
-struct ChainLu { double rinv, g, r, pv, sv, jw; };   // pv = T^-1 xmc, sv = T^-1 xms, jw: frozen integral weight
+struct ChainLu {
+  double rinv, g, r, pv, sv, jw;   // pv = T^-1 xmc, sv = T^-1 xms, jw: frozen integral weight
+  double al[LONG ? 6 : 1], ga[LONG ? 6 : 1];   // (long tails) multipliers of the six levels of the wave-wide cyclic reduction
+};
+// (long tails) value held by lane - S (DOWN) or lane + S of the wave, 0 beyond its ends: the LDS crossbar, executed by every lane
+template <int S, bool DOWN>
+static __device__ __forceinline__ double lane_far(double v) {
+  const int lane = (int)(threadIdx.x & 63u), src = DOWN ? lane - S : lane + S;
+  const double g = gather(v, (src & 63) * 4);
+  return (src >= 0 && src < 64) ? g : 0.;
+}
+// one level of parallel cyclic reduction over the whole wavefront (a tail of up to 64 multipoles is one chain per wave): row l loses
+// its couplings to l -+ S and gains couplings to l -+ 2S.  Six levels instead of 2 x (length - 1) dependent sweeps per solve.
+template <int S>
+static __device__ __forceinline__ void wave_pcr_level(double& a, double& c, double& d, double& al, double& ga) {
+  const double dm = lane_far<S, true>(d), dq = lane_far<S, false>(d);
+  const double am = lane_far<S, true>(a), cm = lane_far<S, true>(c), aq = lane_far<S, false>(a), cq = lane_far<S, false>(c);
+  al = (a != 0.) ? a * fast_rcp(dm) : 0.;   // (a = 0 where the neighbour does not exist: never 0 * inf)
+  ga = (c != 0.) ? c * fast_rcp(dq) : 0.;
+  d = fma(-al, cm, fma(-ga, aq, d));
+  a = -al * am;
+  c = -ga * cq;
+}
+template <int S>
+static __device__ __forceinline__ double wave_pcr_apply(double b, double al, double ga) {
+  return fma(-al, lane_far<S, true>(b), fma(-ga, lane_far<S, false>(b), b));
+}
 static __device__ __forceinline__ double chain_solve(const ChainLu& F, const ChainEq& ce, double b, int len) {
+  if constexpr (LONG) {
+    b = wave_pcr_apply<1>(b, F.al[0], F.ga[0]);
+    b = wave_pcr_apply<2>(b, F.al[1], F.ga[1]);
+    b = wave_pcr_apply<4>(b, F.al[2], F.ga[2]);
+    b = wave_pcr_apply<8>(b, F.al[3], F.ga[3]);
+    b = wave_pcr_apply<16>(b, F.al[4], F.ga[4]);
+    b = wave_pcr_apply<32>(b, F.al[5], F.ga[5]);
+    return b * F.rinv;
+  }
   double bp = b;
   for (int s = 1; s < len; s++) bp = fma(-F.g, lane_above(bp), b);
   const double u = bp * F.rinv;
@@ -1405,6 +1440,18 @@ static __device__ __forceinline__ void chain_factor(const ChainCoef& jc, const C
   const double a = ce.first ? 0. : -hg * jc.a;
   const double c = ce.last ? 0. : hg * jc.b;
   const double d = 1.0 + hg * jc.d;
+  if constexpr (LONG) {
+    double ta = a, tc = c, td = d;
+#pragma unroll
+    for (int i = 0; i < 6; i++) F.al[i] = F.ga[i] = 0.;
+    if (len > 1) wave_pcr_level<1>(ta, tc, td, F.al[0], F.ga[0]);
+    if (len > 2) wave_pcr_level<2>(ta, tc, td, F.al[1], F.ga[1]);
+    if (len > 4) wave_pcr_level<4>(ta, tc, td, F.al[2], F.ga[2]);
+    if (len > 8) wave_pcr_level<8>(ta, tc, td, F.al[3], F.ga[3]);
+    if (len > 16) wave_pcr_level<16>(ta, tc, td, F.al[4], F.ga[4]);
+    if (len > 32) wave_pcr_level<32>(ta, tc, td, F.al[5], F.ga[5]);
+    F.rinv = fast_rcp(td); F.r = F.g = 0.;
+  } else {
   double dp = d, r = 0.;
   for (int s = 0; s < len; s++) {
     r = a * fast_rcp(dp);
@@ -1415,6 +1462,7 @@ static __device__ __forceinline__ void chain_factor(const ChainCoef& jc, const C
   F.rinv = rinv; F.r = a * rinv;
   const double rinv_up = lane_above(rinv);
   F.g = c * rinv_up;
+  }
   F.jw = jc.wt;
   F.pv = chain_solve(F, ce, jc.xmc, len);
   F.sv = chain_solve(F, ce, jc.xms, len);
@@ -1841,7 +1889,7 @@ static __device__ __forceinline__ int ndf15(const PtParams& P, const Layout& L, 
   if (ROLE == 0) for (int j = 0; j < NC; j++) J.Jc[j * 64 + lane] = 0.;
   J.jdiag = 0.;
   ChainCoef jc = {0., 0., 0., 0., 0., 0.};
-  ChainLu CF = {1., 0., 0., 0., 0., 0.};
+  ChainLu CF = {1., 0., 0., 0., 0., 0., {0.}, {0.}};
   double gmc = 0., gms = 0.;   // wave 0: response of (metric_continuity, metric_shear) to unit core variable `lane`
   NcIn N = {0., 0., 0., nullptr, 0};
   LuReg F;
