@@ -240,3 +240,31 @@ def test_config4_scalars_plus_tensors_with_three_massive_neutrinos():
         assert np.max(np.abs(got[sel, getattr(sp, "index_ct_" + name)] / want - 1)) < (2e-4 if name != "bb" else 1e-2), name
     for _, be_, _, _ in tables.values():
         be_.close()
+
+
+def test_cross_spectra_kernel_properties():
+    """cpt_cl_cross_batch (the ic1 != ic2 body of spectra_compute_cl): with the same table on both sides and the auto spectrum's primordial
+    parameters it IS the auto spectrum, bit for bit; it is symmetric in its two tables, linear in the amplitude, and bilinear in the tables."""
+    from classpp_public_amd.backend import Backend
+    inp = Inputs("small")
+    be = Backend(inp)
+    be.perturb_solve(want_sources=False)
+    tr = be.transfer(None)
+    sp = inp.spectra
+    auto = be.cl(tr).cpu().numpy()
+    same = be.cl_cross(tr, tr, sp.A_s, sp.n_s, sp.alpha_s).cpu().numpy()
+    assert np.array_equal(same, auto)
+    rng = np.random.default_rng(7)
+    other = (tr * torch.as_tensor(1. + 0.3 * rng.standard_normal(tuple(tr.shape)), device=tr.device)).contiguous()
+    ab = be.cl_cross(tr, other, -0.4 * sp.A_s, sp.n_s + 0.02, 0.001).cpu().numpy()
+    ba = be.cl_cross(other, tr, -0.4 * sp.A_s, sp.n_s + 0.02, 0.001).cpu().numpy()
+    scale = np.max(np.abs(ab), axis=0, keepdims=True)
+    scale[scale == 0] = 1
+    assert np.max(np.abs(ab - ba) / scale) < 1e-14                                    # symmetric
+    twice = be.cl_cross(tr, other, -0.8 * sp.A_s, sp.n_s + 0.02, 0.001).cpu().numpy()
+    assert np.max(np.abs(twice - 2 * ab) / scale) < 1e-14                             # linear in the amplitude
+    summed = be.cl_cross(tr, (tr + other).contiguous(), -0.4 * sp.A_s, sp.n_s + 0.02, 0.001).cpu().numpy()
+    auto2 = be.cl_cross(tr, tr, -0.4 * sp.A_s, sp.n_s + 0.02, 0.001).cpu().numpy()
+    assert np.max(np.abs(summed - (auto2 + ab)) / np.maximum(scale, np.max(np.abs(auto2), axis=0, keepdims=True))) < 1e-12   # bilinear
+    assert np.all(ab[:, sp.index_ct_bb] == 0) if sp.index_ct_bb >= 0 else True
+    be.close()
