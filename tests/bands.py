@@ -1,0 +1,46 @@
+"""Tolerance bands of the SOURCE-level parity tests, in one place, each backed by a committed measurement.
+
+The reference's source functions S(k, tau) are defined only up to its rtol = 1e-5 step control.  oracle/make_noise_fixtures.py runs the
+unmodified reference twice on one .ini - default `tol_perturb_integration` and half of it - and commits how far its own outputs move
+(tests/golden/noise_<cfg>.npz; relative to the maximum over tau of each (type, k) column):
+
+                         t0        t1        t2 / p     delta_m    phi+psi    | Delta_l(q)   C_l^TT   C_l^EE   P(k)
+    lcdm.ini             3.3e-3    1.3e-3    1.2e-4     3.0e-5     -          | 7.6e-5       1.1e-5   2.1e-5   5.9e-5
+    explanatory + mPk    4.5e-3    1.2e-3    1.9e-4     3.0e-5     1.8e-5     | 7.6e-5       1.8e-5   2.1e-5   5.9e-5
+    long_full            3.8e-3    1.3e-3    1.2e-4     3.2e-5     3.0e-5     | 2.6e-4       3.6e-5   2.4e-5   6.4e-5
+    ncdm.ini             4.4e-3    1.3e-3    1.7e-4     3.4e-6     2.3e-6     | 7.2e-5       1.7e-5   1.4e-5   6.7e-6
+
+The move at rtol / 2 is about HALF the error of the default run (the error scales with the tolerance); another valid integration at the
+same rtol - a different but equally admissible step sequence: our restatement, the GPU kernels - carries an error of its own of that
+size, so two valid answers differ by up to ~ 4 x the tabulated move.  The bands below are all at or BELOW 2 x the largest move measured for
+the type over these four runs (tests/test_noise_floor.py asserts that against the fixtures): nothing is looser than the reference's own reproducibility
+justifies, most are far tighter.  The contract's 1e-4 is asserted where it is meaningful: on C_l and P(k) (end-to-end tests) and on
+transfer functions fed with identical sources (1e-9).
+"""
+# (max, rms) over tau relative to the column maximum, per source type
+SOURCE_BANDS = {
+    "t0": (3e-3, 3e-4),
+    "t1": (2e-3, 3e-4),
+    "t2": (3e-4, 4.5e-5),
+    "p": (3e-4, 4.5e-5),
+    "delta_m": (1e-5, 1e-5),
+    "phi_plus_psi": (1e-5, 1e-5),
+    "delta_cb": (1e-5, 1e-5),
+}
+# transfer functions computed from OUR sources against the reference's table (its own sources): relative to the maximum over q of a row
+TRANSFER_BAND = 1.5e-4
+# how many times the reference's own move at rtol / 2 a band may be (see above)
+MAX_BAND_OVER_NOISE = 2.0
+
+
+def source_bands(cfg, dm_tol=None):
+    """{type index: (max, rms)} for a cpt_config; dm_tol overrides the matter / potential columns"""
+    out = {}
+    for name, band in SOURCE_BANDS.items():
+        idx = getattr(cfg, "index_tp_" + name, -1)
+        if name == "delta_cb" and not cfg.has_ncdm:
+            continue
+        if idx is None or idx < 0:
+            continue
+        out[idx] = dm_tol if (dm_tol is not None and name in ("delta_m", "phi_plus_psi", "delta_cb")) else band
+    return out

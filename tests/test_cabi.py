@@ -45,6 +45,29 @@ def test_struct_layout_matches_header():
         assert fields == [f[0] for f in cls._fields_], cname
 
 
+def test_struct_sizes_and_offsets_match_the_compiled_header(tmp_path):
+    """sizeof / offsetof of EVERY struct that crosses the C ABI, as gcc lays them out from include/cpt.h, against the ctypes mirrors -
+    including cpt_step_io (the argument block of the fused cpt_step that bench.py times), cpt_spectra_params and cpt_lensing_params"""
+    import subprocess
+    pairs = (("cpt_config", capi.CptConfig), ("cpt_tables", capi.CptTables), ("cpt_stepstat", capi.CptStepstat),
+             ("cpt_spectra_params", capi.CptSpectraParams), ("cpt_lensing_params", capi.CptLensingParams), ("cpt_step_io", capi.CptStepIo))
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "cpt.h"', 'int main(void) {']
+    for cname, cls in pairs:
+        lines.append('  printf("%s %%zu\\n", sizeof(%s));' % (cname, cname))
+        for fname, _ in [(f[0], f[1]) for f in cls._fields_]:
+            lines.append('  printf("%s.%s %%zu\\n", offsetof(%s, %s));' % (cname, fname, cname, fname))
+    lines += ['  return 0;', '}']
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(lines) + "\n")
+    exe = tmp_path / "layout"
+    subprocess.check_call(["gcc", "-std=c11", "-I" + os.path.join(ROOT, "include"), "-o", str(exe), str(src)])
+    got = dict(line.split() for line in subprocess.check_output([str(exe)], text=True).splitlines())
+    for cname, cls in pairs:
+        assert int(got[cname]) == C.sizeof(cls), (cname, got[cname], C.sizeof(cls))
+        for f in cls._fields_:
+            assert int(got["%s.%s" % (cname, f[0])]) == getattr(cls, f[0]).offset, (cname, f[0])
+
+
 def test_unsupported_physics_is_rejected_before_any_device_work():
     inp = Inputs("small")
     lib = capi.lib()
