@@ -171,6 +171,11 @@ int cpt_lensing_impl(cpt_handle* h, const cpt_spectra_params* sp, const cpt_lens
 int cpt_bessel_build(cpt_handle* h, const int* l, int nl, double xmax);
 int cpt_perturb_impl(cpt_handle* h, const double* k, int nk, const double* tau_sampling, int ntau, double* sources_dev,
                      cpt_stepstat* stats, int* status);
+// the register-set kernels (cpt_perturb_sets.inc, one translation unit per family): scalars with non-cold species / hierarchies longer than one wavefront
+#define CPT_SETS_LAUNCH_ARGS cpt_handle* h, const double* d_k, const double* d_tau, const int* d_order, int nk, int ntau, double* d_src, cpt_stepstat* d_stats, int* d_status
+int cpt_perturb_sets_launch_0(CPT_SETS_LAUNCH_ARGS);   // tails (long hierarchies)
+int cpt_perturb_sets_launch_2(CPT_SETS_LAUNCH_ARGS);   // <= 2 momentum-bin sets
+int cpt_perturb_sets_launch_5(CPT_SETS_LAUNCH_ARGS);   // <= 5 momentum-bin sets
 double cpt_sigma_of_R(const double* k, const double* pk, int nk, double R, double k_per_decade);   // host: sigma(R) of a tabulated P(k)
 int cpt_cl_impl(cpt_handle* h, const cpt_spectra_params* sp, const double* transfer_dev, const double* q, int nq, int nl,
                 double* cl_dev, const double* transfer2_dev = nullptr);
