@@ -261,10 +261,15 @@ def main():
     if rank == 0:
         cfg = inp.config
         cosmology = ("flat" if cfg.K == 0 else "closed" if cfg.K > 0 else "open") + " LCDM " + ("tensors" if cfg.mode == 1 else "scalars")
+        n_lanes = 14 + (cfg.l_max_g - 2) + (cfg.l_max_pol_g - 2) + (cfg.l_max_ur - 2 if cfg.has_ur else 0)
+        sets_kernel = cfg.mode == 0 and (cfg.has_ncdm or n_lanes > 64)
         if cfg.has_ncdm:
-            cosmology += " + %d massive neutrino species (%d wavefronts per k-mode)" % (cfg.N_ncdm, 1 + -(-sum(
-                inp.tables.q_size_ncdm[n] for n in range(cfg.N_ncdm)) // (64 // (cfg.l_max_ncdm + 1))) if cfg.mode == 0 else 1)
-        pt_kernel = "k_perturb_ncdm" if (cfg.has_ncdm and cfg.mode == 0) else "k_perturb"
+            nbins = sum(inp.tables.q_size_ncdm[n] for n in range(cfg.N_ncdm))
+            cosmology += " + %d massive neutrino species" % cfg.N_ncdm + (
+                " (%d momentum bins = %d register sets beside the core set of the one wavefront per k-mode)" % (nbins, -(-nbins // (64 // (cfg.l_max_ncdm + 1)))) if cfg.mode == 0 else "")
+        elif sets_kernel:
+            cosmology += " with hierarchies longer than one wavefront (%d equations: the three l >= 3 tails are register sets of the one wavefront per k-mode)" % n_lanes
+        pt_kernel = "k_perturb_sets" if sets_kernel else "k_perturb"
         ms_step = dt / args.steps * 1e3
         k_ms = float(np.mean(kms))
         t_ms = float(np.mean(tms))

@@ -25,14 +25,6 @@ namespace {
 
 template <int GAUGE, int CURV, int MODE, int ROWS>
 __global__ void __launch_bounds__(128) k_perturb(PtParams P) { PT<GAUGE, CURV, MODE, 0, ROWS>::body_perturb(P); }   // integrator wave + sampler wave
-// scalars with non-cold species: 1 + NW wavefronts per k-mode (synchronous gauge)
-// (two register budgets: up to 3 chain waves every wave has a SIMD - and its whole register file - to itself; beyond that two
-//  waves share a SIMD and the kernel is compiled for half the registers)
-template <int CURV, int NW>
-__global__ void __launch_bounds__(64 * (1 + NW)) k_perturb_ncdm(PtParams P) { PT<CPT_GAUGE_SYNCHRONOUS, CURV, 0, 1>::body_perturb(P); }
-// hierarchies longer than one wavefront: the core wave + one wave per l >= 3 tail (photon temperature, polarisation, ur)
-template <int CURV>
-__global__ void __launch_bounds__(256) k_perturb_long(PtParams P) { PT<CPT_GAUGE_SYNCHRONOUS, CURV, 0, 2>::body_perturb(P); }
 template <int GAUGE, int CURV, int MODE, int ROWS>
 __global__ void __launch_bounds__(64) k_dbg_lookup(PtParams P, const double* tau, int n, double* out) { PT<GAUGE, CURV, MODE, 0, ROWS>::body_dbg_lookup(P, tau, n, out); }
 template <int GAUGE, int CURV, int MODE, int ROWS>
@@ -111,43 +103,15 @@ int cpt_perturb_impl(cpt_handle* h, const double* k, int nk, const double* tau, 
   CPT_HIP(h, hipMemsetAsync(h->d_src, 0, nsrc * sizeof(double), h->stream));  // pm.cpp:2767-2771 zero tail
   P.k = d_k; P.tau_s = d_tau; P.order = d_order; P.nk = nk; P.ntau = ntau; P.src = h->d_src; P.stats = d_stats; P.status = d_status;
   cpt_timer_start(h, CPT_T_PERTURB);
-  const char* sets_env = getenv("CPT_SETS");
-  if ((c.has_ncdm || P.long_tails) && c.mode == CPT_MODE_SCALARS && !(sets_env && atoi(sets_env) == 0)) {
-    // more than 64 equations per k-mode: the register-set kernels (one wavefront per mode, cpt_perturb_sets.hip)
-    const int cpw_ = 64 / (c.l_max_ncdm + 1), nsets = P.long_tails ? 0 : (h->ncdm.nchains + cpw_ - 1) / cpw_;
+  if ((c.has_ncdm || P.long_tails) && c.mode == CPT_MODE_SCALARS) {
+    // more than 64 equations per k-mode: the register-set kernels (one wavefront per mode, cpt_perturb_sets.inc; one translation unit
+    // per family)
+    const int cpw = 64 / (c.l_max_ncdm + 1), nsets = P.long_tails ? 0 : (h->ncdm.nchains + cpw - 1) / cpw;
     if (P.long_tails) rc = cpt_perturb_sets_launch_0(h, d_k, d_tau, d_order, nk, ntau, h->d_src, d_stats, d_status);
     else if (nsets <= 2) rc = cpt_perturb_sets_launch_2(h, d_k, d_tau, d_order, nk, ntau, h->d_src, d_stats, d_status);
     else if (nsets <= 5) rc = cpt_perturb_sets_launch_5(h, d_k, d_tau, d_order, nk, ntau, h->d_src, d_stats, d_status);
     else return cpt_fail(h, CPT_ERR_UNSUPPORTED, "%d ncdm momentum bins need %d register sets per k-mode (at most 5)", h->ncdm.nchains, nsets);
     if (rc) return rc;
-  } else
-  if ((c.has_ncdm || P.long_tails) && c.mode == CPT_MODE_SCALARS) {
-    const int cpw = 64 / (c.l_max_ncdm + 1), nw = P.long_tails ? (c.has_ur ? 3 : 2) : (h->ncdm.nchains + cpw - 1) / cpw;
-    if (nw > NCW_MAX)
-      return cpt_fail(h, CPT_ERR_UNSUPPORTED, "%d ncdm momentum bins need %d chain wavefronts per k-mode (at most %d)", h->ncdm.nchains, nw, NCW_MAX);
-    // register budget: a launch with more k-modes than one per CU can hold at a time (3 - 4 wavefronts x 512 registers fill a CU)
-    // is throughput-bound, and two workgroups per CU at 256 registers finish sooner than one at 512; few modes (a k-shard of
-    // an 8-GPU run, the default samplings) are latency-bound and keep the whole register file.  CPT_NCDM_WAVES_PER_SIMD = 1 | 2 overrides.
-    int n_cu = 256;
-    (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, h->device);   // (256 stays if the query fails)
-    bool half_regs = nw > 3 || nk > 3 * n_cu;
-    if (const char* e = getenv("CPT_NCDM_WAVES_PER_SIMD")) half_regs = nw > 3 || atoi(e) >= 2;
-    // last interval: a launch that is resident at once is latency-bound and keeps a helper wave beside the core wave; a larger one
-    // lets every chain wave retire, which makes room for the next k-mode (measured on 2988 modes: 130 ms against 152 ms with helpers)
-    P.ncdm_compact = P.long_tails ? 0 : (nk <= 3 * n_cu) ? 2 : 1;
-    if (const char* e = getenv("CPT_NCDM_COMPACT")) P.ncdm_compact = atoi(e);
-    const size_t dyn = (P.ncdm_compact == 2) ? CPT_NCDM_HELPER_LDS : 0;
-    if (P.long_tails) {
-      if (c.K != 0.) hipLaunchKernelGGL((k_perturb_long<1>), dim3(nk), dim3(64 * (1 + nw)), 0, h->stream, P);
-      else hipLaunchKernelGGL((k_perturb_long<0>), dim3(nk), dim3(64 * (1 + nw)), 0, h->stream, P);
-    } else
-    if (c.K != 0.) {
-      if (!half_regs) hipLaunchKernelGGL((k_perturb_ncdm<1, 3>), dim3(nk), dim3(64 * (1 + nw)), dyn, h->stream, P);
-      else hipLaunchKernelGGL((k_perturb_ncdm<1, NCW_MAX>), dim3(nk), dim3(64 * (1 + nw)), dyn, h->stream, P);
-    } else {
-      if (!half_regs) hipLaunchKernelGGL((k_perturb_ncdm<0, 3>), dim3(nk), dim3(64 * (1 + nw)), dyn, h->stream, P);
-      else hipLaunchKernelGGL((k_perturb_ncdm<0, NCW_MAX>), dim3(nk), dim3(64 * (1 + nw)), dyn, h->stream, P);
-    }
   } else
   CPT_PT_DISPATCH(c, P.rows, k_perturb, dim3(nk), dim3(128), 0, h->stream, P);
   CPT_HIP(h, hipGetLastError());

@@ -1,10 +1,10 @@
 // Device code of hot path A, shared by the translation units that instantiate its kernels (cpt_perturb.hip: the two-wave kernels of the
-// massless configurations and the unit-test kernels; cpt_perturb_sets.hip: the kernels whose k-mode needs more than 64 equations).
+// massless configurations and the unit-test kernels; cpt_perturb_sets_*.hip: the kernels whose k-mode needs more than 64 equations).
 // Everything lives in an anonymous namespace: each translation unit compiles its own copy.
 #pragma once
 // Hot path A on MI355X: per-k stiff integration of the scalar Einstein-Boltzmann system.
 //
-// ONE WAVEFRONT OWNS ONE k-MODE (block = 64 threads = 1 wave).  Lane i owns equation i of the current regime:
+// ONE WAVEFRONT OWNS ONE k-MODE (a second wave of the block helps it: table look-ups and source samples).  Lane i owns equation i of the current regime:
 // the state y, the backward differences dif[0..6], the Newton iterates, the Jacobian and the factors of
 // (I - h*gamma*J) all live in lane registers (the matrix is never stored densely: see "structured linear algebra");
 // the adaptive order/step control is scalar control flow that is uniform in the wave, so divergence between modes
@@ -42,7 +42,6 @@ struct PtParams {
   int has_ncdm, nfa_method, tp_dcb; double nfa_trig, tol_ncdm_w;  // non-cold species (massive neutrinos)
   int long_tails;              // hierarchies longer than one wavefront: the three l >= 3 tails live on chain waves of their own (see "long tails")
   int long_len;                // ... and the longest of them
-  int ncdm_compact;            // last interval of the ncdm kernels (rsa + ufa + ncdmfa): 0 all waves, 1 the core wave alone, 2 core wave + helper wave
   NcdmDev nc;
   int switch_sw, switch_eisw, switch_lisw, switch_dop, switch_pol;
   double eisw_lisw_split_z, three_ceff2_ur, three_cvis2_ur;
@@ -220,24 +219,9 @@ __device__ unsigned long long g_prof[16];
 // instantiations cost code size only.  The same holds for non-flat space (CURV): the s_l factors, k cotK(tau) and the
 // separate 1/tau coefficient cost the flat kernel 35 % when they were run-time values; in the flat instantiation they fold
 // to 1, 1/tau and nothing.
-// NCDM = 1: scalars with non-cold species (massive neutrinos).  The block then holds 1 + NW wavefronts for ONE k-mode: wave 0
-// runs the system above, extended by two auxiliary core unknowns (the ncdm density and momentum sums that enter the
-// Einstein constraints), waves 1..NW hold the momentum-bin hierarchies Psi_l(q), l = 0..l_max_ncdm, one lane per multipole,
-// floor(64 / (l_max_ncdm+1)) bins ("chains") per wave.  All waves execute the same ndf15 control flow; norms are reduced over
-// the block through LDS, and the Newton system is solved as a bordered system (see the ncdm section below).
-constexpr int NCW_MAX = 5;   // chain waves per block (=> at most 6 waves: two per SIMD at most)
-struct NcShared {
-  double bc[5 + NCB_NCOL];     // a^2, a'/a, k cotK, 1/tau, {rho, p, pseudo_p} of every species at the published tau, kappa' (long tails)
-  double sums[NCW_MAX][4];     // per chain wave: partial sums of delta rho, (rho+p) theta, (rho+p) sigma
-  double metric[5];            // metric_continuity, metric_shear of the current RHS evaluation; (long tails) shear_g, pol2, shear_ur
-  double red[2][1 + NCW_MAX];  // block max, double-buffered
-  double ssum[NCW_MAX][2];     // Newton solve: weighted sums of T^-1 r over the chains
-  double z[5];                 // Newton solve: increments of (metric_continuity, metric_shear); (long tails) of the three parents
-  double alpha[NCW_MAX][4];    // factorisation: Schur terms of the two auxiliary rows
-  double ho[CPT_MAX_NCDM * CPT_MAX_Q_NCDM][3];   // hand-over to the fluid regime: per-chain integrals
-  double hf[CPT_MAX_NCDM][3];  // hand-over of (delta, theta, sigma) of every species to the core wave (see "the core wave alone")
-  int abort;
-};
+// NCDM = 1: scalars with non-cold species (massive neutrinos); NCDM = 2: hierarchies longer than one wavefront.  Both lane maps have
+// nine more core lanes (auxiliary unknowns of the bordered Newton system, or the ncdm fluids) and run in the register-set kernels of
+// cpt_perturb_sets.inc: the momentum-bin hierarchies / the long tails are further register sets of the ONE wave that owns the k-mode.
 
 // (NCDM = 0) The block holds TWO wavefronts per k-mode: wave 0 integrates, wave 1 is its HELPER.  Two jobs are taken off the
 // integrator's dependency chain - the one thing that sets the run time of the launch - and done concurrently on the second SIMD:
@@ -265,10 +249,6 @@ struct Mailbox {
 };
 __device__ inline int mb_load(const int* p) { return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP); }
 __device__ inline void mb_store(int* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP); }
-
-// dynamic LDS of an ncdm launch with a helper wave: its two table windows (background + thermodynamics, ncdm) and the mailbox
-constexpr size_t CPT_NCDM_HELPER_WINDOWS = sizeof(double2) * 64 * (BG_NCOL + TH_NCOL + NCB_NCOL);
-constexpr size_t CPT_NCDM_HELPER_LDS = CPT_NCDM_HELPER_WINDOWS + sizeof(Mailbox);
 
 template <int GAUGE, int CURV, int MODE, int NCDM = 0, int ROWS = 0>
 struct PT {
@@ -871,9 +851,8 @@ struct Metric {
 };
 
 // (NCDM) what the non-cold species contribute to the Einstein equations in this RHS evaluation: delta rho, (rho+p) theta,
-// (rho+p) sigma summed over species (pm.cpp:6317-6432).  `sh` != null: publish (metric_continuity, metric_shear) for the
-// chain waves and meet them at the block barrier as soon as the metric is known.
-struct NcIn { double D, T, S; NcShared* sh; int nw; double y3[3]; };   // y3: (long tails) the l = 3 elements of the photon / polarisation / ur tails
+// (rho+p) sigma summed over species (pm.cpp:6317-6432), formed by the caller from the momentum-bin sets or from the fluids.
+struct NcIn { double D, T, S; double y3[3]; };   // y3: (long tails) the l = 3 elements of the photon / polarisation / ur tails
 
 // y of another lane (per-lane byte address): two ds_bpermute_b32, executed by every lane
 static __device__ __forceinline__ double gather(double v, int addr) {
@@ -963,24 +942,7 @@ static __device__ __forceinline__ double rhs(const PtParams& P, const Layout& L,
   if (P.has_cdm) delta_rho += Q.rc * dc;
   if (P.has_ur) { delta_rho += Q.ru * dur; rpt += Q.ru43 * tur; rps += Q.ru43 * sur; }
   if (NCDM) {
-    NcIn& N = *Np;
-    if (N.sh) {   // (B) the chain waves have written their partial integrals (they worked while this wave fetched its neighbours)
-#ifdef CPT_PROFILE
-      const unsigned long long t_b0 = clock64();
-#endif
-      __syncthreads();
-#ifdef CPT_PROFILE
-      Q.prof[9] += clock64() - t_b0;
-#endif
-      if (LONG) {   // the chain waves are the tails: wave 1 + t carries tail t, its first lane the l = 3 element
-        N.D = N.T = N.S = 0.;
-        for (int t = 0; t < N.nw; t++) N.y3[t] = N.sh->sums[t][0];
-      } else {
-      double D = 0., T = 0., S = 0.;
-      for (int w = 0; w < N.nw; w++) { D += N.sh->sums[w][0]; T += N.sh->sums[w][1]; S += N.sh->sums[w][2]; }
-      N.D = D; N.T = T; N.S = S;
-      }
-    }
+    const NcIn& N = *Np;
     delta_rho += N.D; rpt += N.T; rps += N.S;
   }
   // ---- Einstein equations -> the metric terms of the matter equations (pm.cpp:8049-8074):
@@ -1008,13 +970,6 @@ static __device__ __forceinline__ double rhs(const PtParams& P, const Layout& L,
     const double alphap = -2. * aH * alpha + eta - 4.5 * (a2 * inv_k2) * rps;
     M.hp = hp; M.etap = etap; M.alpha = alpha; M.alphap = alphap;
     mc = 0.5 * hp; me = 0.; ms = k2 * alpha; msp = k2 * alphap; mdot = etap;
-    if (NCDM && Np->sh) {   // (C) the chain waves wait for exactly these two numbers
-      if (lane == 0) {
-        Np->sh->metric[0] = mc; Np->sh->metric[1] = ms;
-        if (LONG) { Np->sh->metric[2] = sg; Np->sh->metric[3] = p2; Np->sh->metric[4] = sur; }
-      }
-      __syncthreads();
-    }
   } else {
     // Newtonian gauge (pm.cpp:5869-5897): the LN_ETA lane holds phi; cdm has a velocity
     const double tc = bcast(y, LN_TC);
@@ -1093,7 +1048,7 @@ static __device__ __forceinline__ double rhs(const PtParams& P, const Layout& L,
 // dy is the dense-output derivative (only theta_b' is used, pm.cpp:6883). Lane 0 stores the tp_size values.
 static __device__ __forceinline__ void store_sources(const PtParams& P, const Layout& L, const Lookup& Q, const Metric& M, double k,
                                               double inv_k2, double y, double dy, double tca_shear_prev, int it, int ik, int lane,
-                                              const NcIn& N = NcIn{0., 0., 0., nullptr, 0}) {
+                                              const NcIn& N = NcIn{0., 0., 0., {0., 0., 0.}}) {
   if (MODE) { store_sources_tensor(P, L, Q, y, it, ik, lane); return; }
   struct { double g, dg, expmk; } th;
   th.g = bcast(Q.vth, TH_G); th.dg = bcast(Q.vth, TH_DG); th.expmk = bcast(Q.vth, TH_EXPMK);
@@ -1195,211 +1150,13 @@ static __device__ __forceinline__ double search_flip(const PtParams& P, double k
   return 0.5 * (lo + hi);
 }
 
-// ---- non-cold species (NCDM = 1): the chain waves --------------------------------------------------------------------
-// Every momentum bin (species n, q) is one tridiagonal chain Psi_0..Psi_lmax (pm.cpp:8832-8879) that talks to the rest of the
-// system through two metric scalars only (metric_continuity = h'/2 into l = 0, metric_shear = k^2 alpha into l = 2) and is heard
-// by it through the three integrals of pm.cpp:6369-6395.  In the fluid regime (pm.cpp:8737-8823) the chain of the first
-// momentum bin of each species carries (delta, theta, sigma) in its l = 0..2 lanes - the same tridiagonal shape with
-// time-dependent coefficients - and the other bins idle.
+// ---- what the integrator wave carries beside the equations ------------------------------------------------------------------------
 struct Ctx {
-  int wave, nw, len, cpw;      // this wave (0 = core), number of chain waves, lanes per chain, chains per wave
-  NcShared* sh;
-  int parity, abort;
-  double tau_pub;              // time at which sh->bc was last published (and read by everybody)
-  double kap;                                  // chain waves, long tails: kappa' of the published block
-  double a2, aH, kcot, inv_tau, rho, pr, pp;   // chain waves: copy of the published block (rho, p, pseudo_p of the lane's species)
-  double ca, cb, cd, cxmc, cxms, cwt;          // chain waves: this lane's coefficients at tau_pub (they depend on tau only)
-  Mailbox* mb; int posted, tail_seen;          // (SAMPLER) mailbox, samples posted so far, last value read of the helper's tail
+  Mailbox* mb; int posted, tail_seen;          // mailbox of the helper wave, samples posted so far, last value read of the helper's tail
 };
-struct ChainEq {
-  int ch;                      // which published scalar drives the chain's first source term: 0 metric_continuity (momentum bins), 2.. the parent of a tail
-  int l, cidx, species;
-  bool valid, first, last, holder;
-  double A, B, G, qk, q2, M2, Xmc, Xms, sw;
-};
-struct ChainCoef { double a, b, d, xmc, xms, wt; };   // dy = a y[l-1] - b y[l+1] - d y + xmc mc + xms ms;  wt: weight in its integral
 
-static __device__ __forceinline__ ChainEq make_chain_eq(const PtParams& P, const Ctx& C, int lane, double k) {
-  ChainEq c;
-  c.ch = 0;
-  if (LONG) {
-    // ---- long tails: chain wave 1 + t carries tail t (0 photon temperature, 1 polarisation, 2 ur), lane i its multipole l = 3 + i.
-    //      Streaming coefficients of make_lane_eq; the coupling to the parent (shear_g / pol2 / shear_ur, in the core wave) is the
-    //      first lane's source term, its own value the chain's only output (weight 1).
-    const int t = C.wave - 1, lm = (t == 0) ? P.l_max_g : (t == 1) ? P.l_max_pol_g : P.l_max_ur, l = 3 + lane;
-    const double k2 = k * k;
-    auto S = [&](int ll) { return CURV ? sqrt(fmax(1.0 - P.K * (ll * ll - 1.0) / k2, 0.)) : 1.0; };
-    c.l = lane; c.cidx = t; c.species = t; c.ch = 2 + t;
-    c.valid = (C.wave > 0) && (t < 3) && (l <= lm) && (t < 2 || P.has_ur);
-    c.first = c.valid && lane == 0; c.last = c.valid && l == lm; c.holder = false;
-    c.A = c.B = c.G = c.Xmc = c.Xms = c.sw = 0.; c.qk = c.q2 = c.M2 = 0.;
-    if (c.valid) {
-      if (l == 3 && t != 1) { c.A = 6. * k * S(3) * S(2) / 7.; c.B = 4. * k * S(4) / 7.; }        // pm.cpp:8158-8161: F_2 = 2 s_2 shear
-      else if (l < lm) { c.A = k * l * S(l) / (2. * l + 1.); c.B = k * (l + 1.) * S(l + 1) / (2. * l + 1.); }
-      else { c.A = k * S(l); c.G = 1. + l; }                                                      // pm.cpp:8171-8176
-      if (lane == 0) c.sw = 1.;
-    }
-    return c;
-  }
-  const int slot = lane / C.len;
-  c.l = lane - slot * C.len;
-  c.cidx = (C.wave - 1) * C.cpw + slot;
-  c.valid = (C.wave > 0) && (slot < C.cpw) && (c.cidx < P.nc.nchains);
-  const int ci = c.valid ? c.cidx : 0;
-  c.species = P.nc.species[ci];
-  c.first = c.valid && c.l == 0; c.last = c.valid && c.l == C.len - 1;
-  c.holder = c.valid && (ci == P.nc.first_chain[c.species]) && c.l <= 2;
-  const double q = P.nc.q[ci], dlnf0 = P.nc.dlnf0[ci], fw = P.nc.factor[c.species] * P.nc.w[ci];
-  const double k2 = k * k;
-  auto S = [&](int ll) { return CURV ? sqrt(fmax(1.0 - P.K * (ll * ll - 1.0) / k2, 0.)) : 1.0; };
-  const int l = c.l;
-  c.A = c.B = c.G = c.Xmc = c.Xms = c.sw = 0.;
-  c.qk = q * k; c.q2 = q * q; c.M2 = P.nc.M[c.species] * P.nc.M[c.species];
-  if (c.valid) {
-    if (l == C.len - 1) { c.A = 1.; c.G = 1. + l; }                                   // pm.cpp:8876
-    else if (l == 0) { c.B = 1.; c.Xmc = dlnf0 / 3.; c.sw = fw * q * q; }            // pm.cpp:8856
-    else if (l == 1) { c.A = 1. / 3.; c.B = 2. * S(2) / 3.; c.sw = k * fw * q * q * q; }   // pm.cpp:8860 (metric_euler = 0, synchronous)
-    else if (l == 2) { c.A = 2. * S(2) / 5.; c.B = 3. * S(3) / 5.; c.Xms = -S(2) * 2. / 15. * dlnf0; c.sw = 2. / 3. * fw * q * q * q * q; }   // pm.cpp:8865
-    else { c.A = l * S(l) / (2. * l + 1.); c.B = (l + 1.) * S(l + 1) / (2. * l + 1.); }     // pm.cpp:8870
-  }
-  return c;
-}
-
-// coefficients of this lane's equation at the published time (also the chain's Jacobian: the equations are linear)
-static __device__ __forceinline__ ChainCoef chain_coef(const PtParams& P, const Layout& L, const ChainEq& c, const Ctx& C, double k) {
-  ChainCoef o;
-  if (LONG) {
-    // (the tail exists only in the schemes that evolve it: idle otherwise, like an idle lane of the core wave)
-    const int t = opaque(c.species);
-    const bool on = c.valid && ((t == 0) ? L.gN > 0 : (t == 1) ? L.qN > 0 : L.uN > 0);
-    o.a = (on && !c.first) ? c.A : 0.; o.b = on ? c.B : 0.;
-    o.d = on ? ((t == 2 ? 0. : C.kap) + c.G * C.kcot) : 0.;
-    o.xmc = (on && c.first) ? c.A : 0.; o.xms = 0.; o.wt = on ? c.sw : 0.;
-    return o;
-  }
-  if (!L.nfa) {
-    const double eps = fast_sqrt(c.q2 + C.a2 * c.M2), inv_eps = fast_rcp(eps), f = c.qk * inv_eps, inv_a4 = fast_rcp(C.a2 * C.a2);
-    o.a = f * c.A; o.b = f * c.B; o.d = c.G * C.kcot; o.xmc = c.Xmc; o.xms = c.Xms;
-    const int l = opaque(c.l);
-    o.wt = inv_a4 * c.sw * ((l == 0) ? eps : (l == 2) ? inv_eps : 1.);   // pm.cpp:6384-6393 (a_today = 1)
-  } else {   // pm.cpp:8737-8823 on the holder lanes, identity elsewhere
-    const double rho = C.rho, pr = C.pr, w = pr * fast_rcp(rho), pp_over_p = C.pp * fast_rcp(pr), inv_1pw = fast_rcp(1. + w);
-    const double ca2 = w / 3. * inv_1pw * (5. - pp_over_p), ceff2 = ca2;
-    const double cvis2 = (P.nfa_method == CPT_NCDMFA_HU) ? w : 3. * w * ca2;
-    const double s2 = CURV ? sqrt(fmax(1.0 - 3. * P.K / (k * k), 0.)) : 1.;
-    o.a = o.b = o.d = o.xmc = o.xms = o.wt = 0.;
-    const int l = opaque(c.l);
-    if (c.holder) {
-      if (l == 0) { o.b = 1. + w; o.d = 3. * C.aH * (ceff2 - w); o.xmc = -(1. + w); o.wt = rho; }
-      else if (l == 1) { o.a = ceff2 * inv_1pw * k * k; o.b = k * k; o.d = C.aH * (1. - 3. * ca2); o.wt = rho + pr; }
-      else {
-        o.a = 8. / 3. * cvis2 * inv_1pw * s2; o.wt = rho + pr;
-        if (P.nfa_method == CPT_NCDMFA_HU) { o.d = 3. * C.aH * ca2 / w; o.xms = o.a; }
-        else {
-          o.d = 3. * (C.aH * (2. / 3. - ca2 - pp_over_p / 3.) + C.inv_tau);
-          if (P.nfa_method == CPT_NCDMFA_MB) o.xms = o.a; else o.xmc = o.a;   // ncdmfa_CLASS: metric_ufa_class = h'/2 (pm.cpp:8062)
-        }
-      }
-    }
-  }
-  return o;
-}
-
-// sum over the chains of this wave of the lanes with multipole l (wave-uniform result)
-static __device__ __forceinline__ double chain_sum(double v, int l, const Ctx& C) {
-  double s = 0.;
-  for (int c = 0; c < C.cpw; c++) s += bcast(v, c * C.len + l);
-  return s;
-}
-
-// make the tables' row at tau known to every wave: wave 0 looks it up and publishes, the chain waves copy what they need
-// (ROLE: 0 = the core wave, 1 = a chain wave.  The integrator is instantiated once per role, so that neither role carries the
-//  other's state in registers through the step loop; both instantiations execute the same sequence of block barriers.)
-template <int ROLE>
-static __device__ __forceinline__ void sync_tau(const PtParams& P, const Layout& L, Lookup& Q, Ctx& C, const ChainEq& ce, double k, double tau, int lane) {
-  if (tau == C.tau_pub) return;
-  C.tau_pub = tau;
-  if (ROLE == 0) {
-#ifdef CPT_PROFILE
-    const unsigned long long t_l0 = clock64();
-#endif
-    lookup(P, Q, tau, lane);
-#ifdef CPT_PROFILE
-    Q.prof[8] += clock64() - t_l0;
-#endif
-    const int i = opaque(lane);
-    const double vn = shfl_all(Q.vnc, (lane - 4) & 63);   // (own statement: every lane must execute the cross-lane read)
-    double v = (i == 0) ? Q.a2 : (i == 1) ? Q.aH : (i == 2) ? Q.kcot : (i == 3) ? Q.inv_tau : vn;
-    if (LONG) v = (i == 4 + NCB_NCOL) ? Q.kap : v;
-    if (lane < (LONG ? 5 : 4) + NCB_NCOL) C.sh->bc[lane] = v;
-  }
-  __syncthreads();
-  if (ROLE == 1) {
-    const double* bc = C.sh->bc;
-    C.a2 = bc[0]; C.aH = bc[1]; C.kcot = bc[2]; C.inv_tau = bc[3];
-    if (LONG) C.kap = bc[4 + NCB_NCOL];
-    C.rho = bc[4 + 3 * ce.species]; C.pr = bc[5 + 3 * ce.species]; C.pp = bc[6 + 3 * ce.species];
-    const ChainCoef cc = chain_coef(P, L, ce, C, k);
-    C.ca = cc.a; C.cb = cc.b; C.cd = cc.d; C.cxmc = cc.xmc; C.cxms = cc.xms; C.cwt = cc.wt;
-  }
-}
-
-// RHS of the whole block: returns this lane's dy.  N (wave 0) receives the ncdm integrals of this evaluation.
-template <int ROLE>
-static __device__ __forceinline__ double rhs_all(const PtParams& P, const Layout& L, const LaneEq& e, const ChainEq& ce, Lookup& Q, Metric& M,
-                                                 Ctx& C, NcIn& N, double k, double inv_k2, double tau, double y, int lane) {
-  if (!NCDM) return rhs<true>(P, L, e, Q, M, k, inv_k2, tau, y, lane);   // (the integrator wave of the two-wave kernels)
-#ifdef CPT_PROFILE
-  const unsigned long long t_sync0 = clock64();
-#endif
-  sync_tau<ROLE>(P, L, Q, C, ce, k, tau, lane);
-#ifdef CPT_PROFILE
-  if (ROLE == 0) Q.prof[15] += clock64() - t_sync0;
-#endif
-  if (ROLE == 0) {
-    N.sh = C.sh; N.nw = C.nw;
-    return rhs(P, L, e, Q, M, k, inv_k2, tau, y, lane, &N);   // barriers (B) and (C) inside
-  }
-  const ChainCoef cc = {C.ca, C.cb, C.cd, C.cxmc, C.cxms, C.cwt};
-  {
-    const double v = cc.wt * y;
-    const double D = chain_sum(v, 0, C), T = chain_sum(v, 1, C), S = chain_sum(v, 2, C);
-    if (lane == 0) { double* o = C.sh->sums[C.wave - 1]; o[0] = D; o[1] = T; o[2] = S; }
-  }
-  const double ym = lane_below(y), yp = lane_above(y);
-#ifdef CPT_DEBUG_NCDM
-  if (L.nfa && ce.holder && C.wave == 1 && !(y == y)) printf("nan y in rhs l=%d tau=%g\n", ce.l, tau);
-  if (L.nfa && ce.holder && C.wave == 1 && !(cc.a == cc.a && cc.b == cc.b && cc.d == cc.d)) printf("nan coef l=%d tau=%g a=%g b=%g d=%g rho=%g p=%g pp=%g\n", ce.l, tau, cc.a, cc.b, cc.d, C.rho, C.pr, C.pp);
-#endif
-  __syncthreads();                           // (B)
-  __syncthreads();                           // (C) wave 0 has published the metric
-  const double mc = C.sh->metric[LONG ? ce.ch : 0], ms = C.sh->metric[1];   // (a tail: its parent in the place of metric_continuity, xms = 0)
-  double dy = cc.a * ym - cc.b * yp - cc.d * y;
-  dy = fma(cc.xmc, mc, dy);
-  dy = fma(cc.xms, ms, dy);
-  return dy;
-}
-
-// max over the whole block of a non-negative per-lane quantity (the norms of ndf15); also carries the abort flag across
-static __device__ __forceinline__ double block_max(double v, Ctx& C, int lane) {
-  const double m = wave_max(v);
-  if (!NCDM) return m;
-  const int buf = C.parity;
-  C.parity ^= 1;
-  if (lane == 0) C.sh->red[buf][C.wave] = m;
-  __syncthreads();
-  double r = C.sh->red[buf][0];
-  for (int w = 1; w <= C.nw; w++) r = fmax(r, C.sh->red[buf][w]);
-  C.abort = C.sh->abort;
-  return r;
-}
-
-// factors of one wave's chains: T = I - hg J_chain, tridiagonal per chain (same continued fraction as the tails, no parent)
-struct ChainLu {
-  double rinv, g, r, pv, sv, jw;   // pv = T^-1 xmc, sv = T^-1 xms, jw: frozen integral weight
-  double al[LONG ? 6 : 1], ga[LONG ? 6 : 1];   // (long tails) multipliers of the six levels of the wave-wide cyclic reduction
-};
-// (long tails) value held by lane - S (DOWN) or lane + S of the wave, 0 beyond its ends: the LDS crossbar, executed by every lane
+// ---- wave-wide cyclic reduction (the long tails of cpt_perturb_sets.inc: up to 64 multipoles of one ladder along the lanes) ----------
+// value held by lane - S (DOWN) or lane + S of the wave, 0 beyond its ends: the LDS crossbar, executed by every lane
 template <int S, bool DOWN>
 static __device__ __forceinline__ double lane_far(double v) {
   const int lane = (int)(threadIdx.x & 63u), src = DOWN ? lane - S : lane + S;
@@ -1422,60 +1179,6 @@ template <int S>
 static __device__ __forceinline__ double wave_pcr_apply(double b, double al, double ga) {
   return fma(-al, lane_far<S, true>(b), fma(-ga, lane_far<S, false>(b), b));
 }
-static __device__ __forceinline__ double chain_solve(const ChainLu& F, const ChainEq& ce, double b, int len) {
-  if constexpr (LONG) {
-    b = wave_pcr_apply<1>(b, F.al[0], F.ga[0]);
-    b = wave_pcr_apply<2>(b, F.al[1], F.ga[1]);
-    b = wave_pcr_apply<4>(b, F.al[2], F.ga[2]);
-    b = wave_pcr_apply<8>(b, F.al[3], F.ga[3]);
-    b = wave_pcr_apply<16>(b, F.al[4], F.ga[4]);
-    b = wave_pcr_apply<32>(b, F.al[5], F.ga[5]);
-    return b * F.rinv;
-  }
-  double bp = b;
-  for (int s = 1; s < len; s++) bp = fma(-F.g, lane_above(bp), b);
-  const double u = bp * F.rinv;
-  const double rr = ce.first ? 0. : F.r;
-  double xt = u;
-  for (int s = 1; s < len; s++) xt = fma(-rr, lane_below(xt), u);
-  return xt;
-}
-static __device__ __forceinline__ void chain_factor(const ChainCoef& jc, const ChainEq& ce, double hg, int len, Ctx& C, int lane, ChainLu& F) {
-  const double a = ce.first ? 0. : -hg * jc.a;
-  const double c = ce.last ? 0. : hg * jc.b;
-  const double d = 1.0 + hg * jc.d;
-  if constexpr (LONG) {
-    double ta = a, tc = c, td = d;
-#pragma unroll
-    for (int i = 0; i < 6; i++) F.al[i] = F.ga[i] = 0.;
-    if (len > 1) wave_pcr_level<1>(ta, tc, td, F.al[0], F.ga[0]);
-    if (len > 2) wave_pcr_level<2>(ta, tc, td, F.al[1], F.ga[1]);
-    if (len > 4) wave_pcr_level<4>(ta, tc, td, F.al[2], F.ga[2]);
-    if (len > 8) wave_pcr_level<8>(ta, tc, td, F.al[3], F.ga[3]);
-    if (len > 16) wave_pcr_level<16>(ta, tc, td, F.al[4], F.ga[4]);
-    if (len > 32) wave_pcr_level<32>(ta, tc, td, F.al[5], F.ga[5]);
-    F.rinv = fast_rcp(td); F.r = F.g = 0.;
-  } else {
-  double dp = d, r = 0.;
-  for (int s = 0; s < len; s++) {
-    r = a * fast_rcp(dp);
-    const double r_up = lane_above(r);
-    dp = fma(-c, r_up, d);
-  }
-  const double rinv = fast_rcp(dp);
-  F.rinv = rinv; F.r = a * rinv;
-  const double rinv_up = lane_above(rinv);
-  F.g = c * rinv_up;
-  }
-  F.jw = jc.wt;
-  F.pv = chain_solve(F, ce, jc.xmc, len);
-  F.sv = chain_solve(F, ce, jc.xms, len);
-  // Schur terms of the auxiliary rows: alpha_{D,1} = hg sum wD [T^-1 xmc]_0, ... (see factorise)
-  const double v1 = hg * F.jw * F.pv, v2 = hg * F.jw * F.sv;
-  const double a0 = chain_sum(v1, 0, C), a1 = chain_sum(v2, 0, C), a2 = chain_sum(v1, 1, C), a3 = chain_sum(v2, 1, C);
-  if (lane == 0) { double* o = C.sh->alpha[C.wave - 1]; o[0] = a0; o[1] = a1; o[2] = a2; o[3] = a3; }
-}
-
 // ---- structured linear algebra: (I - hg J) x = b -------------------------------------------------------------------
 // J = [ J_cc  J_ct ]   core (nc <= 16 lanes, dense)        J_ct: only (parent of a tail, its l=3 element)
 //     [ J_tc  J_tt ]   tails (three tridiagonal chains)     J_tc: only (l=3 element, parent)
@@ -1752,68 +1455,6 @@ static __device__ __forceinline__ double lu_solve(const LaneEq& e, const LuReg& 
 }
 
 
-// factorisation / solve of the whole block (NCDM): the chains are eliminated first (tridiagonal solves inside the chain waves),
-// the core with its two auxiliary unknowns second, the chains are back-substituted last
-template <int ROLE>
-static __device__ __forceinline__ void fact_all(const LaneEq& e, const ChainEq& ce, const Jac& J, const ChainCoef& jc, double hg, int maxlen,
-                                                int lane, Ctx& C, LuReg& F, ChainLu& CF, double gmc, double gms, bool* ok, int long_tails = 0) {
-  if (!NCDM) { *ok = factorise(e, J, hg, maxlen, lane, F); return; }
-  *ok = true;
-  if (ROLE == 1) { chain_factor(jc, ce, hg, maxlen, C, lane, CF); __syncthreads(); return; }   // (chain waves: maxlen = sweeps of their chains)
-  __syncthreads();
-  double al[4] = {0., 0., 0., 0.};
-  if (long_tails) { for (int t = 0; t < C.nw; t++) al[t] = C.sh->alpha[t][0]; }
-  else
-  for (int w = 0; w < C.nw; w++)
-#pragma unroll
-    for (int i = 0; i < 4; i++) al[i] += C.sh->alpha[w][i];
-  const bool good = factorise(e, J, hg, maxlen, lane, F, al, gmc, gms, long_tails);
-  if (!good && lane == 0) C.sh->abort = 1;   // every wave leaves at the next block_max
-}
-template <int ROLE>
-static __device__ __forceinline__ double solve_all(const LaneEq& e, const ChainEq& ce, const LuReg& F, const ChainLu& CF, double hg, int maxlen,
-                                                   double b, int lane, Ctx& C, double gmc, double gms, int long_tails = 0) {
-  if (!NCDM) return lu_solve(e, F, maxlen, b, lane);
-  if (ROLE == 1) {
-    const double x = chain_solve(CF, ce, b, maxlen);
-    const double v = CF.jw * x;
-    const double sD = chain_sum(v, 0, C), sT = chain_sum(v, 1, C);
-    if (lane == 0) { C.sh->ssum[C.wave - 1][0] = sD; C.sh->ssum[C.wave - 1][1] = sT; }
-    __syncthreads();
-    __syncthreads();
-    const double z1 = C.sh->z[LONG ? ce.ch : 0], z2 = C.sh->z[1];
-    return x + hg * (CF.pv * z1 + CF.sv * z2);
-  }
-  if (long_tails) {
-    // (long tails) the auxiliary rows take [T_t^-1 r_t]_first from tail wave t; the tails then want the increments of their parents
-    __syncthreads();
-    const int ln = opaque(lane);
-    const double s0 = C.sh->ssum[0][0], s1 = C.sh->ssum[1][0], s2 = (C.nw > 2) ? C.sh->ssum[2][0] : 0.;
-    const double bb = (ln == LN_ND) ? s0 : (ln == LN_ND + 1) ? s1 : (ln == LN_ND + 2) ? s2 : b;
-    const double x = lu_solve(e, F, maxlen, bb, lane);
-    const double x0 = bcast(x, LN_SG), x1 = bcast(x, LN_P2), x2 = bcast(x, LN_SUR);
-    if (lane == 0) { C.sh->z[2] = x0; C.sh->z[3] = x1; C.sh->z[4] = x2; }
-    __syncthreads();
-    return (ln >= LN_ND && ln <= LN_ND + 2) ? 0. : x;
-  }
-  __syncthreads();
-  double sD = 0., sT = 0.;
-  for (int w = 0; w < C.nw; w++) { sD += C.sh->ssum[w][0]; sT += C.sh->ssum[w][1]; }
-  const int ln = opaque(lane);
-  const double bb = (ln == LN_ND) ? sD : (ln == LN_NT) ? sT : b;
-  const double x = lu_solve(e, F, maxlen, bb, lane);
-  // the core lives in row 0 of the wave (NC <= 16, gmc = gms = 0 beyond it): four row_shr steps leave the sums in lane 15
-  double v1 = gmc * x, v2 = gms * x;
-  v1 += row_shr0<1>(v1); v2 += row_shr0<1>(v2);
-  v1 += row_shr0<2>(v1); v2 += row_shr0<2>(v2);
-  v1 += row_shr0<4>(v1); v2 += row_shr0<4>(v2);
-  v1 += row_shr0<8>(v1); v2 += row_shr0<8>(v2);
-  const double z1 = bcast(v1, 15), z2 = bcast(v2, 15);
-  if (lane == 0) { C.sh->z[0] = z1; C.sh->z[1] = z2; }
-  __syncthreads();
-  return (ln == LN_ND || ln == LN_NT) ? 0. : x;
-}
-
 // adjust_stepsize (ev.cpp:907-943): dif(1:k) <- dif(1:k) R(1:k,1:k) U(1:k,1:k) with R[m][p] = prod_{i<=m} (i - (p+1) r)/(i+1) and the
 // constant upper-triangular U.  Evaluated right to left, w[p] = sum_m dif[m] R[m][p] first: ~130 instructions instead of the
 // ~1 500 of forming R U (20 divisions, two 5x5 products) - this runs on every change of step size.  Static indices => registers only.
@@ -1864,432 +1505,11 @@ static __device__ __forceinline__ double dif_get(const double* dif, int i) {
   }
 }
 
-// evolver_ndf15 (ev.cpp:62-705) for one interval of constant approximation scheme, as ONE flat loop so that the RHS
-// is instantiated exactly twice: a "service" slot (Jacobian columns, f(t0), f(t0+tdel), J f0, sampled outputs, the
-// final evaluation) and the Newton slot.  Returns 0 / error code (1 step too small, 2 singular, 4 budget).
-template <int ROLE>
-static __device__ __forceinline__ int ndf15(const PtParams& P, const Layout& L, const LaneEq& e, const ChainEq& ce, Ctx& C, Lookup& Q, Metric& M, double k,
-                                     double inv_k2, int ik, double t0, double tfinal, double& y_io, Stat& st, int lane,
-                                     int& budget, double* jac_lds, double2* fw_lds, unsigned long long* prof) {
-  // Every wave of the block runs this control flow on ITS OWN copy of the control state (t, h, absh, the order, ...), fed by the same
-  // block-wide norms: the copies must stay bit-identical, or one wave takes a branch (and with it a block barrier) that another does
-  // not.  The two roles are separate instantiations, and with floating-point contraction left to the optimiser each may fuse a
-  // multiply-add of the step control differently - so no implicit contraction in this function: what is written is what is computed,
-  // in both roles (fma() where a fused operation is meant).  [Found the hard way: adding unrelated code to the kernel changed the
-  // one-species results at high k from run to run.]
-#pragma clang fp contract(off)
-  PROF_DECL;
-  const double eps = 1e-16, threshold = 1e-15, rtol = P.rtol, inv_rtol = 1.0 / rtol;
-  const int maxit = 4, maxk = 5;
-  // (idle lanes carry y = dy = dif = 0 and identity rows: they drop out of every norm by themselves)
-  const double* ts = P.tau_s;
-  const int tres = P.ntau;
-  const double htspan = fabs(tfinal - t0), hmax = (tfinal - t0) / 10.0;
-  const int maxlen = (ROLE == 1) ? (LONG ? P.long_len : L.nfa ? 3 : C.len) : L.maxlen;   // sweeps of the tails / of the chains
-  enum { B_NONE = 0, B_JAC, B_F0, B_F1, B_JF0, B_SAMPLE, B_FINAL };
-
-  Jac J;
-  J.Jc = jac_lds;
-  if (ROLE == 0) for (int j = 0; j < NC; j++) J.Jc[j * 64 + lane] = 0.;
-  J.jdiag = 0.;
-  ChainCoef jc = {0., 0., 0., 0., 0., 0.};
-  ChainLu CF = {1., 0., 0., 0., 0., 0., {0.}, {0.}};
-  double gmc = 0., gms = 0.;   // wave 0: response of (metric_continuity, metric_shear) to unit core variable `lane`
-  NcIn N = {0., 0., 0., nullptr, 0};
-  LuReg F;
-  F.fw = fw_lds;
-  F.rpivc = 1.; F.rowperm = lane; F.permuted = 0; F.rinv = F.r = F.g = F.cpar = 0.;
-  double y = y_io, ynew = y_io, f0 = 0., f1 = 0., fnewton = 0., wt = 0., tdel = 0.;
-  double dif[7] = {0., 0., 0., 0., 0., 0., 0.};
-  int next = 0;
-  while (next < tres && ts[next] < t0) next++;
-  // time of the next sample, kept in a register: the test "has this step passed a sample time" runs after every step, and a
-  // scalar load there is a trip to the scalar cache (or L2) on the critical path of the step
-  double tnext = (next < tres) ? ts[next] : 1e300;
-  double t = t0, tnew = t0, h = 0., absh = 0., abshlast = 0., hmin = 16.0 * eps * fabs(t0), hinvGak = 0.;
-  int kk = 1, klast = 1, nconhk = 0;
-  bool Jcurrent = false, havrate = false, done = false, at_hmin = false, nofailed = true;
-  bool new_step = false, need_fact = false, post_step = false, init = true;
-  double rate = 0., oldnrm = 0., err = 0., invwt = 0., difkp1 = 0.;
-  double yi = 0., ypi = 0., tn = 0.;
-  int batch = B_JAC;
-  // minnrm = 100 eps max |ynew / wt| (ev.cpp:375): the maximum is 1 whenever one component has not shrunk during the step and never
-  // more, and the test it feeds only fires on corrections at round-off level; its upper bound replaces a reduction per step
-  const double minnrm = 100 * eps;
-  double thr1 = minnrm;        // first Newton iteration converged <=> max |del / wt| <= thr1 (see the Newton loop)
-  bool have_err = false;       // err holds the norm of the accepted correction (formed lazily)
-  // constants of the current order, refreshed where kk changes: 1 / (G (1 - alpha)), the error constant and rtol / error constant
-  double iga = ndf_invGa(0), erc = ndf_erconst(0), errthr = rtol * fast_rcp(ndf_erconst(0));
-  auto set_order = [&]() { iga = ndf_invGa(kk - 1); erc = ndf_erconst(kk - 1); errthr = rtol * fast_rcp(erc); };
-
-  // dense output at the next sample time (ev.cpp:547-571, interp_from_dif :860-905)
-  auto prepare_sample = [&]() {
-    tn = tnext;
-    if (uni(tnew == tn)) { yi = ynew; ypi = fnewton; }
-    else {
-      const double inv_h = fast_rcp(h), s = (tn - tnew) * inv_h;
-      double prod = 1.0, sumfrac = 0.;
-      yi = ynew; ypi = 0.;
-#pragma unroll
-      for (int j = 0; j < 5; j++) {
-        if (j < kk) {
-          const double inv_fact = (j == 0) ? 1.0 : (j == 1) ? 0.5 : (j == 2) ? 1.0 / 6.0 : (j == 3) ? 1.0 / 24.0 : 1.0 / 120.0;
-          prod *= (s + j); sumfrac += fast_rcp(s + j);
-          const double c = prod * inv_fact;
-          yi = fma(c, dif[j], yi);
-          ypi = fma(c * sumfrac * inv_h, dif[j], ypi);
-        }
-      }
-    }
-  };
-
-  for (;;) {
-    if (--budget < 0) return 4;
-    // ------------------------------------------------------------------ service slot
-    if (batch != B_NONE) {
-      PROF_START();
-      const int nreq = (batch == B_JAC) ? NC : 1;
-      const double tca_keep = M.tca_shear_g;
-      if (NCDM && batch == B_JAC) sync_tau<ROLE>(P, L, Q, C, ce, k, t, lane);
-      if (ROLE == 1 && batch == B_JAC) jc = ChainCoef{C.ca, C.cb, C.cd, C.cxmc, C.cxms, C.cwt};   // the chains' Jacobian is their coefficient set
-      else if (SAMPLER && batch == B_SAMPLE) {   // hand the sample to the helper wave: next free slot of the ring
-        if (C.posted - C.tail_seen >= MB_NSLOT) {   // ring full: wait for the helper (it is certain to consume)
-          int spins = 0;
-          while (C.posted - (C.tail_seen = mb_load(&C.mb->tail)) >= MB_NSLOT) {
-            __builtin_amdgcn_s_sleep(1);
-            if (++spins > (1 << 24)) return 5;
-          }
-        }
-        const int slot = C.posted & (MB_NSLOT - 1);
-        C.mb->yi[slot][lane] = yi; C.mb->ypi[slot][lane] = ypi;
-        if (lane == 0) { C.mb->tca_keep[slot] = tca_keep; C.mb->it[slot] = next; C.mb->flags[slot] = L.tca | (L.rsa << 1) | (L.ufa << 2); }
-        C.posted++;
-        mb_store(&C.mb->head, C.posted);
-        st.fevals++;                             // (the evaluation is counted where the reference makes it)
-      }
-      else
-      for (int r = 0; r < nreq; r++) {
-        double tq, yq;
-        if (batch == B_JAC) {  // J e_r = f(t, e_r): exact, the system is linear; idle variables have no column
-          if (!core_present(P, L, r)) continue;
-          tq = t; yq = (lane == r && !(NCDM && r >= LN_ND)) ? 1.0 : 0.0;
-        }
-        else if (batch == B_F0) { tq = t; yq = y; }
-        else if (batch == B_F1) { tq = t + tdel; yq = y; }
-        else if (batch == B_JF0) { tq = t; yq = f0; }                  // J f0 = f(t, f0)
-        else if (batch == B_SAMPLE) { tq = tn; yq = yi; }
-        else { tq = tnew; yq = ynew; }
-        double dyq;
-        if (NCDM && ROLE == 0 && batch == B_JAC) {   // wave 0 alone: unit ncdm integrals for the two auxiliary columns, no block barrier
-          NcIn Nj = {r == LN_ND ? 1. : 0., r == LN_NT ? 1. : 0., 0., nullptr, 0, {0., 0., 0.}};
-          if (LONG) { Nj.D = Nj.T = 0.; Nj.y3[0] = (r == LN_ND) ? 1. : 0.; Nj.y3[1] = (r == LN_ND + 1) ? 1. : 0.; Nj.y3[2] = (r == LN_ND + 2) ? 1. : 0.; }
-          dyq = rhs(P, L, e, Q, M, k, inv_k2, tq, yq, lane, &Nj);
-          if (lane == r) { gmc = 0.5 * M.hp; gms = k * k * M.alpha; }
-        } else dyq = rhs_all<ROLE>(P, L, e, ce, Q, M, C, N, k, inv_k2, tq, yq, lane);
-        st.fevals++;
-        if (batch == B_JAC) J.Jc[r * 64 + lane] = (lane < NC) ? dyq : 0.;
-        else if (batch == B_F0) {
-          f0 = dyq;
-#ifdef CPT_DEBUG_NCDM
-          if (!(y == y) || !(dyq == dyq)) printf("nan at F0: k=%g wave=%d lane=%d y=%g dy=%g t=%g\n", k, C.wave, lane, y, dyq, t);
-#endif
-        }
-        else if (batch == B_F1) f1 = dyq;
-        else if (batch == B_JF0) fnewton = dyq;  // temporarily J f0
-        else if (batch == B_SAMPLE) { if (ROLE == 0) store_sources(P, L, Q, M, k, inv_k2, yi, ypi, tca_keep, next, ik, lane, N); }
-      }
-      if (batch == B_FINAL) { PROF_STOP(3); break; }  // ev.cpp:653-662: M, Q left at (tfinal, y) for the hand-over
-      if (batch == B_JAC) {
-        // the tails' diagonal is analytic: freeze kappa' and 1/tau at the time of this Jacobian
-        if (ROLE == 0) J.jdiag = -(e.D * Q.kap + e.G * Q.kcot + (CURV ? e.Gt * Q.inv_tau : 0.));
-        st.jacs++;
-        M.tca_shear_g = tca_keep;
-        Jcurrent = true;
-        if (init) { batch = B_F0; PROF_STOP(3); continue; }
-        st.fevals++;  // the reference also re-evaluates f(t,y) here (ev.cpp:451)
-        need_fact = true;
-        batch = B_NONE;
-        PROF_STOP(3);
-      } else if (batch == B_F0) {
-        // first guess of h (ev.cpp:225-250)
-        wt = fmax(fabs(y), threshold);
-        const double rh = block_max(1.25 / sqrt(rtol) * fabs(f0 / wt), C, lane);
-        absh = fmin(hmax, htspan);
-        if (absh * rh > 1.0) absh = 1.0 / rh;
-        absh = fmax(absh, hmin);
-        h = absh;
-        tdel = (t + fmin(sqrt(eps) * fmax(fabs(t), fabs(t + h)), absh)) - t;
-        batch = B_F1;
-        PROF_STOP(3);
-        continue;
-      } else if (batch == B_F1) {
-        batch = B_JF0;
-        PROF_STOP(3);
-        continue;
-      } else if (batch == B_JF0) {
-        // ddfddt = J f0 + (f(t+tdel) - f0)/tdel  (ev.cpp:261-283)
-        const double acc = fnewton + (f1 - f0) / tdel;
-        const double rh = block_max(1.25 * sqrt(0.5 * fabs(acc / wt) / rtol), C, lane);
-        absh = fmin(hmax, htspan);
-        if (absh * rh > 1.0) absh = 1.0 / rh;
-        absh = fmax(absh, hmin);
-        h = absh;
-        kk = 1; klast = 1; abshlast = absh;
-        set_order();
-        dif[0] = h * f0;
-        hinvGak = h * iga;
-        nconhk = 0;
-        need_fact = true;
-        new_step = true;
-        init = false;
-        batch = B_NONE;
-        PROF_STOP(3);
-      } else {  // B_SAMPLE
-        M.tca_shear_g = tca_keep;
-        next++;
-        tnext = (next < tres) ? ts[next] : 1e300;
-        if (uni(tnew - tnext >= 0.0)) {
-          prepare_sample();  // stay in B_SAMPLE
-          PROF_STOP(4);
-          continue;
-        } else {
-          batch = B_NONE;
-          post_step = true;
-        }
-        PROF_STOP(4);
-      }
-    }
-    // ------------------------------------------------------------------ after an accepted step (ev.cpp:573-635)
-    if (post_step) {
-      post_step = false;
-      if (done) { batch = B_FINAL; continue; }
-      PROF_START();
-      klast = kk;
-      abshlast = absh;
-      nconhk = min(nconhk + 1, maxk + 2);
-      if (nconhk >= kk + 2) {
-        // (the norm of the accepted correction is only formed here, where its value steers the step size: one step in ~five)
-        if (!have_err) err = block_max(fabs(difkp1 * invwt), C, lane) * erc;
-        double temp = 1.2 * fast_root(err * inv_rtol, kk + 1);
-        double hopt = uni(temp > 0.1) ? absh * fast_rcp(temp) : 10 * absh;
-        int kopt = kk;
-        if (kk > 1) {
-          const double errkm1 = block_max(fabs(dif_get(dif, kk - 1) * invwt), C, lane) * ndf_erconst(kk - 2);
-          temp = 1.3 * fast_root(errkm1 * inv_rtol, kk);
-          const double hkm1 = uni(temp > 0.1) ? absh * fast_rcp(temp) : 10 * absh;
-          if (uni(hkm1 > hopt)) { hopt = hkm1; kopt = kk - 1; }
-        }
-        if (kk < maxk) {
-          const double errkp1 = block_max(fabs(dif_get(dif, kk + 1) * invwt), C, lane) * ndf_erconst(kk);
-          temp = 1.4 * fast_root(errkp1 * inv_rtol, kk + 2);
-          const double hkp1 = uni(temp > 0.1) ? absh * fast_rcp(temp) : 10 * absh;
-          if (uni(hkp1 > hopt)) { hopt = hkp1; kopt = kk + 1; }
-        }
-        if (uni(hopt > absh)) { absh = hopt; if (kopt != kk) { kk = kopt; set_order(); } }
-      }
-      t = tnew;
-      y = ynew;
-      Jcurrent = false;
-      new_step = true;
-#ifndef CPT_PROFILE_LOOKUP
-      PROF_STOP(12);
-#endif
-    }
-    // ------------------------------------------------------------------ start of a step (ev.cpp:299-334)
-    if (new_step) {
-      new_step = false;
-      PROF_START();
-      hmin = P.min_var;
-      absh = fmin(hmax, fmax(hmin, absh));
-      if (uni(fabs(absh - hmin) < 100 * eps)) { if (at_hmin) absh = abshlast; at_hmin = true; } else at_hmin = false;
-      h = absh;
-      if (uni(1.1 * absh >= fabs(tfinal - t))) { h = tfinal - t; absh = fabs(h); done = true; }
-      if (uni(fabs(absh - abshlast) > 1e-6 * absh) || (kk != klast)) {   // (ev.cpp:318: |dh| / h > 1e-6, without the division)
-        adjust_stepsize(dif, absh * fast_rcp(abshlast), kk);
-        hinvGak = h * iga;
-        nconhk = 0;
-        need_fact = true;
-      }
-      nofailed = true;
-      // the time of this step is known: ask the helper for its table row now (a no-op when the step size did not change - the
-      // row was requested a whole step ago - and otherwise early enough to arrive behind the factorisation)
-      if (SAMPLER) mb_request(Q, done ? tfinal : t + h, lane);
-#ifndef CPT_PROFILE_LOOKUP
-      PROF_STOP(13);
-#endif
-    }
-    if (need_fact) {
-      need_fact = false;
-      PROF_START();
-      bool fact_ok;
-      fact_all<ROLE>(e, ce, J, jc, hinvGak, maxlen, lane, C, F, CF, gmc, gms, &fact_ok, LONG ? 1 : 0);
-      if (!fact_ok) return 2;
-      PROF_STOP(2);
-      st.lus++;
-      havrate = false;
-      thr1 = minnrm;
-    }
-    // ------------------------------------------------------------------ predictor + simplified Newton (ev.cpp:342-445)
-#ifdef CPT_PROFILE
-    const unsigned long long t_newton0 = clock64();
-    unsigned long long t_inner = 0;
-#endif
-    // psi = (1 / (G_k (1 - alpha_k))) sum_j G_j dif_j,  pred = y + sum_j dif_j over the kk differences in use: one straight-line
-    // variant per order, reached by a scalar jump
-    double psi, pred;
-    switch (__builtin_amdgcn_readfirstlane(kk)) {
-      case 1: psi = dif[0]; pred = y + dif[0]; break;
-      case 2: psi = fma(1.5, dif[1], dif[0]); pred = y + (dif[0] + dif[1]); break;
-      case 3: psi = fma(11.0 / 6.0, dif[2], fma(1.5, dif[1], dif[0])); pred = y + ((dif[0] + dif[1]) + dif[2]); break;
-      case 4: psi = fma(25.0 / 12.0, dif[3], fma(11.0 / 6.0, dif[2], fma(1.5, dif[1], dif[0]))); pred = y + ((dif[0] + dif[1]) + (dif[2] + dif[3])); break;
-      default: psi = fma(137.0 / 60.0, dif[4], fma(25.0 / 12.0, dif[3], fma(11.0 / 6.0, dif[2], fma(1.5, dif[1], dif[0]))));
-               pred = y + (((dif[0] + dif[1]) + (dif[2] + dif[3])) + dif[4]); break;
-    }
-    psi *= iga;
-    tnew = t + h;
-    if (done) tnew = tfinal;
-    h = tnew - t;
-    ynew = pred;
-    difkp1 = 0.;
-    {  // weights of the norms (ev.cpp:367-374): the seed + one Newton step (2e-15) is ample for a weight
-      const double w = fmax(fmax(fabs(ynew), fabs(y)), threshold);
-      const double r = __builtin_amdgcn_rcp(w);
-      invwt = fma(r, fma(-w, r, 1.0), r);
-    }
-    if (NCDM && C.abort) return 2;
-    bool tooslow = false;
-    double newnrm = 0.;
-    for (int iter = 1; iter <= maxit; iter++) {
-      PROF_START();
-      fnewton = rhs_all<ROLE>(P, L, e, ce, Q, M, C, N, k, inv_k2, tnew, ynew, lane);
-      // the row of THIS step is in registers: speculate that the step size stays and ask for the next one (t' + h' = tnew + absh)
-      if (SAMPLER && iter == 1 && !done) mb_request(Q, tnew + absh, lane);
-      PROF_STOP(0);
-#ifdef CPT_PROFILE
-      t_inner += clock64() - pf_t0;
-#endif
-      st.fevals++;
-      const double rhsv = hinvGak * fnewton - (psi + difkp1);
-      PROF_START();
-      const double del = solve_all<ROLE>(e, ce, F, CF, hinvGak, maxlen, rhsv, lane, C, gmc, gms, LONG ? 1 : 0);
-      PROF_STOP(1);
-#ifdef CPT_PROFILE
-      t_inner += clock64() - pf_t0;
-#endif
-      st.solves++;
-      const double dn = fabs(del * invwt);
-      difkp1 += del;
-      ynew = pred + difkp1;
-      if (iter == 1) {
-        // converged when |del| <= minnrm or, with a rate estimate, |del| rate / (1 - rate) <= 0.05 rtol: both are "max over the
-        // lanes <= thr1" with thr1 kept up to date where the rate changes, i.e. one compare + one scalar test, no reduction
-        if (NCDM) {
-          newnrm = block_max(dn, C, lane);
-          if (NCDM && C.abort) return 2;
-          if (uni(newnrm <= thr1)) break;
-        } else {
-          if (wave_all_le(dn, thr1)) break;
-          newnrm = wave_max(dn);
-        }
-        if (!havrate) rate = 0.0;
-      } else {
-        newnrm = block_max(dn, C, lane);
-        if (NCDM && C.abort) return 2;
-        if (uni(newnrm <= minnrm)) break;
-        if (uni(newnrm > 0.9 * oldnrm)) { tooslow = true; break; }
-        rate = fmax(0.9 * rate, newnrm * fast_rcp(oldnrm));
-        havrate = true;
-        const double q = rate * fast_rcp(1.0 - rate), errit = newnrm * q;
-        thr1 = fmax(minnrm, 0.05 * rtol * fast_rcp(q));
-        if (uni(errit <= 0.5 * rtol)) break;
-        else if (iter == maxit) { tooslow = true; break; }
-        else if (uni(0.5 * rtol < errit * fast_powi(rate, maxit - iter))) { tooslow = true; break; }
-      }
-      oldnrm = newnrm;
-    }
-#ifdef CPT_PROFILE
-    prof[5] += clock64() - t_newton0 - t_inner;  // predictor + Newton control without rhs / solve
-#endif
-    if (tooslow) {  // ev.cpp:446-479
-      st.failed++;
-      if (!Jcurrent) { batch = B_JAC; continue; }
-#ifdef CPT_DEBUG_NCDM
-      if (absh <= hmin && lane == 0) printf("hmin(tooslow) k=%g wave=%d t=%g h=%g kk=%d flags tca%d rsa%d ufa%d nfa%d steps=%d\n", k, C.wave, t, absh, kk, L.tca, L.rsa, L.ufa, L.nfa, st.steps);
-#endif
-      if (uni(absh <= hmin)) return 1;
-      abshlast = absh;
-      absh = fmax(0.3 * absh, hmin);
-      h = absh;
-      done = false;
-      if (SAMPLER) mb_request(Q, t + h, lane);
-      adjust_stepsize(dif, absh * fast_rcp(abshlast), kk);
-      hinvGak = h * iga;
-      nconhk = 0;
-      need_fact = true;
-      continue;
-    }
-    // ------------------------------------------------------------------ error test (ev.cpp:483-532)
-    PROF_START();
-    // err = max |difkp1 / wt| * erconst > rtol  <=>  some lane has |difkp1 / wt| > rtol / erconst: a compare, not a reduction
-    bool err_ok;
-    {
-      const double dn = fabs(difkp1 * invwt);
-      if (NCDM) { err = block_max(dn, C, lane) * erc; have_err = true; err_ok = !uni(err > rtol); }
-      else { have_err = false; err_ok = wave_all_le(dn, errthr); if (!err_ok) { err = wave_max(dn) * erc; have_err = true; } }
-    }
-    if (!err_ok) {
-      st.failed++;
-#ifdef CPT_DEBUG_NCDM
-      if (absh <= hmin && lane == 0) printf("hmin(err) k=%g wave=%d t=%g h=%g kk=%d err=%g flags tca%d rsa%d ufa%d nfa%d steps=%d\n", k, C.wave, t, absh, kk, err, L.tca, L.rsa, L.ufa, L.nfa, st.steps);
-#endif
-      if (uni(absh <= hmin)) return 1;
-      abshlast = absh;
-      if (nofailed) {
-        nofailed = false;
-        double hopt = absh * fmax(0.1, 0.833 * fast_root(rtol * fast_rcp(err), kk + 1));
-        if (kk > 1) {
-          const double errkm1 = block_max(fabs((dif_get(dif, kk - 1) + difkp1) * invwt), C, lane) * ndf_erconst(kk - 2);
-          const double hkm1 = absh * fmax(0.1, 0.769 * fast_root(rtol * fast_rcp(errkm1), kk));
-          if (uni(hkm1 > hopt)) { hopt = fmin(absh, hkm1); kk = kk - 1; set_order(); }
-        }
-        absh = fmax(hmin, hopt);
-      } else absh = fmax(hmin, 0.5 * absh);
-      h = absh;
-      if (uni(absh < abshlast)) done = false;
-      if (SAMPLER) mb_request(Q, done ? tfinal : t + h, lane);
-      adjust_stepsize(dif, absh * fast_rcp(abshlast), kk);
-      hinvGak = h * iga;
-      nconhk = 0;
-      need_fact = true;
-      continue;
-    }
-    // ------------------------------------------------------------------ accepted: update differences (ev.cpp:537-545)
-    st.steps++;
-    // dif[kk+1] = difkp1 - dif[kk]; dif[kk] = difkp1; dif[j-1] += dif[j] for j = kk..1: one straight-line variant per order
-    switch (__builtin_amdgcn_readfirstlane(kk)) {
-      case 1: dif[2] = difkp1 - dif[1]; dif[1] = difkp1; dif[0] += dif[1]; break;
-      case 2: dif[3] = difkp1 - dif[2]; dif[2] = difkp1; dif[1] += dif[2]; dif[0] += dif[1]; break;
-      case 3: dif[4] = difkp1 - dif[3]; dif[3] = difkp1; dif[2] += dif[3]; dif[1] += dif[2]; dif[0] += dif[1]; break;
-      case 4: dif[5] = difkp1 - dif[4]; dif[4] = difkp1; dif[3] += dif[4]; dif[2] += dif[3]; dif[1] += dif[2]; dif[0] += dif[1]; break;
-      default: dif[6] = difkp1 - dif[5]; dif[5] = difkp1; dif[4] += dif[5]; dif[3] += dif[4]; dif[2] += dif[3]; dif[1] += dif[2]; dif[0] += dif[1]; break;
-    }
-    if (uni(tnew - tnext >= 0.0)) { batch = B_SAMPLE; prepare_sample(); }
-    else post_step = true;
-#ifndef CPT_PROFILE_LOOKUP
-    PROF_STOP(14);
-#endif
-  }
-  y_io = ynew;
-  return 0;
-}
-
-// ---- non-cold species: the core wave alone -----------------------------------------------------------------------------------
-// Once the ncdm fluid approximation is on (and tight coupling off) every species is three variables (delta, theta, sigma) - yet these
-// intervals hold 90 % of the steps of the heaviest mode (the fluids oscillate until today), and the general ncdm machinery (one wave per
-// three momentum bins, three block barriers per RHS and per solve, block-wide norms) costs the same per step whatever the size of the
-// system.  So at that switch the chain waves hand their fluid variables to the core wave and retire (the first of them stays as the
-// helper wave when the launch is latency-bound, PtParams::ncdm_compact); the core wave integrates alone with the structured integrator
-// ndf15s - no barrier, no chain, no auxiliary unknowns: the fluid variables are ordinary members of the dense core in lanes LN_F0...
+// ---- non-cold species in the fluid approximation -------------------------------------------------------------------------------
+// Once the ncdm fluid approximation is on every species is three variables (delta, theta, sigma) - yet these intervals hold 90 % of the
+// steps of the heaviest mode (the fluids oscillate until today).  At that switch the register-set kernels (cpt_perturb_sets.inc)
+// integrate the momentum hierarchies into the fluid variables, which become ordinary members of the dense core in lanes LN_F0.., and
+// go on with the structured integrator ndf15s below - no sets, no auxiliary unknowns:
 //   SYS = 2: any scheme of the other species (photon / ur hierarchies still running): the general RHS + the fluid equations
 //   SYS = 1: radiation streaming and the ur fluid on as well (the last interval): baryons, cdm, eta and the fluids are all that is left,
 //            4 + 3 N variables, and the RHS is written out for exactly that
@@ -2314,7 +1534,7 @@ static __device__ __forceinline__ double rhs_fluid(const PtParams& P, const Layo
     const bool mine = (ln >= l0) && (ln <= l0 + 2);
     rho_l = mine ? rho : rho_l; p_l = mine ? pr : p_l; pp_l = mine ? pp : pp_l;
   }
-  N.D = D; N.T = T; N.S = S; N.sh = nullptr; N.nw = 0;
+  N.D = D; N.T = T; N.S = S;
   double dy, mc, ms;
   if (SYS == 2) {
     dy = rhs<2>(P, L, e, Q, M, k, inv_k2, tau, y, lane, &N);   // (0 on the fluid lanes: their LaneEq is empty)
@@ -2370,16 +1590,14 @@ static __device__ __forceinline__ double rhs_fluid(const PtParams& P, const Layo
   return dy;
 }
 
-// evolver_ndf15 (ev.cpp:62-705) for the INTEGRATOR wave of the two-wave kernels (NCDM = 0), one interval of constant
-// approximation scheme.  Same algorithm and same arithmetic as ndf15<ROLE> above (which the multi-wave ncdm kernels keep: their
-// waves must walk through one barrier sequence), written as structured code: now that the table look-ups live on the helper wave
-// an inlined RHS is ~300 instructions, so the flat one-call-site loop with its state flags - every variable live everywhere, a
-// dozen register moves at every merge point - is no longer worth its price.  Returns 0 / error code (1 step too small,
-// 2 singular, 4 budget, 5 helper unresponsive).
-// SYS = 0: the integrator wave of the two-wave kernels.  SYS = 1, 2: the core wave of the ncdm kernels on its own (rhs_fluid above);
-// HELPED: with the first chain wave kept as its helper (launches that are resident at once: latency is all that counts) - or without,
-// own table look-ups and samples evaluated in place (the form for grids larger than the chip, where a retired wave makes room for
-// the next k-mode).
+// evolver_ndf15 (ev.cpp:62-705) for one interval of constant approximation scheme, as structured code (initial step, step loop, Newton
+// loop, order selection): with the table look-ups on the helper wave an inlined RHS is ~300 instructions.  ONE wave runs it on ONE copy
+// of the control state; every condition is wave-uniform.  Returns 0 / error code (1 step too small, 2 singular, 4 budget, 5 helper
+// unresponsive).
+// SYS = 0: the integrator wave of the two-wave kernels (NCDM = 0).  SYS = 1, 2: the compact intervals of the register-set kernels
+// (cpt_perturb_sets.inc) once the ncdm fluid approximation is on - every species three core variables (rhs_fluid above).
+// HELPED: with a helper wave (look-ups one step ahead, source samples: launches that are resident at once, latency is all that counts) -
+// or without, own table look-ups and samples evaluated in place (grids larger than the chip: a lone wave leaves room for more k-modes).
 template <int SYS, bool HELPED = true>
 static __device__ __forceinline__ int ndf15s(const PtParams& P, const Layout& L, const LaneEq& e, Ctx& C, Lookup& Q, Metric& M, double k, double inv_k2,
                                              double t0, double tfinal, double& y_io, Stat& st, int lane, int& budget, double* jac_lds,
@@ -2408,7 +1626,7 @@ static __device__ __forceinline__ int ndf15s(const PtParams& P, const Layout& L,
   while (next < tres && ts[next] < t0) next++;
   double tnext = (next < tres) ? ts[next] : 1e300, tnext2 = (next + 1 < tres) ? ts[next + 1] : 1e300;
 
-  NcIn N = {0., 0., 0., nullptr, 0};
+  NcIn N = {0., 0., 0., {0., 0., 0.}};
   auto eval = [&](double tq, double yq) {
     st.fevals++;
     if constexpr (SYS != 0) return rhs_fluid<SYS, HELPED ? 1 : 0>(P, L, e, Q, M, N, k, inv_k2, tq, yq, lane);
@@ -2806,34 +2024,28 @@ static __device__ __noinline__ double initial_conditions(DevTables T, int has_cd
   }
 }
 
-// the integration of one mode over its intervals of constant approximation scheme, for one role (see sync_tau): the core wave
-// and the chain waves run separate instantiations, so neither carries the other's state
+// the integration of one mode over its intervals of constant approximation scheme (the integrator wave of the two-wave kernels)
 struct Sched { double tau_ini, tau_end, sw0, sw1, sw2, sw3; int nsw, ap0, ap1, ap2, ap3, fi0, fi1, fi2, fi3; };
-struct HelperWindows { double2 *bgw2, *thw2, *ncw2; };   // second set of table windows (the helper's sample look-ups)
-template <int ROLE>
 static __device__ __forceinline__ int run_intervals(const PtParams& P, Ctx& C, const Sched& sc, double k, double inv_k2, int ik, int lane,
-                                                    double2* bgw, double2* thw, double2* ncw, const HelperWindows& hw, double* jacw, double2* fww, Stat& st, int& n_regimes,
+                                                    double2* bgw, double2* thw, double* jacw, double2* fww, Stat& st, int& n_regimes,
                                                     int& budget, unsigned long long* prof
 #ifdef CPT_PROFILE
                                                     , unsigned long long t_begin
 #endif
                                                     ) {
+  static_assert(NCDM == 0, "the register-set kernels have their own driver (cpt_perturb_sets.inc)");
   int status = 0;
   const double tau_ini = sc.tau_ini, tau_end = sc.tau_end, sw0 = sc.sw0, sw1 = sc.sw1, sw2 = sc.sw2, sw3 = sc.sw3;
-  const int nsw = sc.nsw, ap0 = sc.ap0, ap1 = sc.ap1, ap2 = sc.ap2, ap3 = sc.ap3, fi0 = sc.fi0, fi1 = sc.fi1, fi2 = sc.fi2, fi3 = sc.fi3;
+  const int nsw = sc.nsw, ap0 = sc.ap0, ap1 = sc.ap1, ap2 = sc.ap2, ap3 = sc.ap3, fi0 = sc.fi0, fi1 = sc.fi1, fi2 = sc.fi2;
   {
     Lookup Q;
-    // (NCDM: the table windows belong to wave 0 alone - a chain wave staging them late would overwrite a window that wave 0
-    //  has already moved; the chain waves get what they need through sync_tau)
-    // (SAMPLER: the integrator wave owns no windows - its rows come from the helper wave through the mailbox)
-    if (ROLE == 0 && !SAMPLER) lookup_init(P, Q, bgw, thw, lane, ncw);
-    else {   // (never read by a chain wave; plain stores keep the struct in registers)
-      Q.bgw = bgw; Q.thw = thw; Q.ncw = ncw; Q.tau_cached = -1.; Q.bg_base = Q.th_base = 0; Q.bg_inf = Q.th_inf = -1;
-      Q.bgx = Q.thx = Q.vbg = Q.vth = Q.vnc = 0.; Q.zmax = Q.xe_last = Q.taud_last = 0.;
-      Q.bg_lo = Q.bg_hi = Q.th_lo = Q.th_hi = Q.nc_lo = Q.nc_hi = make_double2(0., 0.);
-      Q.rg = Q.rb = Q.rc = Q.ru = Q.kap = Q.ddkappa = Q.cb2 = Q.a2 = Q.aH = Q.two_over_aH = Q.R = Q.inv_1pR = Q.inv_R = 0.;
-      Q.tau_c = Q.dtau_c = Q.F = Q.Fp = Q.app = Q.inv_tau = Q.rg43 = Q.ru43 = Q.kcot = 0.;
-    }
+    // (the integrator wave owns no table windows - its rows come from the helper wave through the mailbox; plain stores keep the
+    //  struct in registers)
+    Q.bgw = bgw; Q.thw = thw; Q.ncw = nullptr; Q.tau_cached = -1.; Q.bg_base = Q.th_base = 0; Q.bg_inf = Q.th_inf = -1;
+    Q.bgx = Q.thx = Q.vbg = Q.vth = Q.vnc = 0.; Q.zmax = Q.xe_last = Q.taud_last = 0.;
+    Q.bg_lo = Q.bg_hi = Q.th_lo = Q.th_hi = Q.nc_lo = Q.nc_hi = make_double2(0., 0.);
+    Q.rg = Q.rb = Q.rc = Q.ru = Q.kap = Q.ddkappa = Q.cb2 = Q.a2 = Q.aH = Q.two_over_aH = Q.R = Q.inv_1pR = Q.inv_R = 0.;
+    Q.tau_c = Q.dtau_c = Q.F = Q.Fp = Q.app = Q.inv_tau = Q.rg43 = Q.ru43 = Q.kcot = 0.;
     Q.mb = C.mb; Q.my_req = 0; Q.req_tau = -1.;
     lookup_set_mode(P, Q, k);
 #ifdef CPT_PROFILE
@@ -2842,10 +2054,9 @@ static __device__ __forceinline__ int run_intervals(const PtParams& P, Ctx& C, c
     Metric M;
     M.hp = M.etap = M.alpha = M.alphap = 0.;
     M.tca_shear_g = 0.; M.rsa_dg = M.rsa_tg = 0.;
-    int f_tca = fi0, f_rsa = fi1, f_ufa = fi2, f_nfa = fi3;
-    Layout L = make_layout(P, f_tca, f_rsa, f_ufa, f_nfa);
-    LaneEq e = make_lane_eq(P, L, ROLE == 1 ? -1 : lane, k);   // (chain waves: an all-idle description)
-    const ChainEq ce = make_chain_eq(P, C, lane, k);
+    int f_tca = fi0, f_rsa = fi1, f_ufa = fi2;
+    Layout L = make_layout(P, f_tca, f_rsa, f_ufa);
+    LaneEq e = make_lane_eq(P, L, lane, k);
     double y;
     if (MODE) {  // tensors (pm.cpp:5386-5403): only the gravitational wave starts non-zero
       y = 0.;
@@ -2857,26 +2068,11 @@ static __device__ __forceinline__ int run_intervals(const PtParams& P, Ctx& C, c
           if (P.K < 0.) y = (k2 + 3. * P.K >= 0.) ? y * sqrt(tanh(1.5707963267948966 * sqrt(k2 + 3. * P.K) / sqrt(-P.K))) : 0.;
         }
       }
-    } else if (ROLE == 1 && LONG) {   // (long tails) only the ur ladder starts with a non-zero l = 3 element (pm.cpp:4863-4941)
-      y = 0.;
-      if (ce.valid && ce.species == 2 && ce.l == 0)
-        y = initial_conditions(P.tabs, P.has_cdm, P.has_ur, P.curvature_ini, P.K, P.ic, P.entropy_ini, GAUGE, R_LUR, 3, k, tau_ini);
-    } else if (ROLE == 1) {   // pm.cpp:5229-5256: the relativistic-relic series times the momentum dependence of f0
-      const int l = ce.l;
-      const int role = (l == 0) ? R_DELTA_UR : (l == 1) ? R_THETA_UR : (l == 2) ? R_SHEAR_UR : (l == 3) ? R_LUR : R_NONE;
-      const double v = initial_conditions(P.tabs, P.has_cdm, P.has_ur, P.curvature_ini, P.K, P.ic, P.entropy_ini, GAUGE, role, 3, k, tau_ini);
-      const AHK q0 = lookup_aHk(P.tabs, P.n_e, tau_ini);
-      const int ci = ce.valid ? ce.cidx : 0;
-      const double eps = sqrt(ce.q2 + q0.a * q0.a * ce.M2), dl = P.nc.dlnf0[ci];
-      const double f = (l == 0) ? -0.25 : (l == 1) ? -eps / (3. * ce.qk) : (l == 2) ? -0.5 : -0.25;
-      y = (ce.valid && l <= 3) ? f * v * dl : 0.;
     } else
       y = initial_conditions(P.tabs, P.has_cdm, P.has_ur, P.curvature_ini, P.K, P.ic, P.entropy_ini, GAUGE, e.role, e.ell, k, tau_ini);
 #ifdef CPT_PROFILE
     prof[6] = clock64() - t_begin;  // schedule search + initial conditions
 #endif
-    int single = 0;                        // (NCDM) the core wave integrates alone, the ncdm fluids in its core lanes
-    const int cmode = P.ncdm_compact;
     for (int iv = 0; iv <= nsw && status == 0; iv++) {
       const double ta = (iv == 0) ? tau_ini : (iv == 1) ? sw0 : (iv == 2) ? sw1 : (iv == 3) ? sw2 : sw3;
       const double tb = (iv == nsw) ? tau_end : (iv == 0) ? sw0 : (iv == 1) ? sw1 : (iv == 2) ? sw2 : sw3;
@@ -2885,51 +2081,10 @@ static __device__ __forceinline__ int run_intervals(const PtParams& P, Ctx& C, c
         // drops are zeroed, the ones it adds are seeded
         const int was_tca = L.tca;
         const int ap = (iv == 1) ? ap0 : (iv == 2) ? ap1 : (iv == 3) ? ap2 : ap3;
-        if (ap == 0) f_tca ^= 1; else if (ap == 1) f_rsa ^= 1; else if (ap == 2) f_ufa ^= 1; else f_nfa ^= 1;
-        // (NCDM) from the first scheme with the ncdm fluids on and tight coupling off the core wave goes on alone; a launch too
-        // large to be resident at once (cmode 1) waits for radiation streaming and the ur fluid as well
-        bool entering = false;
-        if (NCDM && !single && cmode != 0 && f_nfa && !f_tca && (cmode == 2 || (f_rsa && f_ufa))) { entering = true; single = 1; }
-        L = make_layout(P, f_tca, f_rsa, f_ufa, f_nfa, single);
-        e = make_lane_eq(P, L, ROLE == 1 ? -1 : lane, k);
+        if (ap == 0) f_tca ^= 1; else if (ap == 1) f_rsa ^= 1; else f_ufa ^= 1;
+        L = make_layout(P, f_tca, f_rsa, f_ufa);
+        e = make_lane_eq(P, L, lane, k);
         double yn = (e.role == R_NONE) ? 0. : y;
-        if (ROLE == 1) yn = y;          // the momentum hierarchies ride through the photon / ur switches (pm.cpp:3968-3975 etc.)
-        if (NCDM && LONG) {
-          // (long tails) a tail the new scheme drops is zeroed; when tight coupling ends the photon tails are seeded from the
-          // tight-coupling shear, which the core wave knows (pm.cpp:3893-3916)
-          if (ROLE == 0 && lane == 0) { C.sh->hf[0][0] = M.tca_shear_g; C.sh->hf[0][1] = k * Q.tau_c; }
-          __syncthreads();
-          if (ROLE == 1) {
-            const int t = ce.species;
-            const bool on = ce.valid && ((t == 0) ? L.gN > 0 : (t == 1) ? L.qN > 0 : L.uN > 0);
-            yn = on ? y : 0.;
-            if (was_tca && !L.tca && on && ce.first) {
-              const double sh = C.sh->hf[0][0], kod = C.sh->hf[0][1];
-              const double s3 = CURV ? sqrt(fmax(1. - 8. * P.K / (k * k), 0.)) : 1.;
-              if (t == 0) yn = 6. / 7. * kod * s3 * sh;
-              else if (t == 1) yn = kod * 3. * s3 / 14. * sh;
-            }
-          }
-        }
-        if (NCDM && ap == 3) {
-          // fluid approximation switched on (pm.cpp:4479-4517): integrate every chain into its species' delta, theta, sigma.
-          // The published block still holds the background at the switch time (the final RHS evaluation of the last interval).
-          if (ROLE == 1) {
-            if (ce.valid && ce.l <= 2) C.sh->ho[ce.cidx][ce.l] = C.cwt * y;   // (coefficients of the old scheme at the switch time)
-          }
-          __syncthreads();
-          if (ROLE == 1) {
-            yn = 0.;
-            if (ce.holder) {
-              double sum = 0.;
-              for (int c = P.nc.first_chain[ce.species]; c < P.nc.first_chain[ce.species + 1]; c++) sum += C.sh->ho[c][ce.l];
-              yn = sum / ((ce.l == 0) ? C.rho : C.rho + C.pr);
-#ifdef CPT_DEBUG_NCDM
-              printf("handover k=%g l=%d sum=%g rho=%g p=%g pp=%g a2=%g yn=%g\n", k, ce.l, sum, C.rho, C.pr, C.pp, C.a2, yn);
-#endif
-            }
-          }
-        }
         if (MODE) {  // tensors (pm.cpp:4640-4648): photons re-enter with delta_g = -4/3 gw'/kappa', pol0 = gw'/(3 kappa')
           if (was_tca && !L.tca) {
             const double gwd = bcast(y, TL_GWD);
@@ -2951,59 +2106,33 @@ static __device__ __forceinline__ int run_intervals(const PtParams& P, Ctx& C, c
             else yn = 0.;
           }
         }
-        if constexpr (NCDM == 1) if (entering) {
-          // the chain waves pass (delta, theta, sigma) of every species to the core wave and retire (see "the core wave alone")
-          if (ROLE == 1 && ce.holder) C.sh->hf[ce.species][ce.l] = yn;
-          __syncthreads();
-          if (ROLE == 1) {
-            // the first chain wave stays as the core wave's helper (table look-ups one step ahead, source samples) when the launch is
-            // latency-bound; the others have nothing left to do: no barrier follows
-            if (C.wave == 1 && cmode == 2) run_helper(P, C.mb, k, inv_k2, ik, lane, hw.bgw2, hw.thw2, bgw, thw, hw.ncw2, ncw);
-            break;
-          }
-          if (cmode == 2) { Q.mb = C.mb; Q.my_req = 0; Q.req_tau = -1.; Q.tau_cached = -1.; }   // from here on the rows come from the helper
-          const int ln = opaque(lane);
-          for (int n = 0; n < P.nc.n_species; n++)
-            for (int j = 0; j < 3; j++)
-              if (ln == fluid_lane(n, j)) yn = C.sh->hf[n][j];
-        }
         y = yn;
-        C.tau_pub = -1.;   // (the chain coefficients cached for this time belong to the old scheme)
       }
       n_regimes++;
-      int rc;
 #ifdef CPT_PROFILE_INTERVALS
       const unsigned long long iv_t0 = clock64(); const int iv_s0 = st.steps;
 #endif
-      if constexpr (SAMPLER) rc = ndf15s<0>(P, L, e, C, Q, M, k, inv_k2, ta, tb, y, st, lane, budget, jacw, fww, prof);
-      else if constexpr (NCDM == 1 && ROLE == 0) {
-        if (single) {
-          if (cmode != 2) rc = ndf15s<1, false>(P, L, e, C, Q, M, k, inv_k2, ta, tb, y, st, lane, budget, jacw, fww, prof, ik);
-          else if (L.rsa && L.ufa) rc = ndf15s<1, true>(P, L, e, C, Q, M, k, inv_k2, ta, tb, y, st, lane, budget, jacw, fww, prof, ik);
-          else rc = ndf15s<2, true>(P, L, e, C, Q, M, k, inv_k2, ta, tb, y, st, lane, budget, jacw, fww, prof, ik);
-        } else rc = ndf15<ROLE>(P, L, e, ce, C, Q, M, k, inv_k2, ik, ta, tb, y, st, lane, budget, jacw, fww, prof);
-      } else rc = ndf15<ROLE>(P, L, e, ce, C, Q, M, k, inv_k2, ik, ta, tb, y, st, lane, budget, jacw, fww, prof);
+      const int rc = ndf15s<0>(P, L, e, C, Q, M, k, inv_k2, ta, tb, y, st, lane, budget, jacw, fww, prof);
       if (rc) status = 10 + rc;
 #ifdef CPT_PROFILE_INTERVALS
-      if (lane == 0 && blockIdx.x == 0 && ROLE == 0)
-        printf("interval %d [%g, %g] tca %d rsa %d ufa %d nfa %d single %d: %d steps, %llu cycles\n", iv, ta, tb, L.tca, L.rsa, L.ufa, L.nfa, single,
-               st.steps - iv_s0, clock64() - iv_t0);
+      if (lane == 0 && blockIdx.x == 0)
+        printf("interval %d [%g, %g] tca %d rsa %d ufa %d: %d steps, %llu cycles\n", iv, ta, tb, L.tca, L.rsa, L.ufa, st.steps - iv_s0, clock64() - iv_t0);
 #endif
     }
   }
   return status;
 }
 
-// the helper wave (SAMPLER, see Mailbox): answers the integrator's table look-ups and evaluates perturb_sources
-// (pm.cpp:6731-7285) for every sample the integrator posts.  Two sets of table windows: the samples walk monotonically through
-// the sample times, the look-ups run one step ahead of the integration.
-// (NCDM: the helper of the core wave on its own - the first chain wave; samples go through rhs_fluid, answers carry the ncdm columns)
+// the helper wave (see Mailbox): answers the integrator's table look-ups and evaluates perturb_sources (pm.cpp:6731-7285) for every
+// sample the integrator posts.  Two sets of table windows: the samples walk monotonically through the sample times, the look-ups run
+// one step ahead of the integration.
 static __device__ __forceinline__ void run_helper(const PtParams& P, Mailbox* mb, double k, double inv_k2, int ik, int lane, double2* bgw_s, double2* thw_s,
-                                                  double2* bgw_p, double2* thw_p, double2* ncw_s = nullptr, double2* ncw_p = nullptr) {
+                                                  double2* bgw_p, double2* thw_p) {
+  static_assert(NCDM == 0, "the register-set kernels have their own helper (cpt_perturb_sets.inc)");
   Lookup Q, Qp;
-  lookup_init(P, Q, bgw_s, thw_s, lane, ncw_s);
+  lookup_init(P, Q, bgw_s, thw_s, lane);
   lookup_set_mode(P, Q, k);
-  lookup_init(P, Qp, bgw_p, thw_p, lane, ncw_p);
+  lookup_init(P, Qp, bgw_p, thw_p, lane);
   lookup_set_mode(P, Qp, k);
 #ifdef CPT_PROFILE
   unsigned long long sprof[16];
@@ -3013,9 +2142,8 @@ static __device__ __forceinline__ void run_helper(const PtParams& P, Mailbox* mb
   M.hp = M.etap = M.alpha = M.alphap = 0.; M.psi = M.phip = 0.;
   M.tca_shear_g = 0.; M.rsa_dg = M.rsa_tg = 0.;
   int flags = -1, tail = 0, answered = 0;
-  Layout L = NCDM ? make_layout(P, 0, 1, 1, 1, 1) : make_layout(P, 1, 0, 0);
+  Layout L = make_layout(P, 1, 0, 0);
   LaneEq e = make_lane_eq(P, L, lane, k);
-  NcIn N = {0., 0., 0., nullptr, 0};
   for (;;) {
     // look-ups first: the integrator may be waiting for one, a sample never holds it up while the ring has room
     const int rq = mb_load(&mb->req_seq);
@@ -3028,7 +2156,6 @@ static __device__ __forceinline__ void run_helper(const PtParams& P, Mailbox* mb
         a[8] = Qp.aH; a[9] = Qp.two_over_aH; a[10] = Qp.R; a[11] = Qp.inv_1pR; a[12] = Qp.inv_R; a[13] = Qp.tau_c; a[14] = Qp.dtau_c; a[15] = Qp.F;
         a[16] = Qp.Fp; a[17] = Qp.app; a[18] = Qp.inv_tau; a[19] = Qp.rg43; a[20] = Qp.ru43; a[21] = Qp.kcot;
       }
-      if (NCDM && lane < NCB_NCOL) mb->ans[22 + lane] = Qp.vnc;   // lane c holds column c of the ncdm row
       answered = rq;
       mb_store(&mb->ans_seq, rq);
       continue;
@@ -3043,13 +2170,8 @@ static __device__ __forceinline__ void run_helper(const PtParams& P, Mailbox* mb
       const double tn = P.tau_s[it];
       if (f != flags) {                          // the integrator entered another approximation scheme
         flags = f;
-        L = make_layout(P, f & 1, (f >> 1) & 1, (f >> 2) & 1, NCDM ? 1 : 0, NCDM ? 1 : 0);
+        L = make_layout(P, f & 1, (f >> 1) & 1, (f >> 2) & 1);
         e = make_lane_eq(P, L, lane, k);
-      }
-      if (NCDM) {
-        (void)rhs_fluid<2, 0>(P, L, e, Q, M, N, k, inv_k2, tn, yi, lane);
-        store_sources(P, L, Q, M, k, inv_k2, yi, ypi, tca_keep, it, ik, lane, N);
-        continue;
       }
       (void)rhs<false>(P, L, e, Q, M, k, inv_k2, tn, yi, lane);   // leaves Q and M describing (tn, yi)
       store_sources(P, L, Q, M, k, inv_k2, yi, ypi, tca_keep, it, ik, lane);
@@ -3107,81 +2229,59 @@ static __device__ __forceinline__ int make_schedule(const PtParams& P, double k,
   return status;
 }
 
-// ---- the kernel: perturb_solve (pm.cpp:2463-2787) for one mode per wavefront ---------------------
+// ---- the kernel: perturb_solve (pm.cpp:2463-2787) for one mode per workgroup of two wavefronts (integrator + helper) -------------
 static __device__ __forceinline__ void body_perturb(const PtParams& P) {
-  __shared__ __attribute__((aligned(16))) double2 tabw[64 * (BG_NCOL + TH_NCOL)];
+  static_assert(NCDM == 0, "the register-set kernels have their own body (cpt_perturb_sets.inc)");
+  __shared__ __attribute__((aligned(16))) double2 tabw[64 * (BG_NCOL + TH_NCOL)];      // the helper's windows of the look-ups ahead
+  __shared__ __attribute__((aligned(16))) double2 tabw2[64 * (BG_NCOL + TH_NCOL)];     // ... and of the samples
   __shared__ double jacw[NC * 64];
-  __shared__ __attribute__((aligned(16))) double2 fwsh[FW_PAIRS * 64];   // the integrator / core wave's factors (LuReg)
-  __shared__ __attribute__((aligned(16))) double2 ncw[NCDM ? 64 * NCB_NCOL : 1];
-  __shared__ __attribute__((aligned(8))) char ncsh_raw[NCDM ? sizeof(NcShared) : 8];
-  // the helper's second set of table windows and the mailbox: static in the two-wave kernels; dynamic in the ncdm kernels, which
-  // only allocate them when the launch runs with a helper (CPT_NCDM_HELPER_LDS bytes, cpt_perturb_impl)
-  __shared__ __attribute__((aligned(16))) double2 tabw2_s[SAMPLER ? 64 * (BG_NCOL + TH_NCOL) : 1];
-  __shared__ __attribute__((aligned(16))) unsigned char mbox_s[SAMPLER ? sizeof(Mailbox) : 16];
-  extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];
-  double2* tabw2 = SAMPLER ? tabw2_s : (double2*)dyn_lds;
-  double2* ncw2 = tabw2 + 64 * (BG_NCOL + TH_NCOL);
-  Mailbox* mbox = SAMPLER ? (Mailbox*)mbox_s : (Mailbox*)(dyn_lds + CPT_NCDM_HELPER_WINDOWS);
-  const bool has_helper = SAMPLER || P.ncdm_compact == 2;
-  const HelperWindows hwin = {tabw2, tabw2 + 64 * BG_NCOL, ncw2};
+  __shared__ __attribute__((aligned(16))) double2 fwsh[FW_PAIRS * 64];   // the integrator's factors (LuReg)
+  __shared__ __attribute__((aligned(16))) unsigned char mbox_s[sizeof(Mailbox)];
+  Mailbox* mbox = (Mailbox*)mbox_s;
   const int lane = threadIdx.x & 63;
+  const int wave = (int)(threadIdx.x >> 6);
   const int ik = P.order[blockIdx.x];
   const double k = P.k[ik];
   const double inv_k2 = 1.0 / (k * k);
   double2* bgw = tabw;
   double2* thw = tabw + 64 * BG_NCOL;
   Ctx C;
-  C.wave = (int)(threadIdx.x >> 6); C.nw = NCDM ? (int)(blockDim.x >> 6) - 1 : 0;
   C.mb = mbox; C.posted = 0; C.tail_seen = 0;
-  if (has_helper) {   // (the only barrier of the two-wave kernels: the counters are zero before any wave looks at them)
-    if (threadIdx.x == 0) { mbox->head = mbox->tail = mbox->done = mbox->req_seq = mbox->ans_seq = 0; mbox->req_tau = -1.; }
-    __syncthreads();
+  // (the only barrier of the kernel: the counters are zero before any wave looks at them)
+  if (threadIdx.x == 0) { mbox->head = mbox->tail = mbox->done = mbox->req_seq = mbox->ans_seq = 0; mbox->req_tau = -1.; }
+  __syncthreads();
+  if (wave == 1) {   // the helper polls `done` whatever happens to the integrator, drains the ring and leaves
+    run_helper(P, mbox, k, inv_k2, ik, lane, tabw2, tabw2 + 64 * BG_NCOL, bgw, thw);
+    return;
   }
-  C.len = (NCDM && !LONG) ? P.nc.lmax + 1 : 64; C.cpw = 64 / C.len;   // (long tails: one tail per chain wave)
-  C.sh = (NcShared*)ncsh_raw; C.parity = 0; C.abort = 0; C.tau_pub = -1.;
-  C.a2 = C.aH = C.kcot = C.inv_tau = C.rho = C.pr = C.pp = C.kap = 1.;
-  if (NCDM) { if (threadIdx.x == 0) C.sh->abort = 0; __syncthreads(); }
-
   Stat st = {0, 0, 0, 0, 0, 0};
   unsigned long long prof[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #ifdef CPT_PROFILE
   const unsigned long long t_begin = clock64();
 #endif
-  int status = 0, n_regimes = 0;
+  int n_regimes = 0;
   int budget = P.max_steps;
-  const double tau_end = P.tau_s[P.ntau - 1];
-
   Sched sc;
-  status = make_schedule(P, k, lane, sc);
-  const double tau_ini = sc.tau_ini;
+  int status = make_schedule(P, k, lane, sc);
   if (status == 0) {
 #ifdef CPT_PROFILE
-#define CPT_RUN_ARGS P, C, sc, k, inv_k2, ik, lane, bgw, thw, ncw, hwin, jacw, fwsh, st, n_regimes, budget, prof, t_begin
+    status = run_intervals(P, C, sc, k, inv_k2, ik, lane, bgw, thw, jacw, fwsh, st, n_regimes, budget, prof, t_begin);
 #else
-#define CPT_RUN_ARGS P, C, sc, k, inv_k2, ik, lane, bgw, thw, ncw, hwin, jacw, fwsh, st, n_regimes, budget, prof
+    status = run_intervals(P, C, sc, k, inv_k2, ik, lane, bgw, thw, jacw, fwsh, st, n_regimes, budget, prof);
 #endif
-    if constexpr (NCDM != 0) { if (C.wave > 0) status = run_intervals<1>(CPT_RUN_ARGS); else status = run_intervals<0>(CPT_RUN_ARGS); }
-    else { if (C.wave == 0) status = run_intervals<0>(CPT_RUN_ARGS); }
-#undef CPT_RUN_ARGS
   }
-  if (SAMPLER) {   // every path of wave 0 ends here: tell the helper (which polls `done` whatever happened above) to drain and leave
-    if (C.wave == 0) mb_store(&mbox->done, 1);
-    else run_helper(P, mbox, k, inv_k2, ik, lane, tabw2, tabw2 + 64 * BG_NCOL, bgw, thw);
-  } else if (NCDM && has_helper && C.wave == 0) mb_store(&mbox->done, 1);   // (the helper of the core wave on its own, if it got that far)
+  mb_store(&mbox->done, 1);   // every path of the integrator ends here
 #ifdef CPT_PROFILE
   prof[7] = clock64() - t_begin;
-#ifndef CPT_PROFILE_WAVE
-#define CPT_PROFILE_WAVE 0   // which wavefront of the workgroup reports (1...: a chain wave of the ncdm kernel)
-#endif
-  if (lane == 0 && blockIdx.x == 0 && C.wave == CPT_PROFILE_WAVE)  // the heaviest mode = the critical path
+  if (lane == 0 && blockIdx.x == 0)  // the heaviest mode = the critical path
     for (int i = 0; i < 16; i++) g_prof[i] = prof[i];
 #endif
-  if (lane == 0 && C.wave == 0) {
+  if (lane == 0) {
     if (P.status) P.status[ik] = status;
     if (P.stats) {
       cpt_stepstat s;
       s.steps = st.steps; s.failed = st.failed; s.fevals = st.fevals; s.jacobians = st.jacs; s.factorisations = st.lus;
-      s.solves = st.solves; s.n_regimes = n_regimes; s.tau_ini = tau_ini;
+      s.solves = st.solves; s.n_regimes = n_regimes; s.tau_ini = sc.tau_ini;
       P.stats[ik] = s;
     }
   }
@@ -3296,7 +2396,6 @@ static void fill_params(const cpt_handle* h, PtParams& P) {
   P.has_ncdm = c.has_ncdm; P.nfa_method = c.ncdm_fluid_approximation; P.nfa_trig = c.ncdm_fluid_trigger_tau_over_tau_k;
   P.tol_ncdm_w = c.has_ncdm ? c.tol_ncdm_initial_w : 1e300; P.tp_dcb = c.has_ncdm ? c.index_tp_delta_cb : -1;
   P.nc = h->ncdm;
-  P.ncdm_compact = 1;   // (cpt_perturb_impl picks 1 or 2 from the size of the launch)
   P.max_steps = 400000;
   // hierarchies longer than one wavefront (synchronous scalars without non-cold species): the tails go to chain waves of their own
   {
