@@ -477,6 +477,10 @@ static __device__ __noinline__ AHK lookup_aHk(DevTables T, double n_e, double ta
   return r;
 }
 
+// Rows of a table window.  64 = one row per lane; the register-set kernels, whose resident k-modes per CU are limited by LDS, stage
+// half-windows (lanes >= 32 hold a +huge abscissa and are never selected): twice as many slides, half the LDS.
+static constexpr int WR = NCDM ? 32 : 64;
+static constexpr int wsize(int ncol) { return ((WR * ncol + 63) / 64) * 64; }   // double2 entries of a window of `ncol` columns in LDS (whole 64-entry DMA blocks)
 // Wave-cooperative cached lookup used by the RHS / sampler (all arguments and results wave-uniform).
 // A window of 64 consecutive table rows is staged in LDS (one coalesced copy when the wave walks out of it), its 64
 // abscissae sit in lane registers: the bracket is one ballot+popcount, the two rows come from LDS, and a step that
@@ -521,10 +525,10 @@ static __device__ __forceinline__ void window_stage(const double* __restrict__ x
   const size_t g0 = (size_t)base * NCOL, glast = (size_t)n * NCOL - 1;
   // (the wave's own earlier LDS reads of this window have returned: they fed registers that were consumed before this call)
 #pragma unroll
-  for (int c = 0; c < NCOL; c++)
+  for (int c = 0; c < (WR * NCOL + 63) / 64; c++)
     __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(rows + min(g0 + (size_t)(lane + 64 * c), glast)),
                                      (void __attribute__((address_space(3)))*)(w + 64 * c), 16, 0, 0);
-  *xw = (i < n) ? xv : 1e300;
+  *xw = (i < n && (WR == 64 || lane < WR)) ? xv : 1e300;
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the DMA writes have landed (and xv has arrived)
 }
 
@@ -535,21 +539,21 @@ static __device__ __forceinline__ void window_stage(const double* __restrict__ x
 template <int NCOL>
 static __device__ __forceinline__ int window_find(const double* __restrict__ x, const double2* __restrict__ rows, int n, double v,
                                            int lane, double* xw, double2* w, int* base, int bias) {
-  double lo = bcast(*xw, 0), hi = bcast(*xw, 63);
+  double lo = bcast(*xw, 0), hi = bcast(*xw, WR - 1);
   if (!(v >= lo && v < hi)) {
-    int nb = (v >= hi) ? *base + 63 - bias : *base - 63 + (63 - bias);   // slide up / down
-    if (nb > n - 64) nb = n - 64;
+    int nb = (v >= hi) ? *base + (WR - 1) - bias : *base - (WR - 1) + ((WR - 1) - bias);   // slide up / down
+    if (nb > n - WR) nb = n - WR;
     if (nb < 0) nb = 0;
     *base = nb;
     window_stage<NCOL>(x, rows, n, nb, lane, xw, w);
 #ifdef CPT_COUNT_RESTAGE
     if (blockIdx.x == 0 && lane == 0) g_restage[NCOL == TH_NCOL ? 0 : 1]++;
 #endif
-    lo = bcast(*xw, 0); hi = bcast(*xw, 63);
-    if (!(v >= lo && v < hi) && !(nb == 0 && v < lo) && !(nb == n - 64 && v >= hi)) {
+    lo = bcast(*xw, 0); hi = bcast(*xw, WR - 1);
+    if (!(v >= lo && v < hi) && !(nb == 0 && v < lo) && !(nb == n - WR && v >= hi)) {
       const int inf = bsearch_up(x, n, v);  // uniform
       nb = inf - bias;
-      if (nb > n - 64) nb = n - 64;
+      if (nb > n - WR) nb = n - WR;
       if (nb < 0) nb = 0;
       *base = nb;
       window_stage<NCOL>(x, rows, n, nb, lane, xw, w);
@@ -647,7 +651,7 @@ static __device__ __forceinline__ void lookup(const PtParams& P, Lookup& Q, doub
             (c == TH_DDDKAPPA) ? dddk : (c == TH_CB2) ? Q.cb2 : 0.;   // e^-kappa = g = g' = 0
     Q.th_inf = -1;
   } else {
-    const int iz = window_find<TH_NCOL>(T.z_table, (const double2*)T.th, T.tt_size, z, lane, &Q.thx, Q.thw, &Q.th_base, 54);
+    const int iz = window_find<TH_NCOL>(T.z_table, (const double2*)T.th, T.tt_size, z, lane, &Q.thx, Q.thw, &Q.th_base, WR - 10);
     if (iz != Q.th_inf) {
       Q.th_inf = iz;
       if (lane < TH_NCOL) {
@@ -1238,6 +1242,14 @@ struct Jac {
 // diagonal) of lane i < NC, and the cyclic-reduction multipliers of the tails.  Kept in registers they push the integrator past
 // 256 VGPRs, and every use then costs a v_accvgpr_read per dword; from LDS a ds_read_b128 brings two doubles per instruction,
 // issued ahead of their use.  Layout: pair p of lane l at fw[p * 64 + l] (conflict-free b128 accesses).
+// Lane stride of the two LDS arrays below.  Only the core lanes (< NC) hold anything in them; the register-set kernels (NC = 22), whose
+// resident k-modes per CU are limited by LDS, store 32 lanes per row: lanes >= 32 neither write nor use what they read.
+static constexpr int JS = NCDM ? 32 : 64;
+static __device__ __forceinline__ void jc_store(double* Jc, int j, int lane, double v) { if (JS == 64 || lane < JS) Jc[j * JS + lane] = v; }
+static __device__ __forceinline__ double jc_load(const double* Jc, int j, int lane) {
+  const double v = Jc[j * JS + (lane & (JS - 1))];
+  return (JS == 64 || lane < JS) ? v : 0.;
+}
 static constexpr int FW_ACP = (NC + 1) / 2;      // pairs holding Ac[0..NC-1]
 static constexpr int FW_PAIRS = FW_ACP + (PCR ? 4 : 0);   // + (al, ga) of the four reduction levels (row layout only: LDS is what limits
                                                          // the resident k-modes of the ncdm kernels)
@@ -1331,7 +1343,7 @@ static __device__ __forceinline__ bool factorise(const LaneEq& e, const Jac& J, 
   const double schur = cpar * r3;
   double A[NC];
 #pragma unroll
-  for (int j = 0; j < NC; j++) A[j] = ((j == lane) ? 1.0 - schur : 0.0) - hg * J.Jc[j * 64 + lane];   // J.Jc = 0 outside the core
+  for (int j = 0; j < NC; j++) A[j] = ((j == lane) ? 1.0 - schur : 0.0) - hg * jc_load(J.Jc, j, lane);   // J.Jc = 0 outside the core
   if (NCDM) {
     if (long_tails) {
       // (long tails) auxiliary unknown u_t = l = 3 element of tail t, in lane LN_ND + t: u_t - alpha_t x_parent(t) = [T_t^-1 r_t]_first,
@@ -1382,8 +1394,10 @@ static __device__ __forceinline__ bool factorise(const LaneEq& e, const Jac& J, 
   // unit-diagonal U: scale the upper part of every row by its reciprocal pivot
 #pragma unroll
   for (int j = 0; j < NC; j++) A[j] = (j > lane) ? A[j] * rpivc : A[j];
+  if (JS == 64 || lane < JS) {
 #pragma unroll
-  for (int q = 0; q < FW_ACP; q++) F.fw[q * 64 + lane] = make_double2(A[2 * q], (2 * q + 1 < NC) ? A[2 * q + 1] : 0.);
+    for (int q = 0; q < FW_ACP; q++) F.fw[q * JS + lane] = make_double2(A[2 * q], (2 * q + 1 < NC) ? A[2 * q + 1] : 0.);
+  }
   F.rpivc = rpivc;
   F.rowperm = rowperm;
   F.permuted = __builtin_amdgcn_readfirstlane(permuted);
@@ -1399,7 +1413,7 @@ static __device__ __forceinline__ double lu_solve(const LaneEq& e, const LuReg& 
   // the rows of the core factors: requested now, they arrive behind the tail reduction
   double Ac[2 * FW_ACP];
 #pragma unroll
-  for (int q = 0; q < FW_ACP; q++) { const double2 v = F.fw[q * 64 + lane]; Ac[2 * q] = v.x; Ac[2 * q + 1] = v.y; }
+  for (int q = 0; q < FW_ACP; q++) { const double2 v = F.fw[q * JS + (lane & (JS - 1))]; Ac[2 * q] = v.x; Ac[2 * q + 1] = v.y; }   // (JS = 32: lanes >= 32 read rows that are not theirs, see the end)
   if (PCR) u = pcr_apply(F, chain ? b : 0., lane) * F.rinv;   // T^-1 b on every tail lane, 0 on core lanes
   else {
     double bp = b;
@@ -1451,6 +1465,7 @@ static __device__ __forceinline__ double lu_solve(const LaneEq& e, const LuReg& 
     }
     if (chain) x = xt;
   }
+  if (JS < 64) x = (lane >= JS && !chain) ? b : x;   // (identity rows; what these lanes computed from rows of other lanes is dropped)
   return x;
 }
 
@@ -1613,7 +1628,7 @@ static __device__ __forceinline__ int ndf15s(const PtParams& P, const Layout& L,
 
   Jac J;
   J.Jc = jac_lds;
-  for (int j = 0; j < NC; j++) J.Jc[j * 64 + lane] = 0.;
+  for (int j = 0; j < NC; j++) jc_store(J.Jc, j, lane, 0.);
   J.jdiag = 0.;
   LuReg F;
   F.fw = fw_lds;
@@ -1640,7 +1655,7 @@ static __device__ __forceinline__ int ndf15s(const PtParams& P, const Layout& L,
     for (int r = 0; r < NC; r++) {
       if (!((e.pmask >> r) & 1u)) continue;
       const double col = eval(tq, (lane == r) ? 1.0 : 0.0);
-      J.Jc[r * 64 + lane] = (lane < NC) ? col : 0.;
+      jc_store(J.Jc, r, lane, (lane < NC) ? col : 0.);
     }
     J.jdiag = -(e.D * Q.kap + e.G * Q.kcot + (CURV ? e.Gt * Q.inv_tau : 0.));   // frozen at the time of this Jacobian (ev.cpp keeps J fixed)
     M.tca_shear_g = keep;
@@ -2234,8 +2249,8 @@ static __device__ __forceinline__ void body_perturb(const PtParams& P) {
   static_assert(NCDM == 0, "the register-set kernels have their own body (cpt_perturb_sets.inc)");
   __shared__ __attribute__((aligned(16))) double2 tabw[64 * (BG_NCOL + TH_NCOL)];      // the helper's windows of the look-ups ahead
   __shared__ __attribute__((aligned(16))) double2 tabw2[64 * (BG_NCOL + TH_NCOL)];     // ... and of the samples
-  __shared__ double jacw[NC * 64];
-  __shared__ __attribute__((aligned(16))) double2 fwsh[FW_PAIRS * 64];   // the integrator's factors (LuReg)
+  __shared__ double jacw[NC * JS];
+  __shared__ __attribute__((aligned(16))) double2 fwsh[FW_PAIRS * JS];   // the integrator's factors (LuReg)
   __shared__ __attribute__((aligned(16))) unsigned char mbox_s[sizeof(Mailbox)];
   Mailbox* mbox = (Mailbox*)mbox_s;
   const int lane = threadIdx.x & 63;
@@ -2352,17 +2367,17 @@ static __device__ __forceinline__ void body_dbg_solve(const PtParams& P, double 
   Layout L = make_layout(P, tca, rsa, ufa);
   LaneEq e = make_lane_eq(P, L, lane, k);
   const double inv_k2 = 1.0 / (k * k);
-  __shared__ double jacw[NC * 64];
+  __shared__ double jacw[NC * JS];
   Jac J;
   J.Jc = jacw;
-  for (int j = 0; j < NC; j++) J.Jc[j * 64 + lane] = 0.;
+  for (int j = 0; j < NC; j++) jc_store(J.Jc, j, lane, 0.);
   for (int r = 0; r < NC; r++) {
     if (!core_present(P, L, r)) continue;
     const double col = rhs(P, L, e, Q, M, k, inv_k2, tau, (lane == r) ? 1.0 : 0.0, lane);
-    J.Jc[r * 64 + lane] = (lane < NC) ? col : 0.;
+    jc_store(J.Jc, r, lane, (lane < NC) ? col : 0.);
   }
   J.jdiag = -(e.D * Q.kap + e.G * Q.kcot + (CURV ? e.Gt * Q.inv_tau : 0.));
-  __shared__ __attribute__((aligned(16))) double2 fwsh[FW_PAIRS * 64];
+  __shared__ __attribute__((aligned(16))) double2 fwsh[FW_PAIRS * JS];
   LuReg F;
   F.fw = fwsh;
   const bool ok = factorise(e, J, hg, L.maxlen, lane, F);

@@ -506,3 +506,39 @@ def test_row_layout_and_packed_layout_agree(small, monkeypatch):
     check_sources(inp.config, rows.cpu().numpy(), packed.cpu().numpy())
     check_sources(inp.config, rows.cpu().numpy(), inp.d["pt.sources"])
     check_sources(inp.config, packed.cpu().numpy(), inp.d["pt.sources"])
+
+
+@pytest.mark.parametrize("cfg", ["ncdm_small", "ncdm3_small", "long_small", "ncdm3", "long_full"])
+def test_register_set_kernels_repeat_bit_for_bit(cfg):
+    """More than 64 equations per k-mode (momentum bins of massive neutrinos, hierarchies longer than a wavefront): ONE wavefront owns the
+    mode and runs ONE copy of the step control (cpt_perturb_sets.inc) - there is no second copy that could drift, no barrier a wave could
+    miss.  (Round 2 spread such a mode over up to six waves, each with its own copy: results then changed from run to run once.)  Two
+    launches on one handle and one on a fresh handle must agree bit for bit, statistics included - with helper waves and without
+    (CPT_SETS_HELPER: two instantiations of the kernel, each deterministic; between them the compiler may fuse a multiply-add differently,
+    so they agree as two valid step sequences do, not bit for bit)."""
+    from classpp_public_amd.backend import Backend
+    inp = Inputs(cfg)
+    be = Backend(inp)
+    a, sa, _ = be.perturb_solve()
+    a = a.clone()
+    b, sb, _ = be.perturb_solve()
+    assert torch.equal(a, b) and [s.steps for s in sa] == [s.steps for s in sb]
+    be.close()
+    be2 = Backend(inp)
+    c, sc, _ = be2.perturb_solve()
+    assert torch.equal(a, c) and [s.fevals for s in sa] == [s.fevals for s in sc]
+    be2.close()
+    if cfg.endswith("_small"):
+        import os
+        for helper in ("0", "1"):
+            os.environ["CPT_SETS_HELPER"] = helper
+            try:
+                be3 = Backend(inp)
+                d, sd, _ = be3.perturb_solve()
+                d = d.clone()
+                d2, sd2, _ = be3.perturb_solve()
+                assert torch.equal(d, d2) and [s.steps for s in sd] == [s.steps for s in sd2], "helper=%s" % helper
+                check_sources(inp.config, d.cpu().numpy(), a.cpu().numpy())
+                be3.close()
+            finally:
+                del os.environ["CPT_SETS_HELPER"]
