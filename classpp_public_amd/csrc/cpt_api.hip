@@ -176,16 +176,16 @@ static int validate(const cpt_config* c) {
       return cpt_fail(nullptr, CPT_ERR_INVALID, "tensor modes have the source types t2 and p only (pm.cpp:7243-7280)");
   }
   // lane map of cpt_perturb.hip: 14 core lanes (22 with non-cold species) + the three l >= 3 tails
-  // Longer hierarchies of the synchronous scalar system without non-cold species run with one extra wavefront per tail ("long tails"
-  // in cpt_perturb.hip): each tail must then fit a wavefront of its own.
+  // Longer hierarchies of the synchronous scalar system run with each l >= 3 tail as a register set of its own (cpt_perturb_sets.inc):
+  // each tail must then fit the 64 lanes of a set.
   const int core_lanes = c->has_ncdm ? 13 + 3 * CPT_MAX_NCDM : 14;
   if (core_lanes + (c->l_max_g - 2) + (c->l_max_pol_g - 2) + (c->has_ur ? c->l_max_ur - 2 : 0) > CPT_WAVE) {
-    const bool long_ok = c->mode == CPT_MODE_SCALARS && !c->has_ncdm && c->gauge == CPT_GAUGE_SYNCHRONOUS && c->l_max_g - 2 <= CPT_WAVE &&
+    const bool long_ok = c->mode == CPT_MODE_SCALARS && c->gauge == CPT_GAUGE_SYNCHRONOUS && c->l_max_g - 2 <= CPT_WAVE &&
                          c->l_max_pol_g - 2 <= CPT_WAVE && (!c->has_ur || c->l_max_ur - 2 <= CPT_WAVE);
     if (!long_ok)
       return cpt_fail(nullptr, CPT_ERR_UNSUPPORTED,
-                      "hierarchy too large: %d + tails > 64 lanes; hierarchies longer than one wavefront run for synchronous-gauge scalars without "
-                      "non-cold species and l_max_g, l_max_pol_g, l_max_ur <= 66 only", core_lanes);
+                      "hierarchy too large: %d + tails > 64 lanes; hierarchies longer than one wavefront run for synchronous-gauge scalars "
+                      "(with or without non-cold species) and l_max_g, l_max_pol_g, l_max_ur <= 66 only", core_lanes);
   }
   if (c->tp_size < 1 || c->tp_size > 8) return cpt_fail(nullptr, CPT_ERR_INVALID, "tp_size=%d out of range", c->tp_size);
   const int tps[6] = {c->index_tp_t0, c->index_tp_t1, c->index_tp_t2, c->index_tp_p, c->index_tp_delta_m,

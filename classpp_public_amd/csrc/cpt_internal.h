@@ -176,6 +176,7 @@ int cpt_perturb_impl(cpt_handle* h, const double* k, int nk, const double* tau_s
 int cpt_perturb_sets_launch_0(CPT_SETS_LAUNCH_ARGS);   // tails (long hierarchies)
 int cpt_perturb_sets_launch_2(CPT_SETS_LAUNCH_ARGS);   // <= 2 momentum-bin sets
 int cpt_perturb_sets_launch_5(CPT_SETS_LAUNCH_ARGS);   // <= 5 momentum-bin sets
+int cpt_perturb_sets_launch_13(CPT_SETS_LAUNCH_ARGS);  // tails + <= 3 momentum-bin sets
 double cpt_sigma_of_R(const double* k, const double* pk, int nk, double R, double k_per_decade);   // host: sigma(R) of a tabulated P(k)
 int cpt_cl_impl(cpt_handle* h, const cpt_spectra_params* sp, const double* transfer_dev, const double* q, int nq, int nl,
                 double* cl_dev, const double* transfer2_dev = nullptr);

@@ -106,8 +106,10 @@ int cpt_perturb_impl(cpt_handle* h, const double* k, int nk, const double* tau, 
   if ((c.has_ncdm || P.long_tails) && c.mode == CPT_MODE_SCALARS) {
     // more than 64 equations per k-mode: the register-set kernels (one wavefront per mode, cpt_perturb_sets.inc; one translation unit
     // per family)
-    const int cpw = 64 / (c.l_max_ncdm + 1), nsets = P.long_tails ? 0 : (h->ncdm.nchains + cpw - 1) / cpw;
-    if (P.long_tails) rc = cpt_perturb_sets_launch_0(h, d_k, d_tau, d_order, nk, ntau, h->d_src, d_stats, d_status);
+    const int cpw = c.has_ncdm ? 64 / (c.l_max_ncdm + 1) : 1, nsets = c.has_ncdm ? (h->ncdm.nchains + cpw - 1) / cpw : 0;
+    if (P.long_tails && nsets == 0) rc = cpt_perturb_sets_launch_0(h, d_k, d_tau, d_order, nk, ntau, h->d_src, d_stats, d_status);
+    else if (P.long_tails && nsets <= 3) rc = cpt_perturb_sets_launch_13(h, d_k, d_tau, d_order, nk, ntau, h->d_src, d_stats, d_status);
+    else if (P.long_tails) return cpt_fail(h, CPT_ERR_UNSUPPORTED, "hierarchies longer than one wavefront together with %d ncdm momentum bins need %d bin sets (at most 3)", h->ncdm.nchains, nsets);
     else if (nsets <= 2) rc = cpt_perturb_sets_launch_2(h, d_k, d_tau, d_order, nk, ntau, h->d_src, d_stats, d_status);
     else if (nsets <= 5) rc = cpt_perturb_sets_launch_5(h, d_k, d_tau, d_order, nk, ntau, h->d_src, d_stats, d_status);
     else return cpt_fail(h, CPT_ERR_UNSUPPORTED, "%d ncdm momentum bins need %d register sets per k-mode (at most 5)", h->ncdm.nchains, nsets);

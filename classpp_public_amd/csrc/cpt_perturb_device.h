@@ -256,7 +256,8 @@ static constexpr bool SAMPLER = (NCDM == 0);
 // NCDM = 2: the multi-wavefront machinery of the non-cold species with ZERO species and the chain waves carrying the three l >= 3 tails
 // instead ("long tails": hierarchies longer than one wavefront).  An instantiation of its own, so that the ncdm kernels proper pay
 // nothing for it (as run-time branches it cost them 6 - 10 %).
-static constexpr bool LONG = (NCDM == 2);
+static constexpr bool LONG = (NCDM & 2) != 0;       // NCDM = 2: long tails alone; NCDM = 3: long tails AND momentum bins (permille-class hierarchies with massive neutrinos)
+static constexpr bool HAS_BINS = (NCDM & 1) != 0;
 // Lane map.  One lane per equation of pm.cpp:3302-3481, at a FIXED lane whatever the approximation scheme: the (at most
 // 13) densely coupled variables - densities, velocities, shears, polarisation l<=2, metric - are the CORE in lanes
 // 0..12, followed by the three free-streaming hierarchy tails (photon temperature l>=3, polarisation l>=3, ur l>=3)
@@ -270,8 +271,9 @@ enum Lane : int { LN_DG = 0, LN_TG, LN_SG, LN_P0, LN_P1, LN_P2, LN_DB, LN_TB, LN
 // (NCDM: nine more core lanes, 13..21.  While the momentum hierarchies are integrated the first two hold the auxiliary unknowns of the
 //  bordered Newton system; once the ncdm fluid approximation is on and the core wave integrates alone they hold (delta, theta, sigma)
 //  of up to three species - see "the core wave alone" below.  An idle core lane costs nothing: Layout::pmask.)
-static constexpr int NC = MODE ? 17 : ((GAUGE == CPT_GAUGE_NEWTONIAN) ? 14 : 13) + (NCDM ? 3 * CPT_MAX_NCDM : 0);
-static constexpr int LN_ND = 13, LN_NT = 14;   // (NCDM only) auxiliary unknowns: ncdm density / momentum sums
+static constexpr int NC = MODE ? 17 : ((GAUGE == CPT_GAUGE_NEWTONIAN) ? 14 : 13) + (NCDM ? 3 * CPT_MAX_NCDM : 0) + (NCDM == 3 ? 3 : 0);
+static constexpr int LN_ND = 13, LN_NT = 14;   // (momentum bins) auxiliary unknowns: ncdm density / momentum sums
+static constexpr int LN_T3 = (NCDM == 3) ? 22 : 13;   // (long tails) auxiliary unknowns: the l = 3 elements of the three tails, lanes LN_T3 .. LN_T3 + 2
 static constexpr int LN_F0 = 13;               // (NCDM only, fluids in the core) delta of species 0; species n, moment j at LN_F0 + 3 n + j
 static_assert(!NCDM || CPT_MAX_NCDM == 3, "lane map of the ncdm kernels");
 // Tensor modes (MODE = 1; pm.cpp:3519-3586): the same three ladders plus the gravitational wave (gw, gw').  The photon
@@ -324,8 +326,8 @@ static __device__ __forceinline__ Layout make_layout(const PtParams& P, int tca,
 // is core variable `i` evolved in this scheme?  (i wave-uniform)
 static __device__ __forceinline__ bool core_present(const PtParams& P, const Layout& L, int i) {
   if (MODE) return (i <= TL_P4) ? (!L.rsa && !L.tca) : (i <= TL_U4) ? (P.evolve_tensor_ur != 0) : true;
-  if (NCDM && L.lng && i >= LN_ND) return (i == LN_ND) ? L.gN > 0 : (i == LN_ND + 1) ? L.qN > 0 : (i == LN_ND + 2) ? L.uN > 0 : false;
-  if (NCDM && i >= LN_ND) return L.fic ? (i - LN_F0 < 3 * P.nc.n_species) : (i <= LN_NT);
+  if (LONG && i >= LN_T3 && i < LN_T3 + 3) return (i == LN_T3) ? L.gN > 0 : (i == LN_T3 + 1) ? L.qN > 0 : L.uN > 0;
+  if (NCDM && i >= LN_ND) return !HAS_BINS ? false : L.fic ? (i - LN_F0 < 3 * P.nc.n_species) : (i <= LN_NT);
   switch (i) {
     case LN_DG: case LN_TG: return !L.rsa;
     case LN_SG: case LN_P0: case LN_P1: case LN_P2: return !L.rsa && !L.tca;
@@ -360,10 +362,11 @@ static __device__ __forceinline__ void role_of(const PtParams& P, const Layout& 
     return;
   }
   const bool g = !L.rsa, hi = !L.rsa && !L.tca, ur = P.has_ur && !L.rsa;
+  if (LONG && i >= LN_T3 && i < LN_T3 + 3) { if (core_present(P, L, i)) *role = R_NCD; return; }
   if (NCDM && L.fic && i >= LN_F0 && i < NC) { if (i - LN_F0 < 3 * P.nc.n_species) *role = R_FLUID; return; }
-  if (NCDM && L.lng && i >= LN_ND && i < NC) { if (core_present(P, L, i)) *role = R_NCD; return; }
-  if (NCDM && i == LN_ND) { *role = R_NCD; return; }
-  if (NCDM && i == LN_NT) { *role = R_NCT; return; }
+  if (HAS_BINS && i == LN_ND) { *role = R_NCD; return; }
+  if (HAS_BINS && i == LN_NT) { *role = R_NCT; return; }
+  if (NCDM && i >= LN_ND && i < NC) return;   // (core lanes this lane map leaves idle)
   if (i == LN_DG) { if (g) *role = R_DELTA_G; return; }
   if (i == LN_TG) { if (g) { *role = R_THETA_G; *ell = 1; } return; }
   if (i == LN_SG) { if (hi) { *role = R_SHEAR_G; *ell = 2; } return; }
@@ -1125,7 +1128,7 @@ static __device__ __forceinline__ void approx_flags(const PtParams& P, double k,
   }
   *rsa = ((tau * k > P.rsa_trig) && (tau > P.tau_free_streaming) && (P.rsa_method != CPT_RSA_NONE)) ? 1 : 0;
   *ufa = (!MODE && P.has_ur && (tau * k > P.ufa_trig) && (P.ufa_method != CPT_UFA_NONE)) ? 1 : 0;   // no ur fluid for tensors
-  *nfa = (NCDM && !LONG && (tau * k > P.nfa_trig) && (P.nfa_method != CPT_NCDMFA_NONE)) ? 1 : 0;             // pm.cpp:5606-5614
+  *nfa = (HAS_BINS && (tau * k > P.nfa_trig) && (P.nfa_method != CPT_NCDMFA_NONE)) ? 1 : 0;             // pm.cpp:5606-5614
 }
 
 // 64-ary search for the time at which a monotone predicate flips between lo (false) and hi (true):
@@ -1219,11 +1222,13 @@ static __device__ __forceinline__ void for_core(unsigned pm, int lo, F&& f) {
   if (lo <= 12) core_run<12, 12>(lo, f);
   if (lo <= 15 && (pm & (7u << 13))) core_run<13, (NCDM ? 15 : 0)>(lo, f);
   if (lo <= 18 && (pm & (7u << 16))) core_run<16, (NCDM ? 18 : 0)>(lo, f);
-  if (pm & (7u << 19)) core_run<19, (NCDM ? 21 : 0)>(lo, f);
+  if (lo <= 21 && (pm & (7u << 19))) core_run<19, (NCDM ? 21 : 0)>(lo, f);
+  if constexpr (NCDM == 3) { if (pm & (7u << 22)) core_run<22, 24>(lo, f); }
 }
 template <class F>
 static __device__ __forceinline__ void for_core_down(unsigned pm, F&& f) {
   if (!NCDM) { core_run_down<0, NC - 1>(f); return; }
+  if constexpr (NCDM == 3) { if (pm & (7u << 22)) core_run_down<22, 24>(f); }
   if (pm & (7u << 19)) core_run_down<19, (NCDM ? 21 : 0)>(f);
   if (pm & (7u << 16)) core_run_down<16, (NCDM ? 18 : 0)>(f);
   if (pm & (7u << 13)) core_run_down<13, (NCDM ? 15 : 0)>(f);
@@ -1299,7 +1304,7 @@ static __device__ __forceinline__ void pcr_level(double& a, double& c, double& d
 }
 
 static __device__ __forceinline__ bool factorise(const LaneEq& e, const Jac& J, double hg, int maxlen, int lane, LuReg& F,
-                                                 const double* al = nullptr, double gmc = 0., double gms = 0., int long_tails = 0) {
+                                                 const double* al = nullptr, double gmc = 0., double gms = 0., int aux = 0) {
   lane = opaque(lane);
   const int chain = opaque(e.chain);
   // ---- tails ----
@@ -1345,13 +1350,16 @@ static __device__ __forceinline__ bool factorise(const LaneEq& e, const Jac& J, 
 #pragma unroll
   for (int j = 0; j < NC; j++) A[j] = ((j == lane) ? 1.0 - schur : 0.0) - hg * jc_load(J.Jc, j, lane);   // J.Jc = 0 outside the core
   if (NCDM) {
-    if (long_tails) {
-      // (long tails) auxiliary unknown u_t = l = 3 element of tail t, in lane LN_ND + t: u_t - alpha_t x_parent(t) = [T_t^-1 r_t]_first,
-      // alpha_t = hg [T_t^-1 (a_first e_first)]_first from the tail's wave
-      A[LN_SG] -= (lane == LN_ND) ? al[0] : 0.;
-      A[LN_P2] -= (lane == LN_ND + 1) ? al[1] : 0.;
-      A[LN_SUR] -= (lane == LN_ND + 2) ? al[2] : 0.;
-    } else if (al != nullptr) {
+    // aux: which auxiliary rows of the bordered system exist (register-set kernels) - bit 0: the tails' l = 3 elements, al[4..6];
+    // bit 1: the ncdm density / momentum sums, al[0..3]
+    if (LONG && (aux & 1)) {
+      // auxiliary unknown u_t = l = 3 element of tail t, in lane LN_T3 + t: u_t - alpha_t x_parent(t) = [T_t^-1 r_t]_first,
+      // alpha_t = hg [T_t^-1 (a_first e_first)]_first from the tail's set
+      A[LN_SG] -= (lane == LN_T3) ? al[4] : 0.;
+      A[LN_P2] -= (lane == LN_T3 + 1) ? al[5] : 0.;
+      A[LN_SUR] -= (lane == LN_T3 + 2) ? al[6] : 0.;
+    }
+    if (HAS_BINS && (aux & 2)) {
     const double c1 = (lane == LN_ND) ? al[0] : (lane == LN_NT) ? al[2] : 0., c2 = (lane == LN_ND) ? al[1] : (lane == LN_NT) ? al[3] : 0.;
 #pragma unroll
     for (int j = 0; j < NC; j++) A[j] -= c1 * bcast(gmc, j) + c2 * bcast(gms, j);
@@ -1531,11 +1539,14 @@ static __device__ __forceinline__ double dif_get(const double* dif, int i) {
 static __device__ __forceinline__ int fluid_lane(int species, int j) { return LN_F0 + 3 * species + j; }
 // perturb_derivs (pm.cpp:7861-9218 with perturb_einstein, perturb_total_stress_energy, perturb_rsa_delta_and_theta and the fluid
 // equations of pm.cpp:8737-8823 folded in); synchronous gauge.  Leaves M and N describing (tau, y) for the sources.
-template <int SYS, int LK>
+// (FETCH = false: the row of the tables is in Q already; LK then only says where the ncdm columns are: 1 Q.ncv (from the helper), 0 Q.vnc)
+template <int SYS, int LK, bool FETCH = true>
 static __device__ __forceinline__ double rhs_fluid(const PtParams& P, const Layout& L, const LaneEq& e, Lookup& Q, Metric& M, NcIn& N, double k, double inv_k2,
                                                    double tau, double y, int lane) {
-  if (LK == 1) { if (!mb_fetch(Q, tau, lane)) return nan(""); }
-  else lookup(P, Q, tau, lane);
+  if (FETCH) {
+    if (LK == 1) { if (!mb_fetch(Q, tau, lane)) return nan(""); }
+    else lookup(P, Q, tau, lane);
+  }
   const double aH = Q.aH, k2 = k * k;
   const int ln = opaque(lane);
   // the non-cold fluids: integrals for the Einstein equations, and this lane's species (wave-uniform per species, selected per lane)
@@ -1586,7 +1597,7 @@ static __device__ __forceinline__ double rhs_fluid(const PtParams& P, const Layo
   }
   {  // fluid lanes (pm.cpp:8737-8823): j = 0 delta, 1 theta, 2 sigma; ym / yp: the species' neighbouring variable
     const int f = ln - LN_F0, sp = (f >= 6) ? 2 : (f >= 3) ? 1 : 0, j = f - 3 * sp;
-    const bool fluid = (f >= 0) && (sp < P.nc.n_species) && (ln < NC);
+    const bool fluid = (f >= 0) && (f < 3 * CPT_MAX_NCDM) && (sp < P.nc.n_species);
     const double ym = lane_below(y), yp = lane_above(y);
     const double w = p_l * fast_rcp(rho_l), inv_1pw = fast_rcp(1. + w), pp_over_p = pp_l * fast_rcp(p_l);
     const double ca2 = w / 3. * inv_1pw * (5. - pp_over_p), ceff2 = ca2;
@@ -2414,9 +2425,9 @@ static void fill_params(const cpt_handle* h, PtParams& P) {
   P.max_steps = 400000;
   // hierarchies longer than one wavefront (synchronous scalars without non-cold species): the tails go to chain waves of their own
   {
-    const int lanes = 14 + (c.l_max_g - 2) + (c.l_max_pol_g - 2) + (c.has_ur ? c.l_max_ur - 2 : 0);
-    P.long_tails = (c.mode == CPT_MODE_SCALARS && !c.has_ncdm && lanes > CPT_WAVE) ? 1 : 0;
-    if (const char* e = getenv("CPT_LONG_TAILS")) P.long_tails = (c.mode == CPT_MODE_SCALARS && !c.has_ncdm && atoi(e) != 0) ? 1 : P.long_tails;
+    const int lanes = (c.has_ncdm ? 13 + 3 * CPT_MAX_NCDM : 14) + (c.l_max_g - 2) + (c.l_max_pol_g - 2) + (c.has_ur ? c.l_max_ur - 2 : 0);
+    P.long_tails = (c.mode == CPT_MODE_SCALARS && lanes > CPT_WAVE) ? 1 : 0;
+    if (const char* e = getenv("CPT_LONG_TAILS")) P.long_tails = (c.mode == CPT_MODE_SCALARS && atoi(e) != 0) ? 1 : P.long_tails;
     P.long_len = max(c.l_max_g - 2, max(c.l_max_pol_g - 2, c.has_ur ? c.l_max_ur - 2 : 0));
   }
   // one tail per 16-lane row when each fits (defaults: 10 / 8 / 15 lanes), else the packed lane map with sequential sweeps

@@ -23,6 +23,7 @@ TABLES_OF = {
     "tca_mb": "tables_lcdm.npz", "long_small": "tables_lcdm.npz", "long_full": "tables_lcdm.npz", "newt_full": "tables_lcdm.npz", "iso_bi_full": "tables_lcdm.npz", "iso_niv_full": "tables_lcdm.npz", "tens_full": "tables_lcdm.npz",
     "curved": "tables_curved.npz", "curved_full": "tables_curved.npz", "tens_curved": "tables_curved.npz", "open": "tables_open.npz",
     "ncdm": "tables_ncdm1.npz", "ncdm_small": "tables_ncdm1.npz", "ncdm_k3000": "tables_ncdm1.npz",
+    "ncdm_permille": "tables_ncdm1.npz", "ncdm_permille_small": "tables_ncdm1.npz",
     "ncdm3": "tables_ncdm3.npz", "ncdm3_small": "tables_ncdm3.npz", "ncdm3_tens": "tables_ncdm3.npz",
 }
 

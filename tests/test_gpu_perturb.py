@@ -9,6 +9,7 @@ import numpy as np
 import pytest
 import torch
 
+import bands
 import oracle_lib
 from classpp_public_amd.inputs import Inputs
 from test_oracle_perturb import check_sources
@@ -88,7 +89,7 @@ def test_perturb_small_all_modes(small):
     print("\n[small] perturb kernel %.3f ms for %d modes, %d steps" % (ms, inp.nk, gs))
 
 
-@pytest.mark.parametrize("cfg", ["lcdm", "explanatory", "iso_cdi", "iso_nid", "newt", "ncdm", "ncdm3", "ncdm_k3000", "long_full"])
+@pytest.mark.parametrize("cfg", ["lcdm", "explanatory", "iso_cdi", "iso_nid", "newt", "ncdm", "ncdm3", "ncdm_k3000", "long_full", "ncdm_permille"])
 def test_perturb_full_size(cfg):
     """BASELINE configs 1-2: every k-mode integrated on the GPU; the 16 golden columns are compared with the reference."""
     from classpp_public_amd.backend import Backend
@@ -99,15 +100,16 @@ def test_perturb_full_size(cfg):
     got = src.cpu().numpy()
     assert np.all(np.isfinite(got))
     ks = inp.d["pt.sources_k_index"]
-    # (long_full: see the note on its three highest k below)
-    check_sources(inp.config, got[:, :, ks], inp.d["pt.sources_subset"], **({"dm_tol": (1e-4, 1e-4)} if cfg == "long_full" else {}))
+    # (long_full, l_max = 50: delta_m / phi+psi within 5e-5 - the reference moves its own by 3.2e-5 when its rtol is halved,
+    #  tests/golden/noise_long_full.npz; tests/bands.py allows twice that)
+    check_sources(inp.config, got[:, :, ks], inp.d["pt.sources_subset"], **({"dm_tol": bands.LONG_DM_BAND} if cfg in ("long_full", "ncdm_permille") else {}))
     if inp.config.index_tp_delta_m >= 0:  # delta_m(k, tau0) for every k: the P(k) input
         dm, ref_dm = got[inp.config.index_tp_delta_m, -1, :], inp.d["pt.delta_m_today"]
         if inp.config.ic == 0:
-            # (long_full: with l_max = 50 the three highest-k modes are only defined to a few 1e-5 - the dense CPU restatement, another
-            #  equally valid step sequence, sits 2.4e-5, 9e-6 and 5e-9 from the reference there, this kernel 8e-6, 1.4e-5 and 5.7e-5; every
-            #  other mode is below 3e-6, the median below 1e-6)
-            assert np.max(np.abs(dm / ref_dm - 1)) < (1e-5 if cfg != "long_full" else 1e-4)
+            # (long_full: 5e-5, see above)
+            err_dm = np.max(np.abs(dm / ref_dm - 1))
+            print("\n[%s] delta_m today vs reference: max %.2e" % (cfg, err_dm))
+            assert err_dm < (1e-5 if cfg not in ("long_full", "ncdm_permille") else bands.LONG_DM_BAND[0])
             assert np.median(np.abs(dm / ref_dm - 1)) < 1e-6
         else:  # isocurvature delta_m(k) changes sign: relative to the column maximum
             assert np.max(np.abs(dm - ref_dm)) < 1e-5 * np.max(np.abs(ref_dm))
@@ -125,7 +127,7 @@ def test_perturb_full_size(cfg):
     scale[scale == 0] = 1
     err = np.max(np.abs(tr[:, ls, :] - want) / scale)
     print("[%s] chained transfer: max err rel. to row max %.2e" % (cfg, err))
-    assert err < 2e-4
+    assert err < bands.transfer_band(cfg), (err, bands.transfer_band(cfg))
     be.close()
 
 
@@ -341,9 +343,9 @@ def test_hierarchies_longer_than_one_wavefront():
     assert not status.any()
     got = src.cpu().numpy()
     assert np.all(np.isfinite(got))
-    # (delta_m, phi + psi: with l_max = 50 two equally valid step sequences differ by a few 1e-5 at the highest k - the dense CPU
-    #  restatement sits 2.4e-5 from the reference on long_full; the default hierarchies are held to 1e-5)
-    check_sources(inp.config, got, inp.d["pt.sources"], dm_tol=(1e-4, 1e-4))
+    # (delta_m, phi + psi: 5e-5 with l_max = 50, twice the move of the reference against itself - tests/golden/noise_long_full.npz;
+    #  the default hierarchies are held to 1e-5)
+    check_sources(inp.config, got, inp.d["pt.sources"], dm_tol=bands.LONG_DM_BAND)
     ks = np.arange(0, inp.nk, 9)
     _, ostats, _, _ = oracle_lib.perturb(inp, k=inp.k[ks])
     gs, os_ = sum(stats[i].steps for i in ks), sum(s.steps for s in ostats)
@@ -508,7 +510,7 @@ def test_row_layout_and_packed_layout_agree(small, monkeypatch):
     check_sources(inp.config, packed.cpu().numpy(), inp.d["pt.sources"])
 
 
-@pytest.mark.parametrize("cfg", ["ncdm_small", "ncdm3_small", "long_small", "ncdm3", "long_full"])
+@pytest.mark.parametrize("cfg", ["ncdm_small", "ncdm3_small", "long_small", "ncdm_permille_small", "ncdm3", "long_full"])
 def test_register_set_kernels_repeat_bit_for_bit(cfg):
     """More than 64 equations per k-mode (momentum bins of massive neutrinos, hierarchies longer than a wavefront): ONE wavefront owns the
     mode and runs ONE copy of the step control (cpt_perturb_sets.inc) - there is no second copy that could drift, no barrier a wave could
@@ -542,3 +544,27 @@ def test_register_set_kernels_repeat_bit_for_bit(cfg):
                 be3.close()
             finally:
                 del os.environ["CPT_SETS_HELPER"]
+
+
+def test_long_hierarchies_with_massive_neutrinos_all_modes():
+    """l_max_g = 25, l_max_pol_g = 20, l_max_ur = 35, l_max_ncdm = 28 with one massive species (pm.cpp:3302-3481 at any l_max, :3412-3440,
+    :8832-8884): 88 photon / ur lanes AND five momentum hierarchies of 29 multipoles - the three l >= 3 tails and three momentum-bin sets
+    beside the core set of the one wavefront per k-mode; after the ncdm fluid switch the fluids join the core while the tails stay sets.
+    Every mode and every source type against the reference's full table; step counts against the dense CPU restatement."""
+    from classpp_public_amd.backend import Backend
+    inp = Inputs("ncdm_permille_small")
+    c = inp.config
+    assert (c.l_max_g, c.l_max_pol_g, c.l_max_ur, c.l_max_ncdm, c.N_ncdm) == (25, 20, 35, 28, 1)
+    be = Backend(inp)
+    src, stats, status = be.perturb_solve()
+    assert not status.any()
+    got = src.cpu().numpy()
+    assert np.all(np.isfinite(got))
+    check_sources(c, got, inp.d["pt.sources"], dm_tol=bands.LONG_DM_BAND)
+    ks = np.arange(0, inp.nk, 9)
+    _, ostats, _, _ = oracle_lib.perturb(inp, k=inp.k[ks])
+    gs, os_ = sum(stats[i].steps for i in ks), sum(s.steps for s in ostats)
+    assert abs(gs - os_) < 0.02 * os_, (gs, os_)
+    ms, n = be.kernel_ms(0)
+    print("\n[ncdm_permille_small] perturb kernel %.1f ms for %d modes, %d steps" % (ms, inp.nk, sum(s.steps for s in stats)))
+    be.close()

@@ -22,7 +22,7 @@ def main():
     if "--tu" in sys.argv:
         tus = [a for a in sys.argv[sys.argv.index("--tu") + 1:] if not a.startswith("-")]
         defines = [a for a in defines if a != "--tu"]
-    tus = tus or ["cpt_perturb_sets_tails.hip", "cpt_perturb_sets_bins2.hip", "cpt_perturb_sets_bins5.hip"]
+    tus = tus or ["cpt_perturb_sets_tails.hip", "cpt_perturb_sets_bins2.hip", "cpt_perturb_sets_bins5.hip", "cpt_perturb_sets_both3.hip"]
     bdir = os.path.join(CSRC, "build", "alt_" + tag)
     os.makedirs(bdir, exist_ok=True)
     jobs, objs = [], []
