@@ -245,6 +245,24 @@ class Backend:
         self._check((self.lib.cpt_sigma_cb if cb else self.lib.cpt_sigma)(self.h, C.byref(self.inp.spectra), _dptr(k), k.size, float(R), float(k_per_decade), C.byref(out)))
         return out.value
 
+    def pk_at_tau(self, tau_z, ln_tau_size, k=None, cb=False):
+        """linear P(k, z) of the redshift whose conformal time is tau_z (0 < z <= z_max_pk): spline in ln tau over the last ln_tau_size sampling
+        times, on the device (cpt_pk_at_tau); the sources must be those of this handle's last perturb_solve / step"""
+        k = np.ascontiguousarray(self.inp.k if k is None else k, dtype=np.float64)
+        out = torch.empty(k.size, dtype=torch.float64, device=self.device)
+        self._fence()
+        self._check(self.lib.cpt_pk_at_tau(self.h, C.byref(self.inp.spectra), _dptr(k), k.size, int(ln_tau_size), float(tau_z), int(bool(cb)), C.c_void_p(out.data_ptr())))
+        return out
+
+    def sigma_at_tau(self, R, tau_z, ln_tau_size, k=None, k_per_decade=80.0, cb=False):
+        """sigma(R [Mpc], z) of the linear matter field at the redshift whose conformal time is tau_z (cpt_sigma_at_tau)"""
+        k = np.ascontiguousarray(self.inp.k if k is None else k, dtype=np.float64)
+        out = C.c_double()
+        self._fence()
+        self._check(self.lib.cpt_sigma_at_tau(self.h, C.byref(self.inp.spectra), _dptr(k), k.size, int(ln_tau_size), float(tau_z), int(bool(cb)), float(R),
+                                              float(k_per_decade), C.byref(out)))
+        return out.value
+
     def get_sources(self, ntau, nk):
         out = torch.empty((self.inp.config.tp_size, ntau, nk), dtype=torch.float64, device=self.device)
         self._fence()

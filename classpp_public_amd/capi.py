@@ -106,7 +106,7 @@ EXPORTS = [
     "cpt_create", "cpt_destroy", "cpt_last_error", "cpt_create_error", "cpt_perturb_solve_batch",
     "cpt_transfer_batch", "cpt_get_sources", "cpt_last_kernel_ms", "cpt_last_transfer_work",
     "cpt_dbg_lookup", "cpt_dbg_derivs", "cpt_dbg_solve", "cpt_dbg_bessel", "cpt_cl_batch", "cpt_cl_cross_batch", "cpt_sigma_of_pk", "cpt_pk_linear", "cpt_sigma", "cpt_pk_cb_linear", "cpt_sigma_cb",
-    "cpt_lensing_l_size", "cpt_lensing_batch", "cpt_step",
+    "cpt_lensing_l_size", "cpt_lensing_batch", "cpt_step", "cpt_pk_at_tau", "cpt_sigma_at_tau",
     "cpt_comm_get_unique_id", "cpt_comm_init", "cpt_comm_destroy", "cpt_allgather_sources", "cpt_gather_transfer",
     "cpt_dbg_pad_rows", "cpt_dbg_uninterleave",
 ]
@@ -160,6 +160,10 @@ def lib():
     L.cpt_pk_cb_linear.restype = _i
     L.cpt_sigma_cb.argtypes = L.cpt_sigma.argtypes
     L.cpt_sigma_cb.restype = _i
+    L.cpt_pk_at_tau.argtypes = [vp, C.POINTER(CptSpectraParams), _pd, _i, _i, _d, _i, vp]
+    L.cpt_pk_at_tau.restype = _i
+    L.cpt_sigma_at_tau.argtypes = [vp, C.POINTER(CptSpectraParams), _pd, _i, _i, _d, _i, _d, _d, C.POINTER(_d)]
+    L.cpt_sigma_at_tau.restype = _i
     L.cpt_lensing_l_size.argtypes = [pi, _i, C.POINTER(CptLensingParams)]
     L.cpt_lensing_l_size.restype = _i
     L.cpt_lensing_batch.argtypes = [vp, C.POINTER(CptSpectraParams), C.POINTER(CptLensingParams), pi, _i, vp, vp]

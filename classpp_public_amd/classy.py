@@ -133,8 +133,14 @@ def build_parameters(pars, mode, ic="ad"):
     ics_all = initial_conditions(pars)
     if ic not in ics_all and mode == "s":
         raise CosmoSevereError("initial condition %s is not among ic = %s" % (ic, ",".join(ics_all)))
-    if num("z_pk", 0.) != 0. or num("z_max_pk", 0.) != 0.:
-        raise CosmoSevereError("P(k) at z = 0 only")
+    # z_max_pk: given, else the largest entry of the z_pk list (input_module.cpp:2715-2749)
+    try:
+        z_pk = [float(x) for x in str(pars.get("z_pk", "0")).replace("[", "").replace("]", "").split(",") if str(x).strip() != ""]
+    except ValueError:
+        raise CosmoSevereError("could not read a list of numbers for 'z_pk' (got %r)" % (pars.get("z_pk"),))
+    z_max_pk = num("z_max_pk", max(z_pk + [0.]))
+    if z_max_pk < 0. or min(z_pk + [0.]) < 0.:
+        raise CosmoSevereError("asked for negative redshift z=%e" % min(z_pk + [z_max_pk]))
     for a, b in (("h", "H0"), ("omega_b", "Omega_b"), ("omega_cdm", "Omega_cdm"), ("z_reio", "tau_reio"), ("A_s", "ln10^{10}A_s"),
                  ("N_ur", "N_eff"), ("P_k_max_h/Mpc", "P_k_max_1/Mpc")):
         if a in pars and b in pars:
@@ -228,7 +234,7 @@ def build_parameters(pars, mode, ic="ad"):
         kmax = num("P_k_max_1/Mpc", 1.)
     else:
         kmax = 1.
-    d["ppt.k_max_for_pk"] = _arr(kmax); d["ppt.z_max_pk"] = _arr(0.)
+    d["ppt.k_max_for_pk"] = _arr(kmax); d["ppt.z_max_pk"] = _arr(z_max_pk)
     for f in ("switch_sw", "switch_eisw", "switch_lisw", "switch_dop", "switch_pol"):
         d["ppt." + f] = _arr(1, True)
     d["ppt.eisw_lisw_split_z"] = _arr(120.); d["ppt.three_ceff2_ur"] = _arr(1.); d["ppt.three_cvis2_ur"] = _arr(1.); d["ppt.G_eff_ur"] = _arr(0.)
@@ -564,18 +570,47 @@ class Class:
         return out.value
 
     def pk_lin(self, k, z=0.):
-        """linear total-matter P(k) [Mpc^3] at k [1/Mpc], z = 0: natural cubic spline of ln P in ln k over the k grid
-        (nonlinear_module.cpp:2041-2212 nonlinear_pk_at_k_and_z)"""
-        if z != 0.:
-            raise CosmoSevereError("P(k) at z = 0 only")
+        """linear total-matter P(k, z) [Mpc^3] at k [1/Mpc], 0 <= z <= z_max_pk: natural cubic spline of ln P in ln k over the k grid
+        (nonlinear_module.cpp:2041-2212 nonlinear_pk_at_k_and_z; z > 0: the spline in ln tau of nonlinear_pk_at_z first)"""
         r = self._pk_run()
         kk = r.inp.k
         if not (kk[0] <= k <= kk[-1]):
             raise CosmoSevereError("k=%e out of bounds [%e:%e]" % (k, kk[0], kk[-1]))
-        if "lnpk" not in self._cache:
+        key = ("lnpk", float(z))
+        if key not in self._cache:
             from scipy.interpolate import CubicSpline
-            self._cache["lnpk"] = CubicSpline(np.log(kk), np.log(self._pk_total()), bc_type="natural")
-        return float(np.exp(self._cache["lnpk"](np.log(k))))
+            self._cache[key] = CubicSpline(np.log(kk), np.log(self._pk_total() if z == 0. else self._pk_at_z(z)), bc_type="natural")
+        return float(np.exp(self._cache[key](np.log(k))))
+
+    def _late_times(self, z):
+        """(tau(z), ln_tau_size) for 0 < z <= z_max_pk: the redshift's conformal time and the length of the tail of the sampling the sources
+        were kept on (pm.cpp:1554-1592; nonlinear_module.cpp:129-146 for the two errors)"""
+        from . import hostlib
+        r = self._pk_run()
+        if z < 0.:
+            raise CosmoSevereError("asked for negative redshift z=%e" % z)
+        zmax = float(r.inp.d["ppt.z_max_pk"][0])
+        if zmax == 0.:
+            raise CosmoComputationError("You are asking for the matter power spectrum at z=%e but the code was asked to store it only at z=0. You probably "
+                                        "forgot to pass the input parameter z_max_pk (see explanatory.ini)" % z)
+        if "ln_tau_size" not in self._cache:
+            self._cache["ln_tau_size"] = hostlib.ln_tau_size(r.inp.tau, hostlib.tau_of_z(r.inp, zmax))
+        return hostlib.tau_of_z(r.inp, z), self._cache["ln_tau_size"]
+
+    def _pk_at_z(self, z):
+        """linear P(k, z) on the k grid, 0 < z <= z_max_pk: ln P(k, tau_i) splined in ln tau over the tail of the sampling, on the device
+        (Backend.pk_at_tau / cpt_pk_at_tau; NonlinearModule::nonlinear_pk_at_z)"""
+        if len(self._ics) != 1:
+            raise CosmoSevereError("P(k, z > 0) with several correlated initial conditions is outside this package")
+        r = self._pk_run()
+        key = ("pk_z", float(z))
+        if key not in self._cache:
+            tau_z, n = self._late_times(z)
+            try:
+                self._cache[key] = r.be.pk_at_tau(tau_z, n).cpu().numpy()
+            except Exception as e:
+                raise CosmoComputationError(str(e))
+        return self._cache[key]
 
     pk = pk_lin
 
@@ -590,12 +625,18 @@ class Class:
         return self._pk_total().copy(), r.inp.k.copy()
 
     def sigma(self, R, z=0.):
-        if z != 0.:
-            raise CosmoSevereError("sigma(R, z) at z = 0 only")
         r = self._pk_run()
         if float(r.inp.d["ppt.k_max_for_pk"][0]) < self.h():
             raise CosmoSevereError("In order to get sigma(R,z) you must set 'P_k_max_h/Mpc' to 1 or bigger, in order to have k_max > 1 h/Mpc.")
-        return self._sigma_total(R)
+        if z == 0.:
+            return self._sigma_total(R)
+        if len(self._ics) != 1:
+            raise CosmoSevereError("sigma(R, z > 0) with several correlated initial conditions is outside this package")
+        tau_z, n = self._late_times(z)   # (classy.pyx:644-676 -> nonlinear_sigmas_at_z, nonlinear_module.cpp:927-963)
+        try:
+            return r.be.sigma_at_tau(float(R), tau_z, n)
+        except Exception as e:
+            raise CosmoComputationError(str(e))
 
     def sigma8(self):
         """the nonlinear module's sigma8_ (no k_max check here, classy.pyx:805-809)"""

@@ -338,6 +338,7 @@ void cpt_destroy(cpt_handle* h) {
   if (h->d_xrecv) (void)hipFree(h->d_xrecv);
   if (h->d_clw) (void)hipFree(h->d_clw);
   if (h->d_pk_k) (void)hipFree(h->d_pk_k);
+  if (h->d_pkz) (void)hipFree(h->d_pkz);
   cpt_pin_reset(h);
   if (h->pin) (void)hipHostFree(h->pin);
   if (h->pin_out) (void)hipHostFree(h->pin_out);
@@ -436,6 +437,21 @@ int cpt_pk_cb_linear(cpt_handle* h, const cpt_spectra_params* sp, const double* 
   int rc = cpt_pk_impl(h, sp, k, nk, pk_dev, 1);
   if (rc) { (void)hipStreamSynchronize(h->stream); return rc; }
   return cpt_finish(h);
+}
+
+int cpt_pk_at_tau(cpt_handle* h, const cpt_spectra_params* sp, const double* k, int nk, int ln_tau_size, double tau_z, int cb, double* pk_dev) {
+  CPT_ENTER(h);
+  if (!sp || !k || !pk_dev || nk < 1 || !(tau_z > 0.)) return cpt_fail(h, CPT_ERR_INVALID, "bad arguments to cpt_pk_at_tau");
+  int rc = cpt_pk_at_tau_impl(h, sp, k, nk, ln_tau_size, tau_z, cb, pk_dev);
+  if (rc) { (void)hipStreamSynchronize(h->stream); return rc; }
+  return cpt_finish(h);
+}
+
+int cpt_sigma_at_tau(cpt_handle* h, const cpt_spectra_params* sp, const double* k, int nk, int ln_tau_size, double tau_z, int cb, double R, double k_per_decade,
+                     double* sigma) {
+  CPT_ENTER(h);
+  if (!sp || !k || !sigma || nk < 3 || !(R >= 0.) || !(k_per_decade > 0.) || !(tau_z > 0.)) return cpt_fail(h, CPT_ERR_INVALID, "bad arguments to cpt_sigma_at_tau");
+  return cpt_sigma_at_tau_impl(h, sp, k, nk, ln_tau_size, tau_z, cb, R, k_per_decade, sigma);
 }
 
 int cpt_lensing_l_size(const int* l, int nl, const cpt_lensing_params* lp) {

@@ -122,6 +122,8 @@ struct cpt_handle {
   std::vector<double> geo_cl_q; double geo_cl_sp[4] = {0, 0, 0, 0}; bool geo_cl_valid = false;
   double* d_pk_k = nullptr;
   size_t pk_k_cap = 0;
+  double* d_pkz = nullptr;          // scratch of the P(k, z) spline in ln tau, [2][ln_tau_size][nk]
+  size_t pkz_cap = 0;
   // multi-GPU (cpt_comm.hip): RCCL communicator of this rank (null: single GPU) and the padded exchange buffers
   void* comm = nullptr;
   int comm_rank = 0, comm_world = 1;
@@ -181,6 +183,9 @@ double cpt_sigma_of_R(const double* k, const double* pk, int nk, double R, doubl
 int cpt_cl_impl(cpt_handle* h, const cpt_spectra_params* sp, const double* transfer_dev, const double* q, int nq, int nl,
                 double* cl_dev, const double* transfer2_dev = nullptr);
 int cpt_pk_impl(cpt_handle* h, const cpt_spectra_params* sp, const double* k, int nk, double* pk_dev, int cb);
+int cpt_pk_at_tau_impl(cpt_handle* h, const cpt_spectra_params* sp, const double* k, int nk, int ln_tau_size, double tau_z, int cb, double* pk_dev);
+int cpt_sigma_at_tau_impl(cpt_handle* h, const cpt_spectra_params* sp, const double* k, int nk, int ln_tau_size, double tau_z, int cb, double R,
+                          double k_per_decade, double* sigma);
 int cpt_sigma_impl(cpt_handle* h, const cpt_spectra_params* sp, const double* k, int nk, double R, double k_per_decade, double* sigma, int cb);
 int cpt_dbg_lookup_impl(cpt_handle* h, const double* tau, int n, double* out);
 int cpt_dbg_derivs_impl(cpt_handle* h, double k, double tau, int tca_on, int rsa_on, int ufa_on, const double* y,

@@ -145,6 +145,51 @@ __global__ void k_pk(const double* __restrict__ src, const double* __restrict__ 
   pk[i] = 2. * PI * PI / (k[i] * k[i] * k[i]) * dm * dm * pr;  // nonlinear_module.cpp:1952-1991
 }
 
+// linear P(k, z) at 0 < z <= z_max_pk: one thread per k.  ln P(k, tau_j) at the last n sampling times (the tail ln_tau_ of the sampling,
+// pm.cpp:1554-1592; P from the delta_m source as in k_pk, nonlinear_module.cpp:1952-1991) is splined in ln tau with estimated end
+// derivatives (array_spline_table_lines / _SPLINE_EST_DERIV_, tools/arrays.c:261-353) and evaluated at ln tau(z)
+// (NonlinearModule::nonlinear_pk_at_z, nonlinear_module.cpp:81-283).  u, dd: scratch [n][nk] (thread i walks column i: coalesced).
+__global__ void k_pk_z(const double* __restrict__ src, const double* __restrict__ k, const double* __restrict__ tau, double* __restrict__ pk, double* __restrict__ u,
+                       double* __restrict__ dd, int nk, int ntau, int n, int tp_dm, double ln_tau_z, double A_s, double n_s, double alpha_s, double k_pivot) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nk) return;
+  const double PI = 3.1415926535897932384626433832795e0;
+  const double lk = log(k[i] / k_pivot);
+  const double ln_amp = log(2. * PI * PI / (k[i] * k[i] * k[i]) * A_s) + (n_s - 1.) * lk + 0.5 * alpha_s * lk * lk;
+  const double* col = src + ((size_t)tp_dm * nk + i) * ntau + (ntau - n);   // resident sources are k-major: [tp][k][tau]
+  const double* t = tau + (ntau - n);
+  auto X = [&](int j) { return log(t[j]); };
+  auto Y = [&](int j) { const double dm = col[j]; return ln_amp + log(dm * dm); };
+  if (n < 3) { pk[i] = exp(Y(n - 1)); return; }
+  {
+    const double x0 = X(0), x1 = X(1), x2 = X(2), y0 = Y(0), y1 = Y(1), y2 = Y(2);
+    const double dy_first = ((x2 - x0) * (x2 - x0) * (y1 - y0) - (x1 - x0) * (x1 - x0) * (y2 - y0)) / ((x2 - x0) * (x1 - x0) * (x2 - x1));
+    dd[i] = -0.5;
+    u[i] = (3. / (x1 - x0)) * ((y1 - y0) / (x1 - x0) - dy_first);
+  }
+  for (int j = 1; j < n - 1; j++) {
+    const double xm = X(j - 1), x = X(j), xp = X(j + 1), ym = Y(j - 1), y = Y(j), yp = Y(j + 1);
+    const double sig = (x - xm) / (xp - xm);
+    const double p = sig * dd[(size_t)(j - 1) * nk + i] + 2.0;
+    dd[(size_t)j * nk + i] = (sig - 1.0) / p;
+    double uj = (yp - y) / (xp - x) - (y - ym) / (x - xm);
+    uj = (6.0 * uj / (xp - xm) - sig * u[(size_t)(j - 1) * nk + i]) / p;
+    u[(size_t)j * nk + i] = uj;
+  }
+  {
+    const double xa = X(n - 3), xb = X(n - 2), xc = X(n - 1), ya = Y(n - 3), yb = Y(n - 2), yc = Y(n - 1);
+    const double dy_last = ((xa - xc) * (xa - xc) * (yb - yc) - (xb - xc) * (xb - xc) * (ya - yc)) / ((xa - xc) * (xb - xc) * (xa - xb));
+    const double qn = 0.5, un = (3. / (xc - xb)) * (dy_last - (yc - yb) / (xc - xb));
+    dd[(size_t)(n - 1) * nk + i] = (un - qn * u[(size_t)(n - 2) * nk + i]) / (qn * dd[(size_t)(n - 2) * nk + i] + 1.0);
+  }
+  for (int j = n - 2; j >= 0; j--) dd[(size_t)j * nk + i] = dd[(size_t)j * nk + i] * dd[(size_t)(j + 1) * nk + i] + u[(size_t)j * nk + i];
+  // array_interpolate_spline at ln tau(z) (wave-uniform interval)
+  int inf = 0, sup = n - 1;
+  while (sup - inf > 1) { const int mid = (int)(0.5 * (inf + sup)); if (ln_tau_z < X(mid)) sup = mid; else inf = mid; }
+  const double h = X(sup) - X(inf), b = (ln_tau_z - X(inf)) / h, a = 1. - b;
+  pk[i] = exp(a * Y(inf) + b * Y(sup) + ((a * a * a - a) * dd[(size_t)inf * nk + i] + (b * b * b - b) * dd[(size_t)sup * nk + i]) * h * h / 6.);
+}
+
 int cpt_cl_impl(cpt_handle* h, const cpt_spectra_params* sp, const double* transfer_dev, const double* q, int nq, int nl,
                 double* cl_dev, const double* transfer2_dev) {
   const cpt_config& c = h->cfg;
@@ -292,5 +337,53 @@ int cpt_pk_impl(cpt_handle* h, const cpt_spectra_params* sp, const double* k, in
   hipLaunchKernelGGL(k_pk, dim3((nk + 63) / 64), dim3(64), 0, h->stream, h->d_src, h->d_pk_k, pk_dev, nk, h->src_ntau,
                      tp, sp->A_s, sp->n_s, sp->alpha_s, sp->k_pivot);
   CPT_HIP(h, hipGetLastError());
+  return CPT_OK;
+}
+
+// P(k, z) from the resident sources: see k_pk_z.  tau_z: conformal time of the redshift; ln_tau_size: length of the tail of the sampling that
+// covers 0 <= z <= z_max_pk (cpt_host_ln_tau_size / PerturbationsModule::ln_tau_size_)
+int cpt_pk_at_tau_impl(cpt_handle* h, const cpt_spectra_params* sp, const double* k, int nk, int ln_tau_size, double tau_z, int cb, double* pk_dev) {
+  const cpt_config& c = h->cfg;
+  const int tp = cb ? c.index_tp_delta_cb : c.index_tp_delta_m;
+  if (cb && !c.has_ncdm) return cpt_fail(h, CPT_ERR_INVALID, "P_cb(k) is only defined with non-cold species (has_pk_cb, nonlinear_module.cpp:1749)");
+  if (tp < 0) return cpt_fail(h, CPT_ERR_INVALID, "P(k) requested but %s was not among the source types", cb ? "delta_cb" : "delta_m");
+  if (!h->d_src || h->src_nk != nk) return cpt_fail(h, CPT_ERR_INVALID, "no resident sources for %d k-modes: run cpt_perturb_solve_batch first", nk);
+  const int ntau = h->src_ntau;
+  if (!h->geo_pt_valid || (int)h->geo_pt_tau.size() != ntau || (int)h->geo_pt_k.size() != nk)
+    return cpt_fail(h, CPT_ERR_INVALID, "P(k, z) needs the sampling times of the resident sources: they were not left by cpt_perturb_solve_batch / cpt_step on this handle");
+  if (ln_tau_size < 2 || ln_tau_size > ntau)
+    return cpt_fail(h, CPT_ERR_INVALID, "You are asking for the matter power spectrum at z > 0 but the sources were only stored for z = 0 (ln_tau_size = %d). "
+                                        "You probably forgot to pass the input parameter z_max_pk (nonlinear_module.cpp:129-131)", ln_tau_size);
+  const double* ts = h->geo_pt_tau.data() + (ntau - ln_tau_size);
+  double ln_tau = log(tau_z);
+  const double lo = log(ts[0]), hi = log(ts[ln_tau_size - 1]), EPS = 1e-10;
+  if (ln_tau < lo - EPS)
+    return cpt_fail(h, CPT_ERR_INVALID, "requested z was not inside of tau tabulation range (Requested ln(tau_=%.10e, Min %.10e). Solution might be to increase input "
+                                        "parameter z_max_pk (nonlinear_module.cpp:144-146)", ln_tau, lo);
+  if (ln_tau > hi + EPS) return cpt_fail(h, CPT_ERR_INVALID, "requested z was not inside of tau tabulation range (Requested ln(tau_=%.10e, Max %.10e)", ln_tau, hi);
+  ln_tau = fmin(fmax(ln_tau, lo), hi);
+  int rc;
+  if ((rc = cpt_reserve(h, &h->d_pk_k, &h->pk_k_cap, (size_t)nk))) return rc;
+  if ((rc = cpt_upload(h, h->d_pk_k, k, nk * sizeof(double)))) return rc;
+  if ((rc = cpt_reserve(h, &h->d_pkz, &h->pkz_cap, (size_t)2 * ln_tau_size * nk))) return rc;
+  const double* d_tau = (const double*)h->d_pt_scratch + nk;   // (cpt_perturb_impl: k[nk] tau[ntau] | ...)
+  hipLaunchKernelGGL(k_pk_z, dim3((nk + 63) / 64), dim3(64), 0, h->stream, h->d_src, h->d_pk_k, d_tau, pk_dev, h->d_pkz, h->d_pkz + (size_t)ln_tau_size * nk, nk, ntau,
+                     ln_tau_size, tp, ln_tau, sp->A_s, sp->n_s, sp->alpha_s, sp->k_pivot);
+  CPT_HIP(h, hipGetLastError());
+  return CPT_OK;
+}
+
+int cpt_sigma_at_tau_impl(cpt_handle* h, const cpt_spectra_params* sp, const double* k, int nk, int ln_tau_size, double tau_z, int cb, double R, double k_per_decade,
+                          double* sigma) {
+  double* d_pk = nullptr;
+  CPT_HIP(h, hipMalloc((void**)&d_pk, nk * sizeof(double)));
+  int rc = cpt_pk_at_tau_impl(h, sp, k, nk, ln_tau_size, tau_z, cb, d_pk);
+  if (!rc && hipStreamSynchronize(h->stream) != hipSuccess) rc = cpt_fail(h, CPT_ERR_NO_DEVICE, "hipStreamSynchronize failed");
+  std::vector<double> pk(nk);
+  if (!rc && hipMemcpy(pk.data(), d_pk, nk * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) rc = cpt_fail(h, CPT_ERR_NO_DEVICE, "hipMemcpy of P(k) failed");
+  (void)hipFree(d_pk);
+  if (rc) return rc;
+  for (int i = 0; i < nk; i++) if (!(pk[i] > 0.)) return cpt_fail(h, CPT_ERR_RUNTIME, "P(k) is not positive at k[%d]", i);
+  *sigma = cpt_sigma_of_R(k, pk.data(), nk, R, k_per_decade);
   return CPT_OK;
 }

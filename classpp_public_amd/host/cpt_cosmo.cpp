@@ -241,6 +241,17 @@ int cpt_host_background(const cpt_cosmo_params* pp, cpt_background* out) {
   return CPT_OK;
 }
 
+// the same from the two columns alone (a table handed over without its second derivatives: they are rebuilt as background_solve does,
+// array_spline_table_lines with estimated end derivatives, source/background_module.cpp:1478-1487)
+int cpt_host_tau_of_z_from_table(const double* z_table, const double* tau_table, int n, double z, double* tau) {
+  if (!z_table || !tau_table || !tau || n < 4) return fail_msg(CPT_ERR_INVALID, "bad arguments to cpt_host_tau_of_z_from_table");
+  if (z < z_table[n - 1] || z > z_table[0]) return fail_msg(CPT_ERR_INVALID, "out of range: z=%e outside [%e, %e]", z, z_table[n - 1], z_table[0]);
+  std::vector<double> d2(n);
+  spline_table_lines(z_table, n, tau_table, 1, d2.data());
+  if (interpolate_spline(z_table, n, tau_table, d2.data(), 1, z, tau)) return fail_msg(CPT_ERR_INVALID, "tau(z): interpolation failed");
+  return CPT_OK;
+}
+
 int cpt_host_background_tau_of_z(const cpt_background* bg, double z, double* tau) {
   if (z < bg->z_table[bg->bt_size - 1] || z > bg->z_table[0]) return fail_msg(CPT_ERR_INVALID, "out of range: z=%e outside [%e, %e]", z, bg->z_table[bg->bt_size - 1], bg->z_table[0]);
   if (interpolate_spline(bg->z_table, bg->bt_size, bg->tau_table, bg->d2tau_dz2_table, 1, z, tau)) return fail_msg(CPT_ERR_INVALID, "tau(z): interpolation failed");

@@ -133,6 +133,21 @@ int cpt_host_k_list(const cpt_config* c, const cpt_grid_params* g, double* k_out
   return CPT_OK;
 }
 
+// pm.cpp:1554-1592
+int cpt_host_ln_tau_size(const double* tau, int tau_size, double tau_lower, int* ln_tau_size) {
+  if (!tau || !ln_tau_size || tau_size < 1) return fail("bad arguments to cpt_host_ln_tau_size");
+  if (!(tau_lower > 0.)) { *ln_tau_size = 1; return CPT_OK; }
+  if (tau_lower <= tau[0])
+    return fail("you asked for z_max_pk with taumin=%e, smaller than or equal to the first possible value =%e; it should be strictly bigger for a successfull "
+                "interpolation", tau_lower, tau[0]);
+  int index_tau = 0;
+  while (index_tau < tau_size && tau[index_tau] < tau_lower) index_tau++;
+  index_tau--;
+  for (int extra = 0; extra < 4; extra++) if (index_tau > 0) index_tau--;   // a few more values against boundary effects of the interpolation
+  *ln_tau_size = tau_size - index_tau;
+  return CPT_OK;
+}
+
 // pm.cpp:1247-1533 (has_cmb branch)
 int cpt_host_tau_sampling(const cpt_config* c, const cpt_tables* t, const cpt_grid_params* g, double* tau_out, int cap,
                           int* tau_size) {

@@ -105,7 +105,13 @@ PerturbationsModule::PerturbationsModule(const Inputs& in) {
   if (rc) { snprintf(error_message_, sizeof(error_message_), "%s", cpt_host_error()); raise(rc, error_message_); }
   tau_sampling_ = xalloc<double>(tau_size_);
   memcpy(tau_sampling_, tmp.data(), sizeof(double) * tau_size_);
-  ln_tau_size_ = 1;  // z_max_pk = 0 (pm.cpp:1554-1556)
+  // the tail of the sampling kept for P(k, z) at 0 <= z <= z_max_pk (pm.cpp:1554-1592)
+  rc = cpt_host_ln_tau_size(tau_sampling_, tau_size_, in.grid.tau_of_z_max_pk, &ln_tau_size_);
+  if (rc) { snprintf(error_message_, sizeof(error_message_), "%s", cpt_host_error()); raise(rc, error_message_); }
+  if (ln_tau_size_ > 1) {
+    ln_tau_ = xalloc<double>(ln_tau_size_);
+    for (int i = 0; i < ln_tau_size_; i++) ln_tau_[i] = log(tau_sampling_[i - ln_tau_size_ + tau_size_]);
+  }
   k_min_ = 1e300; k_max_ = 0.;
   for (int md = 0; md < md_size_; md++) {
     const cpt_config& cm = (md == 0) ? c0 : in.config_tensors;
@@ -177,7 +183,7 @@ PerturbationsModule::~PerturbationsModule() {
     free(sources_);
   }
   if (k_) { for (int md = 0; md < md_size_; md++) free(k_[md]); free(k_); }
-  free(k_size_); free(k_size_cl_); free(k_size_cmb_); free(tau_sampling_); free(ic_size_); free(tp_size_); free(stats_);
+  free(k_size_); free(k_size_cl_); free(k_size_cmb_); free(tau_sampling_); free(ln_tau_); free(ic_size_); free(tp_size_); free(stats_);
   for (auto& row : h_) for (cpt_handle* h : row) cpt_destroy(h);
 }
 

@@ -21,7 +21,7 @@ class CptGridParams(C.Structure):
         ("k_max_for_pk", _d), ("rs_rec", _d), ("tau_ini_thermo", _d),
         ("start_sources_at_tau_c_over_tau_h", _d), ("perturb_sampling_stepsize", _d),
         ("l_linstep", _d), ("l_logstep", _d), ("q_linstep", _d), ("q_logstep_spline", _d), ("q_logstep_open", _d),
-        ("l_tensor_max", _i), ("q_logstep_trapzd", _d), ("q_numstep_transition", _d),
+        ("l_tensor_max", _i), ("q_logstep_trapzd", _d), ("q_numstep_transition", _d), ("tau_of_z_max_pk", _d),
     ]
 
 
@@ -89,6 +89,8 @@ def lib():
         L.cpt_host_background_free.argtypes = [C.POINTER(CptBackground)]
         L.cpt_host_background_free.restype = None
         L.cpt_host_background_tau_of_z.argtypes = [C.POINTER(CptBackground), _d, _pdd]
+        L.cpt_host_tau_of_z_from_table.argtypes = [pd, pd, _i, _d, pd]
+        L.cpt_host_ln_tau_size.argtypes = [pd, _i, _d, pi]
         L.cpt_host_ncdm_defaults.argtypes = [C.POINTER(CptNcdmParams)]
         L.cpt_host_ncdm_defaults.restype = None
         L.cpt_host_ncdm.argtypes = [C.POINTER(CptNcdmParams), C.POINTER(CptNcdm)]
@@ -182,6 +184,22 @@ def tau_sampling(inp, g=None):
     _check(lib().cpt_host_tau_sampling(C.byref(inp.config), C.byref(inp.tables), C.byref(g), out.ctypes.data_as(C.POINTER(_d)),
                                        out.size, C.byref(n)))
     return out[: n.value].copy()
+
+
+def tau_of_z(inp, z):
+    """conformal time of redshift z from the background table of `inp` (BackgroundModule::background_tau_of_z)"""
+    zt = np.ascontiguousarray(inp.t["bg.z_table"], dtype=np.float64); tt = np.ascontiguousarray(inp.t["bg.tau_table"], dtype=np.float64)
+    out = _d()
+    _check(lib().cpt_host_tau_of_z_from_table(zt.ctypes.data_as(C.POINTER(_d)), tt.ctypes.data_as(C.POINTER(_d)), zt.size, float(z), C.byref(out)))
+    return out.value
+
+
+def ln_tau_size(tau, tau_of_z_max_pk):
+    """length of the tail of the sampling kept for P(k, 0 <= z <= z_max_pk) (pm.cpp:1554-1592); 1 when tau_of_z_max_pk <= 0"""
+    tau = np.ascontiguousarray(tau, dtype=np.float64)
+    n = _i()
+    _check(lib().cpt_host_ln_tau_size(tau.ctypes.data_as(C.POINTER(_d)), tau.size, float(tau_of_z_max_pk), C.byref(n)))
+    return n.value
 
 
 def l_list(inp, g=None):

@@ -253,6 +253,15 @@ int cpt_sigma_of_pk(const double* k, const double* pk, int nk, double R, double 
 int cpt_pk_cb_linear(cpt_handle* h, const cpt_spectra_params* sp, const double* k, int nk, double* pk_dev);
 int cpt_sigma_cb(cpt_handle* h, const cpt_spectra_params* sp, const double* k, int nk, double R, double k_per_decade, double* sigma);
 
+/* linear P(k, z) and sigma(R, z) at 0 < z <= z_max_pk from the resident sources.  ln P(k, tau_i) at the last `ln_tau_size` sampling times
+ * (PerturbationsModule::ln_tau_ / ln_tau_size_, pm.cpp:1554-1592; cpt_host_ln_tau_size in cpt_host.h) is splined in ln tau with estimated end
+ * derivatives and evaluated at ln tau_z on the device (NonlinearModule::nonlinear_pk_at_z, nonlinear_module.cpp:81-283, :1136-1190;
+ * nonlinear_sigmas_at_z :927-963).  tau_z: conformal time of the redshift (BackgroundModule::background_tau_of_z, cpt_host_background_tau_of_z);
+ * cb != 0: baryons + cold dark matter only.  The sources must be those of the handle's last cpt_perturb_solve_batch / cpt_step.  pk_dev device [nk]. */
+int cpt_pk_at_tau(cpt_handle* h, const cpt_spectra_params* sp, const double* k, int nk, int ln_tau_size, double tau_z, int cb, double* pk_dev);
+int cpt_sigma_at_tau(cpt_handle* h, const cpt_spectra_params* sp, const double* k, int nk, int ln_tau_size, double tau_z, int cb, double R, double k_per_decade,
+                     double* sigma);
+
 /* ---- CMB lensing of the C_l's (LensingModule::lensing_init, source/lensing_module.cpp:149-854) ----
  * precision parameters of include/precisions.h:492-495 plus SpectraModule::l_max_tot_ */
 typedef struct cpt_lensing_params {

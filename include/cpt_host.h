@@ -32,6 +32,8 @@ typedef struct cpt_grid_params {
   /* appended: tensors (one mode per handle) and closed space */
   int l_tensor_max;
   double q_logstep_trapzd, q_numstep_transition;
+  /* appended: P(k, z > 0).  Conformal time of ppt->z_max_pk (BackgroundModule::background_tau_of_z); 0 = z_max_pk is 0: sources kept for z = 0 only */
+  double tau_of_z_max_pk;
 } cpt_grid_params;
 
 /* Every function returns CPT_OK or CPT_ERR_INVALID (message via cpt_host_error()); *_size are outputs; `cap` is the
@@ -40,6 +42,9 @@ int cpt_host_k_list(const cpt_config* cfg, const cpt_grid_params* g, double* k, 
                     int* k_size_cmb);
 int cpt_host_tau_sampling(const cpt_config* cfg, const cpt_tables* tabs, const cpt_grid_params* g, double* tau, int cap,
                           int* tau_size);
+/* length ln_tau_size_ of the tail of the sampling that covers 0 <= z <= z_max_pk with four more points for the spline (pm.cpp:1554-1592):
+ * ln_tau_[i] = log(tau[tau_size - ln_tau_size + i]).  tau_of_z_max_pk <= 0 (z_max_pk = 0): 1. */
+int cpt_host_ln_tau_size(const double* tau, int tau_size, double tau_of_z_max_pk, int* ln_tau_size);
 int cpt_host_l_list(const cpt_config* cfg, const cpt_grid_params* g, int* l, int cap, int* l_size);
 int cpt_host_q_list(const cpt_config* cfg, const cpt_grid_params* g, double k_min, double k_max_cl, double* q, int cap,
                     int* q_size);
@@ -91,6 +96,8 @@ int cpt_host_background(const cpt_cosmo_params* p, cpt_background* out);
 void cpt_host_background_free(cpt_background* bg);
 /* conformal time at redshift z by spline interpolation in the table (BackgroundModule::background_tau_of_z, :211-255) */
 int cpt_host_background_tau_of_z(const cpt_background* bg, double z, double* tau);
+/* the same from the z and tau columns of any background table (e.g. the reference's BackgroundModule::z_table_, tau_table_), bt_size rows */
+int cpt_host_tau_of_z_from_table(const double* z_table, const double* tau_table, int bt_size, double z, double* tau);
 
 /* Thermodynamics (ThermodynamicsModule::thermodynamics_init, source/thermodynamics_module.cpp:293-1297): RECFAST 1.5 recombination
  * (:3335-3975, adaptive Cash-Karp integration tools/dei_rkck.c), reionization none / CAMB-like tanh with z_reio or tau_reio given

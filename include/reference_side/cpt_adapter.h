@@ -139,5 +139,7 @@ inline cpt::Inputs MakeCptInputs(const InputModule& in, const BackgroundModule& 
   g.l_linstep = pr.l_linstep; g.l_logstep = pr.l_logstep; g.q_linstep = pr.q_linstep; g.q_logstep_spline = pr.q_logstep_spline;
   g.q_logstep_open = pr.q_logstep_open; g.l_tensor_max = pt.l_tensor_max; g.q_logstep_trapzd = pr.q_logstep_trapzd;
   g.q_numstep_transition = pr.q_numstep_transition;
+  g.tau_of_z_max_pk = 0.;   // z_max_pk > 0: the conformal time of that redshift (pm.cpp:1562)
+  if (pt.z_max_pk > 0. && bg.background_tau_of_z(pt.z_max_pk, &g.tau_of_z_max_pk) != _SUCCESS_) throw std::runtime_error(bg.error_message_);
   return x;
 }

@@ -115,6 +115,6 @@ int main(int argc, char** argv) {
   D(grid, k_step_super_reduction); D(grid, k_per_decade_for_pk); D(grid, k_per_decade_for_bao); D(grid, k_bao_center); D(grid, k_bao_width);
   I(grid, has_cls); I(grid, has_pk_matter); I(grid, l_scalar_max); D(grid, k_max_for_pk); D(grid, rs_rec); D(grid, tau_ini_thermo);
   D(grid, start_sources_at_tau_c_over_tau_h); D(grid, perturb_sampling_stepsize); D(grid, l_linstep); D(grid, l_logstep); D(grid, q_linstep);
-  D(grid, q_logstep_spline); D(grid, q_logstep_open); I(grid, l_tensor_max); D(grid, q_logstep_trapzd); D(grid, q_numstep_transition);
+  D(grid, q_logstep_spline); D(grid, q_logstep_open); I(grid, l_tensor_max); D(grid, q_logstep_trapzd); D(grid, q_numstep_transition); D(grid, tau_of_z_max_pk);
   return 0;
 }

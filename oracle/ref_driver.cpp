@@ -317,6 +317,25 @@ static int do_dump(const char* ini, const char* outpath) {
       put_f8("nl.pk_cb_lin_z0", pk.data(), {nkk});
       put_d("nl.sigma8_cb", nl->sigma8_[nl->index_pk_cb_]);
     }
+    // ---- P(k, z) and sigma(8/h, z) at the redshifts of the .ini's z_pk list (z_max_pk > 0: nonlinear_pk_at_z splines ln P in ln tau over the
+    //      tail ln_tau_ of the sampling, pm.cpp:1554-1592, nonlinear_module.cpp:81-283, :927-963) ----
+    const output* pop = &inp->output_;
+    if (ppt->z_max_pk > 0.) {
+      const int nz = pop->z_pk_num;
+      std::vector<double> zs(nz), pkz((size_t)nz * nkk), s8z(nz), tauz(nz);
+      for (int iz = 0; iz < nz; iz++) {
+        zs[iz] = pop->z_pk[iz];
+        st = nl->nonlinear_pk_at_z(logarithmic, pk_linear, zs[iz], nl->index_pk_m_, lnpk.data(), lnpk_ic.data());
+        if (st != _SUCCESS_) { fprintf(stderr, "nonlinear_pk_at_z(z=%g) failed: %s\n", zs[iz], nl->error_message_); return 1; }
+        for (int i = 0; i < nkk; i++) pkz[(size_t)iz * nkk + i] = exp(lnpk[i]);
+        if (nl->nonlinear_sigmas_at_z(8. / pba->h, zs[iz], nl->index_pk_m_, out_sigma, &s8z[iz]) != _SUCCESS_) { fprintf(stderr, "sigmas_at_z failed\n"); return 1; }
+        if (bg->background_tau_of_z(zs[iz], &tauz[iz]) != _SUCCESS_) { fprintf(stderr, "tau_of_z failed\n"); return 1; }
+      }
+      put_f8("nl.z_pk", zs.data(), {nz}); put_f8("nl.pk_lin_z", pkz.data(), {nz, nkk}); put_f8("nl.sigma8_z", s8z.data(), {nz});
+      put_f8("nl.tau_of_z_pk", tauz.data(), {nz});
+      put_f8("pt.ln_tau", pt->ln_tau_, {pt->ln_tau_size_});
+      put_d("ppt.z_max_pk", ppt->z_max_pk);
+    }
   }
   fclose(g_out);
   return 0;

@@ -23,7 +23,7 @@ def _pars(cfg):
 
 @pytest.mark.parametrize("cfg,mode", [("lcdm", "s"), ("explanatory", "s"), ("curved", "s"), ("tens", "t"), ("tens_curved", "t"),
                                       ("small", "s"), ("newt", "s"), ("open", "s"), ("curved_full", "s"), ("ncdm", "s"), ("ncdm3", "s"),
-                                      ("ncdm3_tens", "t")])
+                                      ("ncdm3_tens", "t"), ("lcdm_zpk", "s")])
 def test_parameter_entries_equal_the_reference_input_module(cfg, mode):
     if not os.path.exists(os.path.join(GOLDEN, cfg + ".ini")):
         pytest.skip("no such fixture")
@@ -247,3 +247,30 @@ def test_scenario_against_the_reference_outputs(cfg):
         assert worst["sigma8"] < 1e-5
     print("\n[%s] max errors vs reference: %s" % (cfg, ", ".join("%s %.1e" % kv for kv in worst.items())))
     c.struct_cleanup()
+
+
+@pytest.mark.gpu
+def test_pk_and_sigma_at_redshift():
+    """classy.pyx:468 pk(k, z), :644 sigma(R, z): z_max_pk = 3 (lcdm_zpk.ini), P(k, z) at z = 0.5, 1, 3 against the reference's
+    nonlinear_pk_at_z on its own k grid and sigma(8/h, z) against nonlinear_sigmas_at_z (fixture entries nl.pk_lin_z, nl.sigma8_z)"""
+    ref = np.load(os.path.join(GOLDEN, "lcdm_zpk.npz"))
+    c = classy.Class(_pars("lcdm_zpk"))
+    c.compute()
+    kk = ref["nl.k"]
+    for iz, z in enumerate(ref["nl.z_pk"]):
+        got = np.array([c.pk(float(k), float(z)) for k in kk[1:-1]])
+        want = ref["nl.pk_lin_z"][iz][1:-1]
+        assert np.max(np.abs(got / want - 1)) < 1e-4, (z, np.max(np.abs(got / want - 1)))
+        s8 = c.sigma(8. / c.h(), float(z))
+        assert abs(s8 / ref["nl.sigma8_z"][iz] - 1) < 1e-5, (z, s8, ref["nl.sigma8_z"][iz])
+    # growth: P(k, z) / P(k, 0) at k = 0.01 / Mpc falls monotonically with z
+    p = [c.pk(0.01, z) for z in (0., 0.5, 1., 2., 3.)]
+    assert all(a > b for a, b in zip(p, p[1:]))
+    with pytest.raises(classy.CosmoComputationError, match="tau tabulation range|out of range"):
+        c.pk(0.01, 4.5)
+    c.struct_cleanup()
+    c0 = classy.Class({k: v for k, v in _pars("lcdm").items()})
+    c0.compute()
+    with pytest.raises(classy.CosmoComputationError, match="z_max_pk"):
+        c0.pk(0.01, 0.5)
+    c0.struct_cleanup()

@@ -269,3 +269,40 @@ def test_cross_spectra_kernel_properties():
     assert np.max(np.abs(summed - (auto2 + ab)) / np.maximum(scale, np.max(np.abs(auto2), axis=0, keepdims=True))) < 1e-12   # bilinear
     assert np.all(ab[:, sp.index_ct_bb] == 0) if sp.index_ct_bb >= 0 else True
     be.close()
+
+
+def test_pk_at_redshift_matches_reference():
+    """P(k, z) at 0 < z <= z_max_pk = 3 on the device (cpt_pk_at_tau: ln P(k, tau_i) over the tail ln_tau_ of the sampling, splined in ln tau,
+    nonlinear_module.cpp:81-283, pm.cpp:1554-1592) and sigma(8/h, z) (cpt_sigma_at_tau) against the reference's nonlinear_pk_at_z /
+    nonlinear_sigmas_at_z on lcdm_zpk.ini; after a fused cpt_step as well as after the staged perturbation call."""
+    from classpp_public_amd import hostlib
+    from classpp_public_amd.backend import Backend, CptInputError
+    inp = Inputs("lcdm_zpk")
+    d = inp.d
+    be = Backend(inp)
+    n = hostlib.ln_tau_size(inp.tau, hostlib.tau_of_z(inp, float(d["ppt.z_max_pk"][0])))
+    assert n == d["pt.ln_tau"].size
+    h = float(d["pba.h"][0])
+    for fused in (False, True):
+        if fused:
+            be.step()
+        else:
+            be.perturb_solve(want_sources=False)
+        for iz, z in enumerate(d["nl.z_pk"]):
+            if z == 0.:
+                pk = be.pk_linear().cpu().numpy()
+                s8 = be.sigma(8. / h)
+            else:
+                tau_z = hostlib.tau_of_z(inp, float(z))
+                pk = be.pk_at_tau(tau_z, n).cpu().numpy()
+                s8 = be.sigma_at_tau(8. / h, tau_z, n)
+            err = np.max(np.abs(pk / d["nl.pk_lin_z"][iz] - 1))
+            print("\n[lcdm_zpk%s] z = %.1f: P(k, z) max err %.1e, sigma8(z) err %.1e" % (" fused" if fused else "", z, err, abs(s8 / d["nl.sigma8_z"][iz] - 1)))
+            assert err < 1e-4 and abs(s8 / d["nl.sigma8_z"][iz] - 1) < 1e-5
+    # the last sampling time is today: the spline evaluated there returns P(k, 0) (to round-off of the exp / log pair)
+    assert np.max(np.abs(be.pk_at_tau(inp.tau[-1], n).cpu().numpy() / be.pk_linear().cpu().numpy() - 1)) < 1e-12
+    with pytest.raises(CptInputError, match="tau tabulation range"):
+        be.pk_at_tau(0.5 * inp.tau[inp.tau.size - n], n)
+    with pytest.raises(CptInputError, match="z_max_pk"):
+        be.pk_at_tau(hostlib.tau_of_z(inp, 1.0), 1)
+    be.close()

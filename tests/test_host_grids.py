@@ -34,3 +34,22 @@ def test_grid_errors_are_reported():
     g.start_sources_at_tau_c_over_tau_h = 1e-9   # earlier than the thermodynamics table
     with pytest.raises(ValueError, match="inappropriate"):
         hostlib.tau_sampling(inp, g)
+
+
+def test_ln_tau_tail_and_tau_of_z_match_reference():
+    """z_max_pk = 3 (lcdm_zpk.ini): the tail of the sampling kept for P(k, z) (pm.cpp:1554-1592) has the reference's length and values,
+    and tau(z) at the requested redshifts is the reference's background_tau_of_z"""
+    from classpp_public_amd import hostlib
+    inp = Inputs("lcdm_zpk")
+    d = inp.d
+    zmax = float(d["ppt.z_max_pk"][0])
+    tau = hostlib.tau_sampling(inp)
+    assert np.array_equal(tau, d["pt.tau_sampling"])
+    n = hostlib.ln_tau_size(tau, hostlib.tau_of_z(inp, zmax))
+    assert n == d["pt.ln_tau"].size
+    assert np.array_equal(np.log(tau[tau.size - n:]), d["pt.ln_tau"])
+    for z, want in zip(d["nl.z_pk"], d["nl.tau_of_z_pk"]):
+        assert abs(hostlib.tau_of_z(inp, z) / want - 1) < 1e-12
+    assert hostlib.ln_tau_size(tau, 0.) == 1
+    with pytest.raises(Exception, match="smaller than or equal to the first possible value"):
+        hostlib.ln_tau_size(tau, 0.5 * tau[0])
