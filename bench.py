@@ -9,11 +9,17 @@ Bessel functions for every (q,l) (hot path B), then C_l, lensed C_l and P(k).  W
 metric is quoted on, explanatory.ini (`output = tCl,pCl,lCl`, `lensing = yes`, /root/reference/explanatory.ini:625-658)
 with mPk added: tests/golden/explanatory_mpk.ini = 603 k-modes x 738 sampling times x 6 source types,
 2655 q x 113 l x 5 transfer types, lensed C_l to l = 2500, linear P(k).  The spline tables are resident in HBM before the
-timed region.  At N>1 the default workload is BASELINE configs[2] at its quoted size - the fixed ncdm_k3000 grid (2 988
-k-modes, one massive neutrino species), k-sharded round-robin over the ranks with the two exchanges of
-classpp_public_amd/sharded.py: total work is fixed => "strong" scaling.  `--weak` instead densifies the k grid of
---config N-fold (per-GPU ODE work fixed).  explanatory.ini itself does not shard usefully (every mode is already
-resident on one GPU, the wall time is the longest chain): for it the multi-GPU answer is "replicas only".
+timed region.
+
+N > 1 (one process per GPU, launched by torch.distributed.run).  explanatory.ini does not shard usefully: all of its k-modes are resident
+on ONE GPU at once and the wall time is the dependency chain of the heaviest mode - "replicas only".  The default at N > 1 is
+therefore N REPLICAS of the headline workload, one cosmology per GPU (a parameter scan, MCMC chains): value = N x k-modes / time of the slowest
+rank, "scaling": "weak", no data-path collective - the same metric on the same configuration at every N.  The path that does shard is
+reported next to it in the same JSON line (`sharded_series`): BASELINE configs[2] at its quoted size (ncdm_k3000: 2 988 k-modes, one massive
+neutrino), k-sharded round-robin over the ranks at fixed total size (strong scaling), the all-gather of the sources and the gather of the
+C_l rows as RCCL operations inside the library (C ABI: cpt_allgather_sources, cpt_gather_cl); at N = 1 the same workload on one GPU, so
+that the N = 1, 2, 4, 8 lines form that curve as well.  A watchdog prints the headline line even if that secondary leg hangs.
+`--sharded` makes the sharded workload the headline measurement instead; `--weak` densifies its k grid N-fold.
 
 Prints ONE JSON line (rank 0).
 """
@@ -92,6 +98,61 @@ def parity_check(inp, cl, cl_lensed, pk, tol=1e-4):
             "max_err": worst, "ok": bool(all(v < tol for v in worst.values()))}
 
 
+def sharded_series(device, rank, world, dist, join_comm, steps=4, warmup=2):
+    """ncdm_k3000 (2 988 k-modes, one massive neutrino, lensed C_l + P(k)) at fixed total size over `world` ranks: k round-robin ->
+    cpt_allgather_sources -> l round-robin (transfer + C_l rows) -> cpt_gather_cl -> lensing, P(k) on rank 0.  world = 1: cpt_step."""
+    inp = Inputs("ncdm_k3000")
+    be = Backend(inp, device)
+    lens = (int(inp.d["le.l_unlensed_max"][0]), int(inp.d["le.delta_l_max"][0]))
+    k_all = np.ascontiguousarray(inp.k, dtype=np.float64)
+    if world > 1:
+        join_comm(be)
+
+    def step():
+        if world == 1:
+            r = be.step(lensing=lens, want_pk=True)
+            return r["cl_lensed"], r["pk"], r["stats"]
+        cl, stats = sharded_step_cabi(be, k_all, inp.l, rank, world, inp.k_size_cl, gather="cl")
+        if rank == 0:
+            return be.lensed_cl(cl, *lens), be.pk_linear(k=k_all), stats
+        return None, None, stats
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+    for _ in range(warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    kms = []
+    for _ in range(steps):
+        cl, pk, stats = step()
+        kms.append(be.kernel_ms(0)[0])
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    res = None
+    if rank == 0:
+        d, sp = inp.d, inp.spectra
+        a = cl.cpu().numpy()
+        sel = d["le.l"].astype(int) <= int(d["le.l_lensed_max"][0])
+        err = {"lensed_tt": float(np.max(np.abs(a[sel, sp.index_ct_tt] / d["le.cl_lens"][sel, sp.index_ct_tt] - 1))),
+               "lensed_ee": float(np.max(np.abs(a[sel, sp.index_ct_ee] / d["le.cl_lens"][sel, sp.index_ct_ee] - 1))),
+               "pk": float(np.max(np.abs(pk.cpu().numpy() / d["nl.pk_lin_z0"] - 1)))}
+        res = {"workload": "ncdm_k3000.ini: %d k-modes (one massive neutrino species), %d q x %d l, lensed C_l + P(k); fixed total size" % (k_all.size, inp.q.size, inp.l.size),
+               "scaling": "strong", "n_gpus": world, "steps": steps, "ms_per_step": dt / steps * 1e3, "value": k_all.size / (dt / steps), "unit": "k-modes/s",
+               "perturb_kernel_ms_rank0": float(np.mean(kms)), "k_modes_rank0": len(stats), "max_steps_per_mode_rank0": max(s.steps for s in stats),
+               "exchanges": None if world == 1 else "cpt_allgather_sources (RCCL all-gather, %.1f MB per rank) + cpt_gather_cl (RCCL send/recv, %d B per rank)" % (
+                   inp.config.tp_size * inp.ntau * (-(-k_all.size // world)) * 8 / 1e6, -(-inp.l.size // world) * sp.ct_size * 8),
+               "parity": {"max_err": err, "tol": 1e-4, "ok": bool(all(v < 1e-4 for v in err.values()))}}
+    be.close()
+    return res
+
+
 def pmc_traffic(kernel, config):
     """HBM bytes per launch of `kernel` from the rocprofv3 --pmc passes committed under profiles/ (FETCH_SIZE and
     WRITE_SIZE are collected in separate runs of this same command, tools/profile_bench.sh <tag> <config>; FETCH_SIZE doubled
@@ -121,7 +182,10 @@ def main():
                     help="torch.distributed backend: nccl (= RCCL over xGMI, one GPU per rank; the measured configuration) or gloo "
                          "(rehearsal of the multi-process path on a box with fewer GPUs than ranks: ranks share GPUs, the two "
                          "exchanges are staged through host memory; not a performance number)")
-    ap.add_argument("--collectives", default="torch", choices=["torch", "cabi"],
+    ap.add_argument("--sharded", action="store_true",
+                    help="N > 1: shard ONE cosmology (default ncdm_k3000) over the ranks as the headline measurement instead of running N replicas")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the secondary `sharded_series` leg of the report")
+    ap.add_argument("--collectives", default="cabi", choices=["torch", "cabi"],
                     help="N > 1: who runs the two exchanges - torch.distributed (nccl = RCCL) on torch tensors, or the library itself behind "
                          "the C ABI (cpt_allgather_sources / cpt_gather_transfer, RCCL on the handle's stream; torch.distributed then only "
                          "carries the rendezvous over gloo)")
@@ -143,18 +207,20 @@ def main():
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     xdev = torch.device("cpu") if args.backend == "gloo" else None
+    replicas = world > 1 and not args.sharded and not args.weak
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if args.backend == "gloo" or args.collectives == "cabi":
+        if args.backend == "gloo" or args.collectives == "cabi" or replicas:
+            # (replicas / the exchanges inside the library: torch.distributed only carries the rendezvous, the barriers and the timing all_reduce)
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
-        if args.collectives == "cabi":
-            xdev = torch.device("cpu")   # (only the timing all_reduce goes through torch.distributed)
+        if args.collectives == "cabi" or replicas:
+            xdev = torch.device("cpu")
 
     if args.config is None:
-        args.config = "explanatory_mpk" if world == 1 else "ncdm_k3000"
+        args.config = "explanatory_mpk" if (world == 1 or replicas) else "ncdm_k3000"
     t_host0 = time.perf_counter()
     if args.from_parameters:
         from classpp_public_amd.pipeline import ParameterInputs
@@ -164,14 +230,17 @@ def main():
     host_tables_ms = (time.perf_counter() - t_host0) * 1e3 if args.from_parameters else None
     be = Backend(inp, device)
     comp = GpuCompute(be)
-    if world > 1 and args.collectives == "cabi":
-        ids = [be.comm_unique_id() if rank == 0 else None]
+    def join_comm(backend):
+        ids = [backend.comm_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(ids, src=0)
-        be.comm_init(ids[0], rank, world)
+        backend.comm_init(ids[0], rank, world)
+
+    if world > 1 and not replicas and args.collectives == "cabi":
+        join_comm(be)
     weak = args.weak and world > 1
     k_all = densify_k(inp.k, world) if weak else np.ascontiguousarray(inp.k, dtype=np.float64)
     k_size_cl = (inp.k_size_cl - 1) * world + 1 if weak else inp.k_size_cl
-    nk_total = k_all.size
+    nk_total = k_all.size * (world if replicas else 1)
 
     def barrier():
         if world > 1:
@@ -184,16 +253,16 @@ def main():
 
     def step():
         # tables-in -> C_l (and P(k)) out, nothing leaves HBM in between
-        if world == 1:
+        if world == 1 or replicas:
             # one library call (cpt_step): every stage enqueued back to back, sources and tables stay in HBM, one synchronisation
             r = be.step(lensing=lens_args, want_pk=has_pk)
             return (r["cl_lensed"] if has_lensing else r["cl"]), r["pk"]
+        # sharded: every rank finishes the C_l rows of its own multipoles, rank 0 receives the C_l table
         if args.collectives == "cabi":
-            out, comp.stats = sharded_step_cabi(be, k_all, inp.l, rank, world, k_size_cl)
+            cl, comp.stats = sharded_step_cabi(be, k_all, inp.l, rank, world, k_size_cl, gather="cl")
         else:
-            out, _ = sharded_step(comp, k_all, inp.l, rank, world, device, k_size_cl, exchange_device=xdev)
-        if rank == 0:   # the same closing steps as on one GPU: C_l (+ lensing), P(k) from the gathered sources now resident in the handle
-            cl = be.cl(out)
+            cl, _ = sharded_step(comp, k_all, inp.l, rank, world, device, k_size_cl, exchange_device=xdev, gather="cl")
+        if rank == 0:   # the closing steps: lensing, P(k) from the gathered sources now resident in the handle
             if has_lensing:
                 cl = be.lensed_cl(cl, *lens_args)
             pk = be.pk_linear(k=k_all) if has_pk else None
@@ -219,7 +288,12 @@ def main():
 
     # work counters of the last step (identical every step: the computation is deterministic)
     parity = cold = frompar = None
-    if world == 1:
+    if world > 1 and replicas:
+        stats = be.step(lensing=lens_args, want_pk=has_pk)["stats"]
+        if rank == 0:
+            last = be.step(lensing=lens_args, want_pk=has_pk)
+            parity = parity_check(inp, last["cl"], last["cl_lensed"], last["pk"])
+    elif world == 1:
         last = be.step(lensing=lens_args, want_pk=has_pk)
         stats = last["stats"]
         # ---- outside the timed region: is the timed answer the reference's answer?
@@ -277,7 +351,7 @@ def main():
         achieved = alg_bytes / (k_ms * 1e-3) / 1e9
         ints, tsamp, fused = be.transfer_work()
         ini = {"explanatory_mpk": "explanatory.ini + mPk"}.get(args.config, args.config + ".ini")
-        gpu_ms = float(np.mean(gms)) if world == 1 else None   # first kernel start -> last kernel end of a step, on the handle's stream
+        gpu_ms = float(np.mean(gms)) if (world == 1 or replicas) else None   # first kernel start -> last kernel end of a step, on the handle's stream
         out = {
             # BASELINE.json's metric; the configuration actually run is named in config.workload
             "metric": "k-modes/s (perturbations) + C_l wall-time, %s, 1/2/4/8 GPUs" % ("explanatory.ini" if args.config.startswith("explanatory") else ini),
@@ -286,7 +360,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_step,
             "higher_is_better": True,
-            "scaling": None if world == 1 else ("weak" if weak else "strong"),
+            "scaling": None if world == 1 else ("weak" if (weak or replicas) else "strong"),
             "vs_baseline": None,   # BASELINE.md holds no published number for this metric
             "dtype": "f64",
             "data": "deterministic functions of the .ini, not random numbers (SURVEY S8d): background/thermodynamics spline tables and "
@@ -295,20 +369,22 @@ def main():
             "config": {"workload": "%s: %s tCl+pCl%s%s, default precision; %d k-modes x %d tau samples x %d source types, "
                                    "%d q x %d l x %d transfer types%s" % (
                                        ini, cosmology, "+lCl" if inp.config.index_tp_phi_plus_psi >= 0 else "",
-                                       "+mPk" if inp.config.index_tp_delta_m >= 0 else "", nk_total, inp.ntau, inp.config.tp_size,
+                                       "+mPk" if inp.config.index_tp_delta_m >= 0 else "", k_all.size, inp.ntau, inp.config.tp_size,
                                        inp.q.size, inp.l.size, inp.config.tt_size,
                                        ("; lensed C_l" if has_lensing else "") +
                                        ("; cosmology of the reference's base_2018_plikHM_TTTEEE_lowl_lowE_lensing.ini, k and l sampling set by name to "
                                         "the size BASELINE configs[2] quotes (the reference tree has no cl_permille.pre); its `non linear = halofit` "
                                         "is dropped: non-linear corrections are outside the path (SURVEY S8)" if args.config == "ncdm_k3000" else "") +
-                                       ("" if world == 1 else ("; k grid densified %dx and sharded round-robin" % world if weak else
-                                                               "; the fixed k grid sharded round-robin over %d ranks" % world))),
-                       "parallelism": ("k-sharded x%d, l-sharded transfer, 2 %s exchanges" % (world, "RCCL (inside the library, C ABI)" if args.collectives == "cabi" else "RCCL (torch.distributed)" if args.backend == "nccl" else "gloo (REHEARSAL: ranks share GPUs)")) if world > 1 else "1 GPU",
+                                       ("" if world == 1 else "; %d replicas, one cosmology per GPU" % world if replicas else
+                                        ("; k grid densified %dx and sharded round-robin" % world if weak else
+                                         "; the fixed k grid sharded round-robin over %d ranks" % world))),
+                       "parallelism": "1 GPU" if world == 1 else ("%d replicas (one cosmology per GPU, no data-path collective)" % world) if replicas else
+                                      ("k-sharded x%d, l-sharded transfer + C_l, 2 %s exchanges" % (world, "RCCL (inside the library, C ABI)" if args.collectives == "cabi" else "RCCL (torch.distributed)" if args.backend == "nccl" else "gloo (REHEARSAL: ranks share GPUs)")),
                        "multi_gpu_note": "explanatory.ini / lcdm.ini: replicas only (all k-modes are resident on one GPU; wall time = the longest mode's "
-                                         "dependency chain, SURVEY S8e); the sharded path is measured on ncdm_k3000 (BASELINE configs[2]), strong scaling: "
-                                         "one GPU is throughput-bound at 2988 k-modes, a shard of <= 768 modes is resident at once and its time "
-                                         "is again the dependency chain of its heaviest mode (ode_work.max_steps_per_mode x us_per_step), "
-                                         "which no further sharding shortens"},
+                                         "dependency chain, SURVEY S8e) - the N > 1 lines run N replicas of this workload, one cosmology per GPU; the path "
+                                         "that shards is measured in `sharded_series` on ncdm_k3000 (BASELINE configs[2]), strong scaling: one GPU is "
+                                         "throughput-bound at 2988 k-modes, a shard of <= 1024 modes is resident at once and its time is the dependency "
+                                         "chain of its heaviest mode (max_steps_per_mode x us_per_step), which no further sharding shortens"},
             "stage_ms": {"perturb_kernel": k_ms, "los_kernel": t_ms, "step_wall": ms_step, "gpu_span": gpu_ms,
                          "host_overhead": (ms_step - gpu_ms) if gpu_ms is not None else None, "host_tables": host_tables_ms,
                          # NOT in `value` (a warm step at a fixed geometry: a parameter scan): first step of a fresh handle, and what it
@@ -339,7 +415,32 @@ def main():
                     out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
             except Exception as e:  # the baseline is a report, never a reason to lose the measurement
                 out["cpu_baseline"] = {"value": None, "unit": "k-modes/s", "cores": 0, "kind": "port", "sample": "failed: %r" % (e,)}
-        print(json.dumps(out))
+    else:
+        out = None
+
+    # ---- secondary leg (all ranks): the workload that shards, BASELINE configs[2] at its quoted size, at fixed total size.
+    #      N = 1: the whole grid on one GPU; N > 1: k-sharded, sources all-gathered and C_l rows gathered by RCCL inside the library.
+    #      A watchdog prints the headline line anyway if a collective never returns (no multi-rank RCCL run exists before the driver's).
+    if (world == 1 or replicas) and not args.no_secondary and not args.from_parameters and args.config == "explanatory_mpk":
+        import threading
+
+        def bail():
+            if rank == 0:
+                out["sharded_series"] = {"error": "the sharded leg did not finish within 120 s (watchdog); the headline measurement above is unaffected"}
+                print(json.dumps(out), flush=True)
+            os._exit(0)
+        dog = threading.Timer(120.0, bail)
+        dog.daemon = True
+        dog.start()
+        try:
+            sec = sharded_series(device, rank, world, dist if world > 1 else None, join_comm)
+        except Exception as e:
+            sec = {"error": repr(e)}
+        dog.cancel()
+        if rank == 0:
+            out["sharded_series"] = sec
+    if rank == 0:
+        print(json.dumps(out), flush=True)
     be.close()
     if world > 1:
         dist.destroy_process_group()

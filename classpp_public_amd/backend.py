@@ -171,6 +171,15 @@ class Backend:
                                                  C.c_void_p(out.data_ptr()) if out is not None else None))
         return out
 
+    def gather_cl(self, cl_local, nl_all):
+        """cl_local: device [nl_local][ct] of this rank's multipoles -> on rank 0 the full device table [nl_all][ct], None elsewhere"""
+        assert cl_local.is_cuda and cl_local.is_contiguous()
+        out = torch.empty((int(nl_all), cl_local.shape[1]), dtype=torch.float64, device=self.device) if self.rank == 0 else None
+        self._fence()
+        self._check(self.lib.cpt_gather_cl(self.h, C.c_void_p(cl_local.data_ptr()), int(nl_all), int(cl_local.shape[1]),
+                                           C.c_void_p(out.data_ptr()) if out is not None else None))
+        return out
+
     def dbg_pad_rows(self, x, n_max):
         out = torch.empty((x.shape[0], n_max, x.shape[2]), dtype=torch.float64, device=self.device)
         self._fence()

@@ -107,7 +107,7 @@ EXPORTS = [
     "cpt_transfer_batch", "cpt_get_sources", "cpt_last_kernel_ms", "cpt_last_transfer_work",
     "cpt_dbg_lookup", "cpt_dbg_derivs", "cpt_dbg_solve", "cpt_dbg_bessel", "cpt_cl_batch", "cpt_cl_cross_batch", "cpt_sigma_of_pk", "cpt_pk_linear", "cpt_sigma", "cpt_pk_cb_linear", "cpt_sigma_cb",
     "cpt_lensing_l_size", "cpt_lensing_batch", "cpt_step", "cpt_pk_at_tau", "cpt_sigma_at_tau",
-    "cpt_comm_get_unique_id", "cpt_comm_init", "cpt_comm_destroy", "cpt_allgather_sources", "cpt_gather_transfer",
+    "cpt_comm_get_unique_id", "cpt_comm_init", "cpt_comm_destroy", "cpt_allgather_sources", "cpt_gather_transfer", "cpt_gather_cl",
     "cpt_dbg_pad_rows", "cpt_dbg_uninterleave",
 ]
 
@@ -180,6 +180,8 @@ def lib():
     L.cpt_allgather_sources.restype = _i
     L.cpt_gather_transfer.argtypes = [vp, vp, _i, _i, vp]
     L.cpt_gather_transfer.restype = _i
+    L.cpt_gather_cl.argtypes = [vp, vp, _i, _i, vp]
+    L.cpt_gather_cl.restype = _i
     L.cpt_dbg_pad_rows.argtypes = [vp, vp, vp, _i, _i, _i, _i]
     L.cpt_dbg_pad_rows.restype = _i
     L.cpt_dbg_uninterleave.argtypes = [vp, vp, vp, _i, _i, _i, _i, _i]

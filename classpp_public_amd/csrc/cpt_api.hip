@@ -66,11 +66,14 @@ int cpt_upload(cpt_handle* h, void* dst_dev, const void* src_host, size_t bytes)
 }
 void cpt_timer_start(cpt_handle* h, int which) {
   Timer& t = h->timers[which];
-  t.armed = hipEventRecord(t.a, h->stream) == hipSuccess;
+  // (armed only by the matching cpt_timer_stop: a stage that returns early with an error leaves no half-recorded pair for cpt_finish to read)
+  t.armed = false;
+  t.started = hipEventRecord(t.a, h->stream) == hipSuccess;
 }
 void cpt_timer_stop(cpt_handle* h, int which) {
   Timer& t = h->timers[which];
-  t.armed = t.armed && hipEventRecord(t.b, h->stream) == hipSuccess;
+  t.armed = t.started && hipEventRecord(t.b, h->stream) == hipSuccess;
+  t.started = false;
 }
 // drain the stream (unless a fused cpt_step is collecting several stages) and read back what the stages left pending
 int cpt_finish(cpt_handle* h) {

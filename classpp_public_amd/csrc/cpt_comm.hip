@@ -36,13 +36,20 @@ Rccl* rccl() {
   static bool tried = false;
   if (tried) return R.so ? &R : nullptr;
   tried = true;
-  const char* names[] = {getenv("CPT_RCCL_PATH"), "librccl.so", "librccl.so.1"};
-  for (const char* n : names) {
-    if (!n || !*n) continue;
-    R.so = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+  // A copy the process has loaded already wins (PyTorch ships its own librccl next to its own HIP runtime: a second RCCL in the process
+  // would talk to another runtime): RTLD_NOLOAD first, then an explicit CPT_RCCL_PATH, then the loader's search path.
+  const char* path = getenv("CPT_RCCL_PATH");
+  for (const char* n : {"librccl.so.1", "librccl.so"}) {
+    R.so = dlopen(n, RTLD_NOW | RTLD_GLOBAL | RTLD_NOLOAD);
     if (R.so) break;
-    R.why = dlerror();
   }
+  if (!R.so && path && *path) { R.so = dlopen(path, RTLD_NOW | RTLD_GLOBAL); if (!R.so) R.why = dlerror(); }
+  if (!R.so)
+    for (const char* n : {"librccl.so.1", "librccl.so"}) {
+      R.so = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+      if (R.so) break;
+      R.why = dlerror();
+    }
   if (!R.so) return nullptr;
   auto sym = [&](const char* name) { return dlsym(R.so, name); };
   R.GetUniqueId = (decltype(R.GetUniqueId))sym("ncclGetUniqueId");
@@ -169,39 +176,58 @@ int cpt_allgather_sources(cpt_handle* h, int nk_all, int ntau) {
   return CPT_OK;
 }
 
-int cpt_gather_transfer(cpt_handle* h, const double* transfer_local_dev, int nl_all, int nq, double* transfer_full_dev) {
-  if (!h) return CPT_ERR_INVALID;
-  h->err.clear();
-  const int world = h->comm_world, rank = h->comm_rank, ntt = h->cfg.tt_size;
-  if (!h->comm) return cpt_fail(h, CPT_ERR_INVALID, "cpt_gather_transfer: no communicator (cpt_comm_init)");
-  if (!transfer_local_dev || (rank == 0 && !transfer_full_dev) || nl_all < 1 || nq < 1) return cpt_fail(h, CPT_ERR_INVALID, "bad arguments to cpt_gather_transfer");
+// rank r holds rows r, r + W, ... of a table [nb][n_all][ninner] as a block [nb][n_local][ninner]: point-to-point sends to rank 0 (ncclSend /
+// ncclRecv in one group), un-interleaved there into the full table
+static int gather_rows(cpt_handle* h, const char* who, const double* local_dev, int nb, int n_all, int ninner, double* full_dev) {
+  const int world = h->comm_world, rank = h->comm_rank;
+  if (!h->comm) return cpt_fail(h, CPT_ERR_INVALID, "%s: no communicator (cpt_comm_init)", who);
+  if (!local_dev || (rank == 0 && !full_dev) || n_all < 1 || ninner < 1 || nb < 1) return cpt_fail(h, CPT_ERR_INVALID, "bad arguments to %s", who);
   Rccl* R = rccl();
   int prev = -1;
   (void)hipGetDevice(&prev);
   if (prev != h->device) (void)hipSetDevice(h->device);
   struct Restore { int prev, dev; ~Restore() { if (prev != dev && prev >= 0) (void)hipSetDevice(prev); } } restore{prev, h->device};
-  const int n_local = shard_size(nl_all, rank, world), n_max = shard_size(nl_all, 0, world);
-  const size_t block = (size_t)ntt * n_max * nq;
+  const int n_local = shard_size(n_all, rank, world), n_max = shard_size(n_all, 0, world);
+  const size_t block = (size_t)nb * n_max * ninner;
   int rc;
   if ((rc = cpt_reserve(h, &h->d_xsend, &h->xsend_cap, block))) return rc;
-  hipLaunchKernelGGL(k_pad_rows, dim3((unsigned)((block + 255) / 256)), dim3(256), 0, h->stream, transfer_local_dev, h->d_xsend, ntt, n_local, n_max, nq);
+  if (rank == 0 && (rc = cpt_reserve(h, &h->d_xrecv, &h->xrecv_cap, block * world))) return rc;
+  hipLaunchKernelGGL(k_pad_rows, dim3((unsigned)((block + 255) / 256)), dim3(256), 0, h->stream, local_dev, h->d_xsend, nb, n_local, n_max, ninner);
   CPT_HIP(h, hipGetLastError());
+  // (a group that was started is always ended, whatever happens inside it: an open group would leave the peers hanging in theirs)
+  int e = R->GroupStart(), e_end = 0;
+  if (e == 0) {
+    if (rank == 0) { for (int r = 1; r < world && e == 0; r++) e = R->Recv(h->d_xrecv + (size_t)r * block, block, kNcclFloat64, r, h->comm, h->stream); }
+    else e = R->Send(h->d_xsend, block, kNcclFloat64, 0, h->comm, h->stream);
+    e_end = R->GroupEnd();
+  }
+  if (e != 0 || e_end != 0) {
+    (void)hipStreamSynchronize(h->stream);
+    return cpt_fail(h, CPT_ERR_RUNTIME, "%s: RCCL send / receive failed: %s", who, R->GetErrorString ? R->GetErrorString(e ? e : e_end) : "RCCL error");
+  }
   if (rank == 0) {
-    if ((rc = cpt_reserve(h, &h->d_xrecv, &h->xrecv_cap, block * world))) return rc;
-    CPT_RCCL(h, R->GroupStart());
-    for (int r = 1; r < world; r++) CPT_RCCL(h, R->Recv(h->d_xrecv + (size_t)r * block, block, kNcclFloat64, r, h->comm, h->stream));
-    CPT_RCCL(h, R->GroupEnd());
     CPT_HIP(h, hipMemcpyAsync(h->d_xrecv, h->d_xsend, block * sizeof(double), hipMemcpyDeviceToDevice, h->stream));   // own block
-    const size_t full = (size_t)ntt * nl_all * nq;
-    hipLaunchKernelGGL(k_uninterleave, dim3((unsigned)((full + 255) / 256)), dim3(256), 0, h->stream, h->d_xrecv, transfer_full_dev, world, ntt, n_max, nl_all, nq);
+    const size_t full = (size_t)nb * n_all * ninner;
+    hipLaunchKernelGGL(k_uninterleave, dim3((unsigned)((full + 255) / 256)), dim3(256), 0, h->stream, h->d_xrecv, full_dev, world, nb, n_max, n_all, ninner);
     CPT_HIP(h, hipGetLastError());
-  } else {
-    CPT_RCCL(h, R->GroupStart());
-    CPT_RCCL(h, R->Send(h->d_xsend, block, kNcclFloat64, 0, h->comm, h->stream));
-    CPT_RCCL(h, R->GroupEnd());
   }
   CPT_HIP(h, hipStreamSynchronize(h->stream));
   return CPT_OK;
+}
+
+int cpt_gather_transfer(cpt_handle* h, const double* transfer_local_dev, int nl_all, int nq, double* transfer_full_dev) {
+  if (!h) return CPT_ERR_INVALID;
+  h->err.clear();
+  return gather_rows(h, "cpt_gather_transfer", transfer_local_dev, h->cfg.tt_size, nl_all, nq, transfer_full_dev);
+}
+
+// the C_l rows of this rank's multipoles [nl_local][ct_size] -> rank 0: [nl_all][ct_size].  The C_l integral over q needs every q of one l, which the
+// rank that projected that multipole holds: the spectra are finished where the transfer functions are, and 7 numbers per multipole travel
+// instead of the transfer table (exchange 2)
+int cpt_gather_cl(cpt_handle* h, const double* cl_local_dev, int nl_all, int ct_size, double* cl_full_dev) {
+  if (!h) return CPT_ERR_INVALID;
+  h->err.clear();
+  return gather_rows(h, "cpt_gather_cl", cl_local_dev, 1, nl_all, ct_size, cl_full_dev);
 }
 
 // unit-test hooks (no communicator needed): the packing and un-interleaving kernels of the two exchanges on caller-provided device buffers

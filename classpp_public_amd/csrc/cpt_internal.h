@@ -43,6 +43,7 @@ struct Timer {
   hipEvent_t a = nullptr, b = nullptr;   // created once with the handle, recorded around the stage on the handle's stream
   double ms = 0;
   int launches = 0;
+  bool started = false;                  // first event recorded, waiting for cpt_timer_stop
   bool armed = false;                    // both events recorded since the last read-out
 };
 // timers of the last call(s): perturbation kernel, line-of-sight kernel, whole transfer stage, whole cpt_step (first to last kernel)

@@ -5,12 +5,14 @@ xGMI on the node; "gloo" on CPU for the tests).
            every rank gets the same mix of cheap low-k and expensive high-k modes).
   exchange 1  all_gather of the local source blocks [tp][ntau][nk_local] -> full sources on every rank.  This exchange
            is real: the transfer stage splines the sources across ALL k (tm.cpp:604-639).
-  stage B  rank r computes Delta_l(q) for multipoles l[r::N] and every q (cost grows with l, round-robin balances it).
-  exchange 2  gather of the [tt][nl_local][nq] blocks on rank 0 (the downstream C_l integral needs every q of a given l,
-           which each rank already holds, so only results travel).
+  stage B  rank r computes Delta_l(q) for multipoles l[r::N] and every q (cost grows with l, round-robin balances it), and - the C_l integral
+           over q needs every q of one l, which the rank holds - finishes the C_l rows of its multipoles (compute.cl).
+  exchange 2  gather of the [nl_local][ct] C_l blocks on rank 0 (7 numbers per multipole), or - when a consumer wants the reference's
+           transfer_ table (the C++ shim's TransferModule) - of the [tt][nl_local][nq] transfer blocks.
+  rank 0   lensing and P(k) (delta_m(k, tau0) is complete on every rank after exchange 1).
 
-Data volumes are tiny (sources 17 MB, transfer 12 MB for explanatory.ini), the collectives are latency-bound; exactly
-two collectives per step, no ring all-reduce.
+Data volumes are tiny (sources 17 MB, C_l 6 KB for explanatory.ini), the collectives are latency-bound; exactly two per step, no ring
+all-reduce.
 """
 import numpy as np
 import torch
@@ -57,8 +59,10 @@ class _Plan:
 _plan = None
 
 
-def sharded_step(compute, k_all, l_all, rank, world, device, k_size_cl=None, exchange_device=None, force_exchange=False):
+def sharded_step(compute, k_all, l_all, rank, world, device, k_size_cl=None, exchange_device=None, force_exchange=False, gather="transfer"):
     """One pass of the hot path over `world` ranks.
+    gather = "transfer": rank 0 receives the full transfer table [tt][nl][nq]; "cl": every rank finishes the C_l rows of its multipoles
+    (compute.cl(transfer_local) -> [nl_local][ct]) and rank 0 receives the C_l table [nl][ct].
 
     compute.perturb(k_subset) -> torch f64 [tp][ntau][len(k_subset)] on `device`
     compute.transfer(sources_full, k_all, l_subset, k_size_cl) -> torch f64 [tt][len(l_subset)][nq] on `device`
@@ -91,8 +95,10 @@ def sharded_step(compute, k_all, l_all, rank, world, device, k_size_cl=None, exc
             full.index_copy_(2, idx, blocks[r][:, :, : idx.numel()].to(device))
     my_l = shard_indices(nl, rank, world)
     tr_local = compute.transfer(full, k_all, l_all[my_l], nk if k_size_cl is None else k_size_cl)
+    if gather == "cl":
+        tr_local = compute.cl(tr_local).unsqueeze(0)      # [1][nl_local][ct]: the same block shape as the transfer rows
     if world == 1 and not force_exchange:
-        return tr_local, full
+        return (tr_local[0] if gather == "cl" else tr_local), full
     # ---- exchange 2: gather on rank 0 ----
     ntt, nq = tr_local.shape[0], tr_local.shape[2]
     lmax = (nl + world - 1) // world
@@ -105,7 +111,7 @@ def sharded_step(compute, k_all, l_all, rank, world, device, k_size_cl=None, exc
         for r in range(world):
             idx = plan.l_idx[r]
             out.index_copy_(1, idx, blocks[r][:, : idx.numel(), :].to(device))
-        return out, full
+        return (out[0] if gather == "cl" else out), full
     dist.gather(buf, None, dst=0)
     return None, full
 
@@ -123,14 +129,20 @@ class GpuCompute:
     def transfer(self, sources_full, k_all, l_subset, k_size_cl):
         return self.be.transfer(sources_full.contiguous(), k=k_all, l=l_subset, k_size_cl=k_size_cl)
 
+    def cl(self, transfer_local):
+        return self.be.cl(transfer_local.contiguous())
 
-def sharded_step_cabi(be, k_all, l_all, rank, world, k_size_cl=None):
-    """The same pass with the two exchanges inside the library (include/cpt.h: cpt_allgather_sources, cpt_gather_transfer - RCCL over
-    xGMI on the handle's stream): nothing but the shard bookkeeping is left to the host language.  `be` must have joined a
-    communicator (Backend.comm_init).  Returns the full transfer table on rank 0 (None elsewhere)."""
+
+def sharded_step_cabi(be, k_all, l_all, rank, world, k_size_cl=None, gather="cl"):
+    """The same pass with the two exchanges inside the library (include/cpt.h: cpt_allgather_sources, cpt_gather_cl / cpt_gather_transfer -
+    RCCL over xGMI on the handle's stream): nothing but the shard bookkeeping is left to the host language.  `be` must have joined a
+    communicator (Backend.comm_init).  Returns, on rank 0 (None elsewhere), the C_l table [nl][ct] (gather = "cl": every rank finishes the
+    spectra of its own multipoles) or the full transfer table (gather = "transfer")."""
     nk, nl = len(k_all), len(l_all)
     my_k, my_l = shard_indices(nk, rank, world), shard_indices(nl, rank, world)
     _, stats, _ = be.perturb_solve(k=k_all[my_k], want_sources=False)
     be.allgather_sources(nk)
     tr_local = be.transfer(None, k=k_all, l=l_all[my_l], k_size_cl=nk if k_size_cl is None else k_size_cl)
+    if gather == "cl":
+        return be.gather_cl(be.cl(tr_local), nl), stats
     return be.gather_transfer(tr_local, nl), stats

@@ -305,7 +305,7 @@ int cpt_step(cpt_handle* h, const cpt_step_io* io);
  *   rank r integrates k_all[r], k_all[r + W], ...  (cpt_perturb_solve_batch on that subset, sources_dev = NULL)
  *   cpt_allgather_sources        -> every rank holds the full k-major sources, resident
  *   rank r computes the multipoles l_all[r], l_all[r + W], ...  (cpt_transfer_batch with sources_dev = NULL and that l subset)
- *   cpt_gather_transfer          -> rank 0 holds transfer_[tt][nl_all][nq]
+ *   cpt_gather_transfer          -> rank 0 holds transfer_[tt][nl_all][nq]   (or: cpt_cl_batch on the local rows, then cpt_gather_cl)
  * The reference has no counterpart (one process, a thread pool: pm.cpp:668-718, tm.cpp:287-318 are its two parallel loops).
  * Rendezvous is the caller's business: rank 0 obtains an id, every rank receives its CPT_COMM_ID_BYTES by any means (a file, MPI,
  * torch.distributed's store) and joins.  RCCL is bound at run time: librccl.so of the process (CPT_RCCL_PATH overrides). */
@@ -319,6 +319,9 @@ int cpt_allgather_sources(cpt_handle* h, int nk_all, int ntau);
 /* transfer_local_dev: device [tt_size][nl_local][nq] of this rank's multipoles; transfer_full_dev: device [tt_size][nl_all][nq],
  * written on rank 0 only (may be NULL elsewhere) */
 int cpt_gather_transfer(cpt_handle* h, const double* transfer_local_dev, int nl_all, int nq, double* transfer_full_dev);
+/* the same for the spectra: cl_local_dev device [nl_local][ct_size] (cpt_cl_batch on this rank's transfer rows) -> cl_full_dev device
+ * [nl_all][ct_size] on rank 0.  The spectra are finished where the transfer functions are; only ct_size numbers per multipole travel. */
+int cpt_gather_cl(cpt_handle* h, const double* cl_local_dev, int nl_all, int ct_size, double* cl_full_dev);
 
 /* Device-side copy of the resident sources into the reference layout [tp_size][ntau][nk] (device pointer). */
 int cpt_get_sources(cpt_handle* h, double* sources_dev);

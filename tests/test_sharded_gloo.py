@@ -39,6 +39,10 @@ class OracleCompute:
         assert rc == 0
         return torch.from_numpy(out)
 
+    def cl(self, transfer_local):
+        import oracle_lib
+        return torch.from_numpy(oracle_lib.cl_table(self.inp, transfer_local.numpy()))
+
 
 def _worker(rank, world, port, ret):
     sys.path.insert(0, ROOT)
@@ -154,3 +158,53 @@ def test_gpu_compute_interface_two_ranks():
     scale = np.max(np.abs(b), axis=-1, keepdims=True)
     scale[scale == 0] = 1
     assert np.array_equal(a == 0, b == 0) and np.max(np.abs(a - b) / scale) < 1e-10
+
+
+# ---- four ranks, uneven shards (35 k-modes and 46 multipoles do not divide by 4), spectra finished where the transfer functions are:
+#      exchange 2 gathers the C_l rows (7 numbers per multipole) instead of the transfer table
+def _worker_cl(rank, world, port, ret):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from classpp_public_amd.inputs import Inputs
+    from classpp_public_amd.sharded import shard_indices, sharded_step
+    inp = Inputs("small")
+    k_all = np.ascontiguousarray(inp.k[::4])
+    assert k_all.size % world != 0 and inp.l.size % world != 0
+    comp = OracleCompute(inp)
+    out, full = sharded_step(comp, k_all, inp.l, rank, world, torch.device("cpu"), k_all.size, gather="cl")
+    ret["nk%d" % rank] = shard_indices(k_all.size, rank, world).size
+    if rank == 0:
+        ret["cl"] = out.numpy().copy()
+        ret["full_sources"] = full.numpy().copy()
+        ret["k_all"] = k_all
+    else:
+        assert out is None
+    dist.destroy_process_group()
+
+
+def test_four_ranks_uneven_shards_gather_cl():
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib
+    from classpp_public_amd.inputs import Inputs
+    from classpp_public_amd.sharded import sharded_step
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    port = 29500 + ((os.getpid() + 13) % 1000)
+    mp.spawn(_worker_cl, args=(4, port, ret), nprocs=4, join=True)
+    inp = Inputs("small")
+    k_all = ret["k_all"]
+    assert sorted(ret["nk%d" % r] for r in range(4)) == [8, 9, 9, 9] and sum(ret["nk%d" % r] for r in range(4)) == k_all.size
+    comp = OracleCompute(inp)
+    cl1, full1 = sharded_step(comp, k_all, inp.l, 0, 1, torch.device("cpu"), k_all.size, gather="cl")
+    assert np.array_equal(ret["full_sources"], full1.numpy())          # k-modes are independent units: bit for bit
+    a, b = ret["cl"], cl1.numpy()
+    assert a.shape == (inp.l.size, inp.spectra.ct_size)
+    scale = np.max(np.abs(b), axis=0, keepdims=True)
+    scale[scale == 0] = 1
+    assert np.max(np.abs(a - b) / scale) < 1e-10                        # multipoles are independent units: round-off of the Bessel recurrences
+    # and it IS the spectrum of the gathered transfer table
+    tr1, _ = sharded_step(comp, k_all, inp.l, 0, 1, torch.device("cpu"), k_all.size)
+    assert np.array_equal(b, oracle_lib.cl_table(inp, tr1.numpy()))
