@@ -251,6 +251,8 @@ def main():
     has_lensing = "le.l_unlensed_max" in inp.d   # the .ini asks for lensed C_l (explanatory.ini; lcdm.ini has lensing = no)
     lens_args = (int(inp.d["le.l_unlensed_max"][0]), int(inp.d["le.delta_l_max"][0])) if has_lensing else None
 
+    keep = {}
+
     def step():
         # tables-in -> C_l (and P(k)) out, nothing leaves HBM in between
         if world == 1 or replicas:
@@ -263,6 +265,7 @@ def main():
         else:
             cl, _ = sharded_step(comp, k_all, inp.l, rank, world, device, k_size_cl, exchange_device=xdev, gather="cl")
         if rank == 0:   # the closing steps: lensing, P(k) from the gathered sources now resident in the handle
+            keep["cl_unlensed"] = cl
             if has_lensing:
                 cl = be.lensed_cl(cl, *lens_args)
             pk = be.pk_linear(k=k_all) if has_pk else None
@@ -327,6 +330,11 @@ def main():
                 frompar = {"error": repr(e)}
     else:
         stats = comp.stats
+        if rank == 0 and not weak:
+            cl_out, pk_out = step()
+            parity = parity_check(inp, keep["cl_unlensed"], cl_out if has_lensing else None, pk_out)
+        elif not weak:
+            step()
     fevals = sum(s.fevals for s in stats)
     steps_tot = sum(s.steps for s in stats)
     steps_max = max(s.steps for s in stats)

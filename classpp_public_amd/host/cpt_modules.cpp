@@ -17,7 +17,7 @@ namespace cpt {
 namespace {
 template <class T>
 T* xalloc(size_t n) {
-  T* p = (T*)malloc(n * sizeof(T));
+  T* p = (T*)calloc(n ? n : 1, sizeof(T));   // (zeroed: release() may meet a table of pointers whose rows were never allocated)
   if (!p) throw std::runtime_error("could not allocate memory");  // class_alloc, include/common.h:140-330
   return p;
 }
@@ -63,7 +63,13 @@ void HostTables::fill(Inputs& in) const {
   in.grid.rs_rec = h.rs_rec; in.grid.tau_ini_thermo = h.tau_ini;
 }
 
+// All work happens in the constructor, and it may throw half way (a device handle or two created, some tables allocated): the destructor of a
+// partly constructed object never runs, so the constructor itself releases what it had built before it lets the exception out.
 PerturbationsModule::PerturbationsModule(const Inputs& in) {
+  try { build(in); } catch (...) { release(); throw; }
+}
+
+void PerturbationsModule::build(const Inputs& in) {
   error_message_[0] = '\n';
   const cpt_config& c0 = in.config;
   // ---- perturb_indices_of_perturbs (pm.cpp:843-1235): modes, initial conditions, source types ----
@@ -173,18 +179,22 @@ PerturbationsModule::PerturbationsModule(const Inputs& in) {
   }
 }
 
-PerturbationsModule::~PerturbationsModule() {
-  if (sources_) {
+PerturbationsModule::~PerturbationsModule() { release(); }
+
+// frees whatever has been built so far (every pointer is null until its allocation succeeded; safe to call twice)
+void PerturbationsModule::release() noexcept {
+  if (sources_ && ic_size_ && tp_size_) {
     for (int md = 0; md < md_size_; md++) {
       if (!sources_[md]) continue;
       for (int i = 0; i < ic_size_[md] * tp_size_[md]; i++) free(sources_[md][i]);
       free(sources_[md]);
     }
-    free(sources_);
   }
-  if (k_) { for (int md = 0; md < md_size_; md++) free(k_[md]); free(k_); }
+  free(sources_); sources_ = nullptr;
+  if (k_) { for (int md = 0; md < md_size_; md++) free(k_[md]); free(k_); k_ = nullptr; }
   free(k_size_); free(k_size_cl_); free(k_size_cmb_); free(tau_sampling_); free(ln_tau_); free(ic_size_); free(tp_size_); free(stats_);
-  for (auto& row : h_) for (cpt_handle* h : row) cpt_destroy(h);
+  k_size_ = k_size_cl_ = k_size_cmb_ = ic_size_ = tp_size_ = nullptr; tau_sampling_ = ln_tau_ = nullptr; stats_ = nullptr;
+  for (auto& row : h_) for (cpt_handle*& h : row) { if (h) cpt_destroy(h); h = nullptr; }   // (also leaves the RCCL communicator of a sharded module)
 }
 
 double PerturbationsModule::kernel_ms() const {
@@ -201,6 +211,10 @@ double PerturbationsModule::kernel_ms() const {
 
 TransferModule::TransferModule(const Inputs& in, std::shared_ptr<const PerturbationsModule> pt)
     : perturbations_module_(std::move(pt)) {
+  try { build(in); } catch (...) { release(); throw; }   // (see PerturbationsModule)
+}
+
+void TransferModule::build(const Inputs& in) {
   error_message_[0] = '\n';
   const cpt_config& c0 = in.config;
   const PerturbationsModule& P = *perturbations_module_;
@@ -313,12 +327,15 @@ TransferModule::TransferModule(const Inputs& in, std::shared_ptr<const Perturbat
   }
 }
 
-TransferModule::~TransferModule() {
-  const int nmd = perturbations_module_->md_size_;
-  if (transfer_) { for (int md = 0; md < nmd; md++) free(transfer_[md]); free(transfer_); }
-  if (k_) { for (int md = 0; md < nmd; md++) free(k_[md]); free(k_); }
-  if (l_size_tt_) { for (int md = 0; md < nmd; md++) free(l_size_tt_[md]); free(l_size_tt_); }
+TransferModule::~TransferModule() { release(); }
+
+void TransferModule::release() noexcept {
+  const int nmd = perturbations_module_ ? perturbations_module_->md_size_ : 0;
+  if (transfer_) { for (int md = 0; md < nmd; md++) free(transfer_[md]); free(transfer_); transfer_ = nullptr; }
+  if (k_) { for (int md = 0; md < nmd; md++) free(k_[md]); free(k_); k_ = nullptr; }
+  if (l_size_tt_) { for (int md = 0; md < nmd; md++) free(l_size_tt_[md]); free(l_size_tt_); l_size_tt_ = nullptr; }
   free(q_); free(l_); free(l_size_); free(tt_size_);
+  q_ = nullptr; l_ = nullptr; l_size_ = tt_size_ = nullptr;
 }
 
 double TransferModule::kernel_ms() const {

@@ -7,7 +7,7 @@ import numpy as np
 from .capi import CptConfig, CptTables
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "host", "libcpt_host.so")
+LIB_PATH = os.environ.get("CPT_HOST_LIB") or os.path.join(_HERE, "host", "libcpt_host.so")   # (CPT_HOST_LIB: a sanitizer build, tools/sanitize_cpu.sh)
 _d, _i = C.c_double, C.c_int
 
 

@@ -89,6 +89,8 @@ class PerturbationsModule {
   double kernel_ms() const;                                // summed over the handles
 
  private:
+  void build(const Inputs& in);
+  void release() noexcept;          // frees whatever has been built (the constructor calls it before rethrowing, the destructor at the end)
   cpt_handle* h_[2][5] = {{nullptr, nullptr, nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr, nullptr, nullptr}};
   cpt_stepstat* stats_ = nullptr;   // (sharded: the counters of this rank's modes, in the order k_[rank], k_[rank + world], ...)
   int* k_size_cmb_ = nullptr;
@@ -119,6 +121,8 @@ class TransferModule {
   double kernel_ms() const;
 
  private:
+  void build(const Inputs& in);
+  void release() noexcept;
   std::shared_ptr<const PerturbationsModule> perturbations_module_;
 };
 

@@ -9,7 +9,7 @@ from classpp_public_amd.capi import CptConfig, CptTables, CptStepstat
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ORACLE_DIR = os.path.join(ROOT, "oracle")
-LIB = os.path.join(ORACLE_DIR, "libcpt_oracle.so")
+LIB = os.environ.get("CPT_ORACLE_LIB") or os.path.join(ORACLE_DIR, "libcpt_oracle.so")   # (CPT_ORACLE_LIB: a sanitizer build, tools/sanitize_cpu.sh)
 
 _lib = None
 _d, _i = C.c_double, C.c_int
