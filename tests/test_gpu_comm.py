@@ -47,9 +47,12 @@ def test_world_of_one_through_rccl(be):
     tr = be.transfer(None).cpu().numpy()
     be.comm_init(be.comm_unique_id(), 0, 1)
     try:
-        out, stats = sharded_step_cabi(be, inp.k, inp.l, 0, 1, inp.k_size_cl)
+        out, stats = sharded_step_cabi(be, inp.k, inp.l, 0, 1, inp.k_size_cl, gather="transfer")
         assert np.array_equal(out.cpu().numpy(), tr)
         assert np.array_equal(be.get_sources(inp.ntau, inp.nk).cpu().numpy(), src.cpu().numpy())
+        # the default exchange 2: every rank finishes the C_l rows of its multipoles, cpt_gather_cl collects them
+        cl, _ = sharded_step_cabi(be, inp.k, inp.l, 0, 1, inp.k_size_cl)
+        assert np.array_equal(cl.cpu().numpy(), be.cl(torch.from_numpy(tr).cuda()).cpu().numpy())
     finally:
         be.lib.cpt_comm_destroy(be.h)
 
