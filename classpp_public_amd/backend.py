@@ -316,10 +316,10 @@ class Backend:
                                             _dptr(dy), C.byref(neq)))
         return dy[: neq.value].copy()
 
-    def dbg_solve(self, k, tau, tca_on, rsa_on, ufa_on, hg, b):
+    def dbg_solve(self, k, tau, tca_on, rsa_on, ufa_on, hg, b, full=False):
         bb = np.zeros(64)
         bb[: len(b)] = b
         x = np.zeros(64)
         self._check(self.lib.cpt_dbg_solve(self.h, float(k), float(tau), int(tca_on), int(rsa_on), int(ufa_on), float(hg),
                                            _dptr(bb), _dptr(x)))
-        return x[: len(b)].copy()
+        return x.copy() if full else x[: len(b)].copy()

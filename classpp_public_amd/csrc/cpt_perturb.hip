@@ -229,6 +229,7 @@ int cpt_dbg_solve_impl(cpt_handle* h, double k, double tau, int tca_on, int rsa_
   PtParams P;
   fill_params(h, P);
   if (!(k > 0.) || !(tau > 0.)) return cpt_fail(h, CPT_ERR_INVALID, "k and tau must be positive");
+  if (const char* e = getenv("CPT_DBG_SOLVE_INVERSE")) P.dbg_inverse = atoi(e);   // (tests: the product form of the core solve)
   double *d_b = nullptr, *d_x = nullptr;
   CPT_HIP(h, hipMalloc((void**)&d_b, 64 * sizeof(double)));
   CPT_HIP(h, hipMalloc((void**)&d_x, 64 * sizeof(double)));

@@ -29,6 +29,13 @@ namespace {
 constexpr double SIGMA_T = 6.6524616e-29, MPC_OVER_M = 3.085677581282e22, K_B = 1.3806504e-23, C_LIGHT = 2.99792458e8,
                  M_H = 1.673575e-27, NOT4 = 3.9715;
 
+// (diagnostic) comment lines in the ISA listing (hipcc -S -DCPT_ISA_MARKS): where a section of the integrator begins and ends
+#ifdef CPT_ISA_MARKS
+#define ISA_MARK(name) asm volatile("; ==== " name)
+#else
+#define ISA_MARK(name)
+#endif
+
 struct PtParams {
   DevTables tabs;
   // config scalars
@@ -56,6 +63,7 @@ struct PtParams {
   cpt_stepstat* stats;
   int* status;
   int max_steps;
+  int dbg_inverse;   // (unit-test kernel k_dbg_solve) solve the core block in the product form of helper_inverse
 };
 
 // ---- wave helpers -------------------------------------------------------------------------------
@@ -244,8 +252,13 @@ struct Mailbox {
   int it[MB_NSLOT], flags[MB_NSLOT];            // sample index; approximation scheme (tca | rsa<<1 | ufa<<2)
   int head, tail, done;                         // samples posted (integrator) / consumed (helper); the mode is finished
   int req_seq, ans_seq;                         // look-ups requested (integrator) / answered (helper)
-  double req_tau;
-  double ans[MB_NANS];
+  int fact_seq, inv_seq;                        // factorisations posted (integrator) / inverted (helper): see helper_inverse
+  double req_tau[2];                            // time of request n in req_tau[n & 1]: up to two requests may be waiting (this step's row after a
+                                                // change of step size and the next step's), the helper answers them in order
+  double rp[32];                                // reciprocal pivots of the posted factorisation (the rest of it is the integrator's LuReg::fw)
+  alignas(16) double ans[2][MB_NANS];           // the answer to request n goes to ans[n & 1]: the integrator reads the row of the step it is
+                                                // working on from LDS (it is never copied to registers) while the helper fills the other half
+                                                // with the row of the step after it
 };
 __device__ inline int mb_load(const int* p) { return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP); }
 __device__ inline void mb_store(int* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP); }
@@ -294,11 +307,13 @@ struct Layout {
   int g3, gN, q3, qN, u3, uN;  // tails: lane of l=3 and length (lengths are 0 when the scheme drops the tail)
   int lmg, lmp, lmu;
   int maxlen;                  // longest tail present
+  int ur_special;              // the rarely used ur variants of the RHS are on: three_ceff2_ur != 1 (pm.cpp:8630-8641) or ufa_hu (pm.cpp:8711-8716)
 };
 
 static __device__ __forceinline__ Layout make_layout(const PtParams& P, int tca, int rsa, int ufa, int nfa = 0, int fic = 0) {
   Layout L;
   L.tca = tca; L.rsa = rsa; L.ufa = ufa; L.nfa = nfa; L.fic = fic; L.lng = 0;
+  L.ur_special = (P.three_ceff2_ur != 1. || (ufa && P.ufa_method == CPT_UFA_HU)) ? 1 : 0;
   if (MODE) {  // tensors: photons are evolved when neither approximation is on; ur always (pm.cpp:3529-3560)
     L.ufa = 0;
     L.lmg = P.l_max_g_ten; L.lmp = P.l_max_pol_g_ten; L.lmu = P.l_max_ur;
@@ -508,7 +523,9 @@ struct Lookup {
   double zmax, xe_last, taud_last;  // last row of the thermodynamics table (analytic continuation beyond it)
   double k2s2, inv_k2s2, s2, s2sq, kcot;  // per-mode curvature factors (set_mode) and k cotK_gen(tau_cached); flat: k^2, 1/k^2, 1, 1, 1/tau
   // (integrator wave of the two-wave kernels) the rows come from the helper wave: mailbox, number of requests posted, time of the last one
-  Mailbox* mb; int my_req; double req_tau;
+  Mailbox* mb; int my_req; double rq_tau0, rq_tau1;   // requests posted so far; time of the last even / odd one
+  int ans_seen;                      // last value read of the helper's ans_seq
+  const double* row;                 // (scalar RHS of the two-wave kernels) the row in work, where the helper left it (mb_take)
   double ncv[NCDM ? NCB_NCOL : 1];   // (rows from the helper, ncdm kernels) {rho, p, pseudo_p} of every species, wave-uniform
 #ifdef CPT_PROFILE
   unsigned long long* prof;
@@ -574,7 +591,7 @@ static __device__ __forceinline__ int window_find(const double* __restrict__ x, 
 
 static __device__ __forceinline__ void lookup_init(const PtParams& P, Lookup& Q, double2* bgw, double2* thw, int lane, double2* ncw = nullptr) {
   Q.bgw = bgw; Q.thw = thw; Q.ncw = ncw; Q.vnc = 0.; Q.nc_lo = Q.nc_hi = make_double2(0., 0.);
-  Q.mb = nullptr; Q.my_req = 0; Q.req_tau = -1.;
+  Q.mb = nullptr; Q.my_req = 0; Q.rq_tau0 = Q.rq_tau1 = -1.; Q.ans_seen = 0; Q.row = nullptr;
   if (NCDM) { double dummy; window_stage<NCB_NCOL>(P.tabs.tau_table, (const double2*)P.tabs.ncb, P.tabs.bt_size, 0, lane, &dummy, ncw); }
   Q.bg_base = 0; Q.th_base = 0; Q.bg_inf = -1; Q.th_inf = -1; Q.tau_cached = -1.;
   window_stage<BG_NCOL>(P.tabs.tau_table, (const double2*)P.tabs.bg, P.tabs.bt_size, 0, lane, &Q.bgx, bgw);
@@ -693,25 +710,36 @@ static __device__ __forceinline__ void lookup(const PtParams& P, Lookup& Q, doub
 }
 
 // ---- look-ups through the helper wave (see Mailbox) ----------------------------------------------------------------
-// ask for the row at tau unless that is what was asked for last (the answer may still be on its way: mb_fetch waits for it)
+// ask for the row at tau unless it is one of the last two that were asked for (the answers may still be on their way: mb_wait).
+// Request n travels in slot n & 1 of the mailbox and so does its answer, which therefore stays where it is until request n + 2 is
+// posted: the integrator posts the row of the NEXT step at the start of every step, when the previous step's row is dead.
 static __device__ __forceinline__ void mb_request(Lookup& Q, double tau, int lane) {
-  if (uni(tau == Q.req_tau)) return;
-  Q.req_tau = tau;
+  if (uni(tau == Q.rq_tau0) || uni(tau == Q.rq_tau1)) return;
   Q.my_req++;
-  if (lane == 0) Q.mb->req_tau = tau;
+  const int p = Q.my_req & 1;
+  if (p) Q.rq_tau1 = tau; else Q.rq_tau0 = tau;
+  if (lane == 0) Q.mb->req_tau[p] = tau;
   mb_store(&Q.mb->req_seq, Q.my_req);
 }
-// Q <- the row at tau; returns false if the helper never answered (cannot happen unless the kernel is broken: the caller turns it
-// into an error status instead of spinning for ever)
+// the slot (0 / 1) that holds the row at tau once the helper has answered - after asking for it if need be and waiting for the answer;
+// -1 if the helper never answered (cannot happen unless the kernel is broken: the caller turns it into an error status instead of spinning for ever)
+static __device__ __forceinline__ int mb_wait(Lookup& Q, double tau, int lane) {
+  mb_request(Q, tau, lane);
+  const int p = uni(tau == Q.rq_tau1) ? 1 : 0;
+  const int want = Q.my_req - (((Q.my_req & 1) == p) ? 0 : 1);
+  if (Q.ans_seen - want >= 0) return p;
+  int spins = 0;
+  while ((Q.ans_seen = mb_load(&Q.mb->ans_seq)) - want < 0) {
+    __builtin_amdgcn_s_sleep(1);
+    if (++spins > (1 << 24)) return -1;
+  }
+  return p;
+}
 static __device__ __forceinline__ bool mb_fetch(Lookup& Q, double tau, int lane) {
   if (uni(tau == Q.tau_cached)) return true;
-  mb_request(Q, tau, lane);
-  int spins = 0;
-  while (mb_load(&Q.mb->ans_seq) != Q.my_req) {
-    __builtin_amdgcn_s_sleep(1);
-    if (++spins > (1 << 24)) return false;
-  }
-  const double* a = Q.mb->ans;
+  const int slot = mb_wait(Q, tau, lane);
+  if (slot < 0) return false;
+  const double* a = Q.mb->ans[slot];
   Q.rg = a[0]; Q.rb = a[1]; Q.rc = a[2]; Q.ru = a[3]; Q.kap = a[4]; Q.ddkappa = a[5]; Q.cb2 = a[6]; Q.a2 = a[7];
   Q.aH = a[8]; Q.two_over_aH = a[9]; Q.R = a[10]; Q.inv_1pR = a[11]; Q.inv_R = a[12]; Q.tau_c = a[13]; Q.dtau_c = a[14]; Q.F = a[15];
   Q.Fp = a[16]; Q.app = a[17]; Q.inv_tau = a[18]; Q.rg43 = a[19]; Q.ru43 = a[20]; Q.kcot = a[21];
@@ -721,6 +749,44 @@ static __device__ __forceinline__ bool mb_fetch(Lookup& Q, double tau, int lane)
   }
   Q.tau_cached = tau;
   return true;
+}
+// The scalar integrator of the two-wave kernels does not copy its rows at all, and it does not find them by their time either: it
+// knows which request is which.  mb_post asks and returns the request's number, mb_take waits for that number and points Q.row at the
+// answer, which every RHS evaluation then reads from LDS (uniform ds_read_b128: eleven instructions behind one wait).
+//  * 44 VGPRs less through the step loop: with them the loop needs more than the 256 architectural registers and the compiler parked
+//    and restored ~150 dwords in AGPRs per step around the factorisation and the sampling block;
+//  * no comparisons of times: a v_cmp_f64 feeding a scalar branch costs a lone wavefront ~45 cycles (tools/ubench.hip), and finding a
+//    row by its time took four to six of them per step.
+// Request n and its answer live in slot n & 1, so an answer stays intact until request n + 2 is posted.  The integrator posts the row
+// of the NEXT step at the start of every step (when the previous step's row is dead) and everything else only after the rows it
+// replaces are dead: at most two requests wait at any time, the helper answers them in order.
+enum RowIdx : int { ROW_rg = 0, ROW_rb, ROW_rc, ROW_ru, ROW_kap, ROW_ddkappa, ROW_cb2, ROW_a2, ROW_aH, ROW_two_over_aH, ROW_R, ROW_inv_1pR, ROW_inv_R,
+                    ROW_tau_c, ROW_dtau_c, ROW_F, ROW_Fp, ROW_app, ROW_inv_tau, ROW_rg43, ROW_ru43, ROW_kcot };
+static __device__ __forceinline__ int mb_post(Lookup& Q, double tau, int lane) {
+  // (an integrator uses either this pair or mb_request / mb_fetch, never both on one mailbox: the latter's record of what was asked
+  //  for is not kept here)
+  Q.my_req++;
+  if (lane == 0) Q.mb->req_tau[Q.my_req & 1] = tau;
+  mb_store(&Q.mb->req_seq, Q.my_req);
+  return Q.my_req;
+}
+static __device__ __forceinline__ bool mb_take(Lookup& Q, int seq) {
+  if (Q.ans_seen - seq < 0) {
+    int spins = 0;
+    while ((Q.ans_seen = mb_load(&Q.mb->ans_seq)) - seq < 0) {
+      __builtin_amdgcn_s_sleep(1);
+      if (++spins > (1 << 24)) return false;
+    }
+  }
+  Q.row = Q.mb->ans[seq & 1];
+  return true;
+}
+// (hand-over between schemes, Jacobian diagonal: the few places outside the RHS that read a row's fields)
+static __device__ __forceinline__ void mb_row_to_regs(Lookup& Q) {
+  const double* a = Q.row;
+  Q.rg = a[0]; Q.rb = a[1]; Q.rc = a[2]; Q.ru = a[3]; Q.kap = a[4]; Q.ddkappa = a[5]; Q.cb2 = a[6]; Q.a2 = a[7];
+  Q.aH = a[8]; Q.two_over_aH = a[9]; Q.R = a[10]; Q.inv_1pR = a[11]; Q.inv_R = a[12]; Q.tau_c = a[13]; Q.dtau_c = a[14]; Q.F = a[15];
+  Q.Fp = a[16]; Q.app = a[17]; Q.inv_tau = a[18]; Q.rg43 = a[19]; Q.ru43 = a[20]; Q.kcot = a[21];
 }
 
 // ---- physics ------------------------------------------------------------------------------------
@@ -911,7 +977,8 @@ static __device__ __forceinline__ void store_sources_tensor(const PtParams& P, c
 // perturb_rsa_delta_and_theta (pm.cpp:9530-9636) and perturb_tca_slip_and_shear (pm.cpp:9229-9516) folded in;
 // synchronous gauge, K = 0.  y: this lane's component (named components are broadcast with v_readlane).
 // Returns dy of this lane and leaves M describing the state (tau, y).
-// LK: where the row of the tables comes from - 0 this wave's own look-up, 1 the helper wave, 2 it is in Q already
+// LK: where the row of the tables comes from - 0 this wave's own look-up, 1 the helper wave (copied to Q), 2 it is in Q already,
+//     3 it lies in LDS where the helper wave left it (Q.row, see mb_take)
 template <int LK = 0>
 static __device__ __forceinline__ double rhs(const PtParams& P, const Layout& L, const LaneEq& e, Lookup& Q, Metric& M, double k,
                                       double inv_k2, double tau, double y, int lane, NcIn* Np = nullptr) {
@@ -925,29 +992,40 @@ static __device__ __forceinline__ double rhs(const PtParams& P, const Layout& L,
   //  tests, shrinks to the minimal step and the mode ends with "step size too small" instead of spinning for ever)
   if (LK == 1) { if (!mb_fetch(Q, tau, lane)) return nan(""); }
   else if (LK == 0) lookup(P, Q, tau, lane);
+  // a field of the row at tau: from LDS where the helper left it (LK = 3, see mb_take: eleven uniform b128 reads issued together
+  // here, behind one wait) or from this wave's registers
+  double rw[22];
+  if (LK == 3) {
+    const double2* r2 = reinterpret_cast<const double2*>(Q.row);
+#pragma unroll
+    for (int i = 0; i < 11; i++) { const double2 v = r2[i]; rw[2 * i] = v.x; rw[2 * i + 1] = v.y; }
+  }
+#define QV(f) ((LK == 3) ? rw[ROW_##f] : Q.f)
 #ifdef CPT_PROFILE
   PROF_STOP(8); PROF_START();
 #endif
   // neighbours on the multipole ladders: issued first, their LDS-crossbar latency hides behind the scalar algebra
   const double ym = gather(y, e.dn);
   const double yp = gather(y, e.up);
-  const double a2 = Q.a2, aH = Q.aH, k2 = k * k, R = Q.R, kap = Q.kap;
+  const double a2 = QV(a2), aH = QV(aH), k2 = k * k, R = QV(R), kap = QV(kap);
   // ---- named components ----
   // (a variable the scheme does not evolve reads as 0 from its idle lane)
   double dg = bcast(y, LN_DG), tg = bcast(y, LN_TG);
   const double sg = bcast(y, LN_SG), p0 = bcast(y, LN_P0), p2 = bcast(y, LN_P2);
   const double dur = bcast(y, LN_DUR), tur = bcast(y, LN_TUR), sur = bcast(y, LN_SUR);
   const double db = bcast(y, LN_DB), tb = bcast(y, LN_TB), eta = bcast(y, LN_ETA), dc = bcast(y, LN_DC);
-  const double cb2 = Q.cb2;
+  const double cb2 = QV(cb2);
 #ifdef CPT_PROFILE
   PROF_STOP(9); PROF_START();
 #endif
   // ---- stress-energy sums ----
-  double delta_rho = Q.rg * dg + Q.rb * db;
-  double rpt = Q.rg43 * tg + Q.rb * tb;
-  double rps = Q.rg43 * sg;
-  if (P.has_cdm) delta_rho += Q.rc * dc;
-  if (P.has_ur) { delta_rho += Q.ru * dur; rpt += Q.ru43 * tur; rps += Q.ru43 * sur; }
+  double delta_rho = QV(rg) * dg + QV(rb) * db;
+  double rpt = QV(rg43) * tg + QV(rb) * tb;
+  double rps = QV(rg43) * sg;
+  // (a species that is absent has zero density in the tables and an idle lane: no test - a scalar branch costs a lone wavefront five
+  //  multiply-adds)
+  delta_rho += QV(rc) * dc;
+  delta_rho += QV(ru) * dur; rpt += QV(ru43) * tur; rps += QV(ru43) * sur;
   if (NCDM) {
     const NcIn& N = *Np;
     delta_rho += N.D; rpt += N.T; rps += N.S;
@@ -956,32 +1034,32 @@ static __device__ __forceinline__ double rhs(const PtParams& P, const Layout& L,
   //      mc = metric_continuity, me = metric_euler, ms = metric_shear, msp = its derivative, mdot = eta' or phi'
   double mc, me, ms, msp, mdot;
   if (GAUGE == CPT_GAUGE_SYNCHRONOUS) {
-    const double hp = (Q.k2s2 * eta + 1.5 * a2 * delta_rho) * Q.two_over_aH;          // pm.cpp:5913-5914, k2s2 = k^2 (1 - 3K/k^2)
+    const double hp = (Q.k2s2 * eta + 1.5 * a2 * delta_rho) * QV(two_over_aH);          // pm.cpp:5913-5914, k2s2 = k^2 (1 - 3K/k^2)
     if (L.rsa) {
       double rdg = 0., rtg = 0., rdur = 0., rtur = 0.;
       if (P.rsa_method != CPT_RSA_NULL) { rdg = 4. * inv_k2 * (aH * hp - k2 * eta); rtg = -0.5 * hp; }
       if (P.rsa_method == CPT_RSA_MD_WITH_REIO) {
         rdg += -4. * inv_k2 * kap * (tb + 0.5 * hp);
-        rtg += 3. * inv_k2 * (Q.ddkappa * (tb + 0.5 * hp) + kap * (-aH * tb + cb2 * k2 * db - aH * hp + k2 * eta));
+        rtg += 3. * inv_k2 * (QV(ddkappa) * (tb + 0.5 * hp) + kap * (-aH * tb + cb2 * k2 * db - aH * hp + k2 * eta));
       }
-      if (P.has_ur && P.rsa_method != CPT_RSA_NULL) { rdur = 4. * inv_k2 * (aH * hp - k2 * eta); rtur = -0.5 * hp; }
-      delta_rho += Q.rg * rdg;
-      rpt += Q.rg43 * rtg;
-      if (P.has_ur) { delta_rho += Q.ru * rdur; rpt += Q.ru43 * rtur; }
+      if (P.rsa_method != CPT_RSA_NULL) { rdur = 4. * inv_k2 * (aH * hp - k2 * eta); rtur = -0.5 * hp; }
+      delta_rho += QV(rg) * rdg;
+      rpt += QV(rg43) * rtg;
+      delta_rho += QV(ru) * rdur; rpt += QV(ru43) * rtur;
       M.rsa_dg = rdg; M.rsa_tg = rtg;
       dg = rdg; tg = rtg;  // pm.cpp:8085-8088: the equations below use the streaming values
     }
     const double etap = (1.5 * a2 * rpt + (CURV ? 0.5 * P.K * hp : 0.)) * Q.inv_k2s2;                 // pm.cpp:5938
     const double alpha = (hp + 6. * etap) * 0.5 * inv_k2;
-    if (L.tca) rps += Q.rg43 * (16. / 45. * Q.tau_c * (tg + k2 * alpha));
+    if (L.tca) rps += QV(rg43) * (16. / 45. * QV(tau_c) * (tg + k2 * alpha));
     const double alphap = -2. * aH * alpha + eta - 4.5 * (a2 * inv_k2) * rps;
     M.hp = hp; M.etap = etap; M.alpha = alpha; M.alphap = alphap;
     mc = 0.5 * hp; me = 0.; ms = k2 * alpha; msp = k2 * alphap; mdot = etap;
   } else {
     // Newtonian gauge (pm.cpp:5869-5897): the LN_ETA lane holds phi; cdm has a velocity
     const double tc = bcast(y, LN_TC);
-    if (P.has_cdm) rpt += Q.rc * tc;
-    if (L.tca) rps += Q.rg43 * (16. / 45. * Q.tau_c * tg);                            // pm.cpp:6134-6136
+    rpt += QV(rc) * tc;
+    if (L.tca) rps += QV(rg43) * (16. / 45. * QV(tau_c) * tg);                            // pm.cpp:6134-6136
     const double psi = eta - 4.5 * (a2 * inv_k2) * rps;
     const double phip = -aH * psi + 1.5 * (a2 * inv_k2) * rpt;
     if (L.rsa) {                                                                      // pm.cpp:9549-9592
@@ -989,7 +1067,7 @@ static __device__ __forceinline__ double rhs(const PtParams& P, const Layout& L,
       if (P.rsa_method != CPT_RSA_NULL) { rdg = -4. * eta; rtg = 6. * phip; }
       if (P.rsa_method == CPT_RSA_MD_WITH_REIO) {
         rdg += -4. * inv_k2 * kap * tb;
-        rtg += 3. * inv_k2 * (Q.ddkappa * tb + kap * (-aH * tb + cb2 * k2 * db + k2 * eta));
+        rtg += 3. * inv_k2 * (QV(ddkappa) * tb + kap * (-aH * tb + cb2 * k2 * db + k2 * eta));
       }
       M.rsa_dg = rdg; M.rsa_tg = rtg;
       dg = rdg; tg = rtg;
@@ -1003,21 +1081,21 @@ static __device__ __forceinline__ double rhs(const PtParams& P, const Layout& L,
     dtb = -aH * tb + me + k2 * cb2 * db + R * kap * (tg - tb);  // pm.cpp:8108-8113
     S4 = kap * tb;
   } else {
-    const double tau_c = Q.tau_c, dtau_c = Q.dtau_c, F = Q.F;
+    const double tau_c = QV(tau_c), dtau_c = QV(dtau_c), F = QV(F);
     // first order: dkappa ~ a^-2 assumed (Ma & Bertschinger, pm.cpp:9351-9361) or not (CAMB form, :9364-9373)
-    const double slip_c = (P.tca_method == CPT_TCA_FIRST_ORDER_MB) ? 2. * R * Q.inv_1pR * aH : dtau_c * kap - 2. * aH * Q.inv_1pR;
+    const double slip_c = (P.tca_method == CPT_TCA_FIRST_ORDER_MB) ? 2. * R * QV(inv_1pR) * aH : dtau_c * kap - 2. * aH * QV(inv_1pR);
     double slip = slip_c * (tb - tg) +
-                  F * (-Q.app * tb + k2 * (-aH * dg * 0.5 + cb2 * (-tb - mc) - (-tg - mc) * (1. / 3.)) - aH * me);
+                  F * (-QV(app) * tb + k2 * (-aH * dg * 0.5 + cb2 * (-tb - mc) - (-tg - mc) * (1. / 3.)) - aH * me);
     double shear = 16. / 45. * tau_c * (tg + ms);
-    const double theta_prime = (-aH * tb + k2 * (cb2 * db + R * 0.25 * dg)) * Q.inv_1pR + me;
+    const double theta_prime = (-aH * tb + k2 * (cb2 * db + R * 0.25 * dg)) * QV(inv_1pR) + me;
     const double shear_prime = 16. / 45. * (tau_c * (theta_prime + msp) + dtau_c * (tg + ms));
     if (P.tca_method == CPT_TCA_COMPROMISE_CLASS) {
-      slip = (1. - 2. * aH * F) * slip + F * k2 * (Q.s2sq * (2. * aH * shear + shear_prime) - (1. / 3. - cb2) * (F * theta_prime + 2. * Q.Fp * tb));  // pm.cpp:9501
+      slip = (1. - 2. * aH * F) * slip + F * k2 * (Q.s2sq * (2. * aH * shear + shear_prime) - (1. / 3. - cb2) * (F * theta_prime + 2. * QV(Fp) * tb));  // pm.cpp:9501
       shear = (1. - 11. / 6. * dtau_c) * shear - (11. / 6. * 16. / 45.) * tau_c * tau_c * (theta_prime + msp);
     }
     M.tca_shear_g = shear;
-    dtb = (-aH * tb + k2 * (cb2 * db + R * (dg * 0.25 - Q.s2sq * shear)) + R * slip) * Q.inv_1pR + me;  // pm.cpp:8123-8129
-    S4 = -(dtb + aH * tb - k2 * cb2 * db) * Q.inv_R + k2 * (0.25 * dg - Q.s2sq * shear) + (1. + R) * Q.inv_R * me;  // pm.cpp:8214-8222
+    dtb = (-aH * tb + k2 * (cb2 * db + R * (dg * 0.25 - Q.s2sq * shear)) + R * slip) * QV(inv_1pR) + me;  // pm.cpp:8123-8129
+    S4 = -(dtb + aH * tb - k2 * cb2 * db) * QV(inv_R) + k2 * (0.25 * dg - Q.s2sq * shear) + (1. + R) * QV(inv_R) * me;  // pm.cpp:8214-8222
   }
   const double SP = kap * (p0 + p2 + 2. * Q.s2 * sg) * 0.125;  // kappa' Pi,  Pi = (G_gamma0 + G_gamma2 + F_gamma2)/8 (pm.cpp:8142)
 #ifdef CPT_PROFILE
@@ -1026,7 +1104,7 @@ static __device__ __forceinline__ double rhs(const PtParams& P, const Layout& L,
   // ---- every equation: streaming + damping + sources ----
   double yup = yp;
   if (NCDM) { if (LONG) { const int rem = opaque(e.rem); yup = (rem == 1) ? Np->y3[0] : (rem == 2) ? Np->y3[1] : (rem == 3) ? Np->y3[2] : yp; } }
-  double dy = e.A * ym - e.B * yup - (e.D * kap + e.G * Q.kcot + (CURV ? e.Gt * Q.inv_tau : 0.)) * y;
+  double dy = e.A * ym - e.B * yup - (e.D * kap + e.G * QV(kcot) + (CURV ? e.Gt * QV(inv_tau) : 0.)) * y;
   dy = fma(e.Xmc, mc, dy);
   dy = fma(e.Xms, ms, dy);
   dy = fma(e.XP, SP, dy);
@@ -1038,8 +1116,8 @@ static __device__ __forceinline__ double rhs(const PtParams& P, const Layout& L,
     if (opaque(e.role) == R_THETA_CDM) dy -= aH * y;                                  // pm.cpp:8235
   }
   // rarely used variants: non-standard ur sound speed (pm.cpp:8630-8641), ufa_hu (pm.cpp:8711-8716)
-  const double c3 = P.three_ceff2_ur;
-  if (c3 != 1. || (L.ufa && P.ufa_method == CPT_UFA_HU)) {
+  if (L.ur_special) {   // (Layout: three_ceff2_ur != 1 or ufa_hu)
+    const double c3 = P.three_ceff2_ur;
     const int role = opaque(e.role);
     if (role == R_DELTA_UR) dy += (1. - c3) * aH * (dur + 4. * aH * tur * inv_k2);
     if (role == R_THETA_UR) dy -= (1. - c3) * aH * tur;
@@ -1048,6 +1126,7 @@ static __device__ __forceinline__ double rhs(const PtParams& P, const Layout& L,
 #ifdef CPT_PROFILE
   PROF_STOP(11);
 #endif
+#undef QV
   return dy;
 }
 
@@ -1160,6 +1239,7 @@ static __device__ __forceinline__ double search_flip(const PtParams& P, double k
 // ---- what the integrator wave carries beside the equations ------------------------------------------------------------------------
 struct Ctx {
   Mailbox* mb; int posted, tail_seen;          // mailbox of the helper wave, samples posted so far, last value read of the helper's tail
+  int fact_posted;   // factorisations handed to the helper wave for inversion (helper_inverse)
 };
 
 // ---- wave-wide cyclic reduction (the long tails of cpt_perturb_sets.inc: up to 64 multipoles of one ladder along the lanes) ----------
@@ -1260,6 +1340,7 @@ static constexpr int FW_PAIRS = FW_ACP + (PCR ? 4 : 0);   // + (al, ga) of the f
                                                          // the resident k-modes of the ncdm kernels)
 struct LuReg {
   double2* fw;     // LDS [FW_PAIRS][64]
+  const double2* inv;  // LDS [FW_ACP][64]: rows of the inverse of the core block, written by the helper wave (helper_inverse); same layout as fw
   double rpivc;    // lane j < nc: reciprocal of the j-th core pivot
   int rowperm;     // lane i < nc: original row now at position i (identity on tail lanes)
   int permuted;    // (wave-uniform) some rows were exchanged: rowperm is not the identity
@@ -1305,6 +1386,7 @@ static __device__ __forceinline__ void pcr_level(double& a, double& c, double& d
 
 static __device__ __forceinline__ bool factorise(const LaneEq& e, const Jac& J, double hg, int maxlen, int lane, LuReg& F,
                                                  const double* al = nullptr, double gmc = 0., double gms = 0., int aux = 0) {
+  ISA_MARK("FACT_BEGIN");
   lane = opaque(lane);
   const int chain = opaque(e.chain);
   // ---- tails ----
@@ -1341,6 +1423,7 @@ static __device__ __forceinline__ bool factorise(const LaneEq& e, const Jac& J, 
   F.rinv = chain ? rinv : 0.; F.r = chain ? r : 0.;
   F.g = c * rinv_up;
   }
+  ISA_MARK("FACT_CORE");
   // ---- core: A_cc = I - hg J_cc, Schur-corrected on the diagonal of the parents of the tails ----
   const double cpar = hg * e.Bpar;               // row parent, column l3:  -hg * (-B);  0 on every other lane
   F.cpar = cpar;
@@ -1399,6 +1482,7 @@ static __device__ __forceinline__ bool factorise(const LaneEq& e, const Jac& J, 
       A[cidx] = fma(-m, pj, A[cidx]);   // m = 0 on rows <= j
     });
   });
+  ISA_MARK("FACT_SCALE");
   // unit-diagonal U: scale the upper part of every row by its reciprocal pivot
 #pragma unroll
   for (int j = 0; j < NC; j++) A[j] = (j > lane) ? A[j] * rpivc : A[j];
@@ -1409,10 +1493,12 @@ static __device__ __forceinline__ bool factorise(const LaneEq& e, const Jac& J, 
   F.rpivc = rpivc;
   F.rowperm = rowperm;
   F.permuted = __builtin_amdgcn_readfirstlane(permuted);
+  ISA_MARK("FACT_END");
   return ok;
 }
 
 // solve (I - hg J) x = b; lane i holds b_i on entry and x_i on return
+template <bool USE_INV = false>
 static __device__ __forceinline__ double lu_solve(const LaneEq& e, const LuReg& F, int maxlen, double b, int lane) {
   lane = opaque(lane);
   const int chain = opaque(e.chain);
@@ -1421,7 +1507,7 @@ static __device__ __forceinline__ double lu_solve(const LaneEq& e, const LuReg& 
   // the rows of the core factors: requested now, they arrive behind the tail reduction
   double Ac[2 * FW_ACP];
 #pragma unroll
-  for (int q = 0; q < FW_ACP; q++) { const double2 v = F.fw[q * JS + (lane & (JS - 1))]; Ac[2 * q] = v.x; Ac[2 * q + 1] = v.y; }   // (JS = 32: lanes >= 32 read rows that are not theirs, see the end)
+  for (int q = 0; q < FW_ACP; q++) { const double2 v = (USE_INV ? F.inv : F.fw)[q * JS + (lane & (JS - 1))]; Ac[2 * q] = v.x; Ac[2 * q + 1] = v.y; }   // (JS = 32: lanes >= 32 read rows that are not theirs, see the end)
   if (PCR) u = pcr_apply(F, chain ? b : 0., lane) * F.rinv;   // T^-1 b on every tail lane, 0 on core lanes
   else {
     double bp = b;
@@ -1439,12 +1525,25 @@ static __device__ __forceinline__ double lu_solve(const LaneEq& e, const LuReg& 
   const double bc = fma(-F.cpar, t3, b);
   // 3. core solve with the register-resident factors (idle rows / lanes >= NC are identity rows: x = b there)
   // (rows are only exchanged when a diagonal entry was not an acceptable pivot: almost never, and then the gather is skipped)
-  double x = chain ? 0. : bc;
+  double x;
+  const unsigned pm = e.pmask;
+  if constexpr (USE_INV) {
+    // x = A_cc^-1 bc with row i of the inverse in lane i (zero rows on the tail lanes): NC independent broadcasts and two chains of
+    // multiply-adds instead of 2 NC dependent (broadcast, multiply-add) pairs - 210 against 670 cycles on a lone wavefront
+    static_assert(NCDM == 0, "inverse of the core: two-wave kernels only");
+    double x0 = 0., x1 = 0.;
+#pragma unroll
+    for (int j = 0; j < NC; j++) {
+      const double bj = bcast(bc, j);
+      if (j & 1) x1 = fma(Ac[j], bj, x1); else x0 = fma(Ac[j], bj, x0);
+    }
+    x = x0 + x1;
+  } else {
+  x = chain ? 0. : bc;
   if (F.permuted) x = gather(x, F.rowperm * 4);
   // Row i keeps its L entries (columns j < i) and its U entries (j > i) in ONE register array, so each substitution step must
   // switch the entry off on the rows it does not concern.  Clearing the HIGH word alone does that in one v_cndmask instead of
   // two: what is left is a subnormal (|m| < 2^-1022), and m * xj then vanishes against x unless |xj / x| > 2^970.
-  const unsigned pm = e.pmask;
   for_core(pm, 0, [&](const int j) {   // forward, unit lower
     const double xj = bcast(x, j);
     const double m = __hiloint2double((lane > j) ? __double2hiint(Ac[j]) : 0, __double2loint(Ac[j]));
@@ -1456,6 +1555,7 @@ static __device__ __forceinline__ double lu_solve(const LaneEq& e, const LuReg& 
     const double uj = __hiloint2double((lane < j) ? __double2hiint(Ac[j]) : 0, __double2loint(Ac[j]));
     x = fma(-uj, xj, x);
   });
+  }
   // 4. tails, upward sweep: x_l = b'_l / d'_l - (a_l / d'_l) x_{l-1}; the l=3 element takes x_{l-1} from its core parent
   if (maxlen > 0) {
     double xpar;
@@ -1477,6 +1577,60 @@ static __device__ __forceinline__ double lu_solve(const LaneEq& e, const LuReg& 
   return x;
 }
 
+
+// ---- the inverse of the core block, by the helper wave -------------------------------------------------------------------------
+// The two triangular sweeps of a solve are 2 NC dependent (broadcast, multiply-add) pairs: 670 cycles of a lone wavefront, 11 % of the
+// kernel.  With row i of A_cc^-1 in lane i the same product is NC independent broadcasts and two short chains: 210 cycles.  Forming
+// the inverse costs more than the factorisation, and the integrator would lose what it wins - but the helper wave idles three quarters
+// of the time.  So: the integrator factorises as before, posts (fact_seq) and goes on with the LU solve for the FIRST Newton iteration;
+// the helper reads the factors from LDS, computes U^-1 D^-1 L^-1 with one COLUMN per lane (the factors' entries are wave-uniform
+// broadcast reads, the arithmetic NC (NC - 1) multiply-adds per lane with no cross-lane traffic), stores it row-wise and posts
+// (inv_seq); every later solve with these factors - eight of nine - takes the product form.  Which solve takes which form is fixed
+// by the program, not by timing: results are reproducible bit for bit.  A factorisation that had to exchange rows (almost never) is
+// not posted and keeps the LU solve.  The Newton iteration does not care that the two forms round differently.
+// Safe without further handshakes: the integrator accepts an inverse only if inv_seq equals the factorisation it posted last; the helper
+// tags its result with the fact_seq it read BEFORE reading the factors, so an inverse computed from factors that were being overwritten
+// carries a stale tag and is never used.
+static constexpr bool INV = (NCDM == 0);
+static __device__ __forceinline__ void helper_inverse(const double2* fw, const double* rp, double2* inv, int lane) {
+  ISA_MARK("INV_BEGIN");
+  double X[NC];
+#pragma unroll
+  for (int i = 0; i < NC; i++) X[i] = (i == lane) ? 1.0 : 0.0;
+  // L (unit lower triangle of the rows), then D^-1
+#pragma unroll
+  for (int i = 1; i < NC; i++) {
+    double acc = X[i];
+#pragma unroll
+    for (int q = 0; 2 * q < i; q++) {
+      const double2 v = fw[q * JS + i];          // (row i, columns 2q and 2q + 1: the same address on every lane)
+      acc = fma(-v.x, X[2 * q], acc);
+      if (2 * q + 1 < i) acc = fma(-v.y, X[2 * q + 1], acc);
+    }
+    X[i] = acc;
+  }
+#pragma unroll
+  for (int i = 0; i < NC; i++) X[i] *= rp[i];
+  // U (unit upper triangle)
+#pragma unroll
+  for (int i = NC - 2; i >= 0; i--) {
+    double acc = X[i];
+#pragma unroll
+    for (int q = (i + 1) / 2; q < FW_ACP; q++) {
+      const double2 v = fw[q * JS + i];
+      if (2 * q > i) acc = fma(-v.x, X[2 * q], acc);
+      if (2 * q + 1 < NC) acc = fma(-v.y, X[2 * q + 1], acc);
+    }
+    X[i] = acc;
+  }
+  // lane c holds column c: entry (i, c) goes to pair c / 2 of row i
+  if (lane < NC) {
+    double* o = reinterpret_cast<double*>(inv) + ((lane >> 1) * JS) * 2 + (lane & 1);
+#pragma unroll
+    for (int i = 0; i < NC; i++) o[2 * i] = X[i];
+  }
+  ISA_MARK("INV_END");
+}
 
 // adjust_stepsize (ev.cpp:907-943): dif(1:k) <- dif(1:k) R(1:k,1:k) U(1:k,1:k) with R[m][p] = prod_{i<=m} (i - (p+1) r)/(i+1) and the
 // constant upper-triangular U.  Evaluated right to left, w[p] = sum_m dif[m] R[m][p] first: ~130 instructions instead of the
@@ -1643,6 +1797,9 @@ static __device__ __forceinline__ int ndf15s(const PtParams& P, const Layout& L,
   J.jdiag = 0.;
   LuReg F;
   F.fw = fw_lds;
+  F.inv = fw_lds + FW_PAIRS * JS;
+  constexpr bool USE_INV = INV && HELPED && SYS == 0;   // the helper inverts the core block behind the integrator's back (helper_inverse)
+  int inv_want = -1; bool inv_ok = false, lu_first = true;
   F.rpivc = 1.; F.rowperm = lane; F.permuted = 0; F.rinv = F.r = F.g = F.cpar = 0.;
   double y = y_io;
   double dif[7] = {0., 0., 0., 0., 0., 0., 0.};
@@ -1653,12 +1810,18 @@ static __device__ __forceinline__ int ndf15s(const PtParams& P, const Layout& L,
   double tnext = (next < tres) ? ts[next] : 1e300, tnext2 = (next + 1 < tres) ? ts[next + 1] : 1e300;
 
   NcIn N = {0., 0., 0., {0., 0., 0.}};
+  // ROWQ: the scalar integrator of the two-wave kernels handles its table rows by request number (mb_post / mb_take): it says which row
+  // an evaluation uses before it evaluates, and the RHS reads it from LDS
+  constexpr bool ROWQ = (SYS == 0 && HELPED && MODE == 0 && NCDM == 0);
+  int seq_this = 0, seq_next = 0;
+  bool have_next = false, post_this = true, post_next = true;
   auto eval = [&](double tq, double yq) {
     st.fevals++;
     if constexpr (SYS != 0) return rhs_fluid<SYS, HELPED ? 1 : 0>(P, L, e, Q, M, N, k, inv_k2, tq, yq, lane);
+    else if constexpr (ROWQ) return rhs<3>(P, L, e, Q, M, k, inv_k2, tq, yq, lane);
     else return rhs<1>(P, L, e, Q, M, k, inv_k2, tq, yq, lane);
   };
-  auto request = [&](double tq) { if constexpr (HELPED) mb_request(Q, tq, lane); };
+  auto request = [&](double tq) { if constexpr (HELPED && !ROWQ) mb_request(Q, tq, lane); };
   const double no_alpha[4] = {0., 0., 0., 0.};
   // J e_r = f(t, e_r): exact, the system is linear and homogeneous; idle variables have no column; tails analytic
   auto jacobian = [&](double tq) {
@@ -1668,7 +1831,8 @@ static __device__ __forceinline__ int ndf15s(const PtParams& P, const Layout& L,
       const double col = eval(tq, (lane == r) ? 1.0 : 0.0);
       jc_store(J.Jc, r, lane, (lane < NC) ? col : 0.);
     }
-    J.jdiag = -(e.D * Q.kap + e.G * Q.kcot + (CURV ? e.Gt * Q.inv_tau : 0.));   // frozen at the time of this Jacobian (ev.cpp keeps J fixed)
+    if constexpr (ROWQ) J.jdiag = -(e.D * Q.row[ROW_kap] + e.G * Q.row[ROW_kcot] + (CURV ? e.Gt * Q.row[ROW_inv_tau] : 0.));
+    else J.jdiag = -(e.D * Q.kap + e.G * Q.kcot + (CURV ? e.Gt * Q.inv_tau : 0.));   // frozen at the time of this Jacobian (ev.cpp keeps J fixed)
     M.tca_shear_g = keep;
     st.jacs++;
   };
@@ -1677,6 +1841,7 @@ static __device__ __forceinline__ int ndf15s(const PtParams& P, const Layout& L,
   double t = t0, absh, h;
   const double hmin0 = 16.0 * eps * fabs(t0);
   PROF_START();
+  if constexpr (ROWQ) { if (!mb_take(Q, mb_post(Q, t, lane))) return 5; }
   jacobian(t);
   {
     const double f0 = eval(t, y);
@@ -1686,8 +1851,15 @@ static __device__ __forceinline__ int ndf15s(const PtParams& P, const Layout& L,
     if (uni(absh * rh > 1.0)) absh = 1.0 / rh;
     absh = fmax(absh, hmin0);
     const double tdel = (t + fmin(sqrt(eps) * fmax(fabs(t), fabs(t + absh)), absh)) - t;
-    const double f1 = eval(t + tdel, y);
-    const double Jf0 = eval(t, f0);                      // J f0 = f(t, f0)
+    double f1, Jf0;
+    if constexpr (ROWQ) {                                // (the evaluations at t first: one row at a time)
+      Jf0 = eval(t, f0);
+      if (!mb_take(Q, mb_post(Q, t + tdel, lane))) return 5;
+      f1 = eval(t + tdel, y);
+    } else {
+      f1 = eval(t + tdel, y);
+      Jf0 = eval(t, f0);                                 // J f0 = f(t, f0)
+    }
     const double acc = Jf0 + (f1 - f0) / tdel;           // ddfddt (ev.cpp:261-283)
     rh = wave_max(1.25 * sqrt(0.5 * fabs(acc / wt) / rtol));
     absh = fmin(hmax, htspan);
@@ -1702,34 +1874,62 @@ static __device__ __forceinline__ int ndf15s(const PtParams& P, const Layout& L,
   auto set_order = [&]() { iga = ndf_invGa(kk - 1); erc = ndf_erconst(kk - 1); errthr = rtol * fast_rcp(erc); };
   double abshlast = absh, hinvGak = h * iga, hmin = hmin0;
   double rate = 0., thr1 = minnrm, err = 0.;
-  bool Jcurrent = true, havrate = false, done = false, at_hmin = false, need_fact = true;
+  bool Jcurrent = true, havrate = false, done = false, at_hmin = false, need_fact = true, first_step = true;
   double tnew = t0, ynew = y, fnewton = 0., difkp1 = 0., invwt = 0.;
 
   for (;;) {   // ------------------------------------------------ one turn = one accepted step
     // ---------------------------------------------------------------- start of a step (ev.cpp:299-334)
     PROF_START();
+    ISA_MARK("STEP_START");
+    // (nothing below can change absh while it is what the previous step used and that step was not at the minimal step: the clamp and
+    //  the test of the minimal step size are then skipped - every test here is a v_cmp_f64 feeding a scalar branch, ~45 cycles)
     hmin = P.min_var;
-    absh = fmin(hmax, fmax(hmin, absh));
-    if (uni(fabs(absh - hmin) < 100 * eps)) { if (at_hmin) absh = abshlast; at_hmin = true; } else at_hmin = false;
+    bool moved = first_step || at_hmin || uni(absh != abshlast);
+    first_step = false;
+    if (moved) {
+      absh = fmin(hmax, fmax(hmin, absh));
+      if (uni(fabs(absh - hmin) < 100 * eps)) { if (at_hmin) absh = abshlast; at_hmin = true; } else at_hmin = false;
+    }
     h = absh;
-    if (uni(1.1 * absh >= fabs(tfinal - t))) { h = tfinal - t; absh = fabs(h); done = true; }
-    if (uni(fabs(absh - abshlast) > 1e-6 * absh) || (kk != klast)) {   // (ev.cpp:318: |dh| / h > 1e-6, without the division)
-      adjust_stepsize(dif, absh * fast_rcp(abshlast), kk);
-      hinvGak = h * iga;
-      nconhk = 0;
-      need_fact = true;
+    if (uni(1.1 * absh >= fabs(tfinal - t))) { h = tfinal - t; absh = fabs(h); done = true; moved = true; }
+    if (moved || (kk != klast)) {
+      if (uni(fabs(absh - abshlast) > 1e-6 * absh) || (kk != klast)) {   // (ev.cpp:318: |dh| / h > 1e-6, without the division)
+        adjust_stepsize(dif, absh * fast_rcp(abshlast), kk);
+        hinvGak = h * iga;
+        nconhk = 0;
+        need_fact = true;
+      }
     }
     // the time of this step is known: ask the helper for its table row now (a no-op when the step size did not change - the row
     // was requested a whole step ago - and otherwise early enough to arrive behind the factorisation)
-    request(done ? tfinal : t + h);
+    if constexpr (ROWQ) {
+      if (have_next && !moved) { seq_this = seq_next; post_this = false; } else post_this = true;
+      post_next = true;               // ... and the row of the step after this one, on the guess that the step size stays
+    } else {
+      request(done ? tfinal : t + h);
+      if (!done) request((t + h) + absh);
+    }
     bool nofailed = true;
     PROF_STOP(13);
     for (;;) {   // -------------------------------------------- attempts at this step
       if (--budget < 0) return 4;
+      if constexpr (ROWQ) {
+        if (post_this) seq_this = mb_post(Q, done ? tfinal : t + h, lane);
+        if (post_next) { have_next = !done; if (!done) seq_next = mb_post(Q, (t + h) + absh, lane); }
+        post_this = post_next = false;
+      }
       if (need_fact) {
         need_fact = false;
         PROF_START();
         if (!factorise(e, J, hinvGak, maxlen, lane, F, nullptr, 0., 0.)) return 2;
+        if constexpr (USE_INV) {
+          inv_want = -1; inv_ok = false; lu_first = true;
+          if (!F.permuted) {
+            if (lane < NC) C.mb->rp[lane] = F.rpivc;
+            inv_want = ++C.fact_posted;
+            mb_store(&C.mb->fact_seq, inv_want);
+          }
+        }
         PROF_STOP(2);
         st.lus++;
         havrate = false;
@@ -1741,6 +1941,7 @@ static __device__ __forceinline__ int ndf15s(const PtParams& P, const Layout& L,
       unsigned long long t_inner = 0;
 #endif
       double psi, pred;
+      ISA_MARK("NEWT_PRED");
       switch (__builtin_amdgcn_readfirstlane(kk)) {
         case 1: psi = dif[0]; pred = y + dif[0]; break;
         case 2: psi = fma(1.5, dif[1], dif[0]); pred = y + (dif[0] + dif[1]); break;
@@ -1762,18 +1963,42 @@ static __device__ __forceinline__ int ndf15s(const PtParams& P, const Layout& L,
       }
       bool tooslow = false;
       double newnrm = 0., oldnrm = 0.;
+      if constexpr (ROWQ) { if (!mb_take(Q, seq_this)) return 5; }
       for (int iter = 1; iter <= maxit; iter++) {
         PROF_START();
+        ISA_MARK("NEWT_EVAL");
         fnewton = eval(tnew, ynew);
-        // the row of THIS step is in registers: speculate that the step size stays and ask for the next one (t' + h' = tnew + absh)
-        if (iter == 1 && !done) request(tnew + absh);
         PROF_STOP(0);
 #ifdef CPT_PROFILE
         t_inner += clock64() - pf_t0;
 #endif
         const double rhsv = hinvGak * fnewton - (psi + difkp1);
         PROF_START();
-        const double del = lu_solve(e, F, maxlen, rhsv, lane);
+        ISA_MARK("NEWT_SOLVE");
+        double del;
+        if constexpr (USE_INV) {
+          if (!lu_first && inv_want >= 0) {
+            if (!inv_ok) {   // (once per factorisation; the helper has had a whole RHS evaluation and a solve to get there)
+#ifdef CPT_PROFILE
+              const unsigned long long t_wait0 = clock64();
+#endif
+              int spins = 0;
+              while (mb_load(&C.mb->inv_seq) != inv_want) {
+                __builtin_amdgcn_s_sleep(1);
+                if (++spins > (1 << 24)) return 5;
+              }
+              inv_ok = true;
+#ifdef CPT_PROFILE
+              prof[15] += clock64() - t_wait0;
+#endif
+            }
+            del = lu_solve<true>(e, F, maxlen, rhsv, lane);
+          } else {
+            del = lu_solve<false>(e, F, maxlen, rhsv, lane);
+            lu_first = false;
+          }
+        } else del = lu_solve(e, F, maxlen, rhsv, lane);
+        ISA_MARK("NEWT_CTRL");
         PROF_STOP(1);
 #ifdef CPT_PROFILE
         t_inner += clock64() - pf_t0;
@@ -1799,7 +2024,9 @@ static __device__ __forceinline__ int ndf15s(const PtParams& P, const Layout& L,
           else if (uni(0.5 * rtol < errit * fast_powi(rate, maxit - iter))) { tooslow = true; break; }
         }
         oldnrm = newnrm;
+        ISA_MARK("NEWT_ITER_END");
       }
+      ISA_MARK("NEWT_END");
 #ifdef CPT_PROFILE
       prof[5] += clock64() - t_newton0 - t_inner;  // predictor + Newton control without rhs / solve
 #endif
@@ -1807,6 +2034,10 @@ static __device__ __forceinline__ int ndf15s(const PtParams& P, const Layout& L,
         st.failed++;
         if (!Jcurrent) {
           PROF_START();
+          if constexpr (ROWQ) {   // (the rows of this attempt are dead; both are asked for again at the next attempt)
+            if (!mb_take(Q, mb_post(Q, t, lane))) return 5;
+            post_this = post_next = true;
+          }
           jacobian(t);
           st.fevals++;  // the reference also re-evaluates f(t,y) here (ev.cpp:451)
           Jcurrent = true;
@@ -1819,7 +2050,8 @@ static __device__ __forceinline__ int ndf15s(const PtParams& P, const Layout& L,
         absh = fmax(0.3 * absh, hmin);
         h = absh;
         done = false;
-        request(t + h);
+        if constexpr (ROWQ) post_this = post_next = true;
+        else { request(t + h); request((t + h) + absh); }
         adjust_stepsize(dif, absh * fast_rcp(abshlast), kk);
         hinvGak = h * iga;
         nconhk = 0;
@@ -1847,7 +2079,8 @@ static __device__ __forceinline__ int ndf15s(const PtParams& P, const Layout& L,
       } else absh = fmax(hmin, 0.5 * absh);
       h = absh;
       if (uni(absh < abshlast)) done = false;
-      request(done ? tfinal : t + h);
+      if constexpr (ROWQ) post_this = post_next = true;
+      else { request(done ? tfinal : t + h); if (!done) request((t + h) + absh); }
       adjust_stepsize(dif, absh * fast_rcp(abshlast), kk);
       hinvGak = h * iga;
       nconhk = 0;
@@ -1856,6 +2089,7 @@ static __device__ __forceinline__ int ndf15s(const PtParams& P, const Layout& L,
     }
     // ------------------------------------------------------------------ accepted: update differences (ev.cpp:537-545)
     st.steps++;
+    ISA_MARK("ACCEPTED");
     switch (__builtin_amdgcn_readfirstlane(kk)) {
       case 1: dif[2] = difkp1 - dif[1]; dif[1] = difkp1; dif[0] += dif[1]; break;
       case 2: dif[3] = difkp1 - dif[2]; dif[2] = difkp1; dif[1] += dif[2]; dif[0] += dif[1]; break;
@@ -1919,6 +2153,7 @@ static __device__ __forceinline__ int ndf15s(const PtParams& P, const Layout& L,
     if (done) break;
     // ------------------------------------------------------------------ after an accepted step (ev.cpp:573-635)
     PROF_START();
+    ISA_MARK("POST_STEP");
     klast = kk;
     abshlast = absh;
     nconhk = min(nconhk + 1, maxk + 2);
@@ -1949,6 +2184,7 @@ static __device__ __forceinline__ int ndf15s(const PtParams& P, const Layout& L,
   }
   // ev.cpp:653-662: one last evaluation leaves M and Q describing (tfinal, y) for the hand-over to the next scheme
   (void)eval(tnew, ynew);
+  if constexpr (ROWQ) mb_row_to_regs(Q);   // (the hand-over reads fields of the row)
   y_io = ynew;
   return 0;
 }
@@ -2072,7 +2308,7 @@ static __device__ __forceinline__ int run_intervals(const PtParams& P, Ctx& C, c
     Q.bg_lo = Q.bg_hi = Q.th_lo = Q.th_hi = Q.nc_lo = Q.nc_hi = make_double2(0., 0.);
     Q.rg = Q.rb = Q.rc = Q.ru = Q.kap = Q.ddkappa = Q.cb2 = Q.a2 = Q.aH = Q.two_over_aH = Q.R = Q.inv_1pR = Q.inv_R = 0.;
     Q.tau_c = Q.dtau_c = Q.F = Q.Fp = Q.app = Q.inv_tau = Q.rg43 = Q.ru43 = Q.kcot = 0.;
-    Q.mb = C.mb; Q.my_req = 0; Q.req_tau = -1.;
+    Q.mb = C.mb; Q.my_req = 0; Q.rq_tau0 = Q.rq_tau1 = -1.; Q.ans_seen = 0;
     lookup_set_mode(P, Q, k);
 #ifdef CPT_PROFILE
     Q.prof = prof;
@@ -2153,8 +2389,11 @@ static __device__ __forceinline__ int run_intervals(const PtParams& P, Ctx& C, c
 // sample the integrator posts.  Two sets of table windows: the samples walk monotonically through the sample times, the look-ups run
 // one step ahead of the integration.
 static __device__ __forceinline__ void run_helper(const PtParams& P, Mailbox* mb, double k, double inv_k2, int ik, int lane, double2* bgw_s, double2* thw_s,
-                                                  double2* bgw_p, double2* thw_p) {
+                                                  double2* bgw_p, double2* thw_p, const double2* fw, double2* inv) {
   static_assert(NCDM == 0, "the register-set kernels have their own helper (cpt_perturb_sets.inc)");
+  // (rows of the tail lanes and the padding column of the inverse: zero for good)
+  for (int q = 0; q < FW_ACP; q++) inv[q * JS + lane] = make_double2(0., 0.);
+  int inverted = 0;
   Lookup Q, Qp;
   lookup_init(P, Q, bgw_s, thw_s, lane);
   lookup_set_mode(P, Q, k);
@@ -2172,18 +2411,26 @@ static __device__ __forceinline__ void run_helper(const PtParams& P, Mailbox* mb
   LaneEq e = make_lane_eq(P, L, lane, k);
   for (;;) {
     // look-ups first: the integrator may be waiting for one, a sample never holds it up while the ring has room
-    const int rq = mb_load(&mb->req_seq);
-    if (rq != answered) {
-      const double tau = mb->req_tau;            // (a request posted meanwhile is picked up on the next turn)
+    if (mb_load(&mb->req_seq) != answered) {
+      const int rq = answered + 1;               // (in order: two requests may be waiting)
+      const double tau = mb->req_tau[rq & 1];
       lookup(P, Qp, tau, lane);
       if (lane == 0) {
-        double* a = mb->ans;
+        double* a = mb->ans[rq & 1];
         a[0] = Qp.rg; a[1] = Qp.rb; a[2] = Qp.rc; a[3] = Qp.ru; a[4] = Qp.kap; a[5] = Qp.ddkappa; a[6] = Qp.cb2; a[7] = Qp.a2;
         a[8] = Qp.aH; a[9] = Qp.two_over_aH; a[10] = Qp.R; a[11] = Qp.inv_1pR; a[12] = Qp.inv_R; a[13] = Qp.tau_c; a[14] = Qp.dtau_c; a[15] = Qp.F;
         a[16] = Qp.Fp; a[17] = Qp.app; a[18] = Qp.inv_tau; a[19] = Qp.rg43; a[20] = Qp.ru43; a[21] = Qp.kcot;
       }
       answered = rq;
       mb_store(&mb->ans_seq, rq);
+      continue;
+    }
+    // then the inverse of a factorisation the integrator has posted (it will want it at its next Newton iteration but one)
+    const int fs = mb_load(&mb->fact_seq);
+    if (fs != inverted) {
+      helper_inverse(fw, mb->rp, inv, lane);
+      inverted = fs;
+      mb_store(&mb->inv_seq, fs);
       continue;
     }
     const int head = mb_load(&mb->head);
@@ -2261,7 +2508,7 @@ static __device__ __forceinline__ void body_perturb(const PtParams& P) {
   __shared__ __attribute__((aligned(16))) double2 tabw[64 * (BG_NCOL + TH_NCOL)];      // the helper's windows of the look-ups ahead
   __shared__ __attribute__((aligned(16))) double2 tabw2[64 * (BG_NCOL + TH_NCOL)];     // ... and of the samples
   __shared__ double jacw[NC * JS];
-  __shared__ __attribute__((aligned(16))) double2 fwsh[FW_PAIRS * JS];   // the integrator's factors (LuReg)
+  __shared__ __attribute__((aligned(16))) double2 fwsh[(FW_PAIRS + FW_ACP) * JS];   // the integrator's factors (LuReg::fw), then the helper's inverse of the core block (LuReg::inv)
   __shared__ __attribute__((aligned(16))) unsigned char mbox_s[sizeof(Mailbox)];
   Mailbox* mbox = (Mailbox*)mbox_s;
   const int lane = threadIdx.x & 63;
@@ -2272,12 +2519,12 @@ static __device__ __forceinline__ void body_perturb(const PtParams& P) {
   double2* bgw = tabw;
   double2* thw = tabw + 64 * BG_NCOL;
   Ctx C;
-  C.mb = mbox; C.posted = 0; C.tail_seen = 0;
+  C.mb = mbox; C.posted = 0; C.tail_seen = 0; C.fact_posted = 0;
   // (the only barrier of the kernel: the counters are zero before any wave looks at them)
-  if (threadIdx.x == 0) { mbox->head = mbox->tail = mbox->done = mbox->req_seq = mbox->ans_seq = 0; mbox->req_tau = -1.; }
+  if (threadIdx.x == 0) { mbox->head = mbox->tail = mbox->done = mbox->req_seq = mbox->ans_seq = mbox->fact_seq = mbox->inv_seq = 0; mbox->req_tau[0] = mbox->req_tau[1] = -1.; }
   __syncthreads();
   if (wave == 1) {   // the helper polls `done` whatever happens to the integrator, drains the ring and leaves
-    run_helper(P, mbox, k, inv_k2, ik, lane, tabw2, tabw2 + 64 * BG_NCOL, bgw, thw);
+    run_helper(P, mbox, k, inv_k2, ik, lane, tabw2, tabw2 + 64 * BG_NCOL, bgw, thw, fwsh, fwsh + FW_PAIRS * JS);
     return;
   }
   Stat st = {0, 0, 0, 0, 0, 0};
@@ -2388,14 +2635,25 @@ static __device__ __forceinline__ void body_dbg_solve(const PtParams& P, double 
     jc_store(J.Jc, r, lane, (lane < NC) ? col : 0.);
   }
   J.jdiag = -(e.D * Q.kap + e.G * Q.kcot + (CURV ? e.Gt * Q.inv_tau : 0.));
-  __shared__ __attribute__((aligned(16))) double2 fwsh[FW_PAIRS * JS];
+  __shared__ __attribute__((aligned(16))) double2 fwsh[(FW_PAIRS + FW_ACP) * JS];
+  __shared__ double rps[32];
   LuReg F;
   F.fw = fwsh;
+  F.inv = fwsh + FW_PAIRS * JS;
   const bool ok = factorise(e, J, hg, L.maxlen, lane, F);
   int nref;
   const int ri = ref_index_of(P, tca, rsa, ufa, e.role, e.ell, &nref);
   const double bl = (ri >= 0) ? b[ri] : 0.;
-  const double xl = lu_solve(e, F, L.maxlen, bl, lane);
+  double xl;
+  if (INV && P.dbg_inverse && !F.permuted) {   // the product form of the core solve (helper_inverse), here by the one wave of the test kernel
+    for (int q = 0; q < FW_ACP; q++) fwsh[(FW_PAIRS + q) * JS + lane] = make_double2(0., 0.);
+    if (lane < NC) rps[lane] = F.rpivc;
+    __syncthreads();
+    helper_inverse(fwsh, rps, fwsh + FW_PAIRS * JS, lane);
+    __syncthreads();
+    xl = lu_solve<true>(e, F, L.maxlen, bl, lane);
+    if (lane == 0) x[63] = 1.0;                // (tells the test that this form ran)
+  } else xl = lu_solve(e, F, L.maxlen, bl, lane);
   if (ri >= 0) x[ri] = ok ? xl : nan("");
 }
 
@@ -2423,6 +2681,7 @@ static void fill_params(const cpt_handle* h, PtParams& P) {
   P.tol_ncdm_w = c.has_ncdm ? c.tol_ncdm_initial_w : 1e300; P.tp_dcb = c.has_ncdm ? c.index_tp_delta_cb : -1;
   P.nc = h->ncdm;
   P.max_steps = 400000;
+  P.dbg_inverse = 0;
   // hierarchies longer than one wavefront (synchronous scalars without non-cold species): the tails go to chain waves of their own
   {
     const int lanes = (c.has_ncdm ? 13 + 3 * CPT_MAX_NCDM : 14) + (c.l_max_g - 2) + (c.l_max_pol_g - 2) + (c.has_ur ? c.l_max_ur - 2 : 0);

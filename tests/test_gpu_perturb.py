@@ -73,6 +73,30 @@ def test_structured_solve_matches_dense(small, flags):
         assert np.max(np.abs(got - want)) < 1e-8 * np.max(np.abs(want)), (k, tau, hg)
 
 
+@pytest.mark.parametrize("flags", [(1, 0, 0), (0, 0, 0), (0, 0, 1), (0, 1, 1), (1, 0, 1)])
+def test_product_form_of_the_core_solve(small, flags, monkeypatch):
+    """The same systems with the core block solved as x = A_cc^-1 b (the inverse the helper wave forms from the integrator's factors,
+    one column per lane) instead of by the two triangular sweeps: the form every Newton iteration but the first after a factorisation
+    takes.  An explicit inverse is not backward stable; what the simplified Newton iteration needs is a forward error far below its
+    convergence rate, and the two forms must agree to that."""
+    inp, be = small
+    rng = np.random.default_rng(2)
+    ran = 0
+    for k, tau, hg in [(0.03, 150.0, 0.4), (0.03, 290.0, 2.5), (0.2, 3000.0, 1.0), (0.5, 900.0, 30.0), (1e-3, 5000.0, 500.0)]:
+        n = oracle_lib.derivs(inp, k, tau, *flags, np.zeros(64)).size
+        b = rng.normal(size=n)
+        monkeypatch.setenv("CPT_DBG_SOLVE_INVERSE", "0")
+        lu = be.dbg_solve(k, tau, *flags, hg, b, full=True)
+        monkeypatch.setenv("CPT_DBG_SOLVE_INVERSE", "1")
+        got = be.dbg_solve(k, tau, *flags, hg, b, full=True)
+        assert lu[63] == 0.0                        # (the kernel says which form ran: a factorisation that had to exchange rows keeps
+        ran += int(got[63] == 1.0)                  #  the triangular sweeps - the tightly coupled regime at large hg kappa')
+        lu, got = lu[:n], got[:n]
+        assert np.all(np.isfinite(got))
+        assert np.max(np.abs(got - lu)) < 1e-9 * np.max(np.abs(lu)), (k, tau, hg, np.max(np.abs(got - lu)) / np.max(np.abs(lu)))
+    assert ran >= (1 if flags[0] else 4), ran
+
+
 def test_perturb_small_all_modes(small):
     inp, be = small
     src, stats, status = be.perturb_solve()

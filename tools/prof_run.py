@@ -27,6 +27,6 @@ print("heaviest mode: steps", s.steps, "fevals", s.fevals, "lus", s.factorisatio
 for n, v in zip(names, out):
     print("%-12s %12d cycles %5.1f%%" % (n, v, 100.0 * v / tot))
 print("inside every rhs call (all slots): lookup %d  gather+bcast %d  algebra %d  combine %d   [calls %d]" % (out[8], out[9], out[10], out[11], s.fevals))
-print("post_step %d  new_step %d  errtest+accept %d  sync_tau(ncdm) %d" % (out[12], out[13], out[14], out[15]))
+print("post_step %d  new_step %d  errtest+accept %d  wait for the inverse %d" % (out[12], out[13], out[14], out[15]))
 print("cycles/step %.0f  rhs cycles/call %.0f  solve cycles/call %.0f  factorise cycles/call %.0f  jac cycles/call %.0f" % (
     tot / s.steps, out[0] / s.solves, out[1] / s.solves, out[2] / max(s.factorisations, 1), out[3] / max(s.jacobians, 1)))

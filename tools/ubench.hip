@@ -35,6 +35,12 @@ __global__ void __launch_bounds__(64) k(double* out, long long* cyc, double a, d
     if (SEL == 14) { R16(asm volatile("v_fma_f64 %0, %0, %1, %2\n v_mov_b32 %3, %3\n v_mov_b32 %3, %3\n v_mov_b32 %3, %3" : "+v"(x) : "v"(va), "v"(vb), "v"(addr));) }
     if (SEL == 15) { R16(asm volatile("s_mov_b32 s20, s20" : : : "s20");) }
     if (SEL == 16) { R16(asm volatile("v_cmp_lt_f64 vcc, %0, %1\n v_cndmask_b32 %2, %2, %3, vcc" : : "v"(x), "v"(va), "v"(addr), "v"(la) : "vcc");) }
+    if (SEL == 18) { R16(asm volatile("s_branch 1f\n v_mov_b32 %0, %0\n1:\n v_add_u32 %0, %0, %1" : "+v"(addr) : "v"(lane));) }
+    if (SEL == 19) { R16(asm volatile("s_cmp_lg_u32 0, 0\n s_cbranch_scc1 1f\n v_add_u32 %0, %0, %1\n1:" : "+v"(addr) : "v"(lane) : "scc");) }
+    if (SEL == 20) { R16(asm volatile("s_cmp_eq_u32 0, 0\n s_cbranch_scc1 1f\n .rept 100\n v_mov_b32 %0, %0\n .endr\n1:\n v_add_u32 %0, %0, %1" : "+v"(addr) : "v"(lane) : "scc");) }
+    if (SEL == 21) { R16(asm volatile("v_add_u32 %0, %0, %1" : "+v"(addr) : "v"(lane));) }
+    if (SEL == 22) { R16(asm volatile("v_cmp_lt_f64 vcc, %1, %2\n s_cbranch_vccz 1f\n .rept 100\n v_mov_b32 %0, %0\n .endr\n1:\n v_add_u32 %0, %0, %3" : "+v"(addr) : "v"(va), "v"(x), "v"(lane) : "vcc");) }
+    if (SEL == 23) { R16(asm volatile("v_cmp_lt_f64 vcc, %1, %2\n s_cbranch_vccnz 1f\n v_add_u32 %0, %0, %3\n1:" : "+v"(addr) : "v"(va), "v"(x), "v"(lane) : "vcc");) }
     if (SEL == 17) { R16(asm volatile("v_mul_f64 %0, %0, %2\n v_mul_f64 %1, %1, %2" : "+v"(x), "+v"(y) : "v"(va));) }
   }
   long long t1 = clock64();
@@ -72,5 +78,11 @@ int main() {
   run<14>("fma_f64 + 3 independent v_mov", out, cyc, 4);
   run<15>("s_mov_b32", out, cyc, 1);
   run<16>("v_cmp_f64 + cndmask", out, cyc, 2);
+  run<21>("dependent v_add_u32 (reference for the next four)", out, cyc, 1);
+  run<18>("taken s_branch over 1 instr + add", out, cyc, 2);
+  run<19>("s_cmp + NOT taken s_cbranch + add", out, cyc, 3);
+  run<20>("s_cmp + taken s_cbranch over 100 instr + add", out, cyc, 3);
+  run<22>("v_cmp_f64 + taken cbranch_vccz over 100 + add", out, cyc, 3);
+  run<23>("v_cmp_f64 + NOT taken cbranch_vccnz + add", out, cyc, 3);
   return 0;
 }
