@@ -175,6 +175,8 @@ extern "C" int cpt_dbg_profile(unsigned long long* out) {
     fprintf(stderr, "[restage] thermo slides %llu  background slides %llu  bsearch fallbacks %llu  lookups %llu (block 0, cumulative)\n", r[0], r[1], r[2], r[3]);
 #endif
 #ifdef CPT_PROFILE
+  // (out[0..15]: the integrator of the heaviest mode; a caller that passes room for 32 also gets its helper wave: CPT_PROFILE_HELPER=1)
+  if (getenv("CPT_PROFILE_HELPER") && hipMemcpyFromSymbol(out + 16, HIP_SYMBOL(g_prof_helper), 16 * sizeof(unsigned long long)) != hipSuccess) return 3;
   return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_prof), 16 * sizeof(unsigned long long)) == hipSuccess ? 0 : 3;
 #else
   for (int i = 0; i < 8; i++) out[i] = 0;

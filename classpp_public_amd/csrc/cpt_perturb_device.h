@@ -212,6 +212,7 @@ __device__ unsigned long long g_restage[4];   // diagnostic: window slides (ther
 #endif
 #ifdef CPT_PROFILE
 __device__ unsigned long long g_prof[16];
+__device__ unsigned long long g_prof_helper[16];   // the helper wave of the heaviest mode: cycles and counts of look-ups, inversions, samples; idle turns
 #define PROF_DECL unsigned long long pf_t0 = 0
 #define PROF_START() pf_t0 = clock64()
 #define PROF_STOP(slot) prof[slot] += clock64() - pf_t0
@@ -250,9 +251,10 @@ struct Mailbox {
   double yi[MB_NSLOT][64], ypi[MB_NSLOT][64];   // dense output at the sample time, one entry per lane
   double tca_keep[MB_NSLOT];                    // tight-coupling shear left by the evolver's last RHS call (pm.cpp:6810)
   int it[MB_NSLOT], flags[MB_NSLOT];            // sample index; approximation scheme (tca | rsa<<1 | ufa<<2)
-  int head, tail, done;                         // samples posted (integrator) / consumed (helper); the mode is finished
-  int req_seq, ans_seq;                         // look-ups requested (integrator) / answered (helper)
-  int fact_seq, inv_seq;                        // factorisations posted (integrator) / inverted (helper): see helper_inverse
+  // what the helper polls, in one 16-byte read (mb_poll): look-ups requested, factorisations posted (see helper_inverse), samples posted,
+  // the mode is finished - all written by the integrator
+  alignas(16) int req_seq; int fact_seq, head, done;
+  int tail, ans_seq, inv_seq;                   // samples consumed, look-ups answered, factorisations inverted (helper)
   double req_tau[2];                            // time of request n in req_tau[n & 1]: up to two requests may be waiting (this step's row after a
                                                 // change of step size and the next step's), the helper answers them in order
   double rp[32];                                // reciprocal pivots of the posted factorisation (the rest of it is the integrator's LuReg::fw)
@@ -261,6 +263,16 @@ struct Mailbox {
                                                 // with the row of the step after it
 };
 __device__ inline int mb_load(const int* p) { return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP); }
+// (no wait is attached to this load: the value is looked at later, behind other work - see mb_take)
+__device__ inline int mb_peek(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+// the four counters the helper polls, one LDS round trip; what they announce is read after an acquire fence
+struct MbPoll { int req_seq, fact_seq, head, done; };
+__device__ inline MbPoll mb_poll(const Mailbox* mb) {
+  MbPoll c;
+  c.req_seq = mb_peek(&mb->req_seq); c.fact_seq = mb_peek(&mb->fact_seq); c.head = mb_peek(&mb->head); c.done = mb_peek(&mb->done);
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  return c;
+}
 __device__ inline void mb_store(int* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP); }
 
 template <int GAUGE, int CURV, int MODE, int NCDM = 0, int ROWS = 0>
@@ -525,7 +537,8 @@ struct Lookup {
   // (integrator wave of the two-wave kernels) the rows come from the helper wave: mailbox, number of requests posted, time of the last one
   Mailbox* mb; int my_req; double rq_tau0, rq_tau1;   // requests posted so far; time of the last even / odd one
   int ans_seen;                      // last value read of the helper's ans_seq
-  const double* row;                 // (scalar RHS of the two-wave kernels) the row in work, where the helper left it (mb_take)
+  const double* row;                 // the row in work, in LDS where the helper left it (mb_take, mb_fetch_row) or this wave put it (row_store)
+  double row_tau;                    // ... and its time (mb_fetch_row, row_store; tau_cached is the time of the row in the registers below)
   double ncv[NCDM ? NCB_NCOL : 1];   // (rows from the helper, ncdm kernels) {rho, p, pseudo_p} of every species, wave-uniform
 #ifdef CPT_PROFILE
   unsigned long long* prof;
@@ -591,7 +604,7 @@ static __device__ __forceinline__ int window_find(const double* __restrict__ x, 
 
 static __device__ __forceinline__ void lookup_init(const PtParams& P, Lookup& Q, double2* bgw, double2* thw, int lane, double2* ncw = nullptr) {
   Q.bgw = bgw; Q.thw = thw; Q.ncw = ncw; Q.vnc = 0.; Q.nc_lo = Q.nc_hi = make_double2(0., 0.);
-  Q.mb = nullptr; Q.my_req = 0; Q.rq_tau0 = Q.rq_tau1 = -1.; Q.ans_seen = 0; Q.row = nullptr;
+  Q.mb = nullptr; Q.my_req = 0; Q.rq_tau0 = Q.rq_tau1 = -1.; Q.ans_seen = 0; Q.row = nullptr; Q.row_tau = -1.;
   if (NCDM) { double dummy; window_stage<NCB_NCOL>(P.tabs.tau_table, (const double2*)P.tabs.ncb, P.tabs.bt_size, 0, lane, &dummy, ncw); }
   Q.bg_base = 0; Q.th_base = 0; Q.bg_inf = -1; Q.th_inf = -1; Q.tau_cached = -1.;
   window_stage<BG_NCOL>(P.tabs.tau_table, (const double2*)P.tabs.bg, P.tabs.bt_size, 0, lane, &Q.bgx, bgw);
@@ -778,15 +791,43 @@ static __device__ __forceinline__ bool mb_take(Lookup& Q, int seq) {
       if (++spins > (1 << 24)) return false;
     }
   }
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");   // (the answer may have been seen by a relaxed mb_peek)
   Q.row = Q.mb->ans[seq & 1];
   return true;
+}
+// The register-set kernels (cpt_perturb_sets.inc) read their rows from LDS as well - they spill as it is, 62 VGPRs of row were what
+// pushed the per-lane coefficients of the RHS into scratch memory (seven serialised scratch reloads per evaluation) - but still find
+// them by time, with the helper (mb_fetch_row: valid while at most one request has been posted since the row was asked for, which is
+// how ndf15v asks) or without (row_store: this wave's own look-up, written out once per new time).
+static __device__ __forceinline__ bool mb_fetch_row(Lookup& Q, double tau, int lane) {
+  if (uni(tau == Q.row_tau) && uni(tau == ((Q.row == Q.mb->ans[1]) ? Q.rq_tau1 : Q.rq_tau0))) return true;
+  const int slot = mb_wait(Q, tau, lane);
+  if (slot < 0) return false;
+  Q.row = Q.mb->ans[slot];
+  Q.row_tau = tau;
+  return true;
+}
+static __device__ __forceinline__ void row_store(Lookup& Q, double* a, int lane) {
+  if (lane == 0) {
+    a[0] = Q.rg; a[1] = Q.rb; a[2] = Q.rc; a[3] = Q.ru; a[4] = Q.kap; a[5] = Q.ddkappa; a[6] = Q.cb2; a[7] = Q.a2;
+    a[8] = Q.aH; a[9] = Q.two_over_aH; a[10] = Q.R; a[11] = Q.inv_1pR; a[12] = Q.inv_R; a[13] = Q.tau_c; a[14] = Q.dtau_c; a[15] = Q.F;
+    a[16] = Q.Fp; a[17] = Q.app; a[18] = Q.inv_tau; a[19] = Q.rg43; a[20] = Q.ru43; a[21] = Q.kcot;
+  }
+  if (NCDM) { if (lane < NCB_NCOL) a[22 + lane] = Q.vnc; }   // lane c holds column c of the ncdm row
+  Q.row = a;
+  Q.row_tau = Q.tau_cached;
 }
 // (hand-over between schemes, Jacobian diagonal: the few places outside the RHS that read a row's fields)
 static __device__ __forceinline__ void mb_row_to_regs(Lookup& Q) {
   const double* a = Q.row;
+  if (NCDM) {
+#pragma unroll
+    for (int i = 0; i < NCB_NCOL; i++) Q.ncv[i] = a[22 + i];
+  }
   Q.rg = a[0]; Q.rb = a[1]; Q.rc = a[2]; Q.ru = a[3]; Q.kap = a[4]; Q.ddkappa = a[5]; Q.cb2 = a[6]; Q.a2 = a[7];
   Q.aH = a[8]; Q.two_over_aH = a[9]; Q.R = a[10]; Q.inv_1pR = a[11]; Q.inv_R = a[12]; Q.tau_c = a[13]; Q.dtau_c = a[14]; Q.F = a[15];
   Q.Fp = a[16]; Q.app = a[17]; Q.inv_tau = a[18]; Q.rg43 = a[19]; Q.ru43 = a[20]; Q.kcot = a[21];
+  if (Q.row_tau >= 0.) Q.tau_cached = Q.row_tau;   // (mb_take does not keep times: the scalar integrator never looks a row up by its time)
 }
 
 // ---- physics ------------------------------------------------------------------------------------
@@ -811,10 +852,19 @@ struct LaneEq {
   int rem;             // (long tails) 1, 2, 3: this lane is the parent of the photon / polarisation / ur tail, whose l = 3 element lives on a chain wave
   unsigned pmask;      // (wave-uniform) bit i: core variable i is evolved in this scheme.  An idle core lane is an identity row AND column
                        // of the Newton matrix: the factorisation and the substitutions skip its pivot altogether.
+  const double2* cw;   // LDS [6][64] or null: the twelve coefficients again (lane_eq_store), for an RHS that fetches them per evaluation
+                       // (rhs<LK, true>) instead of holding 24 VGPRs through the step loop
 };
+static constexpr int CW_PAIRS = 6;
+static __device__ __forceinline__ void lane_eq_store(LaneEq& e, double2* cw, int lane) {
+  cw[0 * 64 + lane] = make_double2(e.A, e.B); cw[1 * 64 + lane] = make_double2(e.D, e.G); cw[2 * 64 + lane] = make_double2(e.Xmc, e.Xms);
+  cw[3 * 64 + lane] = make_double2(e.XP, e.X4); cw[4 * 64 + lane] = make_double2(e.Xeta, e.Xtb); cw[5 * 64 + lane] = make_double2(e.Gt, e.Xeu);
+  e.cw = cw;
+}
 
 static __device__ __forceinline__ LaneEq make_lane_eq(const PtParams& P, const Layout& L, int lane, double k) {
   LaneEq e;
+  e.cw = nullptr;
   role_of(P, L, lane, &e.role, &e.ell);
   e.A = e.B = e.D = e.G = e.Gt = 0.;
   e.Xmc = e.Xms = e.XP = e.X4 = e.Xeta = e.Xtb = e.Xeu = 0.;
@@ -979,7 +1029,9 @@ static __device__ __forceinline__ void store_sources_tensor(const PtParams& P, c
 // Returns dy of this lane and leaves M describing the state (tau, y).
 // LK: where the row of the tables comes from - 0 this wave's own look-up, 1 the helper wave (copied to Q), 2 it is in Q already,
 //     3 it lies in LDS where the helper wave left it (Q.row, see mb_take)
-template <int LK = 0>
+// ECO: the per-lane coefficients are fetched from LDS (LaneEq::cw) instead of being read from e's registers: the register-set kernels,
+//      which spill, otherwise reload them one by one from scratch memory inside every evaluation
+template <int LK = 0, bool ECO = false>
 static __device__ __forceinline__ double rhs(const PtParams& P, const Layout& L, const LaneEq& e, Lookup& Q, Metric& M, double k,
                                       double inv_k2, double tau, double y, int lane, NcIn* Np = nullptr) {
   if (MODE) return rhs_tensor<(LK == 1)>(P, L, e, Q, M, k, tau, y, lane);
@@ -1104,15 +1156,21 @@ static __device__ __forceinline__ double rhs(const PtParams& P, const Layout& L,
   // ---- every equation: streaming + damping + sources ----
   double yup = yp;
   if (NCDM) { if (LONG) { const int rem = opaque(e.rem); yup = (rem == 1) ? Np->y3[0] : (rem == 2) ? Np->y3[1] : (rem == 3) ? Np->y3[2] : yp; } }
-  double dy = e.A * ym - e.B * yup - (e.D * kap + e.G * QV(kcot) + (CURV ? e.Gt * QV(inv_tau) : 0.)) * y;
-  dy = fma(e.Xmc, mc, dy);
-  dy = fma(e.Xms, ms, dy);
-  dy = fma(e.XP, SP, dy);
-  dy = fma(e.X4, S4, dy);
-  dy = fma(e.Xeta, mdot, dy);
-  dy = fma(e.Xtb, dtb, dy);
+  double eA = e.A, eB = e.B, eD = e.D, eG = e.G, eGt = e.Gt, eXmc = e.Xmc, eXms = e.Xms, eXP = e.XP, eX4 = e.X4, eXeta = e.Xeta, eXtb = e.Xtb, eXeu = e.Xeu;
+  if (ECO) {
+    const double2 c0 = e.cw[0 * 64 + lane], c1 = e.cw[1 * 64 + lane], c2 = e.cw[2 * 64 + lane], c3 = e.cw[3 * 64 + lane], c4 = e.cw[4 * 64 + lane];
+    eA = c0.x; eB = c0.y; eD = c1.x; eG = c1.y; eXmc = c2.x; eXms = c2.y; eXP = c3.x; eX4 = c3.y; eXeta = c4.x; eXtb = c4.y;
+    if (CURV || GAUGE == CPT_GAUGE_NEWTONIAN) { const double2 c5 = e.cw[5 * 64 + lane]; eGt = c5.x; eXeu = c5.y; }
+  }
+  double dy = eA * ym - eB * yup - (eD * kap + eG * QV(kcot) + (CURV ? eGt * QV(inv_tau) : 0.)) * y;
+  dy = fma(eXmc, mc, dy);
+  dy = fma(eXms, ms, dy);
+  dy = fma(eXP, SP, dy);
+  dy = fma(eX4, S4, dy);
+  dy = fma(eXeta, mdot, dy);
+  dy = fma(eXtb, dtb, dy);
   if (GAUGE == CPT_GAUGE_NEWTONIAN) {
-    dy = fma(e.Xeu, me, dy);
+    dy = fma(eXeu, me, dy);
     if (opaque(e.role) == R_THETA_CDM) dy -= aH * y;                                  // pm.cpp:8235
   }
   // rarely used variants: non-standard ur sound speed (pm.cpp:8630-8641), ufa_hu (pm.cpp:8711-8716)
@@ -1240,6 +1298,8 @@ static __device__ __forceinline__ double search_flip(const PtParams& P, double k
 struct Ctx {
   Mailbox* mb; int posted, tail_seen;          // mailbox of the helper wave, samples posted so far, last value read of the helper's tail
   int fact_posted;   // factorisations handed to the helper wave for inversion (helper_inverse)
+  double* rowbuf;    // (register-set kernels without a helper) LDS [MB_NANS]: the row of this wave's own look-up (row_store)
+  double2* cwbuf;    // (register-set kernels with room in LDS) [CW_PAIRS][64]: the per-lane coefficients of the core RHS (lane_eq_store)
 };
 
 // ---- wave-wide cyclic reduction (the long tails of cpt_perturb_sets.inc: up to 64 multipoles of one ladder along the lanes) ----------
@@ -1693,21 +1753,34 @@ static __device__ __forceinline__ double dif_get(const double* dif, int i) {
 static __device__ __forceinline__ int fluid_lane(int species, int j) { return LN_F0 + 3 * species + j; }
 // perturb_derivs (pm.cpp:7861-9218 with perturb_einstein, perturb_total_stress_energy, perturb_rsa_delta_and_theta and the fluid
 // equations of pm.cpp:8737-8823 folded in); synchronous gauge.  Leaves M and N describing (tau, y) for the sources.
-// (FETCH = false: the row of the tables is in Q already; LK then only says where the ncdm columns are: 1 Q.ncv (from the helper), 0 Q.vnc)
-template <int SYS, int LK, bool FETCH = true>
+// (FETCH = false: the row of the tables is there already; LK then says where: 1 in Q with the ncdm columns in Q.ncv (from the helper),
+//  0 in Q with the ncdm columns in Q.vnc (own look-up), 3 in LDS at Q.row - SYS = 2 only)
+template <int SYS, int LK, bool FETCH = true, bool ECO = false>
 static __device__ __forceinline__ double rhs_fluid(const PtParams& P, const Layout& L, const LaneEq& e, Lookup& Q, Metric& M, NcIn& N, double k, double inv_k2,
                                                    double tau, double y, int lane) {
   if (FETCH) {
     if (LK == 1) { if (!mb_fetch(Q, tau, lane)) return nan(""); }
     else lookup(P, Q, tau, lane);
   }
-  const double aH = Q.aH, k2 = k * k;
+  static_assert(LK != 3 || !FETCH, "rows in LDS: the caller has put the row there");
+  // (LK = 3: the whole row - 22 doubles and the nine ncdm columns - by sixteen uniform b128 reads issued together, behind one wait)
+  double rw[32];
+  if (LK == 3) {
+    const double2* r2 = reinterpret_cast<const double2*>(Q.row);
+#pragma unroll
+    for (int i = 0; i < 16; i++) { const double2 v = r2[i]; rw[2 * i] = v.x; rw[2 * i + 1] = v.y; }
+  }
+#define QF(f) ((LK == 3) ? rw[ROW_##f] : Q.f)
+  const double aH = QF(aH), k2 = k * k;
   const int ln = opaque(lane);
   // the non-cold fluids: integrals for the Einstein equations, and this lane's species (wave-uniform per species, selected per lane)
   double D = 0., T = 0., S = 0., rho_l = 1., p_l = 1., pp_l = 1.;
-  for (int n = 0; n < P.nc.n_species; n++) {
+#pragma unroll
+  for (int n = 0; n < CPT_MAX_NCDM; n++) {
+    if (n >= P.nc.n_species) break;
     double rho, pr, pp;
-    if (LK == 1) { rho = reg_get(Q.ncv, 3 * n); pr = reg_get(Q.ncv, 3 * n + 1); pp = reg_get(Q.ncv, 3 * n + 2); }
+    if (LK == 3) { rho = rw[22 + 3 * n]; pr = rw[23 + 3 * n]; pp = rw[24 + 3 * n]; }
+    else if (LK == 1) { rho = reg_get(Q.ncv, 3 * n); pr = reg_get(Q.ncv, 3 * n + 1); pp = reg_get(Q.ncv, 3 * n + 2); }
     else { rho = bcast(Q.vnc, 3 * n); pr = bcast(Q.vnc, 3 * n + 1); pp = bcast(Q.vnc, 3 * n + 2); }
     const int l0 = fluid_lane(n, 0);
     D = fma(rho, bcast(y, l0), D); T = fma(rho + pr, bcast(y, l0 + 1), T); S = fma(rho + pr, bcast(y, l0 + 2), S);
@@ -1717,32 +1790,32 @@ static __device__ __forceinline__ double rhs_fluid(const PtParams& P, const Layo
   N.D = D; N.T = T; N.S = S;
   double dy, mc, ms;
   if (SYS == 2) {
-    dy = rhs<2>(P, L, e, Q, M, k, inv_k2, tau, y, lane, &N);   // (0 on the fluid lanes: their LaneEq is empty)
+    dy = rhs<(LK == 3) ? 3 : 2, ECO>(P, L, e, Q, M, k, inv_k2, tau, y, lane, &N);   // (0 on the fluid lanes: their LaneEq is empty)
     mc = 0.5 * M.hp; ms = k2 * M.alpha;
   } else {
-    const double a2 = Q.a2, kap = Q.kap, cb2 = Q.cb2;
+    const double a2 = QF(a2), kap = QF(kap), cb2 = QF(cb2);
     const double db = bcast(y, LN_DB), tb = bcast(y, LN_TB), dc = bcast(y, LN_DC), eta = bcast(y, LN_ETA);
-    double delta_rho = Q.rb * db + D, rpt = Q.rb * tb + T;
+    double delta_rho = QF(rb) * db + D, rpt = QF(rb) * tb + T;
     const double rps = S;
-    if (P.has_cdm) delta_rho += Q.rc * dc;
-    const double hp = (Q.k2s2 * eta + 1.5 * a2 * delta_rho) * Q.two_over_aH;                       // pm.cpp:5913-5914
+    delta_rho += QF(rc) * dc;   // (an absent species has zero density in the tables)
+    const double hp = (Q.k2s2 * eta + 1.5 * a2 * delta_rho) * QF(two_over_aH);                       // pm.cpp:5913-5914
     // radiation streaming: photons and ur follow the metric (pm.cpp:9530-9636)
     double rdg = 0., rtg = 0., rdur = 0., rtur = 0.;
     if (P.rsa_method != CPT_RSA_NULL) { rdg = 4. * inv_k2 * (aH * hp - k2 * eta); rtg = -0.5 * hp; }
     if (P.rsa_method == CPT_RSA_MD_WITH_REIO) {
       rdg += -4. * inv_k2 * kap * (tb + 0.5 * hp);
-      rtg += 3. * inv_k2 * (Q.ddkappa * (tb + 0.5 * hp) + kap * (-aH * tb + cb2 * k2 * db - aH * hp + k2 * eta));
+      rtg += 3. * inv_k2 * (QF(ddkappa) * (tb + 0.5 * hp) + kap * (-aH * tb + cb2 * k2 * db - aH * hp + k2 * eta));
     }
-    if (P.has_ur && P.rsa_method != CPT_RSA_NULL) { rdur = 4. * inv_k2 * (aH * hp - k2 * eta); rtur = -0.5 * hp; }
-    delta_rho += Q.rg * rdg;
-    rpt += Q.rg43 * rtg;
-    if (P.has_ur) { delta_rho += Q.ru * rdur; rpt += Q.ru43 * rtur; }
+    if (P.rsa_method != CPT_RSA_NULL) { rdur = 4. * inv_k2 * (aH * hp - k2 * eta); rtur = -0.5 * hp; }
+    delta_rho += QF(rg) * rdg;
+    rpt += QF(rg43) * rtg;
+    delta_rho += QF(ru) * rdur; rpt += QF(ru43) * rtur;
     const double etap = (1.5 * a2 * rpt + (CURV ? 0.5 * P.K * hp : 0.)) * Q.inv_k2s2;             // pm.cpp:5938
     const double alpha = (hp + 6. * etap) * 0.5 * inv_k2;
     const double alphap = -2. * aH * alpha + eta - 4.5 * (a2 * inv_k2) * rps;
     M.hp = hp; M.etap = etap; M.alpha = alpha; M.alphap = alphap; M.rsa_dg = rdg; M.rsa_tg = rtg;
     mc = 0.5 * hp; ms = k2 * alpha;
-    const double dtb = -aH * tb + k2 * cb2 * db + Q.R * kap * (rtg - tb);                          // pm.cpp:8108-8113 with the streaming theta_g
+    const double dtb = -aH * tb + k2 * cb2 * db + QF(R) * kap * (rtg - tb);                          // pm.cpp:8108-8113 with the streaming theta_g
     dy = 0.;
     dy = (ln == LN_DB) ? -(tb + mc) : dy;
     dy = (ln == LN_TB) ? dtb : dy;
@@ -1763,10 +1836,11 @@ static __device__ __forceinline__ double rhs_fluid(const PtParams& P, const Layo
     else {
       const double src = 8. / 3. * cvis2 * inv_1pw * s2;
       if (P.nfa_method == CPT_NCDMFA_HU) fv = src * (ym + ms) - 3. * aH * ca2 * fast_rcp(w) * y;
-      else fv = src * (ym + ((P.nfa_method == CPT_NCDMFA_MB) ? ms : mc)) - 3. * (aH * (2. / 3. - ca2 - pp_over_p / 3.) + Q.inv_tau) * y;
+      else fv = src * (ym + ((P.nfa_method == CPT_NCDMFA_MB) ? ms : mc)) - 3. * (aH * (2. / 3. - ca2 - pp_over_p / 3.) + QF(inv_tau)) * y;
     }
     dy = fluid ? fv : dy;
   }
+#undef QF
   return dy;
 }
 
@@ -1812,12 +1886,17 @@ static __device__ __forceinline__ int ndf15s(const PtParams& P, const Layout& L,
   NcIn N = {0., 0., 0., {0., 0., 0.}};
   // ROWQ: the scalar integrator of the two-wave kernels handles its table rows by request number (mb_post / mb_take): it says which row
   // an evaluation uses before it evaluates, and the RHS reads it from LDS
-  constexpr bool ROWQ = (SYS == 0 && HELPED && MODE == 0 && NCDM == 0);
+  constexpr bool ROWQ = (HELPED && MODE == 0);
   int seq_this = 0, seq_next = 0;
   bool have_next = false, post_this = true, post_next = true;
+  if constexpr (ROWQ) { Q.rq_tau0 = Q.rq_tau1 = -1.; Q.row_tau = -1.; }   // (what an integrator that finds its rows by time knew is void: mb_post does not keep it)
   auto eval = [&](double tq, double yq) {
     st.fevals++;
-    if constexpr (SYS != 0) return rhs_fluid<SYS, HELPED ? 1 : 0>(P, L, e, Q, M, N, k, inv_k2, tq, yq, lane);
+#ifdef CPT_CHECK_ROWS
+    if constexpr (ROWQ) { if (Q.row[31] != tq && lane == 0) printf("row mismatch: block %d SYS %d row %.17g eval %.17g (step %d)\n", (int)blockIdx.x, SYS, Q.row[31], tq, st.steps); }
+#endif
+    if constexpr (SYS != 0 && ROWQ) return rhs_fluid<SYS, 3, false>(P, L, e, Q, M, N, k, inv_k2, tq, yq, lane);
+    else if constexpr (SYS != 0) return rhs_fluid<SYS, HELPED ? 1 : 0>(P, L, e, Q, M, N, k, inv_k2, tq, yq, lane);
     else if constexpr (ROWQ) return rhs<3>(P, L, e, Q, M, k, inv_k2, tq, yq, lane);
     else return rhs<1>(P, L, e, Q, M, k, inv_k2, tq, yq, lane);
   };
@@ -1940,6 +2019,7 @@ static __device__ __forceinline__ int ndf15s(const PtParams& P, const Layout& L,
       const unsigned long long t_newton0 = clock64();
       unsigned long long t_inner = 0;
 #endif
+      if constexpr (ROWQ) Q.ans_seen = mb_peek(&Q.mb->ans_seq);   // (looked at behind the predictor: mb_take)
       double psi, pred;
       ISA_MARK("NEWT_PRED");
       switch (__builtin_amdgcn_readfirstlane(kk)) {
@@ -1963,7 +2043,14 @@ static __device__ __forceinline__ int ndf15s(const PtParams& P, const Layout& L,
       }
       bool tooslow = false;
       double newnrm = 0., oldnrm = 0.;
+#ifdef CPT_PROFILE
+      const unsigned long long t_take0 = clock64();
+#endif
       if constexpr (ROWQ) { if (!mb_take(Q, seq_this)) return 5; }
+#ifdef CPT_PROFILE
+      prof[8] += clock64() - t_take0;
+      t_inner += clock64() - t_take0;
+#endif
       for (int iter = 1; iter <= maxit; iter++) {
         PROF_START();
         ISA_MARK("NEWT_EVAL");
@@ -2012,15 +2099,19 @@ static __device__ __forceinline__ int ndf15s(const PtParams& P, const Layout& L,
           newnrm = wave_max(dn);
           if (!havrate) rate = 0.0;
         } else {
+          // (ev.cpp:401-437.  The tests are evaluated together and decided by ONE scalar branch in the usual case - converged at this
+          //  iteration; each `if (uni(...))` of its own would be a v_cmp_f64 feeding a branch, ~45 cycles of a lone wavefront)
           newnrm = wave_max(dn);
-          if (uni(newnrm <= minnrm)) break;
-          if (uni(newnrm > 0.9 * oldnrm)) { tooslow = true; break; }
-          rate = fmax(0.9 * rate, newnrm * fast_rcp(oldnrm));
+          const double rate_new = fmax(0.9 * rate, newnrm * fast_rcp(oldnrm));
+          const double q = rate_new * fast_rcp(1.0 - rate_new), errit = newnrm * q;
+          const bool c_min = newnrm <= minnrm, c_slow = newnrm > 0.9 * oldnrm, c_ok = errit <= 0.5 * rtol;
+          const bool upd = !(c_min || c_slow);          // the rate estimate is only renewed past the first two tests
+          rate = upd ? rate_new : rate;
+          thr1 = upd ? fmax(minnrm, 0.05 * rtol * fast_rcp(q)) : thr1;
+          if (uni(c_min || (!c_slow && c_ok))) { havrate = havrate || !uni(c_min); break; }
+          if (uni(c_slow)) { tooslow = true; break; }
           havrate = true;
-          const double q = rate * fast_rcp(1.0 - rate), errit = newnrm * q;
-          thr1 = fmax(minnrm, 0.05 * rtol * fast_rcp(q));
-          if (uni(errit <= 0.5 * rtol)) break;
-          else if (iter == maxit) { tooslow = true; break; }
+          if (iter == maxit) { tooslow = true; break; }
           else if (uni(0.5 * rtol < errit * fast_powi(rate, maxit - iter))) { tooslow = true; break; }
         }
         oldnrm = newnrm;
@@ -2161,19 +2252,22 @@ static __device__ __forceinline__ int ndf15s(const PtParams& P, const Layout& L,
       // (the norm of the accepted correction is only formed here, where its value steers the step size: one step in ~five)
       err = wave_max(fabs(difkp1 * invwt)) * erc;
       double temp = 1.2 * fast_root(err * inv_rtol, kk + 1);
-      double hopt = uni(temp > 0.1) ? absh * fast_rcp(temp) : 10 * absh;
+      // (selects, not branches: the operands are wave-uniform, a v_cmp_f64 feeding a scalar branch costs ~45 cycles)
+      double hopt = (temp > 0.1) ? absh * fast_rcp(temp) : 10 * absh;
       int kopt = kk;
       if (kk > 1) {
         const double errkm1 = wave_max(fabs(dif_get(dif, kk - 1) * invwt)) * ndf_erconst(kk - 2);
         temp = 1.3 * fast_root(errkm1 * inv_rtol, kk);
-        const double hkm1 = uni(temp > 0.1) ? absh * fast_rcp(temp) : 10 * absh;
-        if (uni(hkm1 > hopt)) { hopt = hkm1; kopt = kk - 1; }
+        const double hkm1 = (temp > 0.1) ? absh * fast_rcp(temp) : 10 * absh;
+        const bool better = uni(hkm1 > hopt);
+        hopt = fmax(hopt, hkm1); kopt = better ? kk - 1 : kopt;
       }
       if (kk < maxk) {
         const double errkp1 = wave_max(fabs(dif_get(dif, kk + 1) * invwt)) * ndf_erconst(kk);
         temp = 1.4 * fast_root(errkp1 * inv_rtol, kk + 2);
-        const double hkp1 = uni(temp > 0.1) ? absh * fast_rcp(temp) : 10 * absh;
-        if (uni(hkp1 > hopt)) { hopt = hkp1; kopt = kk + 1; }
+        const double hkp1 = (temp > 0.1) ? absh * fast_rcp(temp) : 10 * absh;
+        const bool better = uni(hkp1 > hopt);
+        hopt = fmax(hopt, hkp1); kopt = better ? kk + 1 : kopt;
       }
       if (uni(hopt > absh)) { absh = hopt; if (kopt != kk) { kk = kopt; set_order(); } }
     }
@@ -2308,7 +2402,7 @@ static __device__ __forceinline__ int run_intervals(const PtParams& P, Ctx& C, c
     Q.bg_lo = Q.bg_hi = Q.th_lo = Q.th_hi = Q.nc_lo = Q.nc_hi = make_double2(0., 0.);
     Q.rg = Q.rb = Q.rc = Q.ru = Q.kap = Q.ddkappa = Q.cb2 = Q.a2 = Q.aH = Q.two_over_aH = Q.R = Q.inv_1pR = Q.inv_R = 0.;
     Q.tau_c = Q.dtau_c = Q.F = Q.Fp = Q.app = Q.inv_tau = Q.rg43 = Q.ru43 = Q.kcot = 0.;
-    Q.mb = C.mb; Q.my_req = 0; Q.rq_tau0 = Q.rq_tau1 = -1.; Q.ans_seen = 0;
+    Q.mb = C.mb; Q.my_req = 0; Q.rq_tau0 = Q.rq_tau1 = -1.; Q.ans_seen = 0; Q.row = nullptr; Q.row_tau = -1.;
     lookup_set_mode(P, Q, k);
 #ifdef CPT_PROFILE
     Q.prof = prof;
@@ -2409,9 +2503,17 @@ static __device__ __forceinline__ void run_helper(const PtParams& P, Mailbox* mb
   int flags = -1, tail = 0, answered = 0;
   Layout L = make_layout(P, 1, 0, 0);
   LaneEq e = make_lane_eq(P, L, lane, k);
+#ifdef CPT_PROFILE
+  unsigned long long hprof[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  const unsigned long long th_begin = clock64();
+#endif
   for (;;) {
     // look-ups first: the integrator may be waiting for one, a sample never holds it up while the ring has room
-    if (mb_load(&mb->req_seq) != answered) {
+    const MbPoll pc = mb_poll(mb);
+    if (pc.req_seq != answered) {
+#ifdef CPT_PROFILE
+      const unsigned long long th0 = clock64();
+#endif
       const int rq = answered + 1;               // (in order: two requests may be waiting)
       const double tau = mb->req_tau[rq & 1];
       lookup(P, Qp, tau, lane);
@@ -2420,21 +2522,36 @@ static __device__ __forceinline__ void run_helper(const PtParams& P, Mailbox* mb
         a[0] = Qp.rg; a[1] = Qp.rb; a[2] = Qp.rc; a[3] = Qp.ru; a[4] = Qp.kap; a[5] = Qp.ddkappa; a[6] = Qp.cb2; a[7] = Qp.a2;
         a[8] = Qp.aH; a[9] = Qp.two_over_aH; a[10] = Qp.R; a[11] = Qp.inv_1pR; a[12] = Qp.inv_R; a[13] = Qp.tau_c; a[14] = Qp.dtau_c; a[15] = Qp.F;
         a[16] = Qp.Fp; a[17] = Qp.app; a[18] = Qp.inv_tau; a[19] = Qp.rg43; a[20] = Qp.ru43; a[21] = Qp.kcot;
+#ifdef CPT_CHECK_ROWS
+        a[31] = tau;
+#endif
       }
       answered = rq;
       mb_store(&mb->ans_seq, rq);
+#ifdef CPT_PROFILE
+      hprof[0] += clock64() - th0; hprof[1]++;
+#endif
       continue;
     }
     // then the inverse of a factorisation the integrator has posted (it will want it at its next Newton iteration but one)
-    const int fs = mb_load(&mb->fact_seq);
+    const int fs = pc.fact_seq;
     if (fs != inverted) {
+#ifdef CPT_PROFILE
+      const unsigned long long th0 = clock64();
+#endif
       helper_inverse(fw, mb->rp, inv, lane);
       inverted = fs;
       mb_store(&mb->inv_seq, fs);
+#ifdef CPT_PROFILE
+      hprof[2] += clock64() - th0; hprof[3]++;
+#endif
       continue;
     }
-    const int head = mb_load(&mb->head);
+    const int head = pc.head;
     if (tail != head) {
+#ifdef CPT_PROFILE
+      const unsigned long long th0 = clock64();
+#endif
       const int slot = tail & (MB_NSLOT - 1);
       const int f = mb->flags[slot], it = mb->it[slot];
       const double yi = mb->yi[slot][lane], ypi = mb->ypi[slot][lane], tca_keep = mb->tca_keep[slot];
@@ -2448,14 +2565,24 @@ static __device__ __forceinline__ void run_helper(const PtParams& P, Mailbox* mb
       }
       (void)rhs<false>(P, L, e, Q, M, k, inv_k2, tn, yi, lane);   // leaves Q and M describing (tn, yi)
       store_sources(P, L, Q, M, k, inv_k2, yi, ypi, tca_keep, it, ik, lane);
+#ifdef CPT_PROFILE
+      hprof[4] += clock64() - th0; hprof[5]++;
+#endif
       continue;
     }
-    if (mb_load(&mb->done)) {
+    if (pc.done) {
       if (mb_load(&mb->head) == tail) break;     // finished and drained
       continue;
     }
-    __builtin_amdgcn_s_sleep(2);
+#ifdef CPT_PROFILE
+    hprof[6]++;
+#endif
+    __builtin_amdgcn_s_sleep(1);
   }
+#ifdef CPT_PROFILE
+  hprof[7] = clock64() - th_begin;
+  if (lane == 0 && blockIdx.x == 0) for (int i = 0; i < 16; i++) g_prof_helper[i] = hprof[i];
+#endif
 }
 
 // start of the integration (pm.cpp:2545-2635) and the schedule of approximation switches (pm.cpp:2940-3231) of one k-mode; every lane of the
@@ -2519,7 +2646,7 @@ static __device__ __forceinline__ void body_perturb(const PtParams& P) {
   double2* bgw = tabw;
   double2* thw = tabw + 64 * BG_NCOL;
   Ctx C;
-  C.mb = mbox; C.posted = 0; C.tail_seen = 0; C.fact_posted = 0;
+  C.mb = mbox; C.posted = 0; C.tail_seen = 0; C.fact_posted = 0; C.rowbuf = nullptr; C.cwbuf = nullptr;
   // (the only barrier of the kernel: the counters are zero before any wave looks at them)
   if (threadIdx.x == 0) { mbox->head = mbox->tail = mbox->done = mbox->req_seq = mbox->ans_seq = mbox->fact_seq = mbox->inv_seq = 0; mbox->req_tau[0] = mbox->req_tau[1] = -1.; }
   __syncthreads();

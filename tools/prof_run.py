@@ -16,7 +16,8 @@ be = Backend(inp)
 for i in range(2):
     src, stats, status = be.perturb_solve(want_sources=False)
 print("kernel ms", be.kernel_ms(0))
-out = (C.c_ulonglong * 16)()
+os.environ["CPT_PROFILE_HELPER"] = "1"
+out = (C.c_ulonglong * 32)()
 L = capi.lib()
 L.cpt_dbg_profile.argtypes = [C.POINTER(C.c_ulonglong)]
 L.cpt_dbg_profile(out)
@@ -26,7 +27,10 @@ s = stats[len(stats) - 1]
 print("heaviest mode: steps", s.steps, "fevals", s.fevals, "lus", s.factorisations, "solves", s.solves, "jacs", s.jacobians)
 for n, v in zip(names, out):
     print("%-12s %12d cycles %5.1f%%" % (n, v, 100.0 * v / tot))
-print("inside every rhs call (all slots): lookup %d  gather+bcast %d  algebra %d  combine %d   [calls %d]" % (out[8], out[9], out[10], out[11], s.fevals))
+h = out[16:32]
+print("helper wave: look-ups %d cycles / %d = %.0f each; inversions %d / %d = %.0f each; samples %d / %d = %.0f each; idle turns %d; alive %d cycles" % (
+    h[0], h[1], h[0] / max(h[1], 1), h[2], h[3], h[2] / max(h[3], 1), h[4], h[5], h[4] / max(h[5], 1), h[6], h[7]))
+print("inside every rhs call (all slots): take-row %d  gather+bcast %d  algebra %d  combine %d   [calls %d]" % (out[8], out[9], out[10], out[11], s.fevals))
 print("post_step %d  new_step %d  errtest+accept %d  wait for the inverse %d" % (out[12], out[13], out[14], out[15]))
 print("cycles/step %.0f  rhs cycles/call %.0f  solve cycles/call %.0f  factorise cycles/call %.0f  jac cycles/call %.0f" % (
     tot / s.steps, out[0] / s.solves, out[1] / s.solves, out[2] / max(s.factorisations, 1), out[3] / max(s.jacobians, 1)))
