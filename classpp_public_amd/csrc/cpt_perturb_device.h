@@ -985,22 +985,26 @@ static __device__ __forceinline__ double gather(double v, int addr) {
 }
 
 // tensor modes: gw_source (pm.cpp:6616-6660), the Einstein equation for gw'' (:6036-6040) and perturb_derivs :9045-9215
-template <bool VIA_HELPER>
+// (LK as in rhs below: 0 own look-up, 1 from the helper into Q, 3 the row lies in LDS at Q.row)
+template <int LK>
 static __device__ __forceinline__ double rhs_tensor(const PtParams& P, const Layout& L, const LaneEq& e, Lookup& Q, Metric& M, double k,
                                                     double tau, double y, int lane) {
-  if (VIA_HELPER) { if (!mb_fetch(Q, tau, lane)) return nan(""); }
-  else lookup(P, Q, tau, lane);
+  if (LK == 1) { if (!mb_fetch(Q, tau, lane)) return nan(""); }
+  else if (LK == 0) lookup(P, Q, tau, lane);
+#define QT(f) ((LK == 3) ? Q.row[ROW_##f] : Q.f)
+  const double q_a2 = QT(a2), q_rg = QT(rg), q_ru = QT(ru), q_aH = QT(aH), q_kap = QT(kap), q_kcot = QT(kcot);
+#undef QT
   const double ym = gather(y, e.dn), yp = gather(y, e.up);
   const double SQRT6 = 2.449489742783178;
   // (lanes the scheme does not evolve read as 0)
   const double dg = bcast(y, TL_DG), sg = bcast(y, TL_SG), g4 = bcast(y, TL_G4), p0 = bcast(y, TL_P0), p2 = bcast(y, TL_P2), p4 = bcast(y, TL_P4);
   const double dur = bcast(y, TL_DUR), sur = bcast(y, TL_SUR), u4 = bcast(y, TL_U4), gw = bcast(y, TL_GW), gwd = bcast(y, TL_GWD);
   const double P2 = -1.0 / SQRT6 * (0.1 * dg + 2. / 7. * sg + 3. / 70. * g4 - 0.6 * p0 + 6. / 7. * p2 - 3. / 70. * p4);
-  double gw_source = -SQRT6 * 4. * Q.a2 * Q.rg * (1. / 15. * dg + 4. / 21. * sg + 1. / 35. * g4);
-  if (P.evolve_tensor_ur) gw_source += -SQRT6 * 4. * Q.a2 * Q.ru * (1. / 15. * dur + 4. / 21. * sur + 1. / 35. * u4);
-  const double gwpp = -2. * Q.aH * gwd - (k * k + (CURV ? 2. * P.K : 0.)) * gw + gw_source;
-  double dy = e.A * ym - e.B * yp - (e.D * Q.kap + e.G * Q.kcot) * y;
-  dy = fma(e.XP, Q.kap * SQRT6 * P2, dy);
+  double gw_source = -SQRT6 * 4. * q_a2 * q_rg * (1. / 15. * dg + 4. / 21. * sg + 1. / 35. * g4);
+  if (P.evolve_tensor_ur) gw_source += -SQRT6 * 4. * q_a2 * q_ru * (1. / 15. * dur + 4. / 21. * sur + 1. / 35. * u4);
+  const double gwpp = -2. * q_aH * gwd - (k * k + (CURV ? 2. * P.K : 0.)) * gw + gw_source;
+  double dy = e.A * ym - e.B * yp - (e.D * q_kap + e.G * q_kcot) * y;
+  dy = fma(e.XP, q_kap * SQRT6 * P2, dy);
   dy = fma(e.Xmc, SQRT6 * gwd, dy);
   dy = fma(e.Xtb, gwpp, dy);
   return dy;
@@ -1034,7 +1038,7 @@ static __device__ __forceinline__ void store_sources_tensor(const PtParams& P, c
 template <int LK = 0, bool ECO = false>
 static __device__ __forceinline__ double rhs(const PtParams& P, const Layout& L, const LaneEq& e, Lookup& Q, Metric& M, double k,
                                       double inv_k2, double tau, double y, int lane, NcIn* Np = nullptr) {
-  if (MODE) return rhs_tensor<(LK == 1)>(P, L, e, Q, M, k, tau, y, lane);
+  if (MODE) return rhs_tensor<LK>(P, L, e, Q, M, k, tau, y, lane);
 #ifdef CPT_PROFILE
   unsigned long long* prof = Q.prof;
   PROF_DECL;
@@ -1886,7 +1890,7 @@ static __device__ __forceinline__ int ndf15s(const PtParams& P, const Layout& L,
   NcIn N = {0., 0., 0., {0., 0., 0.}};
   // ROWQ: the scalar integrator of the two-wave kernels handles its table rows by request number (mb_post / mb_take): it says which row
   // an evaluation uses before it evaluates, and the RHS reads it from LDS
-  constexpr bool ROWQ = (HELPED && MODE == 0);
+  constexpr bool ROWQ = HELPED;
   int seq_this = 0, seq_next = 0;
   bool have_next = false, post_this = true, post_next = true;
   if constexpr (ROWQ) { Q.rq_tau0 = Q.rq_tau1 = -1.; Q.row_tau = -1.; }   // (what an integrator that finds its rows by time knew is void: mb_post does not keep it)
