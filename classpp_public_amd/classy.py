@@ -614,6 +614,75 @@ class Class:
 
     pk = pk_lin
 
+    # -- baryons + cold dark matter alone (classy.pyx:493-560, 675-708, 811-816): only with non-cold species, otherwise P_cb = P_m is not stored
+    def _cb_run(self):
+        r = self._pk_run()
+        if int(r.inp.config.index_tp_delta_cb) < 0:
+            raise CosmoSevereError("P_cb not computed (probably because there are no massive neutrinos) so you cannot ask for it")
+        if len(self._ics) != 1:
+            raise CosmoSevereError("P_cb with several correlated initial conditions is outside this package")
+        return r
+
+    def pk_cb_lin(self, k, z=0.):
+        r = self._cb_run()
+        kk = r.inp.k
+        if not (kk[0] <= k <= kk[-1]):
+            raise CosmoSevereError("k=%e out of bounds [%e:%e]" % (k, kk[0], kk[-1]))
+        key = ("lnpk_cb", float(z))
+        if key not in self._cache:
+            from scipy.interpolate import CubicSpline
+            try:
+                if z == 0.:
+                    pk = r.be.pk_linear(cb=True).cpu().numpy()
+                else:
+                    tau_z, n = self._late_times(z)
+                    pk = r.be.pk_at_tau(tau_z, n, cb=True).cpu().numpy()
+            except (CosmoSevereError, CosmoComputationError):
+                raise
+            except Exception as e:
+                raise CosmoComputationError(str(e))
+            self._cache[key] = CubicSpline(np.log(kk), np.log(pk), bc_type="natural")
+        return float(np.exp(self._cache[key](np.log(k))))
+
+    pk_cb = pk_cb_lin
+
+    def sigma_cb(self, R, z=0.):
+        r = self._cb_run()
+        if float(r.inp.d["ppt.k_max_for_pk"][0]) < self.h():
+            raise CosmoSevereError("In order to get sigma(R,z) you must set 'P_k_max_h/Mpc' to 1 or bigger, in order to have k_max > 1 h/Mpc.")
+        try:
+            if z == 0.:
+                return r.be.sigma(float(R), cb=True)
+            tau_z, n = self._late_times(z)
+            return r.be.sigma_at_tau(float(R), tau_z, n, cb=True)
+        except (CosmoSevereError, CosmoComputationError):
+            raise
+        except Exception as e:
+            raise CosmoComputationError(str(e))
+
+    def sigma8_cb(self):
+        return self.sigma_cb(8. / self.h())
+
+    def _pk_grid(self, fn, k, z, k_size, z_size, mu_size):
+        """P on a [k_size][z_size][mu_size] array of wavenumbers (classy.pyx:562-640: the fast loops of the likelihoods)"""
+        k = np.asarray(k, dtype=np.float64)
+        out = np.zeros((k_size, z_size, mu_size))
+        for ik in range(k_size):
+            for iz in range(z_size):
+                for im in range(mu_size):
+                    out[ik, iz, im] = fn(float(k[ik, iz, im]), float(z[iz]))
+        return out
+
+    def get_pk(self, k, z, k_size, z_size, mu_size): return self._pk_grid(self.pk, k, z, k_size, z_size, mu_size)
+    def get_pk_lin(self, k, z, k_size, z_size, mu_size): return self._pk_grid(self.pk_lin, k, z, k_size, z_size, mu_size)
+    def get_pk_cb(self, k, z, k_size, z_size, mu_size): return self._pk_grid(self.pk_cb, k, z, k_size, z_size, mu_size)
+    def get_pk_cb_lin(self, k, z, k_size, z_size, mu_size): return self._pk_grid(self.pk_cb_lin, k, z, k_size, z_size, mu_size)
+
+    def get_pk_cb_array(self, k, z, k_size, z_size, nonlinear):
+        if nonlinear:
+            raise CosmoSevereError("non-linear corrections are outside the accelerated path")
+        return np.array([[self.pk_cb_lin(float(kk), float(zz)) for zz in np.asarray(z)[:z_size]] for kk in np.asarray(k)[:k_size]]).ravel()
+
     def get_pk_array(self, k, z, k_size, z_size, nonlinear):
         if nonlinear:
             raise CosmoSevereError("non-linear corrections are outside the accelerated path")
@@ -669,6 +738,102 @@ class Class:
     def z_reio(self): return self._t("th.z_reionization")
     def z_rec(self): return self._t("th.z_rec")
     def theta_s_100(self): return 100. * self._t("th.rs_rec") / self._t("th.ra_rec")
+
+    def rs_drag(self):
+        """comoving sound horizon at baryon drag (thermodynamics_module.cpp:1170-1184): the background's r_s at z_d"""
+        return self._bg_value_at_z(self._t("th.z_d"), "rs")
+
+    def theta_star_100(self):
+        """100 r_s(z_*) / r_a(z_*) (thermodynamics_module.cpp:1138-1154)"""
+        zs = self._t("th.z_star")
+        return 100. * self._bg_value_at_z(zs, "rs") / (self._bg_value_at_z(zs, "ang_distance") * (1. + zs))
+
+    def k_eq(self):
+        """a H at radiation / matter equality (background_module.cpp:1690-1742: bisection in tau on Omega_m / Omega_r = 1)"""
+        t = self._need("background").inp.t
+        tau, tab, d2 = np.asarray(t["bg.tau_table"]), np.asarray(t["bg.background_table"]), np.asarray(t["bg.d2background_dtau2_table"])
+        col = lambda n: int(np.asarray(t["bg.index_bg_" + n]).reshape(-1)[0])
+        im, ir, ia, iH = col("Omega_m"), col("Omega_r"), col("a"), col("H")
+        lo, hi = 0, tau.size - 1
+        while hi - lo > 1:
+            mid = (lo + hi) // 2
+            if tab[mid, im] / tab[mid, ir] > 1.: hi = mid
+            else: lo = mid
+        tlo, thi, row = tau[lo], tau[hi], tab[lo]
+        while thi - tlo > 1e-6:      # (precision parameter tol_tau_eq)
+            tm = 0.5 * (tlo + thi)
+            row = self._spline_row(tau, tab, d2, tm)
+            if row[im] / row[ir] > 1.: thi = tm
+            else: tlo = tm
+        return float(row[ia] * row[iH])
+
+    # -- values at a redshift (classy.pyx:825-1080: background_tau_of_z + background_at_tau with every column, thermodynamics_at_z)
+    @staticmethod
+    def _spline_row(x, tab, d2, v):
+        """row of a table splined in its abscissa x at v (array_interpolate_spline, tools/arrays.c:1558-1640): every column at once"""
+        n = x.size
+        up = x[-1] > x[0]
+        lo, hi = min(x[0], x[-1]), max(x[0], x[-1])
+        if lo - 1e-9 * abs(lo) <= v <= hi + 1e-9 * abs(hi):
+            v = min(max(v, lo), hi)          # (tau(z = 0) is the last abscissa up to rounding)
+        if (v < lo) or (v > hi):
+            raise CosmoSevereError("value %e outside the tabulated range [%e, %e]" % (v, min(x[0], x[-1]), max(x[0], x[-1])))
+        i = int(np.searchsorted(x, v, side="right") - 1) if up else int(n - 1 - np.searchsorted(x[::-1], v, side="left"))
+        i = min(max(i, 0), n - 2)
+        h = x[i + 1] - x[i]
+        b = (v - x[i]) / h
+        a = 1. - b
+        return a * tab[i] + b * tab[i + 1] + ((a * a * a - a) * d2[i] + (b * b * b - b) * d2[i + 1]) * h * h / 6.
+
+    def _background_at_z(self, z):
+        from . import hostlib
+        r = self._need("background")
+        if z < 0.:
+            raise CosmoSevereError("asked for negative redshift z=%e" % z)
+        t = r.inp.t
+        try:
+            tau = hostlib.tau_of_z(r.inp, float(z))
+        except Exception as e:
+            raise CosmoSevereError(str(e))
+        return self._spline_row(np.asarray(t["bg.tau_table"]), np.asarray(t["bg.background_table"]), np.asarray(t["bg.d2background_dtau2_table"]), tau), tau
+
+    def _bg_value_at_z(self, z, name):
+        row, _ = self._background_at_z(z)
+        idx = int(np.asarray(self._need("background").inp.t["bg.index_bg_" + name]).reshape(-1)[0])
+        if idx < 0:
+            raise CosmoSevereError("the background table holds no column %s" % name)
+        return float(row[idx])
+
+    def _th_value_at_z(self, z, name):
+        t = self._need("thermodynamics").inp.t
+        zt = np.asarray(t["th.z_table"])
+        if z < 0.:
+            raise CosmoSevereError("asked for negative redshift z=%e" % z)
+        if z >= zt[-1]:
+            raise CosmoSevereError("z=%e beyond the thermodynamics table (z_max = %e): only the perturbation kernel continues it analytically" % (z, zt[-1]))
+        row = self._spline_row(zt, np.asarray(t["th.thermodynamics_table"]), np.asarray(t["th.d2thermodynamics_dz2_table"]), float(z))
+        return float(row[int(np.asarray(t["th.index_th_" + name]).reshape(-1)[0])])
+
+    def Hubble(self, z): return self._bg_value_at_z(z, "H")
+    def Om_m(self, z): return self._bg_value_at_z(z, "Omega_m")
+    def angular_distance(self, z): return self._bg_value_at_z(z, "ang_distance")
+    def luminosity_distance(self, z): return self._bg_value_at_z(z, "lum_distance")
+    def scale_independent_growth_factor(self, z): return self._bg_value_at_z(z, "D")
+    def scale_independent_growth_factor_f(self, z): return self._bg_value_at_z(z, "f")
+    def ionization_fraction(self, z): return self._th_value_at_z(z, "xe")
+    def baryon_temperature(self, z): return self._th_value_at_z(z, "Tb")
+
+    def z_of_tau(self, tau):
+        t = self._need("background").inp.t
+        row = self._spline_row(np.asarray(t["bg.tau_table"]), np.asarray(t["bg.background_table"]), np.asarray(t["bg.d2background_dtau2_table"]), float(tau))
+        return 1. / float(row[int(np.asarray(t["bg.index_bg_a"]).reshape(-1)[0])]) - 1.
+
+    def z_of_r(self, z_array):
+        """(r(z), dz/dr) for an array of redshifts: comoving distance and H(z) (classy.pyx:395-443)"""
+        z_array = np.asarray(z_array, dtype=np.float64)
+        r = np.array([self._bg_value_at_z(float(z), "conf_distance") for z in z_array])
+        dzdr = np.array([self._bg_value_at_z(float(z), "H") for z in z_array])
+        return r, dzdr
 
     def get_current_derived_parameters(self, names):
         table = {"h": self.h, "H0": lambda: 100. * self.h(), "Omega_Lambda": self.Omega_Lambda, "Omega0_lambda": self.Omega_Lambda,

@@ -337,6 +337,25 @@ static int do_dump(const char* ini, const char* outpath) {
       put_d("ppt.z_max_pk", ppt->z_max_pk);
     }
   }
+  // ---- what the reference's Python wrapper reads "at z" (classy.pyx:825-1080: background_tau_of_z + background_at_tau with long_info,
+  //      thermodynamics_at_z) on a fixed list of redshifts, and the scalars behind rs_drag(), k_eq(), theta_star_100() ----
+  {
+    const double zl[] = {0., 0.1, 0.5, 1., 2., 3., 10., 50., 300., 1000., 1100., 2000.};
+    const int nz = (int)(sizeof(zl) / sizeof(zl[0]));
+    std::vector<double> vb((size_t)nz * bg->bg_size_), vt((size_t)nz * th->th_size_), zs(zl, zl + nz), taus(nz);
+    for (int iz = 0; iz < nz; iz++) {
+      int last = 0;
+      if (bg->background_tau_of_z(zl[iz], &taus[iz]) != _SUCCESS_) { fprintf(stderr, "tau_of_z failed\n"); return 1; }
+      if (bg->background_at_tau(taus[iz], pba->long_info, pba->inter_normal, &last, &vb[(size_t)iz * bg->bg_size_]) != _SUCCESS_) { fprintf(stderr, "background_at_tau failed\n"); return 1; }
+      if (th->thermodynamics_at_z(zl[iz], th->inter_normal_, &last, &vb[(size_t)iz * bg->bg_size_], &vt[(size_t)iz * th->th_size_]) != _SUCCESS_) { fprintf(stderr, "thermodynamics_at_z failed\n"); return 1; }
+    }
+    put_f8("atz.z", zs.data(), {nz}); put_f8("atz.tau", taus.data(), {nz});
+    put_f8("atz.bg", vb.data(), {nz, bg->bg_size_}); put_f8("atz.th", vt.data(), {nz, th->th_size_});
+    put_i("atz.index_bg_ang_distance", bg->index_bg_ang_distance_); put_i("atz.index_bg_lum_distance", bg->index_bg_lum_distance_);
+    put_i("atz.index_bg_time", bg->index_bg_time_); put_i("atz.index_bg_rs", bg->index_bg_rs_);
+    put_d("atz.a_eq", bg->a_eq_); put_d("atz.H_eq", bg->H_eq_);
+    put_d("atz.rs_d", th->rs_d_); put_d("atz.z_d", th->z_d_); put_d("atz.rs_star", th->rs_star_); put_d("atz.ra_star", th->ra_star_);
+  }
   fclose(g_out);
   return 0;
 }

@@ -138,6 +138,17 @@ def test_class_compute_against_the_reference_outputs(cfg):
         assert np.max(np.abs(pk / ref["nl.pk_lin_z0"] - 1)) < 1e-4
         assert abs(c.pk(float(k[100]), 0.) / pk[100] - 1) < 1e-12
         assert abs(c.sigma8() / float(ref["nl.sigma8"][0]) - 1) < 1e-5
+        if "nl.pk_cb_lin_z0" in ref.files:      # baryons + cdm alone (classy.pyx:493-560, 675-708, 811-816)
+            kk = ref["nl.k"]
+            got = np.array([c.pk_cb(float(x), 0.) for x in kk[1:-1]])
+            assert np.max(np.abs(got / ref["nl.pk_cb_lin_z0"][1:-1] - 1)) < 1e-4
+            assert abs(c.sigma8_cb() / float(ref["nl.sigma8_cb"][0]) - 1) < 1e-5
+            grid = np.array([[[0.01, 0.02]], [[0.1, 0.2]]])
+            g = c.get_pk_cb_lin(grid, np.array([0.]), 2, 1, 2)
+            assert g.shape == (2, 1, 2) and abs(g[1, 0, 0] / c.pk_cb_lin(0.1, 0.) - 1) < 1e-14 and g[0, 0, 0] > 0.
+        else:
+            with pytest.raises(classy.CosmoSevereError, match="P_cb not computed"):
+                c.pk_cb(0.1, 0.)
     else:
         with pytest.raises(classy.CosmoSevereError, match="mPk"):
             c.pk(0.1, 0.)
@@ -246,6 +257,42 @@ def test_scenario_against_the_reference_outputs(cfg):
         worst["sigma8"] = abs(c.sigma8() / float(ref["nl.sigma8"][0]) - 1)
         assert worst["sigma8"] < 1e-5
     print("\n[%s] max errors vs reference: %s" % (cfg, ", ".join("%s %.1e" % kv for kv in worst.items())))
+    c.struct_cleanup()
+
+
+def test_values_at_a_redshift_match_the_reference():
+    """classy.pyx:825-1080: Hubble(z), angular_distance(z), luminosity_distance(z), Om_m(z), the growth factor and rate,
+    ionization_fraction(z), baryon_temperature(z), z_of_tau, z_of_r, and the scalars rs_drag(), theta_star_100(), k_eq() - from this
+    package's own background / thermodynamics tables (host library, no GPU) against what the reference's background_at_tau /
+    thermodynamics_at_z return for the same .ini at twelve redshifts (fixture entries atz.*, oracle/ref_driver.cpp)"""
+    ref = np.load(os.path.join(GOLDEN, "lcdm_zpk.npz"))
+    c = classy.Class(_pars("lcdm_zpk"))
+    c.compute(level=["thermodynamics"])
+    tabs = np.load(os.path.join(GOLDEN, "tables_lcdm.npz"))
+    col = lambda n: int(tabs["bg.index_bg_" + n][0]) if ("bg.index_bg_" + n) in tabs.files else int(ref["atz.index_bg_" + n][0])
+    tcol = lambda n: int(tabs["th.index_th_" + n][0])
+    for iz, z in enumerate(ref["atz.z"]):
+        z = float(z)
+        row = ref["atz.bg"][iz]
+        for name, fn, tol in (("H", c.Hubble, 1e-9), ("Omega_m", c.Om_m, 1e-8), ("ang_distance", c.angular_distance, 5e-6),
+                              ("lum_distance", c.luminosity_distance, 5e-6), ("D", c.scale_independent_growth_factor, 5e-6),
+                              ("f", c.scale_independent_growth_factor_f, 5e-6)):
+            want = row[col(name)]
+            got = fn(z)
+            assert abs(got - want) <= tol * max(abs(want), 1e-300) + (1e-12 if want == 0. else 0.), (name, z, got, want)
+        if z > 0.:     # (the two conformal ages differ by 3e-6: the reference's tau(z = 0) lies beyond this table)
+            assert abs(c.z_of_tau(float(ref["atz.tau"][iz])) - z) < 5e-6 * (1. + z)
+        if z < 1999.:
+            th = ref["atz.th"][iz]
+            assert abs(c.ionization_fraction(z) / th[tcol("xe")] - 1.) < 2e-5, (z, c.ionization_fraction(z), th[tcol("xe")])
+            assert abs(c.baryon_temperature(z) / th[tcol("Tb")] - 1.) < 2e-5
+    r, dzdr = c.z_of_r(ref["atz.z"][1:4])
+    assert np.allclose(r, ref["atz.bg"][1:4, col("conf_distance")], rtol=5e-6) and np.allclose(dzdr, ref["atz.bg"][1:4, col("H")], rtol=1e-9)
+    assert abs(c.rs_drag() / float(ref["atz.rs_d"][0]) - 1.) < 1e-5
+    assert abs(c.theta_star_100() / (100. * float(ref["atz.rs_star"][0]) / float(ref["atz.ra_star"][0])) - 1.) < 1e-5
+    assert abs(c.k_eq() / (float(ref["atz.a_eq"][0]) * float(ref["atz.H_eq"][0])) - 1.) < 1e-5
+    with pytest.raises(classy.CosmoSevereError):
+        c.Hubble(-0.5)
     c.struct_cleanup()
 
 
