@@ -167,6 +167,9 @@ __device__ inline int opaque(int v) {
   asm volatile("" : "+v"(v));
   return v;
 }
+// 1 / x: v_rcp_f64 is good to 4.6e-8, one Newton step makes it 2.1e-15 (19 ulp), a second one 1.1e-16 (tools/rcp/rcp_test.hip on gfx950).
+// Both steps stay: with one, the look-ups lose their 1e-15 agreement with the reference's tables and the integrator takes 1 - 2 % MORE
+// steps (more error-test failures: 2 578 -> 2 625 on explanatory_mpk) - the 18 cycles saved per chain do not pay for that.
 __device__ inline double fast_rcp(double x) {
   double r = __builtin_amdgcn_rcp(x);
   r = fma(r, fma(-x, r, 1.0), r);
