@@ -1360,9 +1360,27 @@ static __device__ __forceinline__ void core_run_down(F&& f) {
 #pragma unroll
   for (int j = B; j >= A; j--) f(j);
 }
-template <class F>
+// (SYS = 1: the last compact interval of the register-set kernels - radiation streaming and both fluid approximations on - where the
+//  scheme itself says which groups idle: photons, ur and the tails' auxiliary unknowns.  Five of the eight group tests go, and a
+//  test is a scalar branch, ~20 cycles of a lone wavefront, in every one of the 7 - 13 nested passes of a factorisation.)
+template <int SYS = 0, class F>
 static __device__ __forceinline__ void for_core(unsigned pm, int lo, F&& f) {
   if (!NCDM) { core_run<0, NC - 1>(lo, f); return; }
+  if constexpr (SYS == 1) {
+    if (lo <= 8) core_run<6, 8>(lo, f);
+    if (lo <= 12) core_run<12, 12>(lo, f);
+    if (lo <= 15) core_run<13, (NCDM ? 15 : 0)>(lo, f);
+    if (lo <= 18 && (pm & (7u << 16))) core_run<16, (NCDM ? 18 : 0)>(lo, f);
+    if (lo <= 21 && (pm & (7u << 19))) core_run<19, (NCDM ? 21 : 0)>(lo, f);
+    return;
+  }
+  if constexpr (SYS == 2) {   // (the other compact intervals: whatever idles among the first sixteen is an identity pivot, cheaper than a test)
+    if (lo <= 15) core_run<0, (NCDM ? 15 : 0)>(lo, f);
+    if (lo <= 18 && (pm & (7u << 16))) core_run<16, (NCDM ? 18 : 0)>(lo, f);
+    if (lo <= 21 && (pm & (7u << 19))) core_run<19, (NCDM ? 21 : 0)>(lo, f);
+    if constexpr (NCDM == 3) { if (pm & (7u << 22)) core_run<22, 24>(lo, f); }
+    return;
+  }
   if (lo <= 5 && (pm & 0x3Fu)) core_run<0, 5>(lo, f);
   if (lo <= 8) core_run<6, 8>(lo, f);
   if (lo <= 11 && (pm & 0xE00u)) core_run<9, 11>(lo, f);
@@ -1372,9 +1390,24 @@ static __device__ __forceinline__ void for_core(unsigned pm, int lo, F&& f) {
   if (lo <= 21 && (pm & (7u << 19))) core_run<19, (NCDM ? 21 : 0)>(lo, f);
   if constexpr (NCDM == 3) { if (pm & (7u << 22)) core_run<22, 24>(lo, f); }
 }
-template <class F>
+template <int SYS = 0, class F>
 static __device__ __forceinline__ void for_core_down(unsigned pm, F&& f) {
   if (!NCDM) { core_run_down<0, NC - 1>(f); return; }
+  if constexpr (SYS == 1) {
+    if (pm & (7u << 19)) core_run_down<19, (NCDM ? 21 : 0)>(f);
+    if (pm & (7u << 16)) core_run_down<16, (NCDM ? 18 : 0)>(f);
+    core_run_down<13, (NCDM ? 15 : 0)>(f);
+    core_run_down<12, 12>(f);
+    core_run_down<6, 8>(f);
+    return;
+  }
+  if constexpr (SYS == 2) {
+    if constexpr (NCDM == 3) { if (pm & (7u << 22)) core_run_down<22, 24>(f); }
+    if (pm & (7u << 19)) core_run_down<19, (NCDM ? 21 : 0)>(f);
+    if (pm & (7u << 16)) core_run_down<16, (NCDM ? 18 : 0)>(f);
+    core_run_down<0, (NCDM ? 15 : 0)>(f);
+    return;
+  }
   if constexpr (NCDM == 3) { if (pm & (7u << 22)) core_run_down<22, 24>(f); }
   if (pm & (7u << 19)) core_run_down<19, (NCDM ? 21 : 0)>(f);
   if (pm & (7u << 16)) core_run_down<16, (NCDM ? 18 : 0)>(f);
@@ -1451,6 +1484,7 @@ static __device__ __forceinline__ void pcr_level(double& a, double& c, double& d
   c = -ga * cq;
 }
 
+template <int SYS = 0>
 static __device__ __forceinline__ bool factorise(const LaneEq& e, const Jac& J, double hg, int maxlen, int lane, LuReg& F,
                                                  const double* al = nullptr, double gmc = 0., double gms = 0., int aux = 0) {
   ISA_MARK("FACT_BEGIN");
@@ -1519,7 +1553,7 @@ static __device__ __forceinline__ bool factorise(const LaneEq& e, const Jac& J, 
   double rpivc = 1.;
   bool ok = true;
   const unsigned pm = e.pmask;
-  for_core(pm, 0, [&](const int j) {
+  for_core<SYS>(pm, 0, [&](const int j) {
     const double mag = (lane >= j) ? fabs(A[j]) : 0.;      // rows >= NC hold zeros in the core columns
     const double diag = bcast(mag, j);
     if (__ballot(mag > 1e3 * diag) != 0ull || diag == 0.) {  // rare: the diagonal is not an acceptable pivot
@@ -1544,7 +1578,7 @@ static __device__ __forceinline__ bool factorise(const LaneEq& e, const Jac& J, 
     if (lane == j) rpivc = rp;
     const double m = (lane > j) ? A[j] * rp : 0.;
     if (lane > j) A[j] = m;
-    for_core(pm, j + 1, [&](const int cidx) {
+    for_core<SYS>(pm, j + 1, [&](const int cidx) {
       const double pj = bcast(A[cidx], j);
       A[cidx] = fma(-m, pj, A[cidx]);   // m = 0 on rows <= j
     });
@@ -1565,7 +1599,7 @@ static __device__ __forceinline__ bool factorise(const LaneEq& e, const Jac& J, 
 }
 
 // solve (I - hg J) x = b; lane i holds b_i on entry and x_i on return
-template <bool USE_INV = false>
+template <bool USE_INV = false, int SYS = 0>
 static __device__ __forceinline__ double lu_solve(const LaneEq& e, const LuReg& F, int maxlen, double b, int lane) {
   lane = opaque(lane);
   const int chain = opaque(e.chain);
@@ -1611,13 +1645,13 @@ static __device__ __forceinline__ double lu_solve(const LaneEq& e, const LuReg& 
   // Row i keeps its L entries (columns j < i) and its U entries (j > i) in ONE register array, so each substitution step must
   // switch the entry off on the rows it does not concern.  Clearing the HIGH word alone does that in one v_cndmask instead of
   // two: what is left is a subnormal (|m| < 2^-1022), and m * xj then vanishes against x unless |xj / x| > 2^970.
-  for_core(pm, 0, [&](const int j) {   // forward, unit lower
+  for_core<SYS>(pm, 0, [&](const int j) {   // forward, unit lower
     const double xj = bcast(x, j);
     const double m = __hiloint2double((lane > j) ? __double2hiint(Ac[j]) : 0, __double2loint(Ac[j]));
     x = fma(-m, xj, x);
   });
   x *= F.rpivc;   // 1 outside the core
-  for_core_down(pm, [&](const int j) {  // backward, unit upper
+  for_core_down<SYS>(pm, [&](const int j) {  // backward, unit upper
     const double xj = bcast(x, j);
     const double uj = __hiloint2double((lane < j) ? __double2hiint(Ac[j]) : 0, __double2loint(Ac[j]));
     x = fma(-uj, xj, x);
@@ -2007,7 +2041,7 @@ static __device__ __forceinline__ int ndf15s(const PtParams& P, const Layout& L,
       if (need_fact) {
         need_fact = false;
         PROF_START();
-        if (!factorise(e, J, hinvGak, maxlen, lane, F, nullptr, 0., 0.)) return 2;
+        if (!factorise<SYS>(e, J, hinvGak, maxlen, lane, F, nullptr, 0., 0.)) return 2;
         if constexpr (USE_INV) {
           inv_want = -1; inv_ok = false; lu_first = true;
           if (!F.permuted) {
@@ -2091,7 +2125,7 @@ static __device__ __forceinline__ int ndf15s(const PtParams& P, const Layout& L,
             del = lu_solve<false>(e, F, maxlen, rhsv, lane);
             lu_first = false;
           }
-        } else del = lu_solve(e, F, maxlen, rhsv, lane);
+        } else del = lu_solve<false, SYS>(e, F, maxlen, rhsv, lane);
         ISA_MARK("NEWT_CTRL");
         PROF_STOP(1);
 #ifdef CPT_PROFILE
