@@ -591,4 +591,26 @@ def test_long_hierarchies_with_massive_neutrinos_all_modes():
     assert abs(gs - os_) < 0.02 * os_, (gs, os_)
     ms, n = be.kernel_ms(0)
     print("\n[ncdm_permille_small] perturb kernel %.1f ms for %d modes, %d steps" % (ms, inp.nk, sum(s.steps for s in stats)))
+    be.close()@pytest.mark.gpu
+@pytest.mark.parametrize("cfg", ["lcdm", "tens", "curved", "newt"])
+def test_two_wave_kernels_repeat_bit_for_bit(cfg):
+    """The integrator wave and its helper talk through counters in LDS without a barrier (table rows by request number, the inverse of
+    the core block of the Newton matrix): WHEN the helper's answers arrive depends on timing, WHICH answer the integrator uses and which
+    form of the solve it takes does not (the first solve after a factorisation is the triangular one, every later one waits for the
+    inverse of exactly that factorisation).  Three launches - two on one handle, one on a fresh handle - must agree bit for bit,
+    statistics included."""
+    from classpp_public_amd.backend import Backend
+    inp = Inputs(cfg)
+    be = Backend(inp)
+    a, sa, _ = be.perturb_solve()
+    a = a.clone()
+    b, sb, _ = be.perturb_solve()
+    assert torch.equal(a, b) and [(s.steps, s.fevals, s.solves) for s in sa] == [(s.steps, s.fevals, s.solves) for s in sb]
     be.close()
+    be2 = Backend(inp)
+    c, sc, _ = be2.perturb_solve()
+    assert torch.equal(a, c) and [(s.steps, s.factorisations) for s in sa] == [(s.steps, s.factorisations) for s in sc]
+    be2.close()
+
+
+
