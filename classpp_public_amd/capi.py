@@ -50,7 +50,12 @@ class CptConfig(C.Structure):
         ("hyper_flat_approximation_nu", _d),
         ("N_ncdm", _i), ("l_max_ncdm", _i), ("ncdm_fluid_approximation", _i), ("ncdm_fluid_trigger_tau_over_tau_k", _d),
         ("tol_ncdm_initial_w", _d), ("index_tp_delta_cb", _i), ("tensor_method", _i),
+        ("has_transfers", _i), ("index_tp_transfer", _i * 12),
     ]
+
+
+# cpt_config.index_tp_transfer is indexed by these (enum CPT_TK_* of include/cpt.h; names as in the reference's index_tp_<name>_)
+TK_NAMES = ("delta_tot", "delta_g", "delta_b", "delta_cdm", "delta_ur", "theta_tot", "theta_g", "theta_b", "theta_cdm", "theta_ur", "phi", "psi")
 
 
 _pd = C.POINTER(_d)

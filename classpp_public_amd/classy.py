@@ -200,11 +200,15 @@ def build_parameters(pars, mode, ic="ad"):
 
     # ---- outputs and modes (input_module.cpp:1700-1830, 2960-3000)
     out = [s.strip() for s in str(pars.get("output", "")).replace(" ", ",").split(",") if s.strip()]
-    bad = [s for s in out if s.lower() not in ("tcl", "pcl", "lcl", "mpk")]
+    bad = [s for s in out if s.lower() not in ("tcl", "pcl", "lcl", "mpk", "mtk", "dtk", "vtk")]
     if bad:
-        raise CosmoSevereError("output %s is outside the accelerated path (tCl, pCl, lCl, mPk)" % ", ".join(bad))
+        raise CosmoSevereError("output %s is outside the accelerated path (tCl, pCl, lCl, mPk, mTk / dTk, vTk)" % ", ".join(bad))
     low = [s.lower() for s in out]
     has_t, has_p, has_l, has_pk = "tcl" in low, "pcl" in low, "lcl" in low, "mpk" in low
+    # density / velocity transfer functions (input_module.cpp: mTk = dTk -> has_density_transfers, vTk -> has_velocity_transfers)
+    has_dtk, has_vtk = (("mtk" in low) or ("dtk" in low)) and mode != "t", ("vtk" in low) and mode != "t"
+    if (has_dtk or has_vtk) and N_ncdm > 0:
+        raise CosmoSevereError("density / velocity transfer functions together with non-cold species are outside the accelerated path")
     lensing = _yes(pars.get("lensing", "no"))
     if lensing and not (has_l and (has_t or has_p)):
         raise CosmoSevereError("Lensed Cls only possible if you ask for lensing potential Cls and temperature or polarisation Cls (output must contain lCl and tCl or pCl)")
@@ -268,8 +272,14 @@ def build_parameters(pars, mode, ic="ad"):
 
     # ---- index maps, in the order the modules define them
     tp, n = {}, 0
+    has_cdm_, has_ur_, newt_ = dens["Omega0_cdm"] != 0., dens["Omega0_ur"] != 0., gauge != "synchronous"
     for name, on in (("t2", has_t or has_p), ("p", has_p), ("t0", has_t and not tens), ("t1", has_t and not tens),
-                     ("delta_m", has_pk and not tens), ("delta_cb", has_pk and not tens and N_ncdm > 0), ("phi_plus_psi", has_l and not tens)):
+                     ("delta_m", has_pk and not tens), ("delta_cb", has_pk and not tens and N_ncdm > 0),
+                     # (pm.cpp:1107-1140: the transfer sources sit between delta_cb and phi+psi, psi after it)
+                     ("delta_tot", has_dtk), ("delta_g", has_dtk), ("delta_b", has_dtk), ("delta_cdm", has_dtk and has_cdm_), ("delta_ur", has_dtk and has_ur_),
+                     ("theta_tot", has_vtk), ("theta_g", has_vtk), ("theta_b", has_vtk), ("theta_cdm", has_vtk and has_cdm_ and newt_),
+                     ("theta_ur", has_vtk and has_ur_), ("phi", has_dtk),
+                     ("phi_plus_psi", has_l and not tens), ("psi", has_dtk)):
         tp[name] = n if on else -1
         n += int(on)
     for name, idx in tp.items():
@@ -875,6 +885,49 @@ class Class:
             out[title] = tab[:, idx].copy()
         return out
 
+    def get_transfer(self, z=0., output_format="class"):
+        """density and velocity transfer functions at redshift z (classy.pyx:1303-1388, PerturbationsModule::perturb_output_data,
+        pm.cpp:130-330): {'k (h/Mpc)', 'd_g', 'd_b', 'd_cdm', 'd_ur', 'd_tot', 'phi', 'psi', 't_g', 't_b', 't_cdm', 't_ur', 't_tot'} for the
+        columns the run holds (output = mTk / dTk, vTk); z = 0: the last time sample, 0 < z <= z_max_pk: the sources splined in ln tau
+        over the tail of the sampling, as perturb_sources_at_tau does"""
+        if output_format != "class":
+            raise CosmoSevereError("get_transfer: only the 'class' format is implemented (not 'camb')")
+        self._need("perturb")
+        r = self._runs.get("s")
+        c = r.inp.config if r is not None else None
+        if r is None or not c.has_transfers:
+            raise CosmoSevereError("No density or velocity transfer functions computed. You must add mTk and / or vTk to the list of outputs.")
+        from .capi import TK_NAMES
+        S = r.be.get_sources(r.inp.tau.size, r.inp.k.size).cpu().numpy()       # [tp][tau][k]
+        if z == 0.:
+            at = S[:, -1, :]
+        else:
+            tau_z, n = self._late_times_of(r, z)
+            lt = np.log(r.inp.tau[-n:])
+            if np.log(tau_z) < lt[0]:
+                raise CosmoSevereError("Asking sources at a z bigger than z_max_pk, something probably went wrong")
+            from scipy.interpolate import CubicSpline
+            at = CubicSpline(lt, S[:, -n:, :], axis=1, bc_type="natural")(np.log(tau_z))
+        titles = {"delta_g": "d_g", "delta_b": "d_b", "delta_cdm": "d_cdm", "delta_ur": "d_ur", "delta_tot": "d_tot", "phi": "phi", "psi": "psi",
+                  "theta_g": "t_g", "theta_b": "t_b", "theta_cdm": "t_cdm", "theta_ur": "t_ur", "theta_tot": "t_tot"}
+        out = {"k (h/Mpc)": r.inp.k / self.h()}
+        order = ("delta_g", "delta_b", "delta_cdm", "delta_ur", "delta_tot", "phi", "psi", "theta_g", "theta_b", "theta_cdm", "theta_ur", "theta_tot")
+        for name in order:
+            idx = int(c.index_tp_transfer[TK_NAMES.index(name)])
+            if idx >= 0:
+                out[titles[name]] = at[idx].copy()
+        return out
+
+    def _late_times_of(self, r, z):
+        from . import hostlib
+        if z < 0.:
+            raise CosmoSevereError("asked for negative redshift z=%e" % z)
+        zmax = float(r.inp.d["ppt.z_max_pk"][0])
+        if zmax == 0. or z > zmax:
+            raise CosmoSevereError("get_transfer at z=%e needs z_max_pk >= z in the input (the sources are kept up to z_max_pk = %e)" % (z, zmax))
+        n = hostlib.ln_tau_size(r.inp.tau, hostlib.tau_of_z(r.inp, zmax))
+        return hostlib.tau_of_z(r.inp, z), n
+
     def get_sources(self):
         """(sources, k, tau): the source functions S(k, tau) of the scalar run, {name: [k_size][tau_size]} like the reference's
         get_sources (classy.pyx; perturbations_module.h:11-40 for the types)"""
@@ -887,6 +940,11 @@ class Class:
             idx = getattr(c, "index_tp_" + name)
             if idx >= 0:
                 out[name] = S[idx].T.copy()
+        if c.has_transfers:
+            from .capi import TK_NAMES
+            for i, name in enumerate(TK_NAMES):
+                if c.index_tp_transfer[i] >= 0:
+                    out[name] = S[int(c.index_tp_transfer[i])].T.copy()
         return out, r.inp.k.copy(), r.inp.tau.copy()
 
     def __del__(self):

@@ -53,6 +53,7 @@ struct PtParams {
   int switch_sw, switch_eisw, switch_lisw, switch_dop, switch_pol;
   double eisw_lisw_split_z, three_ceff2_ur, three_cvis2_ur;
   int tp_size, tp_t0, tp_t1, tp_t2, tp_p, tp_dm, tp_pp;
+  int tp_tk[CPT_NTK];   // density / velocity transfer sources (cpt_config::index_tp_transfer; all -1 unless has_transfers)
   double start_small_k, start_large_k, tca_trig_h, tca_trig_k, rsa_trig, ufa_trig, curvature_ini, rtol, tol_tau_approx, min_var;
   // batch
   const double* k;
@@ -1257,6 +1258,34 @@ static __device__ __forceinline__ void store_sources(const PtParams& P, const La
     if (P.tp_pp >= 0) P.src[P.tp_pp * tstride + base] = eta + M.alphap;
     if (P.tp_dm >= 0) P.src[P.tp_dm * tstride + base] = delta_m;
     if (NCDM && P.tp_dcb >= 0) P.src[P.tp_dcb * tstride + base] = delta_cb;   // pm.cpp:7001-7003
+  }
+  // ---- density and velocity transfer functions (output = mTk, vTk; pm.cpp:6930-6975, 7017-7200; no N-body gauge shifts) ----
+  if constexpr (NCDM == 0) {
+    bool any = false;
+#pragma unroll
+    for (int i = 0; i < CPT_NTK; i++) any = any || (P.tp_tk[i] >= 0);
+    if (any) {
+      const double k2 = k * k;
+      double dgam = delta_g, tgam, dur, tur;
+      if (L.rsa) {      // the streaming values (pm.cpp:9530-9636), as the RHS formed them
+        tgam = M.rsa_tg;
+        if (GAUGE == CPT_GAUGE_SYNCHRONOUS) { dur = (P.rsa_method != CPT_RSA_NULL) ? 4. * inv_k2 * (aH * M.hp - k2 * eta) : 0.; tur = (P.rsa_method != CPT_RSA_NULL) ? -0.5 * M.hp : 0.; }
+        else { dur = (P.rsa_method != CPT_RSA_NULL) ? -4. * eta : 0.; tur = (P.rsa_method != CPT_RSA_NULL) ? 6. * M.phip : 0.; }
+      } else { tgam = bcast(y, LN_TG); dur = bcast(y, LN_DUR); tur = bcast(y, LN_TUR); }
+      const double db = bcast(y, LN_DB), dc = bcast(y, LN_DC), tc = (GAUGE == CPT_GAUGE_NEWTONIAN) ? bcast(y, LN_TC) : 0.;
+      // totals: every species but the cosmological constant (pm.cpp:7019-7030), (rho + p) theta over rho + p (pm.cpp:7142-7145)
+      const double rho_tot = Q.rg + Q.rb + Q.rc + Q.ru, rho_p_tot = Q.rg43 + Q.rb + Q.rc + Q.ru43;
+      const double delta_rho = Q.rg * dgam + Q.rb * db + Q.rc * dc + Q.ru * dur;
+      const double rpt = Q.rg43 * tgam + Q.rb * tb + Q.rc * tc + Q.ru43 * tur;
+      const double phi = (GAUGE == CPT_GAUGE_NEWTONIAN) ? eta : eta - aH * M.alpha;
+      const double psi = (GAUGE == CPT_GAUGE_NEWTONIAN) ? M.psi : aH * M.alpha + M.alphap;
+      if (lane == 0) {
+        const size_t base = (size_t)ik * P.ntau + it, tstride = (size_t)P.nk * P.ntau;
+        const double v[CPT_NTK] = {delta_rho / rho_tot, dgam, db, dc, dur, rpt / rho_p_tot, tgam, tb, tc, tur, phi, psi};
+#pragma unroll
+        for (int i = 0; i < CPT_NTK; i++) if (P.tp_tk[i] >= 0) P.src[P.tp_tk[i] * tstride + base] = v[i];
+      }
+    }
   }
 }
 
@@ -2840,6 +2869,7 @@ static void fill_params(const cpt_handle* h, PtParams& P) {
   P.three_ceff2_ur = c.three_ceff2_ur; P.three_cvis2_ur = c.three_cvis2_ur;
   P.tp_size = c.tp_size; P.tp_t0 = c.index_tp_t0; P.tp_t1 = c.index_tp_t1; P.tp_t2 = c.index_tp_t2; P.tp_p = c.index_tp_p;
   P.tp_dm = c.index_tp_delta_m; P.tp_pp = c.index_tp_phi_plus_psi;
+  for (int i = 0; i < CPT_NTK; i++) P.tp_tk[i] = c.has_transfers ? c.index_tp_transfer[i] : -1;
   P.start_small_k = c.start_small_k_at_tau_c_over_tau_h; P.start_large_k = c.start_large_k_at_tau_h_over_tau_k;
   P.tca_trig_h = c.tight_coupling_trigger_tau_c_over_tau_h; P.tca_trig_k = c.tight_coupling_trigger_tau_c_over_tau_k;
   P.rsa_trig = c.radiation_streaming_trigger_tau_over_tau_k; P.ufa_trig = c.ur_fluid_trigger_tau_over_tau_k;

@@ -20,7 +20,7 @@ GOLDEN = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))
 TABLES_OF = {
     "small": "tables_lcdm.npz", "lcdm": "tables_lcdm.npz", "explanatory": "tables_lcdm.npz", "explanatory_mpk": "tables_lcdm.npz",
     "iso_cdi": "tables_lcdm.npz", "iso_nid": "tables_lcdm.npz", "newt": "tables_lcdm.npz", "tens": "tables_lcdm.npz",
-    "tca_mb": "tables_lcdm.npz", "lcdm_zpk": "tables_lcdm.npz", "long_small": "tables_lcdm.npz", "long_full": "tables_lcdm.npz", "newt_full": "tables_lcdm.npz", "iso_bi_full": "tables_lcdm.npz", "iso_niv_full": "tables_lcdm.npz", "tens_full": "tables_lcdm.npz",
+    "tca_mb": "tables_lcdm.npz", "lcdm_zpk": "tables_lcdm.npz", "lcdm_tk": "tables_lcdm.npz", "small_tk": "tables_lcdm.npz", "newt_tk": "tables_lcdm.npz", "long_small": "tables_lcdm.npz", "long_full": "tables_lcdm.npz", "newt_full": "tables_lcdm.npz", "iso_bi_full": "tables_lcdm.npz", "iso_niv_full": "tables_lcdm.npz", "tens_full": "tables_lcdm.npz",
     "curved": "tables_curved.npz", "curved_full": "tables_curved.npz", "tens_curved": "tables_curved.npz", "open": "tables_open.npz",
     "ncdm": "tables_ncdm1.npz", "ncdm_small": "tables_ncdm1.npz", "ncdm_k3000": "tables_ncdm1.npz",
     "ncdm_permille": "tables_ncdm1.npz", "ncdm_permille_small": "tables_ncdm1.npz",
@@ -123,6 +123,10 @@ class Inputs:
         c.tol_ncdm_initial_w = float(_s(d, "ppr.tol_ncdm_initial_w")) if "ppr.tol_ncdm_initial_w" in d else 1e-3
         c.index_tp_delta_cb = int(_s(d, "pt.index_tp_delta_cb")) if "pt.index_tp_delta_cb" in d else -1
         c.tensor_method = int(_s(d, "ppt.tensor_method")) if "ppt.tensor_method" in d else 1
+        from .capi import TK_NAMES
+        for i, name in enumerate(TK_NAMES):      # density / velocity transfer sources (output = mTk, vTk)
+            c.index_tp_transfer[i] = int(_s(d, "pt.index_tp_" + name)) if ("pt.index_tp_" + name) in d else -1
+        c.has_transfers = int(any(c.index_tp_transfer[i] >= 0 for i in range(len(TK_NAMES))))
         # initial condition: one mode per handle (ad unless the fixture says otherwise)
         c.ic = 0
         for code, key in ((1, "ppt.has_bi"), (2, "ppt.has_cdi"), (3, "ppt.has_nid"), (4, "ppt.has_niv")):

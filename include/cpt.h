@@ -77,6 +77,10 @@ extern "C" {
 enum { CPT_MODE_SCALARS = 0, CPT_MODE_TENSORS = 1 };
 enum { CPT_IC_AD = 0, CPT_IC_BI = 1, CPT_IC_CDI = 2, CPT_IC_NID = 3, CPT_IC_NIV = 4 };
 
+/* density / velocity transfer sources (PerturbationsModule::index_tp_delta_tot_ ... index_tp_psi_, perturbations_module.h:93-122) */
+enum { CPT_TK_DELTA_TOT = 0, CPT_TK_DELTA_G, CPT_TK_DELTA_B, CPT_TK_DELTA_CDM, CPT_TK_DELTA_UR,
+       CPT_TK_THETA_TOT, CPT_TK_THETA_G, CPT_TK_THETA_B, CPT_TK_THETA_CDM, CPT_TK_THETA_UR, CPT_TK_PHI, CPT_TK_PSI, CPT_NTK };
+
 typedef struct cpt_config {
   /* --- background (source/background.h) --- */
   double H0;      /* [1/Mpc] */
@@ -144,6 +148,9 @@ typedef struct cpt_config {
                                          present, pm.cpp:996); -1 = absent                                                 */
   int tensor_method;                  /* CPT_TM_PHOTONS_ONLY / MASSLESS_APPROXIMATION / EXACT (pm.cpp:590-611): with ncdm and
                                          the massless approximation the tensor ur hierarchy carries rho_ur + 3 sum p_ncdm  */
+  int has_transfers;                  /* 0: the array below is ignored (a zero-initialised struct asks for none)               */
+  int index_tp_transfer[CPT_NTK];     /* slots of the density / velocity transfer sources (output = mTk, vTk: pm.cpp:1000-1050,
+                                         6930-7200), indexed by CPT_TK_*; -1 = absent.  Scalars without non-cold species.     */
 } cpt_config;
 
 /* Spline tables the RHS samples (all HOST pointers, row-major [n_lines][n_columns], copied to HBM by cpt_create):

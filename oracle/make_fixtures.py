@@ -71,7 +71,7 @@ def main():
             else:
                 out[k] = v
         src = d["pt.sources"]  # [tp][tau][k]
-        if cfg in ("small", "tens", "tens_curved", "ncdm_small", "ncdm3_small", "long_small", "tca_mb", "ncdm_permille_small"):
+        if cfg in ("small", "tens", "tens_curved", "ncdm_small", "ncdm3_small", "long_small", "tca_mb", "ncdm_permille_small", "small_tk", "newt_tk"):
             out["pt.sources"] = src
             if "tr.transfer" in d:
                 out["tr.transfer"] = d["tr.transfer"]
@@ -96,7 +96,8 @@ def main():
             old = np.load(os.path.join(GOLD, "tables_curved.npz"))
             for k in tables:
                 assert np.array_equal(old[k], tables[k]), "tables differ between configs: " + k
-        if cfg.startswith("iso_") or cfg in ("newt", "tens", "explanatory_mpk", "newt_full", "tens_full", "long_small", "long_full", "tca_mb", "lcdm_zpk"):
+        if cfg.startswith("iso_") or cfg in ("newt", "tens", "explanatory_mpk", "newt_full", "tens_full", "long_small", "long_full", "tca_mb", "lcdm_zpk",
+                                             "lcdm_tk", "small_tk", "newt_tk"):
             # same cosmology as small/lcdm/explanatory: the tables must be the committed ones
             old = np.load(os.path.join(GOLD, "tables_lcdm.npz"))
             for k in tables:

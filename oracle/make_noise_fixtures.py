@@ -75,7 +75,8 @@ def main():
             out["pk_dev"] = np.abs(half["nl.pk_lin_z0"] / base["nl.pk_lin_z0"] - 1)
             out["sigma8_dev"] = np.abs(half["nl.sigma8"] / base["nl.sigma8"] - 1)
         for key in ("pt.index_tp_t0", "pt.index_tp_t1", "pt.index_tp_t2", "pt.index_tp_p", "pt.index_tp_delta_m", "pt.index_tp_phi_plus_psi",
-                    "pt.index_tp_delta_cb"):
+                    "pt.index_tp_delta_cb") + tuple("pt.index_tp_" + n for n in ("delta_tot", "delta_g", "delta_b", "delta_cdm", "delta_ur", "theta_tot", "theta_g",
+                                                                                         "theta_b", "theta_cdm", "theta_ur", "phi", "psi")):
             if key in base:
                 out[key] = base[key]
         out["tol_default"] = np.array([1e-5]); out["tol_halved"] = np.array([5e-6])

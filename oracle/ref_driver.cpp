@@ -240,6 +240,19 @@ static int do_dump(const char* ini, const char* outpath) {
   put_i("pt.index_tp_phi_plus_psi", pt->has_source_phi_plus_psi_ ? pt->index_tp_phi_plus_psi_ : -1);
   put_i("pt.index_tp_delta_m", pt->has_source_delta_m_ ? pt->index_tp_delta_m_ : -1);
   put_i("pt.index_tp_delta_cb", pt->has_source_delta_cb_ ? pt->index_tp_delta_cb_ : -1);
+  // density / velocity transfer functions (output = mTk, vTk: pm.cpp:1000-1050, 6930-7200)
+  put_i("pt.index_tp_delta_tot", (pt->has_source_delta_tot_ && !tens) ? pt->index_tp_delta_tot_ : -1);
+  put_i("pt.index_tp_delta_g", (pt->has_source_delta_g_ && !tens) ? pt->index_tp_delta_g_ : -1);
+  put_i("pt.index_tp_delta_b", (pt->has_source_delta_b_ && !tens) ? pt->index_tp_delta_b_ : -1);
+  put_i("pt.index_tp_delta_cdm", (pt->has_source_delta_cdm_ && !tens) ? pt->index_tp_delta_cdm_ : -1);
+  put_i("pt.index_tp_delta_ur", (pt->has_source_delta_ur_ && !tens) ? pt->index_tp_delta_ur_ : -1);
+  put_i("pt.index_tp_theta_tot", (pt->has_source_theta_tot_ && !tens) ? pt->index_tp_theta_tot_ : -1);
+  put_i("pt.index_tp_theta_g", (pt->has_source_theta_g_ && !tens) ? pt->index_tp_theta_g_ : -1);
+  put_i("pt.index_tp_theta_b", (pt->has_source_theta_b_ && !tens) ? pt->index_tp_theta_b_ : -1);
+  put_i("pt.index_tp_theta_cdm", (pt->has_source_theta_cdm_ && !tens) ? pt->index_tp_theta_cdm_ : -1);
+  put_i("pt.index_tp_theta_ur", (pt->has_source_theta_ur_ && !tens) ? pt->index_tp_theta_ur_ : -1);
+  put_i("pt.index_tp_phi", (pt->has_source_phi_ && !tens) ? pt->index_tp_phi_ : -1);
+  put_i("pt.index_tp_psi", (pt->has_source_psi_ && !tens) ? pt->index_tp_psi_ : -1);
   {
     std::vector<double> s((size_t)ntp * ntau * nk);
     for (int tp = 0; tp < ntp; tp++)

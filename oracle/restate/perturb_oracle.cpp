@@ -551,6 +551,27 @@ void derivs(const Model& m, double k, double tau, const double* y, double* dy, c
   dy[L.eta] = (c.gauge == CPT_GAUGE_NEWTONIAN) ? w.phi_prime : w.eta_prime;   // pm.cpp:8892-8902
 }
 
+// density / velocity transfer functions (output = mTk, vTk; pm.cpp:6930-6975, 7017-7200 without the N-body gauge shifts), after einstein()
+static void transfer_sources(const Model& m, double k, const double* y, const Layout& L, const Work& w, double* out) {
+  const cpt_config& c = *m.c;
+  if (!c.has_transfers || c.has_ncdm) return;
+  const Bg& bg = w.bg;
+  const double aH = bg.a * bg.H;
+  const bool newt = (c.gauge == CPT_GAUGE_NEWTONIAN);
+  const double delta_g = L.rsa ? w.rsa_delta_g : y[L.delta_g], theta_g = L.rsa ? w.rsa_theta_g : y[L.theta_g];
+  const double delta_ur = !c.has_ur ? 0. : L.rsa ? w.rsa_delta_ur : y[L.delta_ur], theta_ur = !c.has_ur ? 0. : L.rsa ? w.rsa_theta_ur : y[L.theta_ur];
+  const double rho_cdm = c.has_cdm ? bg.rho_cdm : 0., rho_ur = c.has_ur ? bg.rho_ur : 0.;
+  const double rho_tot = bg.rho_g + bg.rho_b + rho_cdm + rho_ur;            // every species but the cosmological constant (pm.cpp:7019-7030)
+  double v[CPT_NTK];
+  v[CPT_TK_DELTA_TOT] = w.delta_rho / rho_tot;
+  v[CPT_TK_DELTA_G] = delta_g; v[CPT_TK_DELTA_B] = y[L.delta_b]; v[CPT_TK_DELTA_CDM] = c.has_cdm ? y[L.delta_cdm] : 0.; v[CPT_TK_DELTA_UR] = delta_ur;
+  v[CPT_TK_THETA_TOT] = w.rho_plus_p_theta / w.rho_plus_p_tot;
+  v[CPT_TK_THETA_G] = theta_g; v[CPT_TK_THETA_B] = y[L.theta_b]; v[CPT_TK_THETA_CDM] = (newt && c.has_cdm) ? y[L.theta_cdm] : 0.; v[CPT_TK_THETA_UR] = theta_ur;
+  v[CPT_TK_PHI] = newt ? y[L.eta] : y[L.eta] - aH * w.alpha;
+  v[CPT_TK_PSI] = newt ? w.psi : aH * w.alpha + w.alpha_prime;
+  for (int i = 0; i < CPT_NTK; i++) if (c.index_tp_transfer[i] >= 0) out[c.index_tp_transfer[i]] = v[i];
+}
+
 // perturb_sources, pm.cpp:6731-7285 (scalar types t0,t1,t2,p,delta_m,phi+psi in synchronous gauge)
 void sources(const Model& m, double k, double tau, const double* y, const double* dy, const Layout& L, Work& w, double* out) {
   const cpt_config& c = *m.c;
@@ -579,6 +600,7 @@ void sources(const Model& m, double k, double tau, const double* y, const double
     if (L.tca) P = 5. * s_l(c, k, 2) * w.tca_shear_g / 8.;  // NB: left over from the last derivs call (pm.cpp:6810), see SURVEY "hidden state"
     else P = (y[L.pol0_g] + y[L.pol2_g] + 2. * s_l(c, k, 2) * y[L.shear_g]) / 8.;
   }
+  transfer_sources(m, k, y, L, w, out);
   int switch_isw = 1;
   if ((c.switch_eisw == 0) && (z >= c.eisw_lisw_split_z)) switch_isw = 0;
   if ((c.switch_lisw == 0) && (z < c.eisw_lisw_split_z)) switch_isw = 0;
@@ -1251,7 +1273,7 @@ int solve_mode(const Model& m, double k, int ik, int nk, const double* tau_sampl
     }
     auto rhs = [&](double tau, const double* yy, double* dyy) { derivs(m, k, tau, yy, dyy, L, w); };
     auto out = [&](double tau, const double* yy, const double* dyy, int it) {
-      double s[16] = {0};
+      double s[8 + CPT_NTK + 4] = {0};
       sources(m, k, tau, yy, dyy, L, w, s);
       for (int tp = 0; tp < c.tp_size; tp++) src[((size_t)tp * ntau + it) * nk + ik] = s[tp];
     };

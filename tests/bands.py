@@ -28,6 +28,15 @@ SOURCE_BANDS = {
     "phi_plus_psi": (1e-5, 1e-5),
     "delta_cb": (1e-5, 1e-5),
 }
+# density / velocity transfer sources (output = mTk, vTk: cpt_config::index_tp_transfer, in the order of capi.TK_NAMES).  The reference moves its
+# own by (noise_lcdm_tk.npz): delta_tot / delta_b / delta_cdm 3.0e-5, delta_g 5.8e-5, delta_ur 8.9e-4 (free-streaming oscillations at high k),
+# theta_tot 1.5e-5, theta_g 5.7e-5, theta_b 4.2e-5, theta_ur 5.7e-5, phi / psi 1.8e-5; theta_cdm (Newtonian gauge only) shares the band of the densities
+TRANSFER_SOURCE_BANDS = {
+    "delta_tot": (1e-5, 1e-5), "delta_g": (1e-4, 1e-4), "delta_b": (1e-5, 1e-5), "delta_cdm": (1e-5, 1e-5), "delta_ur": (1e-3, 1e-3),
+    "theta_tot": (3e-5, 3e-5), "theta_g": (1e-4, 1e-4), "theta_b": (8e-5, 8e-5), "theta_cdm": (1e-5, 1e-5), "theta_ur": (1e-4, 1e-4),
+    "phi": (1e-5, 1e-5), "psi": (1e-5, 1e-5),
+}
+TK_NAMES = ("delta_tot", "delta_g", "delta_b", "delta_cdm", "delta_ur", "theta_tot", "theta_g", "theta_b", "theta_cdm", "theta_ur", "phi", "psi")
 # matter / potential columns of the runs with hierarchies longer than one wavefront (long_full: l_max 50; ncdm_permille: l_max_g 25, l_max_pol_g 20,
 # l_max_ur 35, l_max_ncdm 28): the reference moves its own delta_m by 3.2e-5 / 2.9e-5 there (noise_long_full.npz, noise_ncdm_permille.npz) and the
 # dense CPU restatement sits 1.3e-5 from it
@@ -48,6 +57,11 @@ def source_bands(cfg, dm_tol=None):
         if idx is None or idx < 0:
             continue
         out[idx] = dm_tol if (dm_tol is not None and name in ("delta_m", "phi_plus_psi", "delta_cb")) else band
+    if getattr(cfg, "has_transfers", 0):
+        for i, name in enumerate(TK_NAMES):
+            idx = int(cfg.index_tp_transfer[i])
+            if idx >= 0:
+                out[idx] = TRANSFER_SOURCE_BANDS[name]
     return out
 
 

@@ -45,6 +45,11 @@ def _compare_struct(tag, got, struct, skip=()):
         key = "%s.%s" % (tag, name)
         if name in skip or key not in got:
             continue
+        if isinstance(ctype, type) and issubclass(ctype, C.Array):      # (printed element by element: "<key>.<i> <value>")
+            for i, want in enumerate(getattr(struct, name)):
+                if int(got["%s.%d" % (key, i)]) != int(want):
+                    bad.append(("%s.%d" % (key, i), int(got["%s.%d" % (key, i)]), int(want)))
+            continue
         want = getattr(struct, name)
         have = float(got[key]) if ctype is C.c_double else int(got[key])
         if not _same(float(have), float(want)):
@@ -53,7 +58,7 @@ def _compare_struct(tag, got, struct, skip=()):
 
 
 @pytest.mark.parametrize("cfg", ["lcdm", "explanatory_mpk", "small", "curved", "open", "newt", "iso_cdi", "iso_nid", "tens", "tens_curved",
-                                 "ncdm_small", "ncdm3", "ncdm3_tens"])
+                                 "ncdm_small", "ncdm3", "ncdm3_tens", "small_tk", "newt_tk"])
 def test_adapter_inputs_equal_the_fixture_inputs(cfg):
     got = _run(cfg)
     inp = Inputs(cfg)

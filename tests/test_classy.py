@@ -23,7 +23,7 @@ def _pars(cfg):
 
 @pytest.mark.parametrize("cfg,mode", [("lcdm", "s"), ("explanatory", "s"), ("curved", "s"), ("tens", "t"), ("tens_curved", "t"),
                                       ("small", "s"), ("newt", "s"), ("open", "s"), ("curved_full", "s"), ("ncdm", "s"), ("ncdm3", "s"),
-                                      ("ncdm3_tens", "t"), ("lcdm_zpk", "s")])
+                                      ("ncdm3_tens", "t"), ("lcdm_zpk", "s"), ("small_tk", "s"), ("newt_tk", "s"), ("lcdm_tk", "s")])
 def test_parameter_entries_equal_the_reference_input_module(cfg, mode):
     if not os.path.exists(os.path.join(GOLDEN, cfg + ".ini")):
         pytest.skip("no such fixture")
@@ -294,6 +294,41 @@ def test_values_at_a_redshift_match_the_reference():
     with pytest.raises(classy.CosmoSevereError):
         c.Hubble(-0.5)
     c.struct_cleanup()
+
+
+@pytest.mark.gpu
+def test_get_transfer_matches_the_reference_sources():
+    """classy.pyx:1303-1388 get_transfer(z = 0): PerturbationsModule::perturb_output_data reads the last time sample of the density /
+    velocity transfer sources (pm.cpp:170-185) and labels them d_g, d_b, d_cdm, d_ur, d_tot, phi, psi, t_g, t_b, t_ur, t_tot
+    (pm.cpp:240-330); against the reference's sources_ table of the same .ini, every k-mode, synchronous and Newtonian gauge"""
+    from classpp_public_amd.capi import TK_NAMES
+    for cfg in ("small_tk", "newt_tk"):
+        ref = np.load(os.path.join(GOLDEN, cfg + ".npz"))
+        c = classy.Class(_pars(cfg))
+        c.compute()
+        tk = c.get_transfer()
+        assert np.allclose(tk["k (h/Mpc)"] * c.h(), ref["pt.k"], rtol=1e-14)
+        titles = {"delta_g": "d_g", "delta_b": "d_b", "delta_cdm": "d_cdm", "delta_ur": "d_ur", "delta_tot": "d_tot", "phi": "phi", "psi": "psi",
+                  "theta_g": "t_g", "theta_b": "t_b", "theta_cdm": "t_cdm", "theta_ur": "t_ur", "theta_tot": "t_tot"}
+        seen = 0
+        for name in TK_NAMES:
+            idx = int(ref["pt.index_tp_" + name][0])
+            if idx < 0:
+                assert titles[name] not in tk
+                continue
+            want = ref["pt.sources"][idx, -1, :]
+            got = tk[titles[name]]
+            assert np.max(np.abs(got - want)) < 1e-4 * np.max(np.abs(want)), (cfg, name, np.max(np.abs(got - want)) / np.max(np.abs(want)))
+            seen += 1
+        assert seen == (11 if cfg == "small_tk" else 12)
+        with pytest.raises(classy.CosmoSevereError, match="z_max_pk"):
+            c.get_transfer(1.0)
+        c.struct_cleanup()
+    c0 = classy.Class(_pars("lcdm"))
+    c0.compute()
+    with pytest.raises(classy.CosmoSevereError, match="mTk"):
+        c0.get_transfer()
+    c0.struct_cleanup()
 
 
 @pytest.mark.gpu

@@ -163,5 +163,7 @@ def test_parameter_inputs_reproduce_the_fixture_inputs(cfg):
         x, y = getattr(a.config, field), getattr(b.config, field)
         if isinstance(x, float):
             assert abs(x - y) <= REF_INTEGRATION_ERROR * abs(y), field
+        elif hasattr(x, "__len__"):          # (ctypes arrays: cpt_config::index_tp_transfer)
+            assert list(x) == list(y), field
         else:
             assert x == y, field

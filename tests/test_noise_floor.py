@@ -43,6 +43,20 @@ def test_source_bands_are_backed_by_the_reference_noise():
             assert brms <= bands.MAX_BAND_OVER_NOISE * nrms, (name, "rms band", brms, "reference moves by", nrms)
 
 
+def test_transfer_source_bands_are_backed_by_the_reference_noise():
+    """density / velocity transfer sources (output = mTk, vTk): noise_lcdm_tk.npz"""
+    d = noise("lcdm_tk")
+    seen = 0
+    for name, (bmax, _) in bands.TRANSFER_SOURCE_BANDS.items():
+        i = type_index(d, name)
+        if i < 0:
+            continue         # (theta_cdm: Newtonian gauge only)
+        seen += 1
+        nmax = float(d["src_dev_max"][i].max())
+        assert bmax <= bands.MAX_BAND_OVER_NOISE * nmax, (name, "max band", bmax, "reference moves by", nmax)
+    assert seen == 11
+
+
 def test_transfer_band_is_backed_by_the_reference_noise():
     move = max(float(noise(cfg)["transfer_dev"].max()) for cfg in ("lcdm", "explanatory_mpk", "ncdm"))
     assert bands.TRANSFER_BAND <= bands.MAX_BAND_OVER_NOISE * move, (bands.TRANSFER_BAND, move)
