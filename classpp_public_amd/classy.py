@@ -906,8 +906,14 @@ class Class:
             lt = np.log(r.inp.tau[-n:])
             if np.log(tau_z) < lt[0]:
                 raise CosmoSevereError("Asking sources at a z bigger than z_max_pk, something probably went wrong")
+            # (array_spline_table_lines with _SPLINE_EST_DERIV_, tools/arrays.c:514-640: a clamped cubic spline whose end slopes are the
+            #  derivatives of the parabolas through the first / last three points)
             from scipy.interpolate import CubicSpline
-            at = CubicSpline(lt, S[:, -n:, :], axis=1, bc_type="natural")(np.log(tau_z))
+            y = S[:, -n:, :]
+            d0 = ((lt[2] - lt[0]) ** 2 * (y[:, 1] - y[:, 0]) - (lt[1] - lt[0]) ** 2 * (y[:, 2] - y[:, 0])) / ((lt[2] - lt[0]) * (lt[1] - lt[0]) * (lt[2] - lt[1]))
+            d1 = ((lt[-3] - lt[-1]) ** 2 * (y[:, -2] - y[:, -1]) - (lt[-2] - lt[-1]) ** 2 * (y[:, -3] - y[:, -1])) / \
+                 ((lt[-3] - lt[-1]) * (lt[-2] - lt[-1]) * (lt[-3] - lt[-2]))
+            at = CubicSpline(lt, y, axis=1, bc_type=((1, d0), (1, d1)))(np.log(tau_z))
         titles = {"delta_g": "d_g", "delta_b": "d_b", "delta_cdm": "d_cdm", "delta_ur": "d_ur", "delta_tot": "d_tot", "phi": "phi", "psi": "psi",
                   "theta_g": "t_g", "theta_b": "t_b", "theta_cdm": "t_cdm", "theta_ur": "t_ur", "theta_tot": "t_tot"}
         out = {"k (h/Mpc)": r.inp.k / self.h()}

@@ -20,7 +20,7 @@ GOLDEN = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))
 TABLES_OF = {
     "small": "tables_lcdm.npz", "lcdm": "tables_lcdm.npz", "explanatory": "tables_lcdm.npz", "explanatory_mpk": "tables_lcdm.npz",
     "iso_cdi": "tables_lcdm.npz", "iso_nid": "tables_lcdm.npz", "newt": "tables_lcdm.npz", "tens": "tables_lcdm.npz",
-    "tca_mb": "tables_lcdm.npz", "lcdm_zpk": "tables_lcdm.npz", "lcdm_tk": "tables_lcdm.npz", "small_tk": "tables_lcdm.npz", "newt_tk": "tables_lcdm.npz", "long_small": "tables_lcdm.npz", "long_full": "tables_lcdm.npz", "newt_full": "tables_lcdm.npz", "iso_bi_full": "tables_lcdm.npz", "iso_niv_full": "tables_lcdm.npz", "tens_full": "tables_lcdm.npz",
+    "tca_mb": "tables_lcdm.npz", "lcdm_zpk": "tables_lcdm.npz", "lcdm_tk": "tables_lcdm.npz", "lcdm_zpk_tk": "tables_lcdm.npz", "small_tk": "tables_lcdm.npz", "newt_tk": "tables_lcdm.npz", "long_small": "tables_lcdm.npz", "long_full": "tables_lcdm.npz", "newt_full": "tables_lcdm.npz", "iso_bi_full": "tables_lcdm.npz", "iso_niv_full": "tables_lcdm.npz", "tens_full": "tables_lcdm.npz",
     "curved": "tables_curved.npz", "curved_full": "tables_curved.npz", "tens_curved": "tables_curved.npz", "open": "tables_open.npz",
     "ncdm": "tables_ncdm1.npz", "ncdm_small": "tables_ncdm1.npz", "ncdm_k3000": "tables_ncdm1.npz",
     "ncdm_permille": "tables_ncdm1.npz", "ncdm_permille_small": "tables_ncdm1.npz",

@@ -97,7 +97,7 @@ def main():
             for k in tables:
                 assert np.array_equal(old[k], tables[k]), "tables differ between configs: " + k
         if cfg.startswith("iso_") or cfg in ("newt", "tens", "explanatory_mpk", "newt_full", "tens_full", "long_small", "long_full", "tca_mb", "lcdm_zpk",
-                                             "lcdm_tk", "small_tk", "newt_tk"):
+                                             "lcdm_tk", "small_tk", "newt_tk", "lcdm_zpk_tk"):
             # same cosmology as small/lcdm/explanatory: the tables must be the committed ones
             old = np.load(os.path.join(GOLD, "tables_lcdm.npz"))
             for k in tables:

@@ -348,6 +348,15 @@ static int do_dump(const char* ini, const char* outpath) {
       put_f8("nl.tau_of_z_pk", tauz.data(), {nz});
       put_f8("pt.ln_tau", pt->ln_tau_, {pt->ln_tau_size_});
       put_d("ppt.z_max_pk", ppt->z_max_pk);
+      if (ppt->has_density_transfers || ppt->has_velocity_transfers) {
+        // every source type at the redshifts of z_pk (perturb_sources_at_tau: what perturb_output_data / classy.get_transfer(z) read)
+        const int md0 = pt->index_md_scalars_, ntp0 = pt->tp_size_[md0], nk0 = pt->k_size_[md0];
+        std::vector<double> sz((size_t)nz * ntp0 * nk0);
+        for (int iz = 0; iz < nz; iz++)
+          for (int tp = 0; tp < ntp0; tp++)
+            if (pt->perturb_sources_at_tau(md0, 0, tp, tauz[iz], &sz[((size_t)iz * ntp0 + tp) * nk0]) != _SUCCESS_) { fprintf(stderr, "sources_at_tau failed\n"); return 1; }
+        put_f8("pt.sources_at_z_pk", sz.data(), {nz, ntp0, nk0});
+      }
     }
   }
   // ---- what the reference's Python wrapper reads "at z" (classy.pyx:825-1080: background_tau_of_z + background_at_tau with long_info,

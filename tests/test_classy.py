@@ -23,7 +23,7 @@ def _pars(cfg):
 
 @pytest.mark.parametrize("cfg,mode", [("lcdm", "s"), ("explanatory", "s"), ("curved", "s"), ("tens", "t"), ("tens_curved", "t"),
                                       ("small", "s"), ("newt", "s"), ("open", "s"), ("curved_full", "s"), ("ncdm", "s"), ("ncdm3", "s"),
-                                      ("ncdm3_tens", "t"), ("lcdm_zpk", "s"), ("small_tk", "s"), ("newt_tk", "s"), ("lcdm_tk", "s")])
+                                      ("ncdm3_tens", "t"), ("lcdm_zpk", "s"), ("small_tk", "s"), ("newt_tk", "s"), ("lcdm_tk", "s"), ("lcdm_zpk_tk", "s")])
 def test_parameter_entries_equal_the_reference_input_module(cfg, mode):
     if not os.path.exists(os.path.join(GOLDEN, cfg + ".ini")):
         pytest.skip("no such fixture")
@@ -329,6 +329,26 @@ def test_get_transfer_matches_the_reference_sources():
     with pytest.raises(classy.CosmoSevereError, match="mTk"):
         c0.get_transfer()
     c0.struct_cleanup()
+    # 0 < z <= z_max_pk: the sources splined in ln tau over the tail of the sampling (perturb_sources_at_tau, pm.cpp:79-132) against the
+    # reference's own interpolation at the z_pk of lcdm_zpk_tk.ini (fixture entry pt.sources_at_z_pk)
+    ref = np.load(os.path.join(GOLDEN, "lcdm_zpk_tk.npz"))
+    c = classy.Class(_pars("lcdm_zpk_tk"))
+    c.compute()
+    titles = {"delta_g": "d_g", "delta_b": "d_b", "delta_cdm": "d_cdm", "delta_ur": "d_ur", "delta_tot": "d_tot", "phi": "phi", "psi": "psi",
+              "theta_g": "t_g", "theta_b": "t_b", "theta_ur": "t_ur", "theta_tot": "t_tot"}
+    for iz, z in enumerate(ref["nl.z_pk"]):
+        tk = c.get_transfer(float(z))
+        for name, title in titles.items():
+            want = ref["pt.sources_at_z_pk"][iz, int(ref["pt.index_tp_" + name][0])]
+            # (one row of the table, every k, relative to the row's maximum: the integration error of the velocities at the LAST sample is
+            #  larger than the per-column figures of tests/bands.py - theta_b 1.8e-4 - the interpolation adds nothing to it)
+            tol = 5e-4 if name.startswith("theta") else 1e-4
+            assert np.max(np.abs(tk[title] - want)) < tol * np.max(np.abs(want)), (z, name, np.max(np.abs(tk[title] - want)) / np.max(np.abs(want)))
+        if z > 0.:   # the spline itself: exact where the redshift is a node's (none is), smooth in between - against the neighbouring samples
+            assert np.all(np.isfinite(tk["d_tot"]))
+    with pytest.raises(classy.CosmoSevereError, match="z_max_pk"):
+        c.get_transfer(3.5)
+    c.struct_cleanup()
 
 
 @pytest.mark.gpu
