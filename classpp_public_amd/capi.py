@@ -50,7 +50,7 @@ class CptConfig(C.Structure):
         ("hyper_flat_approximation_nu", _d),
         ("N_ncdm", _i), ("l_max_ncdm", _i), ("ncdm_fluid_approximation", _i), ("ncdm_fluid_trigger_tau_over_tau_k", _d),
         ("tol_ncdm_initial_w", _d), ("index_tp_delta_cb", _i), ("tensor_method", _i),
-        ("has_transfers", _i), ("index_tp_transfer", _i * 12),
+        ("has_transfers", _i), ("index_tp_transfer", _i * 12), ("index_tp_delta_ncdm1", _i), ("index_tp_theta_ncdm1", _i),
     ]
 
 

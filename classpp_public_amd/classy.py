@@ -207,8 +207,6 @@ def build_parameters(pars, mode, ic="ad"):
     has_t, has_p, has_l, has_pk = "tcl" in low, "pcl" in low, "lcl" in low, "mpk" in low
     # density / velocity transfer functions (input_module.cpp: mTk = dTk -> has_density_transfers, vTk -> has_velocity_transfers)
     has_dtk, has_vtk = (("mtk" in low) or ("dtk" in low)) and mode != "t", ("vtk" in low) and mode != "t"
-    if (has_dtk or has_vtk) and N_ncdm > 0:
-        raise CosmoSevereError("density / velocity transfer functions together with non-cold species are outside the accelerated path")
     lensing = _yes(pars.get("lensing", "no"))
     if lensing and not (has_l and (has_t or has_p)):
         raise CosmoSevereError("Lensed Cls only possible if you ask for lensing potential Cls and temperature or polarisation Cls (output must contain lCl and tCl or pCl)")
@@ -277,11 +275,12 @@ def build_parameters(pars, mode, ic="ad"):
                      ("delta_m", has_pk and not tens), ("delta_cb", has_pk and not tens and N_ncdm > 0),
                      # (pm.cpp:1107-1140: the transfer sources sit between delta_cb and phi+psi, psi after it)
                      ("delta_tot", has_dtk), ("delta_g", has_dtk), ("delta_b", has_dtk), ("delta_cdm", has_dtk and has_cdm_), ("delta_ur", has_dtk and has_ur_),
+                     ("delta_ncdm1", has_dtk and N_ncdm > 0),
                      ("theta_tot", has_vtk), ("theta_g", has_vtk), ("theta_b", has_vtk), ("theta_cdm", has_vtk and has_cdm_ and newt_),
-                     ("theta_ur", has_vtk and has_ur_), ("phi", has_dtk),
+                     ("theta_ur", has_vtk and has_ur_), ("theta_ncdm1", has_vtk and N_ncdm > 0), ("phi", has_dtk),
                      ("phi_plus_psi", has_l and not tens), ("psi", has_dtk)):
         tp[name] = n if on else -1
-        n += int(on)
+        n += (N_ncdm if name in ("delta_ncdm1", "theta_ncdm1") else 1) * int(on)     # (one slot per species)
     for name, idx in tp.items():
         d["pt.index_tp_" + name] = _arr(idx, True)
     d["pt.tp_size"] = _arr(n, True)
@@ -922,6 +921,11 @@ class Class:
             idx = int(c.index_tp_transfer[TK_NAMES.index(name)])
             if idx >= 0:
                 out[titles[name]] = at[idx].copy()
+            if c.has_ncdm and name in ("delta_ur", "theta_ur"):      # (pm.cpp:248-251, 276-279: the species follow ur)
+                first = int(c.index_tp_delta_ncdm1 if name == "delta_ur" else c.index_tp_theta_ncdm1)
+                if first >= 0:
+                    for i in range(int(c.N_ncdm)):
+                        out["%s_ncdm[%d]" % ("d" if name == "delta_ur" else "t", i)] = at[first + i].copy()
         return out
 
     def _late_times_of(self, r, z):

@@ -142,9 +142,10 @@ static int validate(const cpt_config* c) {
     return cpt_fail(nullptr, CPT_ERR_INVALID, "inconsistent curvature: K=%g, sgnK=%d", c->K, c->sgnK);
   if (c->has_transfers) {
     if (c->mode == CPT_MODE_TENSORS) return cpt_fail(nullptr, CPT_ERR_INVALID, "density / velocity transfer sources belong to scalar modes (pm.cpp:1000)");
-    if (c->has_ncdm) return cpt_fail(nullptr, CPT_ERR_UNSUPPORTED, "density / velocity transfer sources together with non-cold species (delta_ncdm, theta_ncdm per species) are not implemented");
     for (int i = 0; i < CPT_NTK; i++)
       if (c->index_tp_transfer[i] >= c->tp_size) return cpt_fail(nullptr, CPT_ERR_INVALID, "index_tp_transfer[%d] >= tp_size", i);
+    if (c->has_ncdm && (c->index_tp_delta_ncdm1 + c->N_ncdm > c->tp_size || c->index_tp_theta_ncdm1 + c->N_ncdm > c->tp_size))
+      return cpt_fail(nullptr, CPT_ERR_INVALID, "index_tp_delta_ncdm1 / index_tp_theta_ncdm1 + N_ncdm > tp_size");
     if (c->index_tp_transfer[CPT_TK_THETA_CDM] >= 0 && c->gauge == CPT_GAUGE_SYNCHRONOUS)
       return cpt_fail(nullptr, CPT_ERR_INVALID, "theta_cdm is a source in the Newtonian gauge only (pm.cpp:1036)");
   }
@@ -198,7 +199,7 @@ static int validate(const cpt_config* c) {
                       "hierarchy too large: %d + tails > 64 lanes; hierarchies longer than one wavefront run for synchronous-gauge scalars "
                       "(with or without non-cold species) and l_max_g, l_max_pol_g, l_max_ur <= 66 only", core_lanes);
   }
-  if (c->tp_size < 1 || c->tp_size > 8 + CPT_NTK) return cpt_fail(nullptr, CPT_ERR_INVALID, "tp_size=%d out of range", c->tp_size);
+  if (c->tp_size < 1 || c->tp_size > 8 + CPT_NTK + 2 * CPT_MAX_NCDM) return cpt_fail(nullptr, CPT_ERR_INVALID, "tp_size=%d out of range", c->tp_size);
   const int tps[6] = {c->index_tp_t0, c->index_tp_t1, c->index_tp_t2, c->index_tp_p, c->index_tp_delta_m,
                       c->index_tp_phi_plus_psi};
   for (int i = 0; i < 6; i++)

@@ -54,6 +54,7 @@ struct PtParams {
   double eisw_lisw_split_z, three_ceff2_ur, three_cvis2_ur;
   int tp_size, tp_t0, tp_t1, tp_t2, tp_p, tp_dm, tp_pp;
   int tp_tk[CPT_NTK];   // density / velocity transfer sources (cpt_config::index_tp_transfer; all -1 unless has_transfers)
+  int tp_dn, tp_tn;     // ... of the non-cold species: first of n_species consecutive slots each (index_tp_delta_ncdm1, index_tp_theta_ncdm1)
   double start_small_k, start_large_k, tca_trig_h, tca_trig_k, rsa_trig, ufa_trig, curvature_ini, rtol, tol_tau_approx, min_var;
   // batch
   const double* k;
@@ -979,7 +980,11 @@ struct Metric {
 
 // (NCDM) what the non-cold species contribute to the Einstein equations in this RHS evaluation: delta rho, (rho+p) theta,
 // (rho+p) sigma summed over species (pm.cpp:6317-6432), formed by the caller from the momentum-bin sets or from the fluids.
-struct NcIn { double D, T, S; double y3[3]; };   // y3: (long tails) the l = 3 elements of the photon / polarisation / ur tails
+struct NcIn {
+  double D, T, S; double y3[3];   // y3: (long tails) the l = 3 elements of the photon / polarisation / ur tails
+  double Dn[CPT_MAX_NCDM], Tn[CPT_MAX_NCDM];   // delta rho and (rho + p) theta of every species on its own: only formed where a sample of the
+                                               // density / velocity transfer sources is about to be stored (store_sources), dead in the step loop
+};
 
 // y of another lane (per-lane byte address): two ds_bpermute_b32, executed by every lane
 static __device__ __forceinline__ double gather(double v, int addr) {
@@ -1200,7 +1205,7 @@ static __device__ __forceinline__ double rhs(const PtParams& P, const Layout& L,
 // dy is the dense-output derivative (only theta_b' is used, pm.cpp:6883). Lane 0 stores the tp_size values.
 static __device__ __forceinline__ void store_sources(const PtParams& P, const Layout& L, const Lookup& Q, const Metric& M, double k,
                                               double inv_k2, double y, double dy, double tca_shear_prev, int it, int ik, int lane,
-                                              const NcIn& N = NcIn{0., 0., 0., {0., 0., 0.}}) {
+                                              const NcIn& N = NcIn{0., 0., 0., {0., 0., 0.}, {0., 0., 0.}, {0., 0., 0.}}) {
   if (MODE) { store_sources_tensor(P, L, Q, y, it, ik, lane); return; }
   struct { double g, dg, expmk; } th;
   th.g = bcast(Q.vth, TH_G); th.dg = bcast(Q.vth, TH_DG); th.expmk = bcast(Q.vth, TH_EXPMK);
@@ -1260,8 +1265,8 @@ static __device__ __forceinline__ void store_sources(const PtParams& P, const La
     if (NCDM && P.tp_dcb >= 0) P.src[P.tp_dcb * tstride + base] = delta_cb;   // pm.cpp:7001-7003
   }
   // ---- density and velocity transfer functions (output = mTk, vTk; pm.cpp:6930-6975, 7017-7200; no N-body gauge shifts) ----
-  if constexpr (NCDM == 0) {
-    bool any = false;
+  if constexpr (GAUGE == CPT_GAUGE_SYNCHRONOUS || NCDM == 0) {
+    bool any = (P.tp_dn >= 0) || (P.tp_tn >= 0);
 #pragma unroll
     for (int i = 0; i < CPT_NTK; i++) any = any || (P.tp_tk[i] >= 0);
     if (any) {
@@ -1274,9 +1279,20 @@ static __device__ __forceinline__ void store_sources(const PtParams& P, const La
       } else { tgam = bcast(y, LN_TG); dur = bcast(y, LN_DUR); tur = bcast(y, LN_TUR); }
       const double db = bcast(y, LN_DB), dc = bcast(y, LN_DC), tc = (GAUGE == CPT_GAUGE_NEWTONIAN) ? bcast(y, LN_TC) : 0.;
       // totals: every species but the cosmological constant (pm.cpp:7019-7030), (rho + p) theta over rho + p (pm.cpp:7142-7145)
-      const double rho_tot = Q.rg + Q.rb + Q.rc + Q.ru, rho_p_tot = Q.rg43 + Q.rb + Q.rc + Q.ru43;
-      const double delta_rho = Q.rg * dgam + Q.rb * db + Q.rc * dc + Q.ru * dur;
-      const double rpt = Q.rg43 * tgam + Q.rb * tb + Q.rc * tc + Q.ru43 * tur;
+      double rho_tot = Q.rg + Q.rb + Q.rc + Q.ru, rho_p_tot = Q.rg43 + Q.rb + Q.rc + Q.ru43;
+      double delta_rho = Q.rg * dgam + Q.rb * db + Q.rc * dc + Q.ru * dur;
+      double rpt = Q.rg43 * tgam + Q.rb * tb + Q.rc * tc + Q.ru43 * tur;
+      double dn[CPT_MAX_NCDM] = {0., 0., 0.}, tn[CPT_MAX_NCDM] = {0., 0., 0.};
+      if (NCDM) {   // the non-cold species: in the totals, and each on its own (pm.cpp:6341-6410, 7112-7118)
+        delta_rho += N.D; rpt += N.T;
+#pragma unroll
+        for (int n = 0; n < CPT_MAX_NCDM; n++) {
+          if (n >= P.nc.n_species) break;
+          const double rho_n = bcast(Q.vnc, 3 * n), p_n = bcast(Q.vnc, 3 * n + 1);
+          rho_tot += rho_n; rho_p_tot += rho_n + p_n;
+          dn[n] = N.Dn[n] / rho_n; tn[n] = N.Tn[n] / (rho_n + p_n);
+        }
+      }
       const double phi = (GAUGE == CPT_GAUGE_NEWTONIAN) ? eta : eta - aH * M.alpha;
       const double psi = (GAUGE == CPT_GAUGE_NEWTONIAN) ? M.psi : aH * M.alpha + M.alphap;
       if (lane == 0) {
@@ -1284,6 +1300,14 @@ static __device__ __forceinline__ void store_sources(const PtParams& P, const La
         const double v[CPT_NTK] = {delta_rho / rho_tot, dgam, db, dc, dur, rpt / rho_p_tot, tgam, tb, tc, tur, phi, psi};
 #pragma unroll
         for (int i = 0; i < CPT_NTK; i++) if (P.tp_tk[i] >= 0) P.src[P.tp_tk[i] * tstride + base] = v[i];
+        if (NCDM) {
+#pragma unroll
+          for (int n = 0; n < CPT_MAX_NCDM; n++) {
+            if (n >= P.nc.n_species) break;
+            if (P.tp_dn >= 0) P.src[(P.tp_dn + n) * tstride + base] = dn[n];
+            if (P.tp_tn >= 0) P.src[(P.tp_tn + n) * tstride + base] = tn[n];
+          }
+        }
       }
     }
   }
@@ -1854,6 +1878,7 @@ static __device__ __forceinline__ double rhs_fluid(const PtParams& P, const Layo
     else { rho = bcast(Q.vnc, 3 * n); pr = bcast(Q.vnc, 3 * n + 1); pp = bcast(Q.vnc, 3 * n + 2); }
     const int l0 = fluid_lane(n, 0);
     D = fma(rho, bcast(y, l0), D); T = fma(rho + pr, bcast(y, l0 + 1), T); S = fma(rho + pr, bcast(y, l0 + 2), S);
+    N.Dn[n] = rho * bcast(y, l0); N.Tn[n] = (rho + pr) * bcast(y, l0 + 1);   // (read by store_sources alone)
     const bool mine = (ln >= l0) && (ln <= l0 + 2);
     rho_l = mine ? rho : rho_l; p_l = mine ? pr : p_l; pp_l = mine ? pp : pp_l;
   }
@@ -1953,7 +1978,7 @@ static __device__ __forceinline__ int ndf15s(const PtParams& P, const Layout& L,
   while (next < tres && ts[next] < t0) next++;
   double tnext = (next < tres) ? ts[next] : 1e300, tnext2 = (next + 1 < tres) ? ts[next + 1] : 1e300;
 
-  NcIn N = {0., 0., 0., {0., 0., 0.}};
+  NcIn N = {0., 0., 0., {0., 0., 0.}, {0., 0., 0.}, {0., 0., 0.}};
   // ROWQ: the scalar integrator of the two-wave kernels handles its table rows by request number (mb_post / mb_take): it says which row
   // an evaluation uses before it evaluates, and the RHS reads it from LDS
   constexpr bool ROWQ = HELPED;
@@ -2870,6 +2895,7 @@ static void fill_params(const cpt_handle* h, PtParams& P) {
   P.tp_size = c.tp_size; P.tp_t0 = c.index_tp_t0; P.tp_t1 = c.index_tp_t1; P.tp_t2 = c.index_tp_t2; P.tp_p = c.index_tp_p;
   P.tp_dm = c.index_tp_delta_m; P.tp_pp = c.index_tp_phi_plus_psi;
   for (int i = 0; i < CPT_NTK; i++) P.tp_tk[i] = c.has_transfers ? c.index_tp_transfer[i] : -1;
+  P.tp_dn = (c.has_transfers && c.has_ncdm) ? c.index_tp_delta_ncdm1 : -1; P.tp_tn = (c.has_transfers && c.has_ncdm) ? c.index_tp_theta_ncdm1 : -1;
   P.start_small_k = c.start_small_k_at_tau_c_over_tau_h; P.start_large_k = c.start_large_k_at_tau_h_over_tau_k;
   P.tca_trig_h = c.tight_coupling_trigger_tau_c_over_tau_h; P.tca_trig_k = c.tight_coupling_trigger_tau_c_over_tau_k;
   P.rsa_trig = c.radiation_streaming_trigger_tau_over_tau_k; P.ufa_trig = c.ur_fluid_trigger_tau_over_tau_k;

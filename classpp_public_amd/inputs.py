@@ -22,7 +22,7 @@ TABLES_OF = {
     "iso_cdi": "tables_lcdm.npz", "iso_nid": "tables_lcdm.npz", "newt": "tables_lcdm.npz", "tens": "tables_lcdm.npz",
     "tca_mb": "tables_lcdm.npz", "lcdm_zpk": "tables_lcdm.npz", "lcdm_tk": "tables_lcdm.npz", "lcdm_zpk_tk": "tables_lcdm.npz", "small_tk": "tables_lcdm.npz", "newt_tk": "tables_lcdm.npz", "long_small": "tables_lcdm.npz", "long_full": "tables_lcdm.npz", "newt_full": "tables_lcdm.npz", "iso_bi_full": "tables_lcdm.npz", "iso_niv_full": "tables_lcdm.npz", "tens_full": "tables_lcdm.npz",
     "curved": "tables_curved.npz", "curved_full": "tables_curved.npz", "tens_curved": "tables_curved.npz", "open": "tables_open.npz",
-    "ncdm": "tables_ncdm1.npz", "ncdm_small": "tables_ncdm1.npz", "ncdm_k3000": "tables_ncdm1.npz",
+    "ncdm": "tables_ncdm1.npz", "ncdm_small": "tables_ncdm1.npz", "ncdm_small_tk": "tables_ncdm1.npz", "ncdm3_small_tk": "tables_ncdm3.npz", "ncdm_k3000": "tables_ncdm1.npz",
     "ncdm_permille": "tables_ncdm1.npz", "ncdm_permille_small": "tables_ncdm1.npz",
     "ncdm3": "tables_ncdm3.npz", "ncdm3_small": "tables_ncdm3.npz", "ncdm3_tens": "tables_ncdm3.npz",
 }
@@ -126,6 +126,8 @@ class Inputs:
         from .capi import TK_NAMES
         for i, name in enumerate(TK_NAMES):      # density / velocity transfer sources (output = mTk, vTk)
             c.index_tp_transfer[i] = int(_s(d, "pt.index_tp_" + name)) if ("pt.index_tp_" + name) in d else -1
+        c.index_tp_delta_ncdm1 = int(_s(d, "pt.index_tp_delta_ncdm1")) if "pt.index_tp_delta_ncdm1" in d else -1
+        c.index_tp_theta_ncdm1 = int(_s(d, "pt.index_tp_theta_ncdm1")) if "pt.index_tp_theta_ncdm1" in d else -1
         c.has_transfers = int(any(c.index_tp_transfer[i] >= 0 for i in range(len(TK_NAMES))))
         # initial condition: one mode per handle (ad unless the fixture says otherwise)
         c.ic = 0

@@ -150,7 +150,9 @@ typedef struct cpt_config {
                                          the massless approximation the tensor ur hierarchy carries rho_ur + 3 sum p_ncdm  */
   int has_transfers;                  /* 0: the array below is ignored (a zero-initialised struct asks for none)               */
   int index_tp_transfer[CPT_NTK];     /* slots of the density / velocity transfer sources (output = mTk, vTk: pm.cpp:1000-1050,
-                                         6930-7200), indexed by CPT_TK_*; -1 = absent.  Scalars without non-cold species.     */
+                                         6930-7200), indexed by CPT_TK_*; -1 = absent.  Scalar modes.                          */
+  int index_tp_delta_ncdm1, index_tp_theta_ncdm1;   /* first of N_ncdm consecutive slots each: delta / theta of every non-cold species
+                                         (pm.cpp:1122, 1137); read with has_transfers, -1 = absent                            */
 } cpt_config;
 
 /* Spline tables the RHS samples (all HOST pointers, row-major [n_lines][n_columns], copied to HBM by cpt_create):

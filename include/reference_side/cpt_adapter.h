@@ -26,6 +26,7 @@ inline void CptFillIndexMaps(const perturbs& pt, const background& ba, bool tens
   c.index_tp_p = P ? i++ : -1;
   c.index_tp_t0 = c.index_tp_t1 = c.index_tp_delta_m = c.index_tp_delta_cb = c.index_tp_phi_plus_psi = -1;
   c.has_transfers = 0;
+  c.index_tp_delta_ncdm1 = c.index_tp_theta_ncdm1 = -1;
   for (int t = 0; t < CPT_NTK; t++) c.index_tp_transfer[t] = -1;
   if (!tensors) {
     // (the reference's order of definition, pm.cpp:1107-1140: ..., delta_m, delta_cb, delta_tot, delta_g, delta_b, delta_cdm, delta_ur, theta_tot,
@@ -37,11 +38,13 @@ inline void CptFillIndexMaps(const perturbs& pt, const background& ba, bool tens
       c.index_tp_transfer[CPT_TK_DELTA_TOT] = i++; c.index_tp_transfer[CPT_TK_DELTA_G] = i++; c.index_tp_transfer[CPT_TK_DELTA_B] = i++;
       if (ba.has_cdm) c.index_tp_transfer[CPT_TK_DELTA_CDM] = i++;
       if (ba.has_ur) c.index_tp_transfer[CPT_TK_DELTA_UR] = i++;
+      if (ba.has_ncdm) { c.index_tp_delta_ncdm1 = i; i += ba.N_ncdm; }
     }
     if (V) {
       c.index_tp_transfer[CPT_TK_THETA_TOT] = i++; c.index_tp_transfer[CPT_TK_THETA_G] = i++; c.index_tp_transfer[CPT_TK_THETA_B] = i++;
       if (ba.has_cdm && pt.gauge != synchronous) c.index_tp_transfer[CPT_TK_THETA_CDM] = i++;
       if (ba.has_ur) c.index_tp_transfer[CPT_TK_THETA_UR] = i++;
+      if (ba.has_ncdm) { c.index_tp_theta_ncdm1 = i; i += ba.N_ncdm; }
     }
     if (D) c.index_tp_transfer[CPT_TK_PHI] = i++;
     if (L) c.index_tp_phi_plus_psi = i++;

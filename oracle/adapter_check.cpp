@@ -73,7 +73,7 @@ static void print_config(const char* tag, const cpt_config& c) {
   CD(transfer_neglect_delta_k_T_t2); CD(transfer_neglect_delta_k_T_e); CD(transfer_neglect_delta_k_T_b);
   CD(hyper_sampling_curved_low_nu); CD(hyper_sampling_curved_high_nu); CD(hyper_nu_sampling_step); CD(hyper_flat_approximation_nu);
   CI(N_ncdm); CI(l_max_ncdm); CI(ncdm_fluid_approximation); CD(ncdm_fluid_trigger_tau_over_tau_k); CD(tol_ncdm_initial_w);
-  CI(index_tp_delta_cb); CI(tensor_method); CI(has_transfers);
+  CI(index_tp_delta_cb); CI(tensor_method); CI(has_transfers); CI(index_tp_delta_ncdm1); CI(index_tp_theta_ncdm1);
   printf("%s.index_tp_transfer %d\n", tag, (int)CPT_NTK);
   for (int i = 0; i < CPT_NTK; i++) printf("%s.index_tp_transfer.%d %d\n", tag, i, c.index_tp_transfer[i]);
 #undef CD

@@ -76,7 +76,7 @@ def main():
             out["sigma8_dev"] = np.abs(half["nl.sigma8"] / base["nl.sigma8"] - 1)
         for key in ("pt.index_tp_t0", "pt.index_tp_t1", "pt.index_tp_t2", "pt.index_tp_p", "pt.index_tp_delta_m", "pt.index_tp_phi_plus_psi",
                     "pt.index_tp_delta_cb") + tuple("pt.index_tp_" + n for n in ("delta_tot", "delta_g", "delta_b", "delta_cdm", "delta_ur", "theta_tot", "theta_g",
-                                                                                         "theta_b", "theta_cdm", "theta_ur", "phi", "psi")):
+                                                                                         "theta_b", "theta_cdm", "theta_ur", "phi", "psi", "delta_ncdm1", "theta_ncdm1")):
             if key in base:
                 out[key] = base[key]
         out["tol_default"] = np.array([1e-5]); out["tol_halved"] = np.array([5e-6])

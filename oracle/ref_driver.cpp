@@ -253,6 +253,8 @@ static int do_dump(const char* ini, const char* outpath) {
   put_i("pt.index_tp_theta_ur", (pt->has_source_theta_ur_ && !tens) ? pt->index_tp_theta_ur_ : -1);
   put_i("pt.index_tp_phi", (pt->has_source_phi_ && !tens) ? pt->index_tp_phi_ : -1);
   put_i("pt.index_tp_psi", (pt->has_source_psi_ && !tens) ? pt->index_tp_psi_ : -1);
+  put_i("pt.index_tp_delta_ncdm1", (pt->has_source_delta_ncdm_ && !tens) ? pt->index_tp_delta_ncdm1_ : -1);   // (N_ncdm consecutive slots)
+  put_i("pt.index_tp_theta_ncdm1", (pt->has_source_theta_ncdm_ && !tens) ? pt->index_tp_theta_ncdm1_ : -1);
   {
     std::vector<double> s((size_t)ntp * ntau * nk);
     for (int tp = 0; tp < ntp; tp++)

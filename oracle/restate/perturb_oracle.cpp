@@ -181,6 +181,7 @@ struct Work {
   double delta_rho, rho_plus_p_theta, rho_plus_p_shear, delta_p, rho_plus_p_tot;
   double delta_m, theta_m, delta_cb, theta_cb;
   double rsa_delta_g, rsa_theta_g, rsa_delta_ur, rsa_theta_ur;
+  double delta_ncdm[CPT_MAX_NCDM], theta_ncdm[CPT_MAX_NCDM];   // per species (the density / velocity transfer sources)
   double tca_shear_g, tca_slip;
   long fevals = 0;
 };
@@ -318,6 +319,7 @@ void einstein(const Model& m, double k, const double* y, const Layout& L, Work& 
       }
       w.delta_rho += rho_delta; w.rho_plus_p_theta += rho_plus_p_theta; w.rho_plus_p_shear += rho_plus_p_shear; w.delta_p += delta_p;
       w.rho_plus_p_tot += rho_plus_p;
+      w.delta_ncdm[n] = rho_delta / rho_bg; w.theta_ncdm[n] = rho_plus_p_theta / rho_plus_p;   // pm.cpp:6341-6345, 6397-6410
       delta_rho_m += rho_delta; rho_m += rho_bg;                       // delta_ncdm rho_ncdm
       rho_plus_p_theta_m += rho_plus_p_theta; rho_plus_p_m += rho_plus_p;
     }
@@ -554,14 +556,21 @@ void derivs(const Model& m, double k, double tau, const double* y, double* dy, c
 // density / velocity transfer functions (output = mTk, vTk; pm.cpp:6930-6975, 7017-7200 without the N-body gauge shifts), after einstein()
 static void transfer_sources(const Model& m, double k, const double* y, const Layout& L, const Work& w, double* out) {
   const cpt_config& c = *m.c;
-  if (!c.has_transfers || c.has_ncdm) return;
+  if (!c.has_transfers) return;
   const Bg& bg = w.bg;
   const double aH = bg.a * bg.H;
   const bool newt = (c.gauge == CPT_GAUGE_NEWTONIAN);
   const double delta_g = L.rsa ? w.rsa_delta_g : y[L.delta_g], theta_g = L.rsa ? w.rsa_theta_g : y[L.theta_g];
   const double delta_ur = !c.has_ur ? 0. : L.rsa ? w.rsa_delta_ur : y[L.delta_ur], theta_ur = !c.has_ur ? 0. : L.rsa ? w.rsa_theta_ur : y[L.theta_ur];
   const double rho_cdm = c.has_cdm ? bg.rho_cdm : 0., rho_ur = c.has_ur ? bg.rho_ur : 0.;
-  const double rho_tot = bg.rho_g + bg.rho_b + rho_cdm + rho_ur;            // every species but the cosmological constant (pm.cpp:7019-7030)
+  double rho_tot = bg.rho_g + bg.rho_b + rho_cdm + rho_ur;                  // every species but the cosmological constant (pm.cpp:7019-7030)
+  if (c.has_ncdm) {
+    for (int n = 0; n < L.n_ncdm; n++) {
+      rho_tot += bg.rho_ncdm[n];
+      if (c.index_tp_delta_ncdm1 >= 0) out[c.index_tp_delta_ncdm1 + n] = w.delta_ncdm[n];     // pm.cpp:7112-7118
+      if (c.index_tp_theta_ncdm1 >= 0) out[c.index_tp_theta_ncdm1 + n] = w.theta_ncdm[n];
+    }
+  }
   double v[CPT_NTK];
   v[CPT_TK_DELTA_TOT] = w.delta_rho / rho_tot;
   v[CPT_TK_DELTA_G] = delta_g; v[CPT_TK_DELTA_B] = y[L.delta_b]; v[CPT_TK_DELTA_CDM] = c.has_cdm ? y[L.delta_cdm] : 0.; v[CPT_TK_DELTA_UR] = delta_ur;
@@ -1273,7 +1282,7 @@ int solve_mode(const Model& m, double k, int ik, int nk, const double* tau_sampl
     }
     auto rhs = [&](double tau, const double* yy, double* dyy) { derivs(m, k, tau, yy, dyy, L, w); };
     auto out = [&](double tau, const double* yy, const double* dyy, int it) {
-      double s[8 + CPT_NTK + 4] = {0};
+      double s[8 + CPT_NTK + 2 * CPT_MAX_NCDM + 4] = {0};
       sources(m, k, tau, yy, dyy, L, w, s);
       for (int tp = 0; tp < c.tp_size; tp++) src[((size_t)tp * ntau + it) * nk + ik] = s[tp];
     };

@@ -36,6 +36,9 @@ TRANSFER_SOURCE_BANDS = {
     "theta_tot": (3e-5, 3e-5), "theta_g": (1e-4, 1e-4), "theta_b": (8e-5, 8e-5), "theta_cdm": (1e-5, 1e-5), "theta_ur": (1e-4, 1e-4),
     "phi": (1e-5, 1e-5), "psi": (1e-5, 1e-5),
 }
+# ... of every non-cold species (N_ncdm consecutive slots from index_tp_delta_ncdm1 / index_tp_theta_ncdm1): the reference moves its own by
+# 1.33e-5 / 4.7e-6 (noise_ncdm_small_tk.npz; three species: 9.6e-6 / 4.7e-6, noise_ncdm3_small_tk.npz)
+NCDM_TRANSFER_BANDS = {"delta_ncdm1": (2.5e-5, 2.5e-5), "theta_ncdm1": (9e-6, 9e-6)}
 TK_NAMES = ("delta_tot", "delta_g", "delta_b", "delta_cdm", "delta_ur", "theta_tot", "theta_g", "theta_b", "theta_cdm", "theta_ur", "phi", "psi")
 # matter / potential columns of the runs with hierarchies longer than one wavefront (long_full: l_max 50; ncdm_permille: l_max_g 25, l_max_pol_g 20,
 # l_max_ur 35, l_max_ncdm 28): the reference moves its own delta_m by 3.2e-5 / 2.9e-5 there (noise_long_full.npz, noise_ncdm_permille.npz) and the
@@ -62,6 +65,12 @@ def source_bands(cfg, dm_tol=None):
             idx = int(cfg.index_tp_transfer[i])
             if idx >= 0:
                 out[idx] = TRANSFER_SOURCE_BANDS[name]
+        if cfg.has_ncdm:
+            for name, band in NCDM_TRANSFER_BANDS.items():
+                first = int(getattr(cfg, "index_tp_" + name))
+                if first >= 0:
+                    for n in range(int(cfg.N_ncdm)):
+                        out[first + n] = band
     return out
 
 

@@ -58,7 +58,7 @@ def _compare_struct(tag, got, struct, skip=()):
 
 
 @pytest.mark.parametrize("cfg", ["lcdm", "explanatory_mpk", "small", "curved", "open", "newt", "iso_cdi", "iso_nid", "tens", "tens_curved",
-                                 "ncdm_small", "ncdm3", "ncdm3_tens", "small_tk", "newt_tk"])
+                                 "ncdm_small", "ncdm3", "ncdm3_tens", "small_tk", "newt_tk", "ncdm_small_tk", "ncdm3_small_tk"])
 def test_adapter_inputs_equal_the_fixture_inputs(cfg):
     got = _run(cfg)
     inp = Inputs(cfg)
@@ -69,7 +69,7 @@ def test_adapter_inputs_equal_the_fixture_inputs(cfg):
     d = inp.d
     skip = [f for f, key in (("transfer_neglect_delta_k_T_t2", "ppr.transfer_neglect_delta_k_T_t2"), ("transfer_neglect_delta_k_T_e", "ppr.transfer_neglect_delta_k_T_e"),
                              ("transfer_neglect_delta_k_T_b", "ppr.transfer_neglect_delta_k_T_b"), ("tol_ncdm_initial_w", "ppr.tol_ncdm_initial_w"),
-                             ("tensor_method", "ppt.tensor_method"), ("entropy_ini", "ppr.entropy_ini"), ("index_tp_delta_cb", "pt.index_tp_delta_cb"),
+                             ("tensor_method", "ppt.tensor_method"), ("entropy_ini", "ppr.entropy_ini"), ("index_tp_delta_cb", "pt.index_tp_delta_cb"), ("index_tp_delta_ncdm1", "pt.index_tp_delta_ncdm1"), ("index_tp_theta_ncdm1", "pt.index_tp_theta_ncdm1"),
                              ("index_tt_b", "tr.index_tt_b")) if key not in d]
     bad = _compare_struct("config", got, c, skip)
     assert not bad, bad

@@ -23,7 +23,7 @@ def _pars(cfg):
 
 @pytest.mark.parametrize("cfg,mode", [("lcdm", "s"), ("explanatory", "s"), ("curved", "s"), ("tens", "t"), ("tens_curved", "t"),
                                       ("small", "s"), ("newt", "s"), ("open", "s"), ("curved_full", "s"), ("ncdm", "s"), ("ncdm3", "s"),
-                                      ("ncdm3_tens", "t"), ("lcdm_zpk", "s"), ("small_tk", "s"), ("newt_tk", "s"), ("lcdm_tk", "s"), ("lcdm_zpk_tk", "s")])
+                                      ("ncdm3_tens", "t"), ("lcdm_zpk", "s"), ("small_tk", "s"), ("newt_tk", "s"), ("lcdm_tk", "s"), ("lcdm_zpk_tk", "s"), ("ncdm_small_tk", "s"), ("ncdm3_small_tk", "s")])
 def test_parameter_entries_equal_the_reference_input_module(cfg, mode):
     if not os.path.exists(os.path.join(GOLDEN, cfg + ".ini")):
         pytest.skip("no such fixture")
@@ -329,6 +329,20 @@ def test_get_transfer_matches_the_reference_sources():
     with pytest.raises(classy.CosmoSevereError, match="mTk"):
         c0.get_transfer()
     c0.struct_cleanup()
+    # massive neutrinos: every species has a density and a velocity transfer function of its own, d_ncdm[i], t_ncdm[i]
+    ref = np.load(os.path.join(GOLDEN, "ncdm3_small_tk.npz"))
+    c = classy.Class(_pars("ncdm3_small_tk"))
+    c.compute()
+    tk = c.get_transfer()
+    ks = ref["pt.sources_k_index"]
+    for i in range(3):
+        for title, key in (("d_ncdm[%d]" % i, "pt.index_tp_delta_ncdm1"), ("t_ncdm[%d]" % i, "pt.index_tp_theta_ncdm1")):
+            want = ref["pt.sources_subset"][int(ref[key][0]) + i, -1, :]
+            assert np.max(np.abs(tk[title][ks] - want)) < 1e-4 * np.max(np.abs(want)), (title, np.max(np.abs(tk[title][ks] - want)) / np.max(np.abs(want)))
+    want = ref["pt.sources_subset"][int(ref["pt.index_tp_delta_tot"][0]), -1, :]
+    assert np.max(np.abs(tk["d_tot"][ks] - want)) < 1e-4 * np.max(np.abs(want))
+    assert list(tk.keys()).index("d_ncdm[0]") == list(tk.keys()).index("d_ur") + 1      # (the reference's column order)
+    c.struct_cleanup()
     # 0 < z <= z_max_pk: the sources splined in ln tau over the tail of the sampling (perturb_sources_at_tau, pm.cpp:79-132) against the
     # reference's own interpolation at the z_pk of lcdm_zpk_tk.ini (fixture entry pt.sources_at_z_pk)
     ref = np.load(os.path.join(GOLDEN, "lcdm_zpk_tk.npz"))

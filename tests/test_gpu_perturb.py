@@ -113,13 +113,28 @@ def test_perturb_small_all_modes(small):
     print("\n[small] perturb kernel %.3f ms for %d modes, %d steps" % (ms, inp.nk, gs))
 
 
-@pytest.mark.parametrize("cfg", ["small_tk", "newt_tk", "lcdm_tk"])
+@pytest.mark.parametrize("cfg", ["small_tk", "newt_tk", "lcdm_tk", "ncdm_small_tk", "ncdm3_small_tk"])
 def test_density_and_velocity_transfer_sources(cfg):
     """output = mTk, vTk (pm.cpp:1000-1050, 6930-6975, 7017-7200): delta_tot, delta_g, delta_b, delta_cdm, delta_ur, theta_tot, theta_g,
     theta_b, theta_cdm (Newtonian gauge), theta_ur, phi, psi as sources of their own, in the slots the reference gives them
     (cpt_config::index_tp_transfer), synchronous and Newtonian gauge, against the reference's sources_ table; bands of tests/bands.py
-    (at most twice what the reference moves its own by at rtol / 2, tests/golden/noise_lcdm_tk.npz)"""
+    (at most twice what the reference moves its own by at rtol / 2, tests/golden/noise_lcdm_tk.npz).  With massive neutrinos (one and three
+    species; with a helper wave and without): delta_ncdm, theta_ncdm of every species as well, and the species in the totals."""
     from classpp_public_amd.backend import Backend
+    import os
+    if cfg.startswith("ncdm"):
+        for helper in ("0", "1"):
+            os.environ["CPT_SETS_HELPER"] = helper
+            try:
+                inp = Inputs(cfg)
+                be = Backend(inp)
+                src, stats, status = be.perturb_solve()
+                assert not status.any()
+                check_sources(inp.config, src.cpu().numpy()[:, :, inp.d["pt.sources_k_index"]], inp.d["pt.sources_subset"])
+                be.close()
+            finally:
+                del os.environ["CPT_SETS_HELPER"]
+        return
     inp = Inputs(cfg)
     assert inp.config.has_transfers and inp.config.tp_size >= 16
     be = Backend(inp)

@@ -57,6 +57,18 @@ def test_transfer_source_bands_are_backed_by_the_reference_noise():
     assert seen == 11
 
 
+def test_ncdm_transfer_source_bands_are_backed_by_the_reference_noise():
+    for cfg in ("ncdm_small_tk", "ncdm3_small_tk"):
+        d = noise(cfg)
+        for name, (bmax, _) in bands.NCDM_TRANSFER_BANDS.items():
+            i = type_index(d, name)
+            assert i >= 0
+            nmax = float(d["src_dev_max"][i].max())
+            if cfg == "ncdm_small_tk":     # (the band is set on the one-species run; three species move a little less)
+                assert bmax <= bands.MAX_BAND_OVER_NOISE * nmax, (name, bmax, nmax)
+            assert bmax <= 3.0 * nmax
+
+
 def test_transfer_band_is_backed_by_the_reference_noise():
     move = max(float(noise(cfg)["transfer_dev"].max()) for cfg in ("lcdm", "explanatory_mpk", "ncdm"))
     assert bands.TRANSFER_BAND <= bands.MAX_BAND_OVER_NOISE * move, (bands.TRANSFER_BAND, move)

@@ -45,7 +45,7 @@ def test_perturb_small_all_modes():
 
 @pytest.mark.parametrize("cfg", ["lcdm", "explanatory", "curved", "open", "iso_cdi", "iso_nid", "newt", "curved_full",
                                  "ncdm_small", "ncdm3_small", "ncdm", "ncdm3", "long_small", "long_full", "tca_mb", "ncdm_permille_small", "ncdm_permille",
-                                 "small_tk", "newt_tk", "lcdm_tk"])
+                                 "small_tk", "newt_tk", "lcdm_tk", "ncdm_small_tk", "ncdm3_small_tk"])
 def test_perturb_full_size_subset(cfg):
     """(long_*: l_max_g = l_max_pol_g = l_max_ur = 50; tca_mb: tight_coupling_approximation = first_order_MB, pm.cpp:9351-9361)
     (ncdm*: massive neutrinos, one and three species -- momentum hierarchies of pm.cpp:8832-8879, fluid regime :8737-8823,
