@@ -1269,7 +1269,7 @@ static __device__ __forceinline__ void store_sources(const PtParams& P, const La
     bool any = (P.tp_dn >= 0) || (P.tp_tn >= 0);
 #pragma unroll
     for (int i = 0; i < CPT_NTK; i++) any = any || (P.tp_tk[i] >= 0);
-    if (any) {
+    if (__builtin_expect(any, 0)) {   // (cold unless output = mTk / vTk: kept out of the way of the lone-wave kernels, which sample in place)
       const double k2 = k * k;
       double dgam = delta_g, tgam, dur, tur;
       if (L.rsa) {      // the streaming values (pm.cpp:9530-9636), as the RHS formed them
@@ -1290,7 +1290,10 @@ static __device__ __forceinline__ void store_sources(const PtParams& P, const La
           if (n >= P.nc.n_species) break;
           const double rho_n = bcast(Q.vnc, 3 * n), p_n = bcast(Q.vnc, 3 * n + 1);
           rho_tot += rho_n; rho_p_tot += rho_n + p_n;
-          dn[n] = N.Dn[n] / rho_n; tn[n] = N.Tn[n] / (rho_n + p_n);
+          // (after the fluid switch delta and theta of a species are its first two fluid variables; before it, the momentum-bin integrals
+          //  that sets_species_integrals of cpt_perturb_sets.inc formed for this sample)
+          if (L.fic) { dn[n] = bcast(y, LN_F0 + 3 * n); tn[n] = bcast(y, LN_F0 + 3 * n + 1); }
+          else { dn[n] = N.Dn[n] / rho_n; tn[n] = N.Tn[n] / (rho_n + p_n); }
         }
       }
       const double phi = (GAUGE == CPT_GAUGE_NEWTONIAN) ? eta : eta - aH * M.alpha;
@@ -1878,7 +1881,6 @@ static __device__ __forceinline__ double rhs_fluid(const PtParams& P, const Layo
     else { rho = bcast(Q.vnc, 3 * n); pr = bcast(Q.vnc, 3 * n + 1); pp = bcast(Q.vnc, 3 * n + 2); }
     const int l0 = fluid_lane(n, 0);
     D = fma(rho, bcast(y, l0), D); T = fma(rho + pr, bcast(y, l0 + 1), T); S = fma(rho + pr, bcast(y, l0 + 2), S);
-    N.Dn[n] = rho * bcast(y, l0); N.Tn[n] = (rho + pr) * bcast(y, l0 + 1);   // (read by store_sources alone)
     const bool mine = (ln >= l0) && (ln <= l0 + 2);
     rho_l = mine ? rho : rho_l; p_l = mine ? pr : p_l; pp_l = mine ? pp : pp_l;
   }
