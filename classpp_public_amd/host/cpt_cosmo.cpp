@@ -204,6 +204,7 @@ int cpt_host_background(const cpt_cosmo_params* pp, cpt_background* out) {
   ode.y[kDtau] = 2. * a_start * work[col.H];
   for (int i = 0; i < n; i++) {
     const double lna = lna0 + i * (lna1 - lna0) / (n - 1);
+    ode.forget_step_size();   // one step per node: the nodes are closer than the tolerance needs, and a step just short of one costs a second
     if (!ode.advance(derivatives, lna) || model_failed) { cpt_host_background_free(out); return fail_msg(CPT_ERR_RUNTIME, "background integration failed at ln a = %g", lna); }
     const double a = std::exp(lna);
     double* row = out->background_table + (size_t)i * col.size;
@@ -276,13 +277,27 @@ struct Background {
   const cpt_background& bg;
   std::vector<double> row;
   explicit Background(const cpt_background& b) : bg(b), row(b.bg_size) {}
-  int tau_of_z(double z, double* tau) const { return cpt_host_background_tau_of_z(&bg, z, tau); }
+  int at_z_bracket = 0, at_tau_bracket = 0;   // where the last look-ups fell: the callers walk along the tables
+  int tau_of_z(double z, double* tau) {
+    if (!cpt_num::spline_eval(bg.z_table, bg.bt_size, bg.tau_table, bg.d2tau_dz2_table, 1, 1, z, tau, &at_z_bracket))
+      return fail_msg(CPT_ERR_INVALID, "out of range: z=%e outside [%e, %e]", z, bg.z_table[bg.bt_size - 1], bg.z_table[0]);
+    return CPT_OK;
+  }
   int at_tau(double tau) {
-    if (interpolate_spline(bg.tau_table, bg.bt_size, bg.background_table, bg.d2background_dtau2_table, bg.bg_size, tau, row.data()))
+    if (!cpt_num::spline_eval(bg.tau_table, bg.bt_size, bg.background_table, bg.d2background_dtau2_table, bg.bg_size, bg.bg_size, tau, row.data(), &at_tau_bracket))
       return fail_msg(CPT_ERR_INVALID, "background_at_tau: tau=%e out of range", tau);
     return CPT_OK;
   }
   int at_z(double z) { double tau; const int rc = tau_of_z(z, &tau); return rc ? rc : at_tau(tau); }
+  // only the columns between two named ones (the recombination equations read H and H', the drag depth rho_g and rho_b: a handful
+  // of neighbouring columns out of two dozen), into the same row
+  int columns_at_tau(double tau, int col_a, int col_b) {
+    const int first = std::min(col_a, col_b), span = std::abs(col_a - col_b) + 1;
+    if (!cpt_num::spline_eval(bg.tau_table, bg.bt_size, bg.background_table + first, bg.d2background_dtau2_table + first, span, bg.bg_size, tau, row.data() + first, &at_tau_bracket))
+      return fail_msg(CPT_ERR_INVALID, "background_at_tau: tau=%e out of range", tau);
+    return CPT_OK;
+  }
+  int expansion_at_z(double z) { double tau; const int rc = tau_of_z(z, &tau); return rc ? rc : columns_at_tau(tau, bg.index_bg_H, bg.index_bg_H_prime); }
   double H() const { return row[bg.index_bg_H]; }
   double Hp() const { return row[bg.index_bg_H_prime]; }
   double rho_g() const { return row[bg.index_bg_rho_g]; }
@@ -340,12 +355,15 @@ class Recfast {
   void operator()(double z, const double* y, double* dy) {
     const double xH = y[0], xHe = y[1], Tm = y[2], xe = xH + fHe_ * xHe;
     const double opz = 1. + z, nH = nH0_ * opz * opz * opz, nHe = fHe_ * nH, Tr = T0_ * opz;
-    if (B_.at_z(z)) { failed_ = true; dy[0] = dy[1] = dy[2] = 0.; return; }
+    if (B_.expansion_at_z(z)) { failed_ = true; dy[0] = dy[1] = dy[2] = 0.; return; }
     const double Hz = B_.H() * kC / kMpc, dt_dz_inv = Hz * opz;   // |dz/dt| = H (1 + z)
-    const double thermal = std::pow(saha_prefactor_ * Tm, 1.5);
+    // (powers as x sqrt x and exp(b ln x) with the logarithms shared: the equations are evaluated some 5e4 times per history and
+    // general pow() calls were most of their cost)
+    const double sT = saha_prefactor_ * Tm, thermal = sT * std::sqrt(sT);
     // --- hydrogen: case-B recombination, photoionisation from n = 2, Peebles factor with the Lyman-alpha escape correction
     const double t4 = Tm / 1.e4;
-    const double alpha_H = 1.e-19 * atom::ppb_a * std::pow(t4, atom::ppb_b) / (1. + atom::ppb_c * std::pow(t4, atom::ppb_d));
+    const double ln_t4 = std::log(t4);
+    const double alpha_H = 1.e-19 * atom::ppb_a * std::exp(atom::ppb_b * ln_t4) / (1. + atom::ppb_c * std::exp(atom::ppb_d * ln_t4));
     const double beta_H = alpha_H * thermal * std::exp(-T_ion_H_n2_ / Tm);
     double K_H = lya_escape_ / Hz;
     if (tp_.recfast_Hswitch) {
@@ -354,7 +372,8 @@ class Recfast {
     }
     // --- helium singlets and triplets (Verner-Ferland fits)
     const double s0 = std::sqrt(Tm / std::pow(10., 0.477121)), s1 = std::sqrt(Tm / std::pow(10., 5.114));
-    auto vf = [&](double amp, double b) { return amp / (s0 * std::pow(1. + s0, 1. - b) * std::pow(1. + s1, 1. + b)); };
+    const double ln_1s0 = std::log1p(s0), ln_1s1 = std::log1p(s1);
+    auto vf = [&](double amp, double b) { return amp / (s0 * std::exp((1. - b) * ln_1s0 + (1. + b) * ln_1s1)); };
     const double alpha_He = vf(std::pow(10., -16.744), atom::vf_b), beta_He = 4. * alpha_He * thermal * std::exp(-T_ion_He_n2_ / Tm);
     const double alpha_He_t = vf(std::pow(10., -16.306), atom::trip_b);
     const double beta_He_t = alpha_He_t * std::exp(-kPlanck * kC * atom::He_2st_ion / (kBoltz * Tm)) * thermal * 4. / 3.;
@@ -403,7 +422,7 @@ class Recfast {
     }
     // matter temperature: tightly coupled to the radiation while Compton scattering is fast (first-order expansion in the
     // coupling time), the full Compton + adiabatic equation afterwards
-    const double t_compton = (1. + xe + fHe_) / (compton_ * Tr * Tr * Tr * Tr * xe), t_hubble = 2. / (3. * H0_ * std::pow(opz, 1.5));
+    const double t_compton = (1. + xe + fHe_) / (compton_ * Tr * Tr * Tr * Tr * xe), t_hubble = 2. / (3. * H0_ * opz * std::sqrt(opz));
     if (t_compton < tp_.recfast_H_frac * t_hubble) {
       const double dlnH_dz = -B_.Hp() / B_.H() / cp_.a_today * kC / kMpc / Hz;
       const double lag = Hz * (1. + xe + fHe_) / (compton_ * Tr * Tr * Tr * xe);
@@ -437,12 +456,16 @@ int recombination_history(const cpt_cosmo_params& cp, const cpt_thermo_params& t
   ode.rtol = 1e-9;
   ode.atol[0] = ode.atol[1] = 1e-14;
   double y[3] = {1., 1., model.T0() * (1. + z_top)};
-  bool ode_running = false;
+  // One step of the integrator per node.  While the state is handed on untouched from node to node (everything by the rate
+  // equations) the integrator keeps its last stage - the derivative at the node, which the table needs as well - as the first
+  // stage of the next step; a caller that overwrites y (a Saha value) makes it start afresh.
   auto integrate_to = [&](double z_from, double z_to) -> int {
-    if (!ode_running) { ode.restart(); ode_running = true; }
-    ode.x = z_from;
-    for (int i = 0; i < 3; i++) ode.y[i] = y[i];
-    ode.restart();   // (the caller may have overwritten y with a Saha value)
+    const bool handed_on = ode.slope() && ode.x == z_from && ode.y[0] == y[0] && ode.y[1] == y[1] && ode.y[2] == y[2];
+    if (!handed_on) {
+      ode.x = z_from;
+      for (int i = 0; i < 3; i++) ode.y[i] = y[i];
+      ode.restart();
+    } else ode.forget_step_size();
     if (!ode.advance(model, z_to) || model.failed()) return fail_msg(CPT_ERR_RUNTIME, "recfast: integration failed in [%g : %g]", z_from, z_to);
     for (int i = 0; i < 3; i++) y[i] = ode.y[i];
     return CPT_OK;
@@ -490,7 +513,9 @@ int recombination_history(const cpt_cosmo_params& cp, const cpt_thermo_params& t
     }
     double* row = &tab[(size_t)(Nz - i - 1) * RE_SIZE];
     double dy[3];
-    model(z, y, dy);
+    const double* kept = (ode.slope() && ode.x == z && ode.y[0] == y[0] && ode.y[1] == y[1] && ode.y[2] == y[2]) ? ode.slope() : nullptr;
+    if (kept) for (int j = 0; j < 3; j++) dy[j] = kept[j];
+    else model(z, y, dy);
     if (model.failed()) return fail_msg(CPT_ERR_RUNTIME, "recfast: background look-up failed at z=%e", z);
     row[RE_Z] = z; row[RE_XE] = xe; row[RE_TB] = y[2];
     row[RE_WB] = kBoltz / (kC * kC * kMH) * (1. + (1. / kHe4OverH - 1.) * tp.YHe + xe * (1. - tp.YHe)) * y[2];
@@ -703,7 +728,7 @@ int cpt_host_thermodynamics(const cpt_cosmo_params* cpp, const cpt_thermo_params
   const cpt_num::ClampedSpline in_tau(tau.data(), nt);
   // baryon drag depth tau_d = integral of kappa' / R, R = 3 rho_b / 4 rho_g, from today backwards
   for (int i = 0; i < nt; i++) {
-    if ((rc = B.at_tau(tau[i]))) return bail(rc);
+    if ((rc = B.columns_at_tau(tau[i], bg->index_bg_rho_g, bg->index_bg_rho_b))) return bail(rc);
     f[i] = -T[(size_t)i * nc + TH_dkappa] * (4. / 3.) * B.rho_g() / B.rho_b();
   }
   in_tau.moments(f.data(), 1, 1, m.data());

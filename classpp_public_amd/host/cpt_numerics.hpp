@@ -39,26 +39,40 @@ class ClampedSpline {
     const double fab = (yb - ya) / (xb - xa), fbc = (yc - yb) / (xc - xb);
     return fab + (fbc - fab) / (xc - xa) * (xa - xb);
   }
-  // second derivatives of `ncol` columns tabulated row-major: y[i * stride + c] -> m[i * stride + c]
+  // second derivatives of `ncol` columns tabulated row-major: y[i * stride + c] -> m[i * stride + c].  The two sweeps walk the
+  // table row by row with the columns innermost: memory is read in order and the columns' recurrences (each a chain of dependent
+  // multiply-adds and one division per node) overlap in the pipeline
   void moments(const double* y, int ncol, int stride, double* m) const {
     const int n = n_;
+    std::vector<double> work(2 * (size_t)ncol);
+    double* d_prev = work.data();
+    double* s_last = d_prev + ncol;
+    auto Y = [&](int i) { return y + (size_t)i * stride; };
+    auto M = [&](int i) { return m + (size_t)i * stride; };
     for (int c = 0; c < ncol; c++) {
-      auto Y = [&](int i) { return y[(size_t)i * stride + c]; };
-      auto M = [&](int i) -> double& { return m[(size_t)i * stride + c]; };
-      const double s0 = end_slope(x_[0], x_[1], x_[2], Y(0), Y(1), Y(2));
-      const double s1 = end_slope(x_[n - 1], x_[n - 2], x_[n - 3], Y(n - 1), Y(n - 2), Y(n - 3));
-      // forward elimination on the right-hand side
-      double d_prev = (Y(1) - Y(0)) / h_[0];
-      M(0) = 6. * (d_prev - s0);
-      for (int i = 1; i < n - 1; i++) {
-        const double d = (Y(i + 1) - Y(i)) / h_[i];
-        M(i) = 6. * (d - d_prev) - low_[i] * M(i - 1);
-        d_prev = d;
+      const double s0 = end_slope(x_[0], x_[1], x_[2], Y(0)[c], Y(1)[c], Y(2)[c]);
+      s_last[c] = end_slope(x_[n - 1], x_[n - 2], x_[n - 3], Y(n - 1)[c], Y(n - 2)[c], Y(n - 3)[c]);
+      d_prev[c] = (Y(1)[c] - Y(0)[c]) / h_[0];
+      M(0)[c] = 6. * (d_prev[c] - s0);
+    }
+    // forward elimination on the right-hand side
+    for (int i = 1; i < n - 1; i++) {
+      const double *y0 = Y(i), *y1 = Y(i + 1), *mp = M(i - 1);
+      double* mi = M(i);
+      const double h = h_[i], low = low_[i];
+      for (int c = 0; c < ncol; c++) {
+        const double d = (y1[c] - y0[c]) / h;
+        mi[c] = 6. * (d - d_prev[c]) - low * mp[c];
+        d_prev[c] = d;
       }
-      M(n - 1) = 6. * (s1 - d_prev) - low_[n - 1] * M(n - 2);
-      // back substitution (super-diagonal entry of row i is h_i)
-      M(n - 1) /= piv_[n - 1];
-      for (int i = n - 2; i >= 0; i--) M(i) = (M(i) - h_[i] * M(i + 1)) / piv_[i];
+    }
+    for (int c = 0; c < ncol; c++) M(n - 1)[c] = (6. * (s_last[c] - d_prev[c]) - low_[n - 1] * M(n - 2)[c]) / piv_[n - 1];
+    // back substitution (super-diagonal entry of row i is h_i)
+    for (int i = n - 2; i >= 0; i--) {
+      const double* mn = M(i + 1);
+      double* mi = M(i);
+      const double h = h_[i], piv = piv_[i];
+      for (int c = 0; c < ncol; c++) mi[c] = (mi[c] - h * mn[c]) / piv;
     }
   }
 
@@ -68,15 +82,35 @@ class ClampedSpline {
   const double* x_;
 };
 
-// value of the spline (y, m) at v, x monotonic in either direction; returns false outside the table
-inline bool spline_eval(const double* x, int n, const double* y, const double* m, int ncol, int stride, double v, double* out) {
-  const bool up = x[0] < x[n - 1];
-  if (up ? (v < x[0] || v > x[n - 1]) : (v > x[0] || v < x[n - 1])) return false;
-  int lo = 0, hi = n - 1;   // bracket by bisection
+// the interval [lo, lo + 1] of a monotonic (either direction) table that holds v: x[lo] <= v < x[lo + 1] going up, x[lo] > v >= x[lo + 1]
+// going down, the first / last interval at the ends.  `hint` (an interval found earlier, or null) is tried first together with its
+// two neighbours, which is what a caller walking along the table needs; the answer does not depend on the hint.
+inline int spline_bracket(const double* x, int n, double v, bool up, const int* hint) {
+  auto holds = [&](int i) {
+    if (i < 0 || i > n - 2) return false;
+    if (up) return (x[i] <= v || i == 0) && (v < x[i + 1] || (i == n - 2 && v == x[n - 1]));
+    return (x[i] > v || i == 0) && v >= x[i + 1];
+  };
+  if (hint) {
+    const int h = *hint;
+    if (holds(h)) return h;
+    if (holds(h + 1)) return h + 1;
+    if (holds(h - 1)) return h - 1;
+  }
+  int lo = 0, hi = n - 1;   // bisection
   while (hi - lo > 1) {
     const int mid = (lo + hi) / 2;
     if ((v < x[mid]) == up) hi = mid; else lo = mid;
   }
+  return lo;
+}
+// value of the spline (y, m) at v, x monotonic in either direction; returns false outside the table.  ncol columns starting at
+// y / m are evaluated (rows `stride` apart); *hint, when given, is read as the caller's guess of the interval and updated
+inline bool spline_eval(const double* x, int n, const double* y, const double* m, int ncol, int stride, double v, double* out, int* hint = nullptr) {
+  const bool up = x[0] < x[n - 1];
+  if (up ? (v < x[0] || v > x[n - 1]) : (v > x[0] || v < x[n - 1])) return false;
+  const int lo = spline_bracket(x, n, v, up, hint), hi = lo + 1;
+  if (hint) *hint = lo;
   const double h = x[hi] - x[lo], t = (v - x[lo]) / h, u = 1. - t;
   const double cu = (u * u * u - u) * h * h / 6., ct = (t * t * t - t) * h * h / 6.;
   for (int c = 0; c < ncol; c++)
@@ -154,7 +188,11 @@ class Dopri5 {
     }
     return false;
   }
-  void restart() { have_k1_ = false; h_next_ = 0.; last_full_h_ = 0.; err_prev_ = 1e-4; just_rejected_ = false; }   // after y was changed by the caller
+  // f(x, y) as left by the last accepted step (its last stage), or null when the caller has to evaluate it (before the first
+  // step, after restart())
+  const double* slope() const { return have_k1_ ? k1_ : nullptr; }
+  void forget_step_size() { h_next_ = 0.; last_full_h_ = 0.; err_prev_ = 1e-4; just_rejected_ = false; }   // the next advance() tries its whole interval first
+  void restart() { have_k1_ = false; forget_step_size(); }   // after y was changed by the caller
 
  private:
   // Butcher tableau
