@@ -101,7 +101,6 @@ class ParameterInputs(Inputs):
         self.name = name
         self.d = dict(params) if params is not None else dict(np.load(os.path.join(golden_dir, name + ".npz")))
         ini = dict(ini) if ini is not None else read_ini(os.path.join(golden_dir, name + ".ini"))
-        self._params_given = params is not None
         if cosmology is not None:
             for k, v in density_parameters(**cosmology).items():
                 self.d["pba." + k] = np.array([v], dtype=np.int32 if k == "sgnK" else np.float64)
@@ -134,7 +133,8 @@ class ParameterInputs(Inputs):
         tables.update(hostlib.thermodynamics(self, cp, tp))
         if ncdm is not None:
             tables.update(ncdm)
-        super().__init__(name, golden_dir, tables=tables, params=self.d if self._params_given else None)
+        # (self.d, not the committed file again: it carries the replaced cosmological parameters)
+        super().__init__(name, golden_dir, tables=tables, params=self.d)
         self.l_tensor_max = int(ini["l_max_tensors"]) if "l_max_tensors" in ini else None
         if A_s is not None:
             self.spectra.A_s = A_s
