@@ -167,3 +167,17 @@ def test_parameter_inputs_reproduce_the_fixture_inputs(cfg):
             assert list(x) == list(y), field
         else:
             assert x == y, field
+
+
+def test_replaced_cosmology_reaches_the_config():
+    """ParameterInputs(name, cosmology=...) without `params`: the replaced densities, H0 and curvature must be the ones the device
+    configuration carries (they were once re-read from the committed fixture while the tables followed the new cosmology)."""
+    from classpp_public_amd.pipeline import ParameterInputs
+    base = Inputs("small")
+    inp = ParameterInputs("small", cosmology=dict(h=0.60, omega_b=0.0200, omega_cdm=0.14, Omega_k=-0.02), YHe=0.25, z_reio=8.5, n_s=0.95)
+    c = inp.config
+    H0 = 0.60 * 1e5 / 2.99792458e8
+    assert abs(c.H0 / H0 - 1) < 1e-14 and c.H0 != base.config.H0
+    assert c.sgnK == 1 and c.has_curvature == 1 and abs(c.K / (0.02 * H0 * H0) - 1) < 1e-12
+    assert c.tau0 == float(inp.t["bg.conformal_age"][0]) and c.tau0 != base.config.tau0
+    assert abs(float(inp.d["pba.H0"][0]) / H0 - 1) < 1e-14
