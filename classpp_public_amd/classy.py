@@ -888,9 +888,9 @@ class Class:
         """density and velocity transfer functions at redshift z (classy.pyx:1303-1388, PerturbationsModule::perturb_output_data,
         pm.cpp:130-330): {'k (h/Mpc)', 'd_g', 'd_b', 'd_cdm', 'd_ur', 'd_tot', 'phi', 'psi', 't_g', 't_b', 't_cdm', 't_ur', 't_tot'} for the
         columns the run holds (output = mTk / dTk, vTk); z = 0: the last time sample, 0 < z <= z_max_pk: the sources splined in ln tau
-        over the tail of the sampling, as perturb_sources_at_tau does"""
-        if output_format != "class":
-            raise CosmoSevereError("get_transfer: only the 'class' format is implemented (not 'camb')")
+        over the tail of the sampling, as perturb_sources_at_tau does; output_format = 'camb': the eight fixed columns -T_x / k^2"""
+        if output_format not in ("class", "camb"):
+            raise CosmoSevereError("get_transfer: output_format is 'class' or 'camb'")
         self._need("perturb")
         r = self._runs.get("s")
         c = r.inp.config if r is not None else None
@@ -913,9 +913,23 @@ class Class:
             d1 = ((lt[-3] - lt[-1]) ** 2 * (y[:, -2] - y[:, -1]) - (lt[-2] - lt[-1]) ** 2 * (y[:, -3] - y[:, -1])) / \
                  ((lt[-3] - lt[-1]) * (lt[-2] - lt[-1]) * (lt[-3] - lt[-2]))
             at = CubicSpline(lt, y, axis=1, bc_type=((1, d0), (1, d1)))(np.log(tau_z))
+        out = {"k (h/Mpc)": r.inp.k / self.h()}
+        if output_format == "camb":
+            # the CMBFAST / CAMB convention (pm.cpp:289-300, titles :377-389): minus the density transfer functions over k^2, fixed
+            # columns; absent species read zero and of several non-cold species only the first is written
+            k2 = r.inp.k * r.inp.k
+
+            def scaled(index):
+                return -at[index] / k2 if index >= 0 else np.zeros_like(k2)
+            for title, name in (("-T_cdm/k2", "delta_cdm"), ("-T_idm_dr/k2", None), ("-T_b/k2", "delta_b"), ("-T_g/k2", "delta_g"),
+                                ("-T_ur/k2", "delta_ur"), ("-T_idr/k2", None), ("-T_ncdm/k2", "ncdm"), ("-T_tot/k2", "delta_tot")):
+                if name == "ncdm":
+                    out[title] = scaled(int(c.index_tp_delta_ncdm1) if c.has_ncdm else -1)
+                else:
+                    out[title] = scaled(int(c.index_tp_transfer[TK_NAMES.index(name)]) if name else -1)
+            return out
         titles = {"delta_g": "d_g", "delta_b": "d_b", "delta_cdm": "d_cdm", "delta_ur": "d_ur", "delta_tot": "d_tot", "phi": "phi", "psi": "psi",
                   "theta_g": "t_g", "theta_b": "t_b", "theta_cdm": "t_cdm", "theta_ur": "t_ur", "theta_tot": "t_tot"}
-        out = {"k (h/Mpc)": r.inp.k / self.h()}
         order = ("delta_g", "delta_b", "delta_cdm", "delta_ur", "delta_tot", "phi", "psi", "theta_g", "theta_b", "theta_cdm", "theta_ur", "theta_tot")
         for name in order:
             idx = int(c.index_tp_transfer[TK_NAMES.index(name)])

@@ -321,6 +321,17 @@ def test_get_transfer_matches_the_reference_sources():
             assert np.max(np.abs(got - want)) < 1e-4 * np.max(np.abs(want)), (cfg, name, np.max(np.abs(got - want)) / np.max(np.abs(want)))
             seen += 1
         assert seen == (11 if cfg == "small_tk" else 12)
+        # the CAMB convention of the same numbers (pm.cpp:289-300): fixed columns, -T / k^2, zeros for absent species
+        camb = c.get_transfer(output_format="camb")
+        assert list(camb.keys()) == ["k (h/Mpc)", "-T_cdm/k2", "-T_idm_dr/k2", "-T_b/k2", "-T_g/k2", "-T_ur/k2", "-T_idr/k2", "-T_ncdm/k2", "-T_tot/k2"]
+        k2 = ref["pt.k"] ** 2
+        for title, name in (("-T_cdm/k2", "delta_cdm"), ("-T_b/k2", "delta_b"), ("-T_g/k2", "delta_g"), ("-T_ur/k2", "delta_ur"), ("-T_tot/k2", "delta_tot")):
+            want = -ref["pt.sources"][int(ref["pt.index_tp_" + name][0]), -1, :] / k2
+            assert np.max(np.abs(camb[title] / want - 1)) < 1e-4 or np.max(np.abs(camb[title] - want)) < 1e-4 * np.max(np.abs(want)), (cfg, title)
+        for title in ("-T_idm_dr/k2", "-T_idr/k2", "-T_ncdm/k2"):
+            assert not camb[title].any()
+        with pytest.raises(classy.CosmoSevereError, match="output_format"):
+            c.get_transfer(output_format="cmbfast")
         with pytest.raises(classy.CosmoSevereError, match="z_max_pk"):
             c.get_transfer(1.0)
         c.struct_cleanup()
@@ -342,6 +353,9 @@ def test_get_transfer_matches_the_reference_sources():
     want = ref["pt.sources_subset"][int(ref["pt.index_tp_delta_tot"][0]), -1, :]
     assert np.max(np.abs(tk["d_tot"][ks] - want)) < 1e-4 * np.max(np.abs(want))
     assert list(tk.keys()).index("d_ncdm[0]") == list(tk.keys()).index("d_ur") + 1      # (the reference's column order)
+    camb = c.get_transfer(output_format="camb")      # (of several species the CAMB columns hold the first)
+    want = -ref["pt.sources_subset"][int(ref["pt.index_tp_delta_ncdm1"][0]), -1, :] / ref["pt.k"][ks] ** 2
+    assert np.max(np.abs(camb["-T_ncdm/k2"][ks] - want)) < 1e-4 * np.max(np.abs(want))
     c.struct_cleanup()
     # 0 < z <= z_max_pk: the sources splined in ln tau over the tail of the sampling (perturb_sources_at_tau, pm.cpp:79-132) against the
     # reference's own interpolation at the z_pk of lcdm_zpk_tk.ini (fixture entry pt.sources_at_z_pk)
