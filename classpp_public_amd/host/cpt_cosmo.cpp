@@ -360,15 +360,19 @@ class Recfast {
     // (powers as x sqrt x and exp(b ln x) with the logarithms shared: the equations are evaluated some 5e4 times per history and
     // general pow() calls were most of their cost)
     const double sT = saha_prefactor_ * Tm, thermal = sT * std::sqrt(sT);
-    // --- hydrogen: case-B recombination, photoionisation from n = 2, Peebles factor with the Lyman-alpha escape correction
-    const double t4 = Tm / 1.e4;
-    const double ln_t4 = std::log(t4);
-    const double alpha_H = 1.e-19 * atom::ppb_a * std::exp(atom::ppb_b * ln_t4) / (1. + atom::ppb_c * std::exp(atom::ppb_d * ln_t4));
-    const double beta_H = alpha_H * thermal * std::exp(-T_ion_H_n2_ / Tm);
-    double K_H = lya_escape_ / Hz;
-    if (tp_.recfast_Hswitch) {
-      const double lz = std::log(opz), g1 = (lz - tp_.recfast_zGauss1) / tp_.recfast_wGauss1, g2 = (lz - tp_.recfast_zGauss2) / tp_.recfast_wGauss2;
-      K_H *= 1. + tp_.recfast_AGauss1 * std::exp(-g1 * g1) + tp_.recfast_AGauss2 * std::exp(-g2 * g2);
+    // --- hydrogen: case-B recombination, photoionisation from n = 2, Peebles factor with the Lyman-alpha escape correction; not
+    //     evaluated while hydrogen is held at its Saha value (two thirds of the nodes: only dT/dz is wanted there)
+    const bool hydrogen_evolves = !(xH > tp_.recfast_x_H0_trigger);
+    double alpha_H = 0., beta_H = 0., K_H = 0.;
+    if (hydrogen_evolves) {
+      const double ln_t4 = std::log(Tm / 1.e4);
+      alpha_H = 1.e-19 * atom::ppb_a * std::exp(atom::ppb_b * ln_t4) / (1. + atom::ppb_c * std::exp(atom::ppb_d * ln_t4));
+      beta_H = alpha_H * thermal * std::exp(-T_ion_H_n2_ / Tm);
+      K_H = lya_escape_ / Hz;
+      if (tp_.recfast_Hswitch) {
+        const double lz = std::log(opz), g1 = (lz - tp_.recfast_zGauss1) / tp_.recfast_wGauss1, g2 = (lz - tp_.recfast_zGauss2) / tp_.recfast_wGauss2;
+        K_H *= 1. + tp_.recfast_AGauss1 * std::exp(-g1 * g1) + tp_.recfast_AGauss2 * std::exp(-g2 * g2);
+      }
     }
     // --- helium singlets and triplets (Verner-Ferland fits)
     const double s0 = std::sqrt(Tm / std::pow(10., 0.477121)), s1 = std::sqrt(Tm / std::pow(10., 5.114));
@@ -404,7 +408,7 @@ class Recfast {
       }
     }
     // --- the three equations
-    if (xH > tp_.recfast_x_H0_trigger) dy[0] = 0.;
+    if (!hydrogen_evolves) dy[0] = 0.;
     else {
       const double n1s = nH * (1. - xH);
       const double peebles = (xH < tp_.recfast_x_H0_trigger2)
