@@ -181,3 +181,15 @@ def test_replaced_cosmology_reaches_the_config():
     assert c.sgnK == 1 and c.has_curvature == 1 and abs(c.K / (0.02 * H0 * H0) - 1) < 1e-12
     assert c.tau0 == float(inp.t["bg.conformal_age"][0]) and c.tau0 != base.config.tau0
     assert abs(float(inp.d["pba.H0"][0]) / H0 - 1) < 1e-14
+
+
+def test_host_tables_repeat_bit_for_bit():
+    """The look-up hints and the integrators' kept stages are state of one call: two calls on the same parameters return the same bits."""
+    inp = Inputs("lcdm")
+    a, b = hostlib.thermodynamics(inp), hostlib.thermodynamics(inp)
+    assert a.keys() == b.keys()
+    for key in a:
+        assert np.array_equal(np.asarray(a[key]), np.asarray(b[key])), key
+    a, b = hostlib.background(inp), hostlib.background(inp)
+    for key in a:
+        assert np.array_equal(np.asarray(a[key]), np.asarray(b[key])), key
